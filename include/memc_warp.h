@@ -1,0 +1,196 @@
+/*
+ * memc_warp.h -- C ABI of libmemc_hip.so: MEMC-Net's adaptive-warp / flow-projection operators as
+ * hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * This is the drop-in boundary.  The reference reaches its CUDA kernels through two C layers that its
+ * cffi loader binds (my_package/_ext/my_lib/__init__.py:5-11):
+ *
+ *   layer entry points   my_package/src/my_lib_cuda.h:37-117   <Op>Layer_gpu_{forward,backward}(THCudaTensor*...)
+ *   kernel launchers     my_package/src/my_lib_kernel.h:67-220 <Op>_gpu_{forward,backward}_kernel(cudaStream_t, ...)
+ *
+ * Both are exported here under the reference's own names.  The kernel launchers keep the reference's
+ * parameter lists verbatim (stream, nElement, w, h, channel, batch, [filter_size | fillhole], four element
+ * strides per tensor, device pointers); only `cudaStream_t` becomes a HIP stream handle.  The layer entry
+ * points keep the reference's names, argument order, checks and return codes; `THCudaTensor*` (of which
+ * the reference reads only size[], stride[] and the data pointer) becomes the POD descriptor
+ * `memc_tensor4`, and the stream the reference took from its global THCState is passed explicitly.
+ *
+ * Contract (identical to the reference):
+ *   - fp32, NCHW, strides in ELEMENTS, w-stride must be 1;
+ *   - every output / gradient buffer is borrowed: allocated AND zero-filled by the caller
+ *     (my_package/functions/FilterInterpolationLayer.py:26-29,46-48; FlowProjectionLayer.py:27-29,54);
+ *   - `output`, `gradoutput` and `gradinput1` are indexed with input1's b/c/h strides
+ *     (my_lib_kernel.cu:1184,1276-1283), `gradinput2`/`gradinput3` with input2's/input3's;
+ *   - work is enqueued asynchronously on `stream`; no host synchronisation, no allocation, no global state;
+ *   - return 0 on success, -1 on a failed shape/stride check or a launch error (my_lib_cuda.c:611-646,
+ *     my_lib_kernel.cu:1559-1566).
+ *
+ * No torch, HIP or C++ types appear in this header; a HIP stream is passed as an opaque pointer
+ * (`hipStream_t` is itself a pointer type; 0 / NULL is the default stream).
+ */
+#ifndef MEMC_WARP_H
+#define MEMC_WARP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *memc_stream_t;            /* hipStream_t */
+
+/* Replaces THCudaTensor at the layer boundary (my_lib_cuda.c reads only these three things through
+ * THCudaTensor_size / THCudaTensor_stride / THCudaTensor_data). */
+typedef struct memc_tensor4 {
+    float  *data;                       /* device pointer */
+    int64_t size[4];                    /* N, C, H, W */
+    int64_t stride[4];                  /* element strides */
+} memc_tensor4;
+
+/* Library / build identification: returns a static string such as "memc_hip 0.1 gfx950". */
+const char *memc_hip_version(void);
+
+/* ======================================================================================================
+ * Layer entry points -- replace my_lib_cuda.h:37-117 (implemented in the reference by my_lib_cuda.c).
+ * ==================================================================================================== */
+
+/* my_lib_cuda.h:37-42 / my_lib_cuda.c:364-417.  Bilinear warp, channel must be 3. */
+int InterpolationLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
+                                   const memc_tensor4 *input2, const memc_tensor4 *output);
+/* my_lib_cuda.h:44-52 / my_lib_cuda.c:419-479 */
+int InterpolationLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
+                                    const memc_tensor4 *input2, const memc_tensor4 *gradoutput,
+                                    const memc_tensor4 *gradinput1, const memc_tensor4 *gradinput2);
+
+/* my_lib_cuda.h:53-58 / my_lib_cuda.c:481-534.  Bilinear warp, any channel count. */
+int InterpolationChLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
+                                     const memc_tensor4 *input2, const memc_tensor4 *output);
+/* my_lib_cuda.h:60-68 / my_lib_cuda.c:536-596 */
+int InterpolationChLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
+                                      const memc_tensor4 *input2, const memc_tensor4 *gradoutput,
+                                      const memc_tensor4 *gradinput1, const memc_tensor4 *gradinput2);
+
+/* my_lib_cuda.h:69-75 / my_lib_cuda.c:598-668.  Flow sample fused with the fs x fs adaptive filter;
+ * input3 has fs*fs channels. */
+int FilterInterpolationLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
+                                         const memc_tensor4 *input2, const memc_tensor4 *input3,
+                                         const memc_tensor4 *output);
+/* my_lib_cuda.h:77-85 / my_lib_cuda.c:669-749 */
+int FilterInterpolationLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
+                                          const memc_tensor4 *input2, const memc_tensor4 *input3,
+                                          const memc_tensor4 *gradoutput,
+                                          const memc_tensor4 *gradinput1,
+                                          const memc_tensor4 *gradinput2,
+                                          const memc_tensor4 *gradinput3);
+
+/* my_lib_cuda.h:87-92 / my_lib_cuda.c:752-799.  Forward splat of -flow, count-normalise, optional
+ * hole fill (fillhole != 0). */
+int FlowProjectionLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
+                                    const memc_tensor4 *count, const memc_tensor4 *output,
+                                    int fillhole);
+/* my_lib_cuda.h:94-99 / my_lib_cuda.c:801-855 */
+int FlowProjectionLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
+                                     const memc_tensor4 *count, const memc_tensor4 *gradoutput,
+                                     const memc_tensor4 *gradinput1);
+
+/* my_lib_cuda.h:101-107 / my_lib_cuda.c:857-914.  Depth-weighted projection; input2 = depth [N,1,H,W]. */
+int DepthFlowProjectionLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
+                                         const memc_tensor4 *input2, const memc_tensor4 *count,
+                                         const memc_tensor4 *output, int fillhole);
+/* my_lib_cuda.h:109-117 / my_lib_cuda.c:916-983 */
+int DepthFlowProjectionLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
+                                          const memc_tensor4 *input2, const memc_tensor4 *count,
+                                          const memc_tensor4 *output, const memc_tensor4 *gradoutput,
+                                          const memc_tensor4 *gradinput1,
+                                          const memc_tensor4 *gradinput2);
+
+/* ======================================================================================================
+ * Kernel launchers -- replace my_lib_kernel.h:67-220 (implemented in the reference by
+ * my_lib_kernel.cu).  Parameter lists are the reference's, with cudaStream_t -> memc_stream_t.
+ * `nElement` is accepted and ignored, as in the reference.
+ * ==================================================================================================== */
+
+/* my_lib_kernel.h:67-81 */
+int InterpolationLayer_gpu_forward_kernel(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int input2_b_stride, const int input2_c_stride, const int input2_h_stride, const int input2_w_stride,
+    const float *input1, const float *input2, float *output);
+
+/* my_lib_kernel.h:83-98 */
+int InterpolationLayer_gpu_backward_kernel(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int input2_b_stride, const int input2_c_stride, const int input2_h_stride, const int input2_w_stride,
+    const float *input1, const float *input2, const float *gradoutput, float *gradinput1, float *gradinput2);
+
+/* my_lib_kernel.h:101-115 */
+int InterpolationChLayer_gpu_forward_kernel(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int input2_b_stride, const int input2_c_stride, const int input2_h_stride, const int input2_w_stride,
+    const float *input1, const float *input2, float *output);
+
+/* my_lib_kernel.h:117-132 */
+int InterpolationChLayer_gpu_backward_kernel(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int input2_b_stride, const int input2_c_stride, const int input2_h_stride, const int input2_w_stride,
+    const float *input1, const float *input2, const float *gradoutput, float *gradinput1, float *gradinput2);
+
+/* my_lib_kernel.h:133-144 */
+int FilterInterpolationLayer_gpu_forward_kernel(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int filter_size,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int input2_b_stride, const int input2_c_stride, const int input2_h_stride, const int input2_w_stride,
+    const int input3_b_stride, const int input3_c_stride, const int input3_h_stride, const int input3_w_stride,
+    const float *input1, const float *input2, const float *input3, float *output);
+
+/* my_lib_kernel.h:146-158 */
+int FilterInterpolationLayer_gpu_backward_kernel(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int filter_size,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int input2_b_stride, const int input2_c_stride, const int input2_h_stride, const int input2_w_stride,
+    const int input3_b_stride, const int input3_c_stride, const int input3_h_stride, const int input3_w_stride,
+    const float *input1, const float *input2, const float *input3,
+    const float *gradoutput, float *gradinput1, float *gradinput2, float *gradinput3);
+
+/* my_lib_kernel.h:161-171 */
+int FlowProjection_gpu_forward_kernel(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int fillhole,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int count_b_stride, const int count_c_stride, const int count_h_stride, const int count_w_stride,
+    const float *input1, float *count, float *output);
+
+/* my_lib_kernel.h:173-187 */
+int FlowProjection_gpu_backward_kernel(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int count_b_stride, const int count_c_stride, const int count_h_stride, const int count_w_stride,
+    const float *input1, const float *count, const float *gradoutput, float *gradinput1);
+
+/* my_lib_kernel.h:189-200 */
+int DepthFlowProjection_gpu_forward_kernel(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int fillhole,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int input2_b_stride, const int input2_c_stride, const int input2_h_stride, const int input2_w_stride,
+    const int count_b_stride, const int count_c_stride, const int count_h_stride, const int count_w_stride,
+    const float *input1, const float *input2, float *count, float *output);
+
+/* my_lib_kernel.h:202-220 */
+int DepthFlowProjection_gpu_backward_kernel(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int input2_b_stride, const int input2_c_stride, const int input2_h_stride, const int input2_w_stride,
+    const int count_b_stride, const int count_c_stride, const int count_h_stride, const int count_w_stride,
+    const float *input1, const float *input2, const float *count, const float *output,
+    const float *gradoutput, float *gradinput1, float *gradinput2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEMC_WARP_H */

@@ -1,0 +1,225 @@
+// layer_api.cpp -- the layer entry points of libmemc_hip.so (host code only).
+//
+// Replaces my_package/src/my_lib_cuda.c:364-983 of the reference: read sizes/strides from the tensor
+// descriptors, validate, call the kernel launcher on the caller's stream, return 0 / -1.
+//
+// Checks: every check the reference performs (cited per function) is performed here.  In addition the
+// descriptors that the kernels index with ANOTHER tensor's strides (output / gradoutput / gradinput1 with
+// input1's, gradinput2 with input2's, gradinput3 with input3's, exactly as my_lib_kernel.cu does) must
+// really have those b/c/h strides, all w-strides must be 1 and all strides must fit the launcher ABI's
+// `int`; the reference leaves those cases unchecked and silently reads/writes the wrong cells.
+#include "memc_internal.h"
+
+#include <math.h>
+#include <stdint.h>
+
+namespace {
+
+constexpr int kErr = -1;
+
+inline bool fits_int(const memc_tensor4 *t)
+{
+    for (int i = 0; i < 4; i++)
+        if (t->size[i] < 0 || t->size[i] > INT32_MAX || t->stride[i] < 0 || t->stride[i] > INT32_MAX)
+            return false;
+    return true;
+}
+
+inline bool same_shape(const memc_tensor4 *a, const memc_tensor4 *b)
+{
+    return a->size[0] == b->size[0] && a->size[1] == b->size[1] && a->size[2] == b->size[2] &&
+           a->size[3] == b->size[3];
+}
+
+// same b/c/h strides (the kernels index `b` with `a`'s strides) and unit w stride
+inline bool same_layout(const memc_tensor4 *a, const memc_tensor4 *b)
+{
+    if (!same_shape(a, b)) return false;
+    for (int i = 0; i < 3; i++)                 // the stride of a size-1 dimension is never used
+        if (a->size[i] > 1 && a->stride[i] != b->stride[i]) return false;
+    return true;
+}
+
+inline int64_t numel(const memc_tensor4 *t) { return t->size[0] * t->size[1] * t->size[2] * t->size[3]; }
+
+// usable descriptor: sizes/strides fit the launcher ABI, unit w stride, non-null data unless empty
+inline bool ok(const memc_tensor4 *t)
+{
+    return t && fits_int(t) && (t->stride[3] == 1 || t->size[3] <= 1) && (t->data || numel(t) == 0);
+}
+
+inline int nelem(const memc_tensor4 *t) { return (int)numel(t); }   // ignored by the launchers
+
+#define S4(t) (int)(t)->stride[0], (int)(t)->stride[1], (int)(t)->stride[2], (int)(t)->stride[3]
+
+// flow tensor [N,2,H,W] matching input1 [N,C,H,W]; my_lib_cuda.c:375-381
+inline bool flow_matches(const memc_tensor4 *in1, const memc_tensor4 *flow)
+{
+    return flow->size[0] == in1->size[0] && flow->size[1] == 2 && flow->size[2] == in1->size[2] &&
+           flow->size[3] == in1->size[3];
+}
+
+int bilinear_forward(bool require_c3, memc_stream_t stream, const memc_tensor4 *input1,
+                     const memc_tensor4 *input2, const memc_tensor4 *output)
+{
+    if (!ok(input1) || !ok(input2) || !ok(output)) return kErr;
+    if (require_c3 && input1->size[1] != 3) return kErr;                       // my_lib_cuda.c:373
+    if (!flow_matches(input1, input2)) return kErr;                            // :375-381
+    if (!same_layout(input1, output)) return kErr;                             // :397-398 (+h, w)
+    return InterpolationLayer_gpu_forward_kernel(
+        stream, nelem(output), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
+        (int)input1->size[0], S4(input1), S4(input2), input1->data, input2->data, output->data);
+}
+
+int bilinear_backward(bool require_c3, memc_stream_t stream, const memc_tensor4 *input1,
+                      const memc_tensor4 *input2, const memc_tensor4 *gradoutput,
+                      const memc_tensor4 *gradinput1, const memc_tensor4 *gradinput2)
+{
+    if (!ok(input1) || !ok(input2) || !ok(gradoutput) || !ok(gradinput1) || !ok(gradinput2)) return kErr;
+    if (require_c3 && input1->size[1] != 3) return kErr;                       // my_lib_cuda.c:430
+    if (!flow_matches(input1, input2)) return kErr;                            // :432-438
+    if (!same_layout(input1, gradinput1) || !same_layout(input2, gradinput2)) return kErr;   // :455-458
+    if (!same_layout(input1, gradoutput)) return kErr;
+    return InterpolationLayer_gpu_backward_kernel(
+        stream, nelem(gradoutput), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
+        (int)input1->size[0], S4(input1), S4(input2), input1->data, input2->data, gradoutput->data,
+        gradinput1->data, gradinput2->data);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *memc_hip_version(void) { return "memc_hip 0.1 gfx950"; }
+
+int InterpolationLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
+                                   const memc_tensor4 *input2, const memc_tensor4 *output)
+{ return bilinear_forward(true, stream, input1, input2, output); }
+
+int InterpolationLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
+                                    const memc_tensor4 *input2, const memc_tensor4 *gradoutput,
+                                    const memc_tensor4 *gradinput1, const memc_tensor4 *gradinput2)
+{ return bilinear_backward(true, stream, input1, input2, gradoutput, gradinput1, gradinput2); }
+
+// The reference's Ch entry points call the InterpolationLayer_*_kernel launchers (my_lib_cuda.c:519,579).
+int InterpolationChLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
+                                     const memc_tensor4 *input2, const memc_tensor4 *output)
+{ return bilinear_forward(false, stream, input1, input2, output); }
+
+int InterpolationChLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
+                                      const memc_tensor4 *input2, const memc_tensor4 *gradoutput,
+                                      const memc_tensor4 *gradinput1, const memc_tensor4 *gradinput2)
+{ return bilinear_backward(false, stream, input1, input2, gradoutput, gradinput1, gradinput2); }
+
+int FilterInterpolationLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
+                                         const memc_tensor4 *input2, const memc_tensor4 *input3,
+                                         const memc_tensor4 *output)
+{
+    if (!ok(input1) || !ok(input2) || !ok(input3) || !ok(output)) return kErr;    // my_lib_cuda.c:641-643
+    if (!flow_matches(input1, input2)) return kErr;                                 // :611-617
+    if (input3->size[0] != input1->size[0] || input3->size[2] != input1->size[2] ||
+        input3->size[3] != input1->size[3])
+        return kErr;
+    const int filter_size = (int)sqrt((float)input3->size[1]);                      // :619-620
+    if (filter_size < 1) return kErr;
+    if (!same_layout(input1, output)) return kErr;                                  // :644-645 (+h)
+    return FilterInterpolationLayer_gpu_forward_kernel(
+        stream, nelem(output), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
+        (int)input1->size[0], filter_size, S4(input1), S4(input2), S4(input3), input1->data, input2->data,
+        input3->data, output->data);
+}
+
+int FilterInterpolationLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
+                                          const memc_tensor4 *input2, const memc_tensor4 *input3,
+                                          const memc_tensor4 *gradoutput, const memc_tensor4 *gradinput1,
+                                          const memc_tensor4 *gradinput2, const memc_tensor4 *gradinput3)
+{
+    if (!ok(input1) || !ok(input2) || !ok(input3) || !ok(gradoutput) || !ok(gradinput1) ||
+        !ok(gradinput2) || !ok(gradinput3))
+        return kErr;                                                                // :716-718
+    if (!flow_matches(input1, input2)) return kErr;                                 // :685-691
+    if (input3->size[0] != input1->size[0] || input3->size[2] != input1->size[2] ||
+        input3->size[3] != input1->size[3])
+        return kErr;
+    const int filter_size = (int)sqrt((float)input3->size[1]);                      // :693-694
+    if (filter_size < 1) return kErr;
+    if (!same_layout(input1, gradinput1) || !same_layout(input2, gradinput2) ||
+        !same_layout(input3, gradinput3))
+        return kErr;                                                                // :719-723
+    if (!same_layout(input1, gradoutput)) return kErr;
+    return FilterInterpolationLayer_gpu_backward_kernel(
+        stream, nelem(gradoutput), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
+        (int)input1->size[0], filter_size, S4(input1), S4(input2), S4(input3), input1->data, input2->data,
+        input3->data, gradoutput->data, gradinput1->data, gradinput2->data, gradinput3->data);
+}
+
+// count tensor [N,1,H,W] matching the flow tensor; my_lib_cuda.c:813-817
+static bool count_matches(const memc_tensor4 *flow, const memc_tensor4 *count)
+{
+    return count->size[0] == flow->size[0] && count->size[1] == 1 && count->size[2] == flow->size[2] &&
+           count->size[3] == flow->size[3];
+}
+
+int FlowProjectionLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
+                                    const memc_tensor4 *count, const memc_tensor4 *output, int fillhole)
+{
+    if (!ok(input1) || !ok(count) || !ok(output)) return kErr;
+    if (input1->size[1] != 2) return kErr;                                          // my_lib_cuda.c:762
+    if (!count_matches(input1, count)) return kErr;
+    if (!same_layout(input1, output)) return kErr;                                  // :781-782 (+h)
+    return FlowProjection_gpu_forward_kernel(
+        stream, nelem(output), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
+        (int)input1->size[0], fillhole, S4(input1), S4(count), input1->data, count->data, output->data);
+}
+
+int FlowProjectionLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
+                                     const memc_tensor4 *count, const memc_tensor4 *gradoutput,
+                                     const memc_tensor4 *gradinput1)
+{
+    if (!ok(input1) || !ok(count) || !ok(gradoutput) || !ok(gradinput1)) return kErr;
+    if (input1->size[1] != 2) return kErr;                                          // :811
+    if (!count_matches(input1, count)) return kErr;                                 // :813-817
+    if (!same_layout(input1, gradinput1)) return kErr;                              // :835-836
+    if (!same_layout(input1, gradoutput)) return kErr;
+    return FlowProjection_gpu_backward_kernel(
+        stream, nelem(gradoutput), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
+        (int)input1->size[0], S4(input1), S4(count), input1->data, count->data, gradoutput->data,
+        gradinput1->data);
+}
+
+int DepthFlowProjectionLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
+                                         const memc_tensor4 *input2, const memc_tensor4 *count,
+                                         const memc_tensor4 *output, int fillhole)
+{
+    if (!ok(input1) || !ok(input2) || !ok(count) || !ok(output)) return kErr;
+    if (input1->size[1] != 2) return kErr;                                          // :868
+    if (input2->size[1] != 1) return kErr;                                          // :870
+    if (!count_matches(input1, input2) || !count_matches(input1, count)) return kErr;
+    if (!same_layout(input1, output)) return kErr;                                  // :895-896 (+h)
+    return DepthFlowProjection_gpu_forward_kernel(
+        stream, nelem(output), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
+        (int)input1->size[0], fillhole, S4(input1), S4(input2), S4(count), input1->data, input2->data,
+        count->data, output->data);
+}
+
+int DepthFlowProjectionLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
+                                          const memc_tensor4 *input2, const memc_tensor4 *count,
+                                          const memc_tensor4 *output, const memc_tensor4 *gradoutput,
+                                          const memc_tensor4 *gradinput1, const memc_tensor4 *gradinput2)
+{
+    if (!ok(input1) || !ok(input2) || !ok(count) || !ok(output) || !ok(gradoutput) || !ok(gradinput1) ||
+        !ok(gradinput2))
+        return kErr;
+    if (input1->size[1] != 2) return kErr;                                          // :929
+    if (input2->size[1] != 1) return kErr;                                          // :933
+    if (!count_matches(input1, input2) || !count_matches(input1, count)) return kErr;   // :931-936
+    if (!same_layout(input1, gradinput1)) return kErr;                              // :959-960
+    if (!same_layout(input1, gradoutput) || !same_layout(input1, output)) return kErr;
+    if (!same_layout(input2, gradinput2)) return kErr;
+    return DepthFlowProjection_gpu_backward_kernel(
+        stream, nelem(gradoutput), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
+        (int)input1->size[0], S4(input1), S4(input2), S4(count), input1->data, input2->data, count->data,
+        output->data, gradoutput->data, gradinput1->data, gradinput2->data);
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// memc_common.hpp -- device-side helpers shared by the gfx950 kernels of libmemc_hip.so.
+//
+// Target: MI355X (gfx950, CDNA4) only: 64-lane wavefronts, 256 CUs in 8 XCDs (one L2 per XCD),
+// 160 KiB LDS per CU.  Everything here is HBM/L2-bound gather/scatter work; there is no MFMA.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace memc {
+
+constexpr int kWave = 64;      // wavefront width on CDNA
+constexpr int kXcds = 8;       // XCDs (private L2s) on MI355X
+
+__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
+
+// Workgroup b is dispatched to XCD b % 8 (observed placement, speed only).  Remap the linear
+// workgroup id so that every XCD owns one contiguous run of tiles: vertically adjacent tiles
+// (which share halo rows of the source image) then hit the same L2.  Bijective for any nwg.
+__device__ __forceinline__ unsigned xcd_chunked_id(unsigned bid, unsigned nwg)
+{
+    const unsigned q = nwg / kXcds, r = nwg % kXcds;
+    const unsigned xcd = bid % kXcds, idx = bid / kXcds;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// Streaming accesses: every filter-tap / flow / output element is touched exactly once per launch,
+// so keep it from displacing the (re-used) source-image lines in L1/L2.
+__device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
+
+// Hardware fp32 atomic add without return (global_atomic_add_f32); device (agent) scope.
+// Buffers are ordinary coarse-grained device allocations, for which the hardware atomic is exact.
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) { (void)unsafeAtomicAdd(p, v); }
+
+// One output site of the adaptive warp: validity test and window origin.
+// Restates my_lib_kernel.cu:1126-1138 (== my_lib.c:973-987).
+struct FiSite {
+    int ix, iy;       // (int)x2, (int)y2  (meaningful only when valid)
+    float a, b;       // alpha, beta
+    bool valid;
+};
+
+__device__ __forceinline__ FiSite fi_locate(int x, int y, int W, int H, float fx, float fy)
+{
+    FiSite s;
+    const float x2 = (float)x + fx, y2 = (float)y + fy;
+    s.valid = x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(W - 1) && y2 <= (float)(H - 1) &&
+              fabsf(fx) < (float)W / 2.0f && fabsf(fy) < (float)H / 2.0f;
+    s.ix = s.valid ? (int)x2 : 0;
+    s.iy = s.valid ? (int)y2 : 0;
+    s.a = x2 - (float)s.ix;
+    s.b = y2 - (float)s.iy;
+    return s;
+}
+
+// Projection / bilinear sites.  strict == false: x2 <= W-1 (FlowProjection, my_lib_kernel.cu:1670);
+// strict == true: x2 < W (Interpolation, my_lib_kernel.cu:543).
+struct BlSite {
+    int L, T, R, Bm;
+    float a, b;
+    bool valid;
+};
+
+template <bool STRICT>
+__device__ __forceinline__ BlSite bl_locate(int x, int y, int W, int H, float fx, float fy)
+{
+    BlSite s;
+    const float x2 = (float)x + fx, y2 = (float)y + fy;
+    if (STRICT)
+        s.valid = x2 >= 0.0f && y2 >= 0.0f && x2 < (float)W && y2 < (float)H;
+    else
+        s.valid = x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(W - 1) && y2 <= (float)(H - 1);
+    s.L = s.valid ? (int)x2 : 0;
+    s.T = s.valid ? (int)y2 : 0;
+    s.R = min(s.L + 1, W - 1);
+    s.Bm = min(s.T + 1, H - 1);
+    s.a = x2 - (float)s.L;
+    s.b = y2 - (float)s.T;
+    return s;
+}
+
+// Error-checked launch epilogue shared by the extern "C" launchers: the reference returns -1 after a
+// failed cudaGetLastError() (my_lib_kernel.cu:1559-1566).
+inline int launch_status()
+{
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace memc

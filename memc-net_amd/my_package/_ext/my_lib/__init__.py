@@ -1,0 +1,132 @@
+"""ctypes loader for libmemc_hip.so -- replaces the reference's cffi loader
+(my_package/_ext/my_lib/__init__.py:1-12, which wrapped every symbol of the compiled ``_my_lib`` so that torch
+tensors were unwrapped to TH tensor pointers).
+
+Every ``<Op>Layer_gpu_{forward,backward}`` symbol declared in include/memc_warp.h is exposed here under the
+reference's name and argument order.  Arguments are torch CUDA float32 tensors (plus the trailing ``fillhole``
+int where the reference has one); the return value is the C function's int (0 ok, -1 failed check).  Work is
+enqueued on the current HIP stream of the tensors' device, as the reference enqueues on
+``THCState_getCurrentStream`` (my_lib_cuda.c:403); nothing synchronises.
+
+The shared library is required: importing this module without it raises ImportError (no fallback).
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libmemc_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libmemc_hip.so not found at %s -- build it with `make -C %s` "
+        "(or `python -c 'import __graft_entry__ as g; g.build()'` at the repo root). "
+        "There is no CPU or PyTorch fallback for these operators."
+        % (LIB_PATH, os.path.join(_PKG_ROOT, "csrc")))
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+
+class _Tensor4(ctypes.Structure):
+    """memc_tensor4 of include/memc_warp.h"""
+    _fields_ = [("data", ctypes.c_void_p),
+                ("size", ctypes.c_int64 * 4),
+                ("stride", ctypes.c_int64 * 4)]
+
+
+_lib.memc_hip_version.restype = ctypes.c_char_p
+
+
+def version():
+    return _lib.memc_hip_version().decode()
+
+
+def _describe(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s: expected a torch.Tensor, got %s" % (name, type(t).__name__))
+    if not t.is_cuda:
+        raise TypeError("%s: expected a CUDA (HIP) tensor; these operators have no CPU path" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s: expected float32, got %s" % (name, t.dtype))
+    if t.dim() != 4:
+        raise TypeError("%s: expected a 4-D NCHW tensor, got %d-D" % (name, t.dim()))
+    d = _Tensor4()
+    d.data = t.data_ptr()
+    for i in range(4):
+        d.size[i] = t.size(i)
+        d.stride[i] = t.stride(i)
+    return d
+
+
+def _bind(symbol, n_tensors, trailing_int=False):
+    cfunc = getattr(_lib, symbol)
+    cfunc.restype = ctypes.c_int
+    cfunc.argtypes = ([ctypes.c_void_p] + [ctypes.POINTER(_Tensor4)] * n_tensors
+                      + ([ctypes.c_int] if trailing_int else []))
+
+    def call(*args):
+        if len(args) != n_tensors + (1 if trailing_int else 0):
+            raise TypeError("%s takes %d arguments (%d given)"
+                            % (symbol, n_tensors + (1 if trailing_int else 0), len(args)))
+        tensors = args[:n_tensors]
+        descs = [_describe(t, "%s arg %d" % (symbol, i)) for i, t in enumerate(tensors)]
+        dev = tensors[0].device
+        for t in tensors[1:]:
+            if t.device != dev:
+                raise TypeError("%s: all tensors must live on the same device" % symbol)
+        extra = [int(args[-1])] if trailing_int else []
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            return int(cfunc(stream, *[ctypes.byref(d) for d in descs], *extra))
+
+    call.__name__ = symbol
+    call.__doc__ = "ctypes binding of %s (include/memc_warp.h)" % symbol
+    return call
+
+
+# name -> (number of tensor arguments, has trailing int); order and names as in my_lib_cuda.h:37-117
+_SYMBOLS = {
+    "InterpolationLayer_gpu_forward": (3, False),
+    "InterpolationLayer_gpu_backward": (5, False),
+    "InterpolationChLayer_gpu_forward": (3, False),
+    "InterpolationChLayer_gpu_backward": (5, False),
+    "FilterInterpolationLayer_gpu_forward": (4, False),
+    "FilterInterpolationLayer_gpu_backward": (7, False),
+    "FlowProjectionLayer_gpu_forward": (3, True),
+    "FlowProjectionLayer_gpu_backward": (4, False),
+    "DepthFlowProjectionLayer_gpu_forward": (4, True),
+    "DepthFlowProjectionLayer_gpu_backward": (7, False),
+}
+
+__all__ = ["version", "LIB_PATH"]
+for _name, (_n, _flag) in _SYMBOLS.items():
+    globals()[_name] = _bind(_name, _n, _flag)
+    __all__.append(_name)
+
+
+def _cpu_unavailable(symbol):
+    def call(*args):
+        raise RuntimeError(
+            "%s: no CPU implementation is shipped (the reference's Python CPU branches are themselves "
+            "unrunnable, e.g. FilterInterpolationLayer.py:23,32); move the tensors to the GPU" % symbol)
+    call.__name__ = symbol
+    return call
+
+
+for _name in list(_SYMBOLS):
+    _cpu = _name.replace("_gpu_", "_cpu_")
+    globals()[_cpu] = _cpu_unavailable(_cpu)
+    __all__.append(_cpu)
+
+
+# measurement hooks (csrc/memc_internal.h); used by tools/bench_ops.py only
+_lib.memc_debug_set_fi_fwd_variant.argtypes = [ctypes.c_int]
+_lib.memc_debug_set_fi_fwd_variant.restype = None
+_lib.memc_debug_set_projection_variant.argtypes = [ctypes.c_int]
+_lib.memc_debug_set_projection_variant.restype = None
+
+
+def _debug_set_variant(op, variant):
+    {"fi_fwd": _lib.memc_debug_set_fi_fwd_variant,
+     "projection": _lib.memc_debug_set_projection_variant}[op](int(variant))

@@ -1,0 +1,55 @@
+"""FilterInterpolationLayer -- flow sample fused with the per-pixel 4x4 (fs x fs) adaptive filter.
+
+Mirrors my_package/functions/FilterInterpolationLayer.py of the reference: same class name, same call
+surface (`FilterInterpolationLayer()(input1, input2, input3)`), same zero-filled caller-allocated buffers,
+same gradients (gradinput1, gradinput2, gradinput3).  The reference is a legacy instance-style
+autograd.Function (rejected by torch >= 1.3); here the instance is a thin callable over a static Function.
+
+Differences, all deliberate:
+  * the reference hands the ORIGINAL (possibly non-contiguous) tensors to C while caching contiguous copies
+    (:14-16,29), so a non-contiguous input makes C return -1 and a zero tensor comes back silently;
+    here the contiguous copies are what the kernel sees;
+  * a non-zero return code raises instead of being ignored (:29) / printed (:56-57);
+  * CPU tensors raise (the reference's CPU branch dies with NameError).
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+import my_package._ext.my_lib as my_lib
+from ._common import check, f32c, require_gpu
+
+
+class _FilterInterpolationFunction(Function):
+    @staticmethod
+    def forward(ctx, input1, input2, input3):
+        require_gpu("FilterInterpolationLayer", input1, input2, input3)
+        input1, input2, input3 = f32c(input1), f32c(input2), f32c(input3)
+        output = torch.zeros_like(input1)                      # reference: .resize_(...).zero_() (:26)
+        err = my_lib.FilterInterpolationLayer_gpu_forward(input1, input2, input3, output)
+        check(err, "FilterInterpolationLayer_gpu_forward")
+        ctx.save_for_backward(input1, input2, input3)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gradoutput):
+        input1, input2, input3 = ctx.saved_tensors
+        gradoutput = f32c(gradoutput)
+        gradinput1 = torch.zeros_like(input1)                   # reference :46-48
+        gradinput2 = torch.zeros_like(input2)
+        gradinput3 = torch.zeros_like(input3)
+        err = my_lib.FilterInterpolationLayer_gpu_backward(
+            input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)
+        check(err, "FilterInterpolationLayer_gpu_backward")
+        return gradinput1, gradinput2, gradinput3
+
+
+class FilterInterpolationLayer(object):
+    def __init__(self):
+        super(FilterInterpolationLayer, self).__init__()
+
+    def __call__(self, input1, input2, input3):
+        return _FilterInterpolationFunction.apply(input1, input2, input3)
+
+    forward = __call__

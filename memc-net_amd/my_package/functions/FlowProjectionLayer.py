@@ -1,0 +1,49 @@
+"""FlowProjectionLayer -- forward-splat of -flow to the intermediate frame, count-normalised, optionally
+hole-filled.
+
+Mirrors my_package/functions/FlowProjectionLayer.py of the reference: `FlowProjectionLayer(requires_grad)`
+then `layer(input1)`; `fillhole = 1 if requires_grad == False else 0` (:15), so holes are filled only at
+inference; `count` is kept for backward (:37).  Deliberate differences as listed in
+FilterInterpolationLayer.py of this directory.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+import my_package._ext.my_lib as my_lib
+from ._common import check, f32c, require_gpu
+
+
+class _FlowProjectionFunction(Function):
+    @staticmethod
+    def forward(ctx, input1, fillhole):
+        require_gpu("FlowProjectionLayer", input1)
+        input1 = f32c(input1)
+        count = input1.new_zeros((input1.size(0), 1, input1.size(2), input1.size(3)))   # reference :27
+        output = torch.zeros_like(input1)                                               # reference :28
+        err = my_lib.FlowProjectionLayer_gpu_forward(input1, count, output, int(fillhole))
+        check(err, "FlowProjectionLayer_gpu_forward")
+        ctx.save_for_backward(input1, count)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gradoutput):
+        input1, count = ctx.saved_tensors
+        gradoutput = f32c(gradoutput)
+        gradinput1 = torch.zeros_like(input1)                                           # reference :54
+        err = my_lib.FlowProjectionLayer_gpu_backward(input1, count, gradoutput, gradinput1)
+        check(err, "FlowProjectionLayer_gpu_backward")
+        return gradinput1, None
+
+
+class FlowProjectionLayer(object):
+    def __init__(self, requires_grad):
+        super(FlowProjectionLayer, self).__init__()
+        self.requires_grad = requires_grad
+
+    def __call__(self, input1):
+        self.fillhole = 1 if self.requires_grad == False else 0    # noqa: E712 -- as the reference, :15
+        return _FlowProjectionFunction.apply(input1, self.fillhole)
+
+    forward = __call__
