@@ -20,8 +20,10 @@
  * (my_package/functions/FilterInterpolationLayer.py:26-29,46-48, FlowProjectionLayer.py:27-29,54).
  * Return value: 0 ok, -1 on a failed shape/stride check (my_lib.c:911-954 and siblings).
  *
- * Batch items are independent in every operator, so the outer batch loop may run under OpenMP; the
- * order of accumulation inside one batch item is the reference's sequential order.
+ * Batch items are independent in every operator, so the outer batch loop may run under OpenMP (the two
+ * forward gathers, whose output sites are all independent, also split over rows); the order of
+ * accumulation inside one batch item is the reference's sequential order, so results do not depend on
+ * the thread count.
  */
 #include <math.h>
 #include <stddef.h>
@@ -57,11 +59,12 @@ static int bilinear_forward(int require_c3, int B, int C, int H, int W,
     if (require_c3 && C != 3) return -1;                       /* my_lib.c:450 */
     if (s1[3] != 1 || s2[3] != 1) return -1;                    /* my_lib.c:474-475 */
     if (s1[0] != so[0] || s1[1] != so[1]) return -1;            /* my_lib.c:476-477 */
-#pragma omp parallel for schedule(static)
+    /* every output site is independent in the forward gather: rows may run in parallel */
+#pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; b++) {
-        const i64 off = b * s1[0];
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) {
+                const i64 off = b * s1[0];
                 float fx = flow[b * s2[0] + 0 * s2[1] + y * s2[2] + x];
                 float fy = flow[b * s2[0] + 1 * s2[1] + y * s2[2] + x];
                 float x2 = (float)x + fx, y2 = (float)y + fy;
@@ -210,11 +213,12 @@ int memc_oracle_filter_interpolation_forward(int B, int C, int H, int W, int fs2
     const int fs = (int)sqrt((float)fs2);                         /* my_lib.c:925 */
     if (s1[3] != 1 || s2[3] != 1 || s3[3] != 1) return -1;          /* :950-952 */
     if (s1[0] != so[0] || s1[1] != so[1]) return -1;                /* :953-954 */
-#pragma omp parallel for schedule(static)
+    /* every output site is independent in the forward gather: rows may run in parallel */
+#pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; b++) {
-        const i64 off = b * s1[0];
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) {
+                const i64 off = b * s1[0];
                 float fx = flow[b * s2[0] + 0 * s2[1] + y * s2[2] + x];
                 float fy = flow[b * s2[0] + 1 * s2[1] + y * s2[2] + x];
                 fi_site s;

@@ -1,0 +1,105 @@
+"""The C-ABI shared library: loads without a GPU, exports every symbol include/memc_warp.h declares, and its
+layer entry points reject malformed descriptors with -1 before touching the device.  CPU only -- no kernel is
+launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "memc_warp.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+char\s*\*\s*|int\s+)(\w+)\s*\(", text, flags=re.M)
+    assert len(names) == 21, names      # 10 layer entry points + 10 kernel launchers + memc_hip_version
+    return names
+
+
+class Tensor4(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("size", ctypes.c_int64 * 4), ("stride", ctypes.c_int64 * 4)]
+
+
+def desc(shape, data=0x1000, strides=None):
+    t = Tensor4()
+    t.data = data
+    n, c, h, w = shape
+    st = strides or (c * h * w, h * w, w, 1)
+    for i in range(4):
+        t.size[i] = shape[i]
+        t.stride[i] = st[i]
+    return t
+
+
+@pytest.fixture(scope="module")
+def lib(hip_lib_path):
+    return ctypes.CDLL(hip_lib_path)
+
+
+def test_exports_every_declared_symbol(lib):
+    for name in declared_symbols():
+        assert hasattr(lib, name), "libmemc_hip.so does not export %s" % name
+
+
+def test_reference_symbol_names_present():
+    # the names the reference's cffi loader binds (my_lib_cuda.h:37-117) and its launchers (my_lib_kernel.h:67-220)
+    want = set()
+    for op in ("InterpolationLayer", "InterpolationChLayer", "FilterInterpolationLayer"):
+        for d in ("forward", "backward"):
+            want.add("%s_gpu_%s" % (op, d))
+            want.add("%s_gpu_%s_kernel" % (op, d))
+    for op in ("FlowProjection", "DepthFlowProjection"):
+        for d in ("forward", "backward"):
+            want.add("%sLayer_gpu_%s" % (op, d))
+            want.add("%s_gpu_%s_kernel" % (op, d))
+    assert want <= set(declared_symbols())
+
+
+def test_version_string(lib):
+    lib.memc_hip_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.memc_hip_version()
+
+
+def test_layer_checks_reject_bad_descriptors(lib):
+    """Same rejections as my_lib_cuda.c (return -1), evaluated on the host before any launch."""
+    P = ctypes.byref
+    x = desc((2, 3, 8, 8)); flow = desc((2, 2, 8, 8)); filt = desc((2, 16, 8, 8)); out = desc((2, 3, 8, 8))
+    f = lib.FilterInterpolationLayer_gpu_forward
+    f.restype = ctypes.c_int
+    # flow with 3 channels (my_lib_cuda.c:612), wrong batch (:611), wrong height (:616)
+    assert f(None, P(x), P(desc((2, 3, 8, 8))), P(filt), P(out)) == -1
+    assert f(None, P(x), P(desc((1, 2, 8, 8))), P(filt), P(out)) == -1
+    assert f(None, P(x), P(desc((2, 2, 7, 8))), P(filt), P(out)) == -1
+    # w-stride != 1 (:641-643)
+    assert f(None, P(desc((2, 3, 8, 8), strides=(384, 128, 16, 2))), P(flow), P(filt), P(out)) == -1
+    # output batch/channel stride differs from input1's (:644-645)
+    assert f(None, P(x), P(flow), P(filt), P(desc((2, 3, 8, 8), strides=(400, 128, 8, 1)))) == -1
+    # strides beyond the launcher ABI's int
+    assert f(None, P(desc((2, 3, 8, 8), strides=(2 ** 33, 64, 8, 1))), P(flow), P(filt), P(out)) == -1
+
+    g = lib.InterpolationLayer_gpu_forward
+    g.restype = ctypes.c_int
+    assert g(None, P(desc((2, 5, 8, 8))), P(flow), P(desc((2, 5, 8, 8)))) == -1      # channel != 3 (:373)
+
+    p = lib.FlowProjectionLayer_gpu_forward
+    p.restype = ctypes.c_int
+    p.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(Tensor4)] * 3 + [ctypes.c_int]
+    assert p(None, P(desc((2, 3, 8, 8))), P(desc((2, 1, 8, 8))), P(desc((2, 3, 8, 8))), 0) == -1   # channel != 2 (:762)
+    assert p(None, P(flow), P(desc((2, 1, 8, 9))), P(desc((2, 2, 8, 8))), 0) == -1
+
+    d = lib.DepthFlowProjectionLayer_gpu_forward
+    d.restype = ctypes.c_int
+    d.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(Tensor4)] * 4 + [ctypes.c_int]
+    assert d(None, P(flow), P(desc((2, 2, 8, 8))), P(desc((2, 1, 8, 8))), P(desc((2, 2, 8, 8))), 0) == -1  # depth channels != 1 (:870)
+
+
+def test_empty_batch_is_a_no_op(lib):
+    """Zero-sized tensors: nothing to launch, return 0 (the reference would launch a zero-sized grid)."""
+    P = ctypes.byref
+    f = lib.FilterInterpolationLayer_gpu_forward
+    f.restype = ctypes.c_int
+    e = lambda c: desc((0, c, 8, 8), data=0)     # noqa: E731
+    assert f(None, P(e(3)), P(e(2)), P(e(16)), P(e(3))) == 0

@@ -1,0 +1,76 @@
+"""The N > 1 plumbing of bench.py (sharding plan, config broadcast, barrier-bracketed timing, max over
+ranks) exercised with world_size 2 on the gloo backend.  CPU only: the step function here is a stand-in that
+sleeps -- it checks the orchestration, not the kernels."""
+import os
+import socket
+import sys
+
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import time
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    assert bench.dist_env() == (rank, rank, world)
+    # rank 0's configuration wins
+    mine = {"batch": 32 if rank == 0 else 7, "height": 720, "width": 1280, "seed": 1234 + 100 * rank}
+    cfg = bench.broadcast_config(mine, world, dev)
+    plan = bench.shard_plan(rank, world, cfg["batch"], cfg["seed"])
+    calls = []
+
+    def step(i):
+        calls.append(i)
+        time.sleep(0.02 if rank == 0 else 0.05)          # rank 1 is the slow one
+    worst, local = bench.timed_steps(step, steps=4, warmup=2, world=world, device=dev)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, cfg, plan, calls, worst, local))
+
+
+def test_two_rank_orchestration():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, cfg0, plan0, calls0, worst0, local0), (r1, cfg1, plan1, calls1, worst1, local1) = res
+    assert cfg0 == cfg1 == {"batch": 32, "height": 720, "width": 1280, "seed": 1234}
+    # weak scaling over independent frame pairs: disjoint, contiguous, complete
+    assert (plan0["first_item"], plan0["items"]) == (0, 32) and (plan1["first_item"], plan1["items"]) == (32, 32)
+    assert plan0["global_batch"] == plan1["global_batch"] == 64
+    assert plan0["seed"] != plan1["seed"]
+    # warmup steps are untimed (None), then exactly K timed steps
+    assert calls0 == calls1 == [None, None, 0, 1, 2, 3]
+    # every rank reports the MAX over ranks, i.e. the slow rank's time
+    assert abs(worst0 - worst1) < 1e-9
+    assert worst0 >= max(local0, local1) - 1e-9 and worst0 >= 4 * 0.05
+
+
+def test_single_rank_plan():
+    sys.path.insert(0, ROOT)
+    import bench
+    plan = bench.shard_plan(0, 1, 32, 1234)
+    assert plan["global_batch"] == 32 and plan["items"] == 32 and plan["seed"] == 1234
+    assert bench.BYTES_PER_SITE["fi_fwd"](3, 4) == 96 and bench.BYTES_PER_SITE["fi_fwd"](64, 4) == 584

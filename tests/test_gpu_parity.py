@@ -1,0 +1,278 @@
+"""Parity of the HIP path (through the C ABI / the drop-in modules) with the CPU oracle.  GPU only.
+
+Tolerance: BASELINE.json's north_star states "within 1e-4 abs float tolerance"; every comparison below is
+`max |hip - oracle| <= 1e-4` (ATOL), plus a relative term RTOL = 1e-5 only where values are sums of many
+scattered contributions whose magnitude exceeds 10 (fp32 atomics add in a different order than the oracle's
+sequential loop).  Integer-valued results (FlowProjection's `count`) must match bit-for-bit.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tools import synth
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4
+RTOL = 1e-5
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test run without a GPU: the HIP path cannot be exercised (no fallback exists)")
+    return torch.device("cuda:0")
+
+
+def T(a, requires_grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    return t.requires_grad_(True) if requires_grad else t
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def close(got, want, what, rtol=0.0):
+    got = np.asarray(got); want = np.asarray(want)
+    assert got.shape == want.shape, what
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    bound = ATOL + rtol * np.abs(want)
+    worst = float((err - bound).max()) if err.size else 0.0
+    assert worst <= 0, "%s: max abs err %.3g (|want| up to %.3g)" % (what, float(err.max()), float(np.abs(want).max()))
+
+
+CASES = [
+    # (B, C, H, W, flow kind, sigma, seed)
+    (1, 3, 128, 128, "iid", 3.0, 0),       # BASELINE configs[0] shape
+    (2, 3, 37, 53, "iid", 6.0, 1),         # ragged: not a multiple of the 64x4 tile
+    (1, 3, 5, 3, "iid", 1.0, 2),           # smaller than one wavefront
+    (3, 1, 17, 70, "smooth", 4.0, 3),
+    (1, 64, 24, 40, "smooth", 4.0, 4),     # the context-feature warp (C = 64)
+    (2, 3, 64, 192, "smooth", 12.0, 5),    # large smooth motion
+    (1, 3, 40, 40, "iid", 30.0, 6),        # mostly out of range: passthrough / |f| < W/2 guard paths
+    (2, 5, 33, 65, "zero", None, 7),
+]
+IDS = ["%dx%dx%dx%d-%s" % c[:5] for c in CASES]
+
+
+def make(case):
+    B, C, H, W, kind, sigma, seed = case
+    rng = np.random.default_rng(seed)
+    return dict(x=synth.np_image(rng, B, C, H, W), flow=synth.np_flow(rng, B, H, W, kind, sigma),
+                filt=synth.np_filter(rng, B, H, W), gout=synth.np_image(rng, B, C, H, W),
+                depth=synth.np_depth(rng, B, H, W), gflow=rng.random((B, 2, H, W), dtype=np.float32))
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_filter_interpolation(oracle, case):
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    d = make(case)
+    x, f, k = T(d["x"], True), T(d["flow"], True), T(d["filt"], True)
+    out = FilterInterpolationModule()(x, f, k)
+    out.backward(T(d["gout"]))
+    close(N(out), oracle.filter_interpolation_forward(d["x"], d["flow"], d["filt"]), "forward")
+    g1, g2, g3 = oracle.filter_interpolation_backward(d["x"], d["flow"], d["filt"], d["gout"])
+    close(N(x.grad), g1, "gradinput1", RTOL)
+    close(N(f.grad), g2, "gradinput2", RTOL)
+    close(N(k.grad), g3, "gradinput3", RTOL)
+
+
+@pytest.mark.parametrize("fs", [2, 3, 6])
+def test_filter_interpolation_other_filter_sizes(oracle, fs):
+    """fs = (int)sqrt(channels of input3) (my_lib.c:925); 3 is odd: window [ix, ix+2]."""
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    rng = np.random.default_rng(20 + fs)
+    B, C, H, W = 2, 3, 21, 34
+    xn, fn = synth.np_image(rng, B, C, H, W), synth.np_flow(rng, B, H, W, "iid", 3.0)
+    kn, gn = synth.np_filter(rng, B, H, W, fs), synth.np_image(rng, B, C, H, W)
+    x, f, k = T(xn, True), T(fn, True), T(kn, True)
+    out = FilterInterpolationModule()(x, f, k)
+    out.backward(T(gn))
+    close(N(out), oracle.filter_interpolation_forward(xn, fn, kn), "forward fs=%d" % fs)
+    g1, g2, g3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+    close(N(x.grad), g1, "gradinput1", RTOL)
+    close(N(f.grad), g2, "gradinput2", RTOL)
+    close(N(k.grad), g3, "gradinput3", RTOL)
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_interpolation_ch(oracle, case):
+    from my_package.modules.InterpolationChModule import InterpolationChModule
+    d = make(case)
+    x, f = T(d["x"], True), T(d["flow"], True)
+    out = InterpolationChModule()(x, f)
+    out.backward(T(d["gout"]))
+    close(N(out), oracle.interpolation_ch_forward(d["x"], d["flow"]), "forward")
+    g1, g2 = oracle.interpolation_ch_backward(d["x"], d["flow"], d["gout"])
+    close(N(x.grad), g1, "gradinput1", RTOL)
+    close(N(f.grad), g2, "gradinput2", RTOL)
+
+
+def test_interpolation_three_channels_only(oracle):
+    from my_package.modules.InterpolationModule import InterpolationModule
+    d = make(CASES[1])
+    x, f = T(d["x"], True), T(d["flow"], True)
+    out = InterpolationModule()(x, f)
+    out.backward(T(d["gout"]))
+    close(N(out), oracle.interpolation_forward(d["x"], d["flow"]), "forward")
+    g1, g2 = oracle.interpolation_backward(d["x"], d["flow"], d["gout"])
+    close(N(x.grad), g1, "gradinput1", RTOL)
+    close(N(f.grad), g2, "gradinput2", RTOL)
+    with pytest.raises(RuntimeError):          # channel != 3 -> -1 (my_lib_cuda.c:373); we raise
+        InterpolationModule()(T(make(CASES[4])["x"]), T(make(CASES[4])["flow"]))
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_flow_projection(oracle, case):
+    from my_package.modules.FlowProjectionModule import FlowProjectionModule
+    import my_package._ext.my_lib as my_lib
+    d = make(case)
+    # inference: requires_grad False -> fillhole 1 (reference FlowProjectionLayer.py:15)
+    with torch.no_grad():
+        out1 = FlowProjectionModule(requires_grad=False)(T(d["flow"]))
+    want1, want_count = oracle.flow_projection_forward(d["flow"], 1)
+    close(N(out1), want1, "forward fillhole=1")
+    # training: fillhole 0, then backward
+    f = T(d["flow"], True)
+    out0 = FlowProjectionModule(requires_grad=True)(f)
+    out0.backward(T(d["gflow"]))
+    want0, _ = oracle.flow_projection_forward(d["flow"], 0)
+    close(N(out0), want0, "forward fillhole=0")
+    close(N(f.grad), oracle.flow_projection_backward(d["flow"], want_count, d["gflow"]), "gradinput1", RTOL)
+    # count is integer-valued: bit-exact
+    flow = T(d["flow"])
+    count = flow.new_zeros((flow.size(0), 1, flow.size(2), flow.size(3)))
+    out = torch.zeros_like(flow)
+    assert my_lib.FlowProjectionLayer_gpu_forward(flow, count, out, 0) == 0
+    assert np.array_equal(N(count), want_count)
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_depth_flow_projection(oracle, case):
+    from my_package.modules.DepthFlowProjectionModule import DepthFlowProjectionModule
+    d = make(case)
+    with torch.no_grad():
+        out1 = DepthFlowProjectionModule(requires_grad=False)(T(d["flow"]), T(d["depth"]))
+    want1, _ = oracle.depth_flow_projection_forward(d["flow"], d["depth"], 1)
+    close(N(out1), want1, "forward fillhole=1", RTOL)
+    f, dp = T(d["flow"], True), T(d["depth"], True)
+    out0 = DepthFlowProjectionModule(requires_grad=True)(f, dp)
+    out0.backward(T(d["gflow"]))
+    want0, wcount = oracle.depth_flow_projection_forward(d["flow"], d["depth"], 0)
+    close(N(out0), want0, "forward fillhole=0", RTOL)
+    g1, g2 = oracle.depth_flow_projection_backward(d["flow"], d["depth"], wcount, want0, d["gflow"])
+    # 1/count amplifies the rounding of tiny depth sums: relative bound
+    close(N(f.grad), g1, "gradinput1", 1e-4)
+    close(N(dp.grad), g2, "gradinput2", 1e-4)
+
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_against_committed_golden_vectors(path):
+    """Same comparison against the stored bytes (no oracle run involved)."""
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    from my_package.modules.FlowProjectionModule import FlowProjectionModule
+    g = np.load(path)
+    x, f, k = T(g["x"], True), T(g["flow"], True), T(g["filt"], True)
+    out = FilterInterpolationModule()(x, f, k)
+    close(N(out), g["fi_out"], "forward")
+    if "fi_g1" in g:
+        out.backward(T(g["gout"]))
+        close(N(x.grad), g["fi_g1"], "gradinput1", RTOL)
+        close(N(f.grad), g["fi_g2"], "gradinput2", RTOL)
+        close(N(k.grad), g["fi_g3"], "gradinput3", RTOL)
+    with torch.no_grad():
+        p = FlowProjectionModule(requires_grad=False)(T(g["flow"]))
+    close(N(p), g["fp_out1"], "projection fillhole=1")
+
+
+def test_non_contiguous_inputs_and_strided_descriptors(oracle):
+    """(a) the modules accept non-contiguous views (made contiguous on the host side);
+    (b) the C ABI honours b/c/h strides, as the reference kernels do (my_lib_kernel.cu:1123-1150)."""
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    import my_package._ext.my_lib as my_lib
+    rng = np.random.default_rng(9)
+    B, C, H, W = 2, 3, 20, 36
+    big = synth.np_image(rng, B, C + 2, H + 3, W)
+    xn = big[:, 1:1 + C, 2:2 + H, :]                              # b, c, h strided view, unit w stride
+    fn, kn = synth.np_flow(rng, B, H, W, "iid", 2.0), synth.np_filter(rng, B, H, W)
+    want = oracle.filter_interpolation_forward(np.ascontiguousarray(xn), fn, kn)
+    tbig = T(big)
+    xv = tbig[:, 1:1 + C, 2:2 + H, :]
+    assert not xv.is_contiguous()
+    close(N(FilterInterpolationModule()(xv, T(fn), T(kn))), want, "module on a view")
+    # strided descriptor straight through the ABI: output must share input1's b/c/h strides
+    obig = torch.zeros_like(tbig)
+    ov = obig[:, 1:1 + C, 2:2 + H, :]
+    assert my_lib.FilterInterpolationLayer_gpu_forward(xv, T(fn), T(kn), ov) == 0
+    close(N(ov), want, "strided descriptors")
+    assert float(obig[:, 0].abs().max()) == 0.0                   # nothing written outside the view
+    # mismatching output strides are rejected, not silently mis-written
+    assert my_lib.FilterInterpolationLayer_gpu_forward(xv, T(fn), T(kn), torch.zeros(B, C, H, W, device=dev())) == -1
+
+
+def test_backward_accumulates_into_caller_buffers(oracle):
+    """gradinput1/gradinput3 are `+=` targets in the reference (caller zero-fills them,
+    FilterInterpolationLayer.py:46-48): a pre-filled buffer must come back as prefill + gradient."""
+    import my_package._ext.my_lib as my_lib
+    d = make(CASES[1])
+    x, f, k, g = T(d["x"]), T(d["flow"]), T(d["filt"]), T(d["gout"])
+    g1 = torch.full_like(x, 0.5); g2 = torch.zeros_like(f); g3 = torch.full_like(k, 0.25)
+    assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+    w1, w2, w3 = oracle.filter_interpolation_backward(d["x"], d["flow"], d["filt"], d["gout"])
+    close(N(g1), w1 + 0.5, "gradinput1 += ", RTOL)
+    # gradinput3 accumulates only at valid sites (invalid sites are never touched)
+    valid = np.abs(w3).sum(axis=1, keepdims=True) > 0
+    close(N(g3), np.where(valid, w3 + 0.25, 0.25), "gradinput3 += ", RTOL)
+    close(N(g2), w2, "gradinput2 = ", RTOL)
+
+
+def test_streams_and_repeatability(oracle):
+    """Work is enqueued on the caller's current stream; two streams give the same answer."""
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    d = make(CASES[0])
+    x, f, k = T(d["x"]), T(d["flow"]), T(d["filt"])
+    a = FilterInterpolationModule()(x, f, k)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        b = FilterInterpolationModule()(x, f, k)
+    s.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)                                       # the forward gather is deterministic
+
+
+def test_full_size_properties():
+    """BASELINE sizes (720p, batch 8 here to bound host time) through size-independent properties:
+      * zero flow + one-hot tap 5 is the identity;
+      * linearity in the image: FI(a*x1 + x2) == a*FI(x1) + FI(x2) for the same flow/taps;
+      * FlowProjection: count sums to 4 * (number of valid source sites) and sum(out*count) == -4 * sum of
+        valid flows (checksum of checksums), holes are all filled when every row has a valid cell."""
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    import my_package._ext.my_lib as my_lib
+    B, C, H, W = 8, 3, 720, 1280
+    t = synth.torch_inputs(dev(), B, C, H, W, flow_kind="smooth", seed=99)
+    fi = FilterInterpolationModule()
+    onehot = torch.zeros_like(t["filt"]); onehot[:, 5] = 1
+    assert torch.equal(fi(t["x"], torch.zeros_like(t["flow"]), onehot), t["x"])
+    x2 = torch.rand_like(t["x"])
+    lhs = fi(2.5 * t["x"] + x2, t["flow"], t["filt"])
+    rhs = 2.5 * fi(t["x"], t["flow"], t["filt"]) + fi(x2, t["flow"], t["filt"])
+    assert float((lhs - rhs).abs().max()) <= ATOL
+    flow = t["flow"]
+    count = flow.new_zeros((B, 1, H, W)); out = torch.zeros_like(flow)
+    assert my_lib.FlowProjectionLayer_gpu_forward(flow, count, out, 0) == 0
+    xs = torch.arange(W, device=dev(), dtype=torch.float32).view(1, 1, W)
+    ys = torch.arange(H, device=dev(), dtype=torch.float32).view(1, H, 1)
+    x2f, y2f = xs + flow[:, 0], ys + flow[:, 1]
+    valid = (x2f >= 0) & (y2f >= 0) & (x2f <= W - 1) & (y2f <= H - 1)
+    assert float(count.sum(dtype=torch.float64)) == 4.0 * float(valid.sum())
+    for k in range(2):
+        got = float((out[:, k] * count[:, 0]).sum(dtype=torch.float64))
+        want = -4.0 * float((flow[:, k] * valid).sum(dtype=torch.float64))
+        assert abs(got - want) <= 1e-3 * max(1.0, abs(want))

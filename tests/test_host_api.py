@@ -1,0 +1,109 @@
+"""Host-side mirror of the reference operator API (my_package.modules / my_package.functions).  CPU only."""
+import inspect
+
+import pytest
+import torch
+
+
+def test_module_paths_and_signatures():
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    from my_package.modules.FlowProjectionModule import FlowProjectionModule
+    from my_package.modules.InterpolationModule import InterpolationModule
+    from my_package.modules.DepthFlowProjectionModule import DepthFlowProjectionModule
+    from my_package.modules.InterpolationChModule import InterpolationChModule
+    # constructor / forward signatures of the reference (my_package/modules/*.py)
+    assert list(inspect.signature(FilterInterpolationModule.forward).parameters) == ["self", "input1", "input2", "input3"]
+    assert list(inspect.signature(InterpolationModule.forward).parameters) == ["self", "input1", "input2"]
+    assert list(inspect.signature(FlowProjectionModule.forward).parameters) == ["self", "input1"]
+    sig = inspect.signature(FlowProjectionModule.__init__)
+    assert sig.parameters["requires_grad"].default is True
+    for cls in (FilterInterpolationModule, InterpolationModule, InterpolationChModule):
+        m = cls()
+        assert isinstance(m, torch.nn.Module) and hasattr(m, "f")
+    assert list(inspect.signature(DepthFlowProjectionModule.forward).parameters) == ["self", "input1", "input2"]
+
+
+def test_function_names_exist():
+    from my_package.functions.FilterInterpolationLayer import FilterInterpolationLayer
+    from my_package.functions.FlowProjectionLayer import FlowProjectionLayer
+    from my_package.functions.InterpolationLayer import InterpolationLayer
+    from my_package.functions.InterpolationChLayer import InterpolationChLayer
+    from my_package.functions.DepthFlowProjectionLayer import DepthFlowProjectionLayer
+    assert callable(FilterInterpolationLayer()) and callable(InterpolationLayer()) and callable(InterpolationChLayer())
+    assert callable(FlowProjectionLayer(True)) and callable(DepthFlowProjectionLayer(False))
+
+
+def test_fillhole_policy():
+    # fillhole = 1 if requires_grad == False else 0 (reference FlowProjectionLayer.py:15)
+    from my_package.functions import FlowProjectionLayer as mod
+    seen = []
+
+    class Spy:
+        @staticmethod
+        def apply(x, fillhole):
+            seen.append(fillhole)
+            return x
+    orig = mod._FlowProjectionFunction
+    mod._FlowProjectionFunction = Spy
+    try:
+        mod.FlowProjectionLayer(True)(torch.zeros(1, 2, 4, 4))
+        mod.FlowProjectionLayer(False)(torch.zeros(1, 2, 4, 4))
+    finally:
+        mod._FlowProjectionFunction = orig
+    assert seen == [0, 1]
+
+
+def test_cpu_tensors_raise_not_fallback():
+    """No CPU path and no silent fallback: CPU tensors must fail loudly."""
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    from my_package.modules.FlowProjectionModule import FlowProjectionModule
+    from my_package.modules.InterpolationModule import InterpolationModule
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FilterInterpolationModule()(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8), torch.zeros(1, 16, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        FlowProjectionModule(False)(torch.zeros(1, 2, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        InterpolationModule()(torch.zeros(1, 3, 8, 8), torch.zeros(1, 2, 8, 8))
+
+
+def test_loader_binds_reference_names_and_rejects_cpu():
+    import my_package._ext.my_lib as my_lib
+    for name in ("FilterInterpolationLayer_gpu_forward", "FilterInterpolationLayer_gpu_backward",
+                 "FlowProjectionLayer_gpu_forward", "FlowProjectionLayer_gpu_backward",
+                 "DepthFlowProjectionLayer_gpu_forward", "DepthFlowProjectionLayer_gpu_backward",
+                 "InterpolationLayer_gpu_forward", "InterpolationLayer_gpu_backward",
+                 "InterpolationChLayer_gpu_forward", "InterpolationChLayer_gpu_backward"):
+        assert callable(getattr(my_lib, name))
+    with pytest.raises(TypeError):
+        my_lib.InterpolationLayer_gpu_forward(torch.zeros(1, 3, 4, 4), torch.zeros(1, 2, 4, 4), torch.zeros(1, 3, 4, 4))
+    with pytest.raises(RuntimeError):
+        my_lib.InterpolationLayer_cpu_forward(torch.zeros(1, 3, 4, 4), torch.zeros(1, 2, 4, 4), torch.zeros(1, 3, 4, 4))
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    """Importing the loader without libmemc_hip.so must raise ImportError (no fallback)."""
+    import importlib.util
+    import os
+    import my_package._ext.my_lib as my_lib
+    src = my_lib.__file__
+    # re-import the same source from a relocated package root that has no lib/
+    fake_root = tmp_path / "pkg" / "my_package" / "_ext" / "my_lib"
+    fake_root.mkdir(parents=True)
+    target = fake_root / "__init__.py"
+    target.write_text(open(src).read())
+    spec = importlib.util.spec_from_file_location("relocated_my_lib", str(target))
+    mod = importlib.util.module_from_spec(spec)
+    with pytest.raises(ImportError, match="libmemc_hip.so not found"):
+        spec.loader.exec_module(mod)
+    assert os.path.exists(src)
+
+
+def test_product_path_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under memc-net_amd/ may reference it."""
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "memc-net_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), "%s mentions the oracle" % os.path.join(dirpath, f)

@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""tools/bench_ops.py -- per-operator / per-variant measurement on one MI355X (HIP events around each launch).
+
+Not the headline bench (that is bench.py); this is the A/B harness used while tuning and the source of the
+secondary rows in DESIGN.md: every operator of the hot path at the BASELINE.json config sizes, with the
+achieved ALGORITHMIC bandwidth (bytes each tensor touched once / median launch time) against the 8 TB/s HBM
+peak.  Variants of one kernel are interleaved in one process (round-robin rounds) so their ratio is reliable.
+
+    python tools/bench_ops.py [--quick] [--only fi_fwd,proj] [--json gpurun_out/bench_ops.json]
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "memc-net_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+import my_package._ext.my_lib as L  # noqa: E402
+from tools import synth  # noqa: E402
+
+PEAK = 8.0e12
+
+
+def time_launches(fn, pre=None, warmup=3, iters=15):
+    """median / min launch time in seconds; `pre` (e.g. zero-filling outputs) runs outside the timed span."""
+    for _ in range(warmup):
+        if pre:
+            pre()
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        if pre:
+            pre()
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3)
+    return statistics.median(ts), min(ts)
+
+
+def report(rows, name, sites, bytes_per_site, med, mn, extra=None):
+    alg = sites * bytes_per_site
+    row = {"op": name, "sites": sites, "bytes_per_site": bytes_per_site, "median_us": round(med * 1e6, 1),
+           "min_us": round(mn * 1e6, 1), "mpix_s": round(sites / med / 1e6, 1),
+           "alg_GBps": round(alg / med / 1e9, 1), "hbm_frac": round(alg / med / PEAK, 4)}
+    if extra:
+        row.update(extra)
+    rows.append(row)
+    print("%-58s %9.1f us  %10.1f Mpix/s  %8.1f GB/s  %5.1f%% of 8 TB/s" %
+          (name, row["median_us"], row["mpix_s"], row["alg_GBps"], 100 * row["hbm_frac"]), flush=True)
+
+
+def bench_fi_fwd(rows, dev, B, C, H, W, flow_kind, variants, tag):
+    t = synth.torch_inputs(dev, B, C, H, W, flow_kind=flow_kind)
+    x, f, k = t["x"], t["flow"], t["filt"]
+    out = torch.zeros_like(x)
+    ref = None
+    for v in variants:
+        L._debug_set_variant("fi_fwd", v)
+        med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_forward(x, f, k, out))
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = out.clone()
+            same = True
+        else:
+            same = bool((out - ref).abs().max().item() <= 1e-5)
+        report(rows, "fi_fwd %s C=%d %dx%dx%d flow=%s variant=%d" % (tag, C, B, H, W, flow_kind, v),
+               B * H * W, 4 * (2 * C + 2 + 16), med, mn, {"variant": v, "matches_first_variant": same})
+    L._debug_set_variant("fi_fwd", -1)
+
+
+def bench_fi_bwd(rows, dev, B, C, H, W, flow_kind, tag):
+    t = synth.torch_inputs(dev, B, C, H, W, flow_kind=flow_kind, with_grad=True)
+    x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
+    g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
+
+    def pre():
+        g1.zero_(); g2.zero_(); g3.zero_()
+    med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre)
+    report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s" % (tag, C, B, H, W, flow_kind), B * H * W,
+           4 * (3 * C + 2 * (2 + 16)), med, mn)
+
+
+def bench_projection(rows, dev, B, H, W, flow_kind, tag):
+    t = synth.torch_inputs(dev, B, 3, H, W, flow_kind=flow_kind, with_depth=True)
+    f, d = t["flow"], t["depth"]
+    cnt = f.new_zeros((B, 1, H, W))
+    out = torch.zeros_like(f)
+    gout = torch.rand_like(f)
+    gin = torch.zeros_like(f)
+    gd = torch.zeros_like(d)
+
+    def pre():
+        cnt.zero_(); out.zero_()
+    for fh in (0, 1):
+        med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, fh), pre)
+        report(rows, "flow_projection_fwd %s %dx%dx%d flow=%s fillhole=%d" % (tag, B, H, W, flow_kind, fh),
+               B * H * W, 20, med, mn)
+    med, mn = time_launches(lambda: L.DepthFlowProjectionLayer_gpu_forward(f, d, cnt, out, 1), pre)
+    report(rows, "depth_flow_projection_fwd %s %dx%dx%d flow=%s fillhole=1" % (tag, B, H, W, flow_kind),
+           B * H * W, 24, med, mn)
+    pre(); L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0)
+    med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_backward(f, cnt, gout, gin), lambda: gin.zero_())
+    report(rows, "flow_projection_bwd %s %dx%dx%d flow=%s" % (tag, B, H, W, flow_kind), B * H * W, 28, med, mn)
+    pre(); L.DepthFlowProjectionLayer_gpu_forward(f, d, cnt, out, 0)
+
+    def pre2():
+        gin.zero_(); gd.zero_()
+    med, mn = time_launches(lambda: L.DepthFlowProjectionLayer_gpu_backward(f, d, cnt, out, gout, gin, gd), pre2)
+    report(rows, "depth_flow_projection_bwd %s %dx%dx%d flow=%s" % (tag, B, H, W, flow_kind), B * H * W, 48, med, mn)
+
+
+def bench_interp(rows, dev, B, C, H, W, flow_kind, tag):
+    t = synth.torch_inputs(dev, B, C, H, W, flow_kind=flow_kind, with_grad=True)
+    x, f, g = t["x"], t["flow"], t["gout"]
+    out = torch.zeros_like(x)
+    med, mn = time_launches(lambda: L.InterpolationChLayer_gpu_forward(x, f, out))
+    report(rows, "interpolation_fwd %s C=%d %dx%dx%d flow=%s" % (tag, C, B, H, W, flow_kind), B * H * W,
+           4 * (2 * C + 2), med, mn)
+    g1, g2 = torch.zeros_like(x), torch.zeros_like(f)
+
+    def pre():
+        g1.zero_(); g2.zero_()
+    med, mn = time_launches(lambda: L.InterpolationChLayer_gpu_backward(x, f, g, g1, g2), pre)
+    report(rows, "interpolation_bwd %s C=%d %dx%dx%d flow=%s" % (tag, C, B, H, W, flow_kind), B * H * W,
+           4 * (3 * C + 4), med, mn)
+
+
+def bench_copy(rows, dev):
+    """calibration: a plain device copy of the same byte volume as the headline launch"""
+    n = 2831155200 // 8
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    med, mn = time_launches(lambda: b.copy_(a))
+    report(rows, "calibration: torch copy_ 1.42 GB read + 1.42 GB write", n, 8, med, mn)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "bench_ops.json"))
+    ap.add_argument("--variants", default="1,0,2,3")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    only = set(filter(None, args.only.split(",")))
+    variants = [int(v) for v in args.variants.split(",")]
+    rows = []
+
+    def want(k):
+        return not only or k in only
+    print(L.version(), torch.cuda.get_device_name(0), flush=True)
+    if want("copy"):
+        bench_copy(rows, dev)
+    if want("fi_fwd"):
+        bench_fi_fwd(rows, dev, 32, 3, 720, 1280, "smooth", variants, "c_headline")
+        bench_fi_fwd(rows, dev, 32, 3, 720, 1280, "iid", variants[:1], "c_headline")
+        bench_fi_fwd(rows, dev, 8, 3, 256, 448, "smooth", variants[:1], "c2")
+        if not args.quick:
+            bench_fi_fwd(rows, dev, 8, 64, 720, 1280, "smooth", variants[:1], "ctx64")
+            bench_fi_fwd(rows, dev, 8, 3, 2160, 3840, "smooth", variants[:1], "c5_4k")
+    if want("fi_bwd"):
+        bench_fi_bwd(rows, dev, 8, 3, 256, 448, "smooth", "c2")
+        if not args.quick:
+            bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "smooth", "720p")
+    if want("proj"):
+        bench_projection(rows, dev, 32, 720, 1280, "smooth", "c3")
+        if not args.quick:
+            bench_projection(rows, dev, 32, 720, 1280, "iid", "c3")
+    if want("interp"):
+        bench_interp(rows, dev, 32, 3, 720, 1280, "smooth", "720p")
+    os.makedirs(os.path.dirname(args.json), exist_ok=True)
+    json.dump({"device": torch.cuda.get_device_name(0), "lib": L.version(), "rows": rows}, open(args.json, "w"),
+              indent=1)
+    print("wrote", args.json)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""Synthetic inputs of the adaptive-warp / flow-projection operators.
+
+numpy generators (seeded, CPU -- used by the parity tests so that the oracle and the HIP path see the very
+same bytes) and torch generators (seeded, on-device -- used by bench.py at the full benchmark sizes, where a
+host-side 2.8 GB batch would only measure PCIe).
+
+  image   x    ~ U[0,1)
+  flow    smooth: bilinear x16 upsample of N(0, 4^2) low-resolution noise (|f| mostly < 12 px -- what a flow
+               field looks like after FlowProjection); iid: N(0, sigma^2) per pixel (defeats any tiling)
+  filter  k    ~ U[0,1) / fs^2   (taps sum to about 1/2: outputs stay O(1))
+  depth   d    ~ U[0.1, 1.1)
+  grad    g    ~ U[0,1)
+"""
+import numpy as np
+
+
+def np_image(rng, B, C, H, W):
+    return rng.random((B, C, H, W), dtype=np.float32)
+
+
+def np_filter(rng, B, H, W, fs=4, scale=None):
+    k = rng.random((B, fs * fs, H, W), dtype=np.float32)
+    return k if scale is None else (k * np.float32(scale)).astype(np.float32)
+
+
+def np_depth(rng, B, H, W):
+    return (rng.random((B, 1, H, W), dtype=np.float32) + np.float32(0.1)).astype(np.float32)
+
+
+def _upsample_bilinear(lo, H, W):
+    """[B,2,h,w] -> [B,2,H,W], align_corners=True style bilinear resampling (pure numpy)."""
+    B, C, h, w = lo.shape
+    ys = np.linspace(0, h - 1, H, dtype=np.float64)
+    xs = np.linspace(0, w - 1, W, dtype=np.float64)
+    y0 = np.floor(ys).astype(int); y1 = np.minimum(y0 + 1, h - 1); wy = (ys - y0)[None, None, :, None]
+    x0 = np.floor(xs).astype(int); x1 = np.minimum(x0 + 1, w - 1); wx = (xs - x0)[None, None, None, :]
+    a = lo[:, :, y0][:, :, :, x0] * (1 - wx) + lo[:, :, y0][:, :, :, x1] * wx
+    b = lo[:, :, y1][:, :, :, x0] * (1 - wx) + lo[:, :, y1][:, :, :, x1] * wx
+    return (a * (1 - wy) + b * wy).astype(np.float32)
+
+
+def np_flow(rng, B, H, W, kind="smooth", sigma=None):
+    if kind == "smooth":
+        s = 4.0 if sigma is None else sigma
+        h, w = max(2, (H + 15) // 16 + 1), max(2, (W + 15) // 16 + 1)
+        lo = rng.normal(0.0, s, (B, 2, h, w))
+        return _upsample_bilinear(lo, H, W)
+    if kind == "iid":
+        s = 3.0 if sigma is None else sigma
+        return rng.normal(0.0, s, (B, 2, H, W)).astype(np.float32)
+    if kind == "zero":
+        return np.zeros((B, 2, H, W), np.float32)
+    raise ValueError(kind)
+
+
+# ------------------------------------------------------------------------------------------- torch (device)
+def torch_inputs(device, B, C, H, W, fs=4, flow_kind="smooth", seed=1234, with_grad=False, with_depth=False):
+    """Device-side generation for bench.py: dict with x, flow, filt (+ gout, depth)."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = {}
+    out["x"] = torch.rand((B, C, H, W), device=device, generator=g, dtype=torch.float32)
+    if flow_kind == "smooth":
+        h, w = (H + 15) // 16 + 1, (W + 15) // 16 + 1
+        lo = torch.randn((B, 2, h, w), device=device, generator=g, dtype=torch.float32) * 4.0
+        out["flow"] = F.interpolate(lo, size=(H, W), mode="bilinear", align_corners=True).contiguous()
+    elif flow_kind == "iid":
+        out["flow"] = torch.randn((B, 2, H, W), device=device, generator=g, dtype=torch.float32) * 3.0
+    else:
+        raise ValueError(flow_kind)
+    out["filt"] = torch.rand((B, fs * fs, H, W), device=device, generator=g, dtype=torch.float32) / (fs * fs)
+    if with_grad:
+        out["gout"] = torch.rand((B, C, H, W), device=device, generator=g, dtype=torch.float32)
+    if with_depth:
+        out["depth"] = torch.rand((B, 1, H, W), device=device, generator=g, dtype=torch.float32) + 0.1
+    return out
