@@ -16,8 +16,367 @@
 //   * 64-bit batch/channel offsets (4K x batch 8 x 64 channels exceeds 2^31 elements), 32-bit in-plane.
 #include "memc_common.hpp"
 #include "memc_internal.h"
+#include "memc_tile.hpp"
+
+#include <stdlib.h>
 
 namespace memc {
+
+// --------------------------------------------------------------------------------------------------
+// Forward, fs == 4, LDS-tiled and fully vectorised -- the production kernel.
+//
+//   workgroup = 256 lanes = a (4*LX) x (256/LX) tile of output sites; one lane = 4 consecutive sites of a row.
+//   1. flow (2 x dwordx4) and the 16 tap planes (16 x dwordx4) of the lane's sites are requested up front
+//      (non-temporal: single-use streams);
+//   2. the tile's source bounding box under its own flow is reduced across the workgroup (memc_tile.hpp) and
+//      staged into LDS as pixel quads, 4 channels at a time (3 real + 1 zero for RGB);
+//   3. per site: 16 ds_read_b128 (all channels of a tap at once), quadrant sums in the reference's order, blend;
+//      sites outside the staged box gather from global instead; invalid sites copy the input pixel;
+//   4. one dwordx4 store per channel (non-temporal).
+//   C > 4 loops steps 2-4 over chunks of four channels with the taps and site geometry kept in registers.
+// --------------------------------------------------------------------------------------------------
+struct FiSite4 {          // geometry of a lane's four sites
+    int ix[4], iy[4];
+    float a[4], b[4];
+    unsigned valid;       // bit j
+};
+
+// Scalar evaluation of ONE site for channels [0, nch) of `plane0`, everything read from global memory
+// (flow, taps, image): the rare path for sites whose source window is not in the staged LDS region, and the
+// body of the any-filter-size kernel.  Same arithmetic order as the fast path.
+__device__ __forceinline__ float fi_quad_sum(const float *p, int s1h, int W, int H, const float *tap_p,
+                                             int64_t s3c, int fs, int L, int T, int j0, int j1, int i0, int i1)
+{
+    float acc = 0.0f;
+    for (int j = j0; j <= j1; j++) {
+        const int jj = clampi(j, H - 1) * s1h;
+        for (int i = i0; i <= i1; i++)
+            acc += p[jj + clampi(i, W - 1)] * tap_p[((j - T) * fs + (i - L)) * s3c];
+    }
+    return acc;
+}
+
+__device__ __noinline__ void fi_site_scalar(int x, int y, int W, int H, int nch, int fs,
+                                            const float *plane0, int64_t s1c, int s1h,
+                                            const float *flow_p, int64_t s2c, const float *tap_p, int64_t s3c,
+                                            float *out_p)
+{
+    const float fx = flow_p[0], fy = flow_p[s2c];
+    const FiSite s = fi_locate(x, y, W, H, fx, fy);
+    if (s.valid) {
+        const int L = s.ix + 1 - fs / 2, T = s.iy + 1 - fs / 2, R = L + fs, Bm = T + fs;
+        for (int c = 0; c < nch; c++) {
+            const float *p = plane0 + c * s1c;
+            const float TL = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, T, s.iy, L, s.ix);
+            const float TR = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, T, s.iy, s.ix + 1, R - 1);
+            const float BL = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, s.iy + 1, Bm - 1, L, s.ix);
+            const float BR = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, s.iy + 1, Bm - 1, s.ix + 1, R - 1);
+            out_p[c * s1c] = (1 - s.a) * (1 - s.b) * TL + s.a * (1 - s.b) * TR +
+                             (1 - s.a) * s.b * BL + s.a * s.b * BR;
+        }
+    } else {
+        const float *p = plane0 + (int64_t)y * s1h + x;
+        for (int c = 0; c < nch; c++) out_p[c * s1c] = p[c * s1c];
+    }
+}
+
+// one chunk of NCH (1..4) channels: stage -> gather -> store.  Everything indexed by channel or site is
+// compile-time unrolled (run-time indexed vectors would live in scratch) and the hot path is branch-free:
+// a site whose window is not staged still issues its 16 LDS reads (at pixel 0, harmless) and is redone
+// afterwards by fi_site_scalar (at the end of the kernel, once for all channels).
+__device__ __forceinline__ float a_dummy(int v) { return __int_as_float(v); }   // ablation arm only
+
+template <int LX, int NCH, int ABL = 0>
+__device__ __forceinline__ void fi_gather_store(
+    const Region &r, const FiSite4 &g, const f32x4 (&tp)[16], bool inb, int x, int y, int W, int H,
+    const float *__restrict__ plane0, float *__restrict__ out_p, int64_t s1c, int s1h, const f32x4 *tile)
+{
+    using G = TileGeom<LX>;
+    if (!inb) return;
+    f32x4 res[4];                                          // res[j][c]: site j, channel c
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int ro[4], co[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ro[k] = clampi(g.iy[j] - 1 + k, H - 1);
+            co[k] = clampi(g.ix[j] - 1 + k, W - 1);
+        }
+        const bool valid = (g.valid >> j) & 1;
+        const bool staged = valid && r.covers(co[0], co[3], ro[0], ro[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ro[k] = staged ? (ro[k] - r.y0) * G::kPitch : 0;
+            co[k] = staged ? swz_col(co[k] - r.x0) : 0;
+        }
+        // quadrant sums, row-major inside each quadrant as in the reference (rows 0,1 top; 2,3 bottom)
+        f32x4 TL = {0.f, 0.f, 0.f, 0.f}, TR = TL, BL = TL, BR = TL;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            f32x4 v[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) v[m] = ABL == 2 ? f32x4{a_dummy(ro[k]), a_dummy(co[m]), 0.f, 0.f} : tile[ro[k] + co[m]];
+            if (k < 2) {
+                TL += v[0] * tp[k * 4 + 0][j];  TL += v[1] * tp[k * 4 + 1][j];
+                TR += v[2] * tp[k * 4 + 2][j];  TR += v[3] * tp[k * 4 + 3][j];
+            } else {
+                BL += v[0] * tp[k * 4 + 0][j];  BL += v[1] * tp[k * 4 + 1][j];
+                BR += v[2] * tp[k * 4 + 2][j];  BR += v[3] * tp[k * 4 + 3][j];
+            }
+        }
+        const float a = g.a[j], bt = g.b[j];
+        res[j] = ((1 - a) * (1 - bt)) * TL + (a * (1 - bt)) * TR + ((1 - a) * bt) * BL + (a * bt) * BR;
+    }
+    if (g.valid != 0xFu) {                                 // out-of-range sites copy the input pixel
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const f32x4 own = ld_cached4(plane0 + c * s1c + (int64_t)y * s1h + x);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (!((g.valid >> j) & 1)) res[j][c] = own[j];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+        st_stream4(out_p + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
+}
+
+template <int LX, int NCH, int ABL = 0>
+__device__ __forceinline__ void fi_fwd_chunk(
+    const Region &r, const FiSite4 &g, const f32x4 (&tp)[16], bool inb, int x, int y, int W, int H,
+    const float *__restrict__ plane0, float *__restrict__ out_p, int64_t s1c, int s1h, f32x4 *tile)
+{
+    if (ABL != 3) tile_stage<LX, NCH>(r, plane0, s1c, s1h, tile);
+    __syncthreads();
+    fi_gather_store<LX, NCH, ABL>(r, g, tp, inb, x, y, W, H, plane0, out_p, s1c, s1h, tile);
+}
+
+// --------------------------------------------------------------------------------------------------
+// Forward, fs == 4, RGB: PERSISTENT variant of the tiled kernel.  One workgroup walks many tiles and
+// requests the NEXT tile's flow while it works on the current one, so that a tile's source box is known
+// the moment the workgroup gets to it and the staging loads, the 16 tap planes and the next flow all go
+// out together: one exposed memory latency per tile instead of two (flow -> box -> staging).
+// Workgroup b is observed on XCD b % 8; it takes every (blocks-per-XCD)-th tile of that XCD's contiguous
+// chunk, so the tiles in flight on one XCD are neighbours and share halo rows in its L2 (measured:
+// FETCH_SIZE equals the algorithmic read bytes with this order, 1.3x with blockIdx order).
+// --------------------------------------------------------------------------------------------------
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void fi_fwd_persist_c3(
+    int W, int H, int tiles_x, int tiles_y, unsigned ntiles,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
+    const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
+    float *__restrict__ out)
+{
+    constexpr int LX = 16;
+    using G = TileGeom<LX>;
+    static_assert(G::kRows <= 32, "staging below keeps at most 4 rows per lane in registers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+
+    // this workgroup's tile sequence: t0, t0 + step, ... inside its XCD's chunk [cbeg, cend)
+    const unsigned xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds;
+    const unsigned step = gridDim.x / kXcds + (xcd < gridDim.x % kXcds ? 1u : 0u);
+    const unsigned q = ntiles / kXcds, rem = ntiles % kXcds;
+    const unsigned cbeg = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    const unsigned cend = cbeg + q + (xcd < rem ? 1u : 0u);
+    unsigned t = cbeg + slot;
+    if (t >= cend) return;
+
+    const int lx4 = 4 * (threadIdx.x % LX), ly = threadIdx.x / LX;
+    const unsigned per_img = (unsigned)tiles_x * tiles_y;
+    int b = t / per_img, tile_x0 = (t % per_img % tiles_x) * G::kTW, tile_y0 = (t % per_img / tiles_x) * G::kTH;
+    int x = tile_x0 + lx4, y = tile_y0 + ly;
+    bool inb = x < W && y < H;
+    // all loads are unconditional at clamped addresses (see fi_fwd_tiled_fs4)
+    const float *fp0 = flow + b * s2b + (int64_t)min(y, H - 1) * s2h + min(x, W - 4);
+    f32x4 fx4 = ld_stream4(fp0), fy4 = ld_stream4(fp0 + s2c);
+    for (;;) {
+        // site geometry, source box (one barrier; it also fences the previous tile's LDS gathers)
+        FiSite4 g;
+        g.valid = 0;
+        int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
+            g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
+            if (inb && s.valid) {
+                g.valid |= 1u << j;
+                cmin = min(cmin, max(s.ix - 1, 0));  cmax = max(cmax, min(s.ix + 2, W - 1));
+                rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
+            }
+        }
+        const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+        unsigned slow = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (((g.valid >> j) & 1) &&
+                !r.covers(max(g.ix[j] - 1, 0), min(g.ix[j] + 2, W - 1), max(g.iy[j] - 1, 0), min(g.iy[j] + 2, H - 1)))
+                slow |= 1u << j;
+
+        // all of this tile's loads go out back to back: staging (to registers), taps, next tile's flow
+        const float *in_b = in1 + b * s1b;
+        const int sq = threadIdx.x & 31, srow0 = threadIdx.x >> 5;
+        const bool sact = 4 * sq < r.w;
+        const float *src = in_b + (int64_t)r.y0 * s1h + r.x0 + 4 * sq;
+        f32x4 sv[4][3];
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int row = srow0 + 8 * it;
+            const float *p = (sact && row < r.h) ? src + (int64_t)row * s1h : in_b;
+#pragma unroll
+            for (int c = 0; c < 3; c++) sv[it][c] = ld_cached4(p + c * s1c);
+        }
+        const int xs = min(x, W - 4), ys = min(y, H - 1);
+        const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
+        const float *tap_p = filt + b * s3b + (int64_t)ys * s3h + xs;
+        f32x4 tp[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) tp[k] = ld_stream4(tap_p + k * s3c);
+        float *out_p = out + b * s1b + (int64_t)y * s1h + x;
+        const int cur_x = x, cur_y = y;
+        const bool cur_inb = inb;
+
+        // next tile (the last iteration re-reads its own flow: harmless, keeps the load unconditional)
+        const unsigned tn = t + step;
+        const unsigned tl = tn < cend ? tn : t;
+        b = tl / per_img;
+        tile_x0 = (tl % per_img % tiles_x) * G::kTW;
+        tile_y0 = (tl % per_img / tiles_x) * G::kTH;
+        x = tile_x0 + lx4;
+        y = tile_y0 + ly;
+        inb = x < W && y < H;
+        const float *fpn = flow + b * s2b + (int64_t)min(y, H - 1) * s2h + min(x, W - 4);
+        const f32x4 nfx = ld_stream4(fpn), nfy = ld_stream4(fpn + s2c);
+
+        // staged rows -> LDS pixel quads
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int row = srow0 + 8 * it;
+            if (sact && row < r.h) {
+                f32x4 *dst = tile + row * G::kPitch;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    dst[swz_col(4 * sq + i)] = f32x4{sv[it][0][i], sv[it][1][i], sv[it][2][i], 0.f};
+            }
+        }
+        __syncthreads();
+        fi_gather_store<LX, 3>(r, g, tp, cur_inb, cur_x, cur_y, W, H, in_b, out_p, s1c, s1h, tile);
+        while (slow) {                        // rare: windows outside the staged region, redone from global
+            const int j = __ffs(slow) - 1;
+            slow &= slow - 1;
+            fi_site_scalar(cur_x + j, cur_y, W, H, 3, 4, in_b, s1c, s1h, flow_p + j, s2c, tap_p + j, s3c, out_p + j);
+        }
+        if (tn >= cend) break;
+        t = tn;
+        fx4 = nfx;
+        fy4 = nfy;
+    }
+}
+
+// CT == 3: RGB, one chunk; CT == 0: any channel count, chunks of four.  MINW = waves per SIMD the register
+// allocator must leave room for (3 <-> 168 VGPRs, matching the 3 workgroups per CU the 48 KiB of LDS admit).
+// ABL (measurement arms): 1 = hardware-ordered tiles, 4 = row-major chunk per XCD (both still correct);
+// 2 = skip the LDS gathers, 3 = skip the staging loads (results WRONG, timing only).
+template <int LX, int CT, int MINW, int ABL>
+__global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
+    int W, int H, int C, int tiles_x, int tiles_y,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
+    const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
+    float *__restrict__ out)
+{
+    using G = TileGeom<LX>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+
+    int tx, ty, b;
+    if (ABL == 4) {                                        // row-major chunks per XCD (measurement arm)
+        const unsigned t = xcd_chunked_id(blockIdx.x, gridDim.x);
+        tx = t % tiles_x;  ty = (t / tiles_x) % tiles_y;  b = t / (tiles_x * tiles_y);
+    } else if (ABL == 1) {                                 // hardware order (measurement arm)
+        const unsigned t = blockIdx.x;
+        tx = t % tiles_x;  ty = (t / tiles_x) % tiles_y;  b = t / (tiles_x * tiles_y);
+    } else {
+        const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+        tx = tc.tx;  ty = tc.ty;  b = tc.b;
+    }
+    const int tile_x0 = tx * G::kTW, tile_y0 = ty * G::kTH;
+    const int x = tile_x0 + 4 * (threadIdx.x % LX);
+    const int y = tile_y0 + threadIdx.x / LX;
+    const bool inb = x < W && y < H;          // W % 4 == 0: a lane's four sites are in or out together
+
+    // 1. streams.  Loads are UNCONDITIONAL (lanes past the image edge read a clamped, in-range address and are
+    // masked at the store): a load under `if` or `?:` makes its result a phi, and the compiler then waits
+    // for it (s_waitcnt vmcnt(0)) at the join instead of at its first use, serialising every phase.
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
+    const float *tap_p = filt + b * s3b + (int64_t)ys * s3h + xs;
+    const f32x4 fx4 = ld_stream4(flow_p);
+    const f32x4 fy4 = ld_stream4(flow_p + s2c);
+    f32x4 tp[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) tp[k] = ld_stream4(tap_p + k * s3c);
+
+    // 2. site geometry and this lane's source box
+    FiSite4 g;
+    g.valid = 0;
+    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
+        g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
+        if (inb && s.valid) {
+            g.valid |= 1u << j;
+            cmin = min(cmin, max(s.ix - 1, 0));  cmax = max(cmax, min(s.ix + 2, W - 1));
+            rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
+        }
+    }
+    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    unsigned slow = 0;                        // valid sites whose window is not inside the staged region
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (((g.valid >> j) & 1) &&
+            !r.covers(max(g.ix[j] - 1, 0), min(g.ix[j] + 2, W - 1), max(g.iy[j] - 1, 0), min(g.iy[j] + 2, H - 1)))
+            slow |= 1u << j;
+
+    // 3./4. channels, four at a time
+    const float *in_b = in1 + b * s1b;
+    float *out_p = out + b * s1b + (int64_t)y * s1h + x;
+    if (CT == 3) {
+        fi_fwd_chunk<LX, 3, ABL>(r, g, tp, inb, x, y, W, H, in_b, out_p, s1c, s1h, tile);
+    } else {
+        int c0 = 0;
+#pragma unroll 1
+        for (; c0 + 4 <= C; c0 += 4) {
+            if (c0 > 0) __syncthreads();                   // the previous chunk's gathers are done
+            // Everything the chunk body derives from the taps and the site geometry (tap splats for the
+            // packed FMAs, 64 LDS addresses, blend weights) is loop-invariant; hoisted out of the loop it
+            // needs ~400 more registers than exist and lands in scratch (1.5 KB per lane).  Laundering the
+            // inputs through empty asm statements once per iteration keeps that arithmetic in the loop.
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
+            fi_fwd_chunk<LX, 4>(r, g, tp, inb, x, y, W, H, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
+        }
+        if (c0 < C) {                                      // tail of 1..3 channels
+            if (c0 > 0) __syncthreads();
+            const int nch = C - c0;
+            const float *plane0 = in_b + c0 * s1c;
+            float *o = out_p + c0 * s1c;
+            if (nch == 3)      fi_fwd_chunk<LX, 3>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
+            else if (nch == 2) fi_fwd_chunk<LX, 2>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
+            else               fi_fwd_chunk<LX, 1>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
+        }
+    }
+    while (slow) {                            // rare: redo those sites from global memory, all channels
+        const int j = __ffs(slow) - 1;
+        slow &= slow - 1;
+        fi_site_scalar(x + j, y, W, H, C, 4, in_b, s1c, s1h, flow_p + j, s2c, tap_p + j, s3c, out_p + j);
+    }
+}
 
 // --------------------------------------------------------------------------------------------------
 // Forward, fs == 4, direct gather from global memory through L1/L2.
@@ -89,18 +448,6 @@ __global__ __launch_bounds__(64 * ROWS) void fi_fwd_direct_fs4(
 // Forward, any filter size (run-time loops, taps read from global per use).  Rare path: the networks
 // only ever use fs == 4 (MEMC_Net_star.py:30 `filter_size = 4`).
 // --------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float fi_quad_sum(const float *p, int s1h, int W, int H, const float *tap_p,
-                                             int64_t s3c, int fs, int L, int T, int j0, int j1, int i0, int i1)
-{
-    float acc = 0.0f;
-    for (int j = j0; j <= j1; j++) {
-        const int jj = clampi(j, H - 1) * s1h;
-        for (int i = i0; i <= i1; i++)
-            acc += p[jj + clampi(i, W - 1)] * tap_p[((j - T) * fs + (i - L)) * s3c];
-    }
-    return acc;
-}
-
 __global__ __launch_bounds__(256) void fi_fwd_generic(
     int W, int H, int C, int fs, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
@@ -337,6 +684,15 @@ using namespace memc;
 // Variant selection for A/B measurement (memc_internal.h); -1 = automatic.
 static int g_fi_fwd_variant = -1;
 extern "C" void memc_debug_set_fi_fwd_variant(int v) { g_fi_fwd_variant = v; }
+// MEMC_FI_FWD_VARIANT=<n> in the environment forces a kernel variant (measurement / test matrix only).
+static int fi_fwd_variant()
+{
+    static const int from_env = [] {
+        const char *e = getenv("MEMC_FI_FWD_VARIANT");
+        return e ? atoi(e) : -1;
+    }();
+    return g_fi_fwd_variant >= 0 ? g_fi_fwd_variant : from_env;
+}
 
 extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
     memc_stream_t stream_, const int nElement, const int w, const int h, const int channel, const int batch,
@@ -349,13 +705,68 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
     (void)nElement; (void)s1w; (void)s2w; (void)s3w;
     hipStream_t stream = (hipStream_t)stream_;
     if (w <= 0 || h <= 0 || channel <= 0 || batch <= 0) return 0;
-    const int variant = g_fi_fwd_variant;
+    const int variant = fi_fwd_variant();
 
     if (variant == 0) {  // reference-structure measurement arm
         dim3 block(32, 16, 1), grid((w + 31) / 32, (h + 15) / 16, batch);
         hipLaunchKernelGGL(fi_fwd_refshape, grid, block, 0, stream, w, h, channel, filter_size,
                            (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
+        return launch_status();
+    }
+    // production path: LDS-tiled, 16 B per lane (needs 4-element-aligned geometry; variants 1-3 force the
+    // scalar direct-gather kernels for A/B measurement)
+    const bool vec = vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h}, {input1, input2, input3, output});
+    if (filter_size == 4 && vec && (variant < 0 || variant >= 4)) {
+#define MEMC_FI_TILED(LX, CT, MINW)   MEMC_FI_TILED_A(LX, CT, MINW, 0)
+#define MEMC_FI_TILED_A(LX, CT, MINW, ABL)                                                                      \
+    do {                                                                                                   \
+        using G = TileGeom<LX>;                                                                            \
+        const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                        \
+        hipLaunchKernelGGL((fi_fwd_tiled_fs4<LX, CT, MINW, ABL>), dim3((unsigned)ntx * nty * batch), dim3(256), \
+                           tile_lds_bytes<LX>(), stream, w, h, channel, ntx, nty, (int64_t)s1b,            \
+                           (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, \
+                           s3h, input1, input2, input3, output);                                           \
+    } while (0)
+        if (variant == 5) {
+            if (channel == 3) MEMC_FI_TILED(8, 3, 3); else MEMC_FI_TILED(8, 0, 3);
+        } else if (variant == 6) {
+            if (channel == 3) MEMC_FI_TILED(16, 3, 2); else MEMC_FI_TILED(16, 0, 2);
+        } else if (variant == 7) {
+            if (channel == 3) MEMC_FI_TILED(8, 3, 2); else MEMC_FI_TILED(8, 0, 2);
+        } else if (variant == 8 && channel == 3) {
+            MEMC_FI_TILED_A(16, 3, 2, 1);
+        } else if (variant == 9 && channel == 3) {
+            MEMC_FI_TILED_A(16, 3, 2, 2);
+        } else if (variant == 10 && channel == 3) {
+            MEMC_FI_TILED_A(16, 3, 2, 3);
+        } else if (variant == 11 && channel == 3) {
+            MEMC_FI_TILED_A(16, 3, 3, 4);
+        } else if ((variant == 12 || variant == 13 || variant == 14) && channel == 3) {
+            using G = TileGeom<16>;
+            const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+            const unsigned ntiles = (unsigned)ntx * nty * batch;
+            const unsigned per_cu = variant == 14 ? 3 : 2;
+            const unsigned grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+            if (variant == 13)
+                hipLaunchKernelGGL(fi_fwd_persist_c3<1>, dim3(grid), dim3(256), tile_lds_bytes<16>(), stream, w, h,
+                                   ntx, nty, ntiles, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                                   (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
+            else if (variant == 14)
+                hipLaunchKernelGGL(fi_fwd_persist_c3<3>, dim3(grid), dim3(256), tile_lds_bytes<16>(), stream, w, h,
+                                   ntx, nty, ntiles, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                                   (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
+            else
+                hipLaunchKernelGGL(fi_fwd_persist_c3<2>, dim3(grid), dim3(256), tile_lds_bytes<16>(), stream, w, h,
+                                   ntx, nty, ntiles, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                                   (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
+        } else if (variant == 4) {
+            if (channel == 3) MEMC_FI_TILED(16, 3, 3); else MEMC_FI_TILED(16, 0, 3);
+        } else {                                           // default: 64x16 tiles, strip walk
+            if (channel == 3) MEMC_FI_TILED(16, 3, 2); else MEMC_FI_TILED(16, 0, 2);
+        }
+#undef MEMC_FI_TILED
+#undef MEMC_FI_TILED_A
         return launch_status();
     }
     const int tiles_x = (w + kWave - 1) / kWave;

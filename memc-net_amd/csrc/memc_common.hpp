@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <limits.h>
+#include <initializer_list>
 
 namespace memc {
 
@@ -23,6 +25,42 @@ __device__ __forceinline__ unsigned xcd_chunked_id(unsigned bid, unsigned nwg)
     const unsigned xcd = bid % kXcds, idx = bid / kXcds;
     const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
+}
+
+// Tile walk used by the LDS-tiled kernels.  Two things are wanted at once:
+//   (a) tiles that share source rows (vertical neighbours: the staged box is ~1.7x taller than the tile) must
+//       run on the SAME XCD, close in time, so the halo is an L2 hit, and
+//   (b) the eight XCDs together should stream one neighbourhood of one image at a time (eight far-apart
+//       streams cost ~7 % of the achievable HBM bandwidth: tools/probes/io_skeleton.hip).
+// So whole column strips (one tile wide, full image height) are dealt round-robin to the XCDs -- strip s of the
+// batch (s = image * tiles_x + tile column) belongs to XCD s % 8 -- and an XCD walks its strips top to bottom.
+// Any position p of that "XCD-major" order is mapped back to (image, tx, ty); xcd_chunked_id() gives the
+// position of hardware workgroup b.  Bijective for any grid.
+struct TileCoord {
+    int b, tx, ty;
+};
+
+__device__ __forceinline__ TileCoord strip_walk(unsigned bid, unsigned nwg, int tiles_x, int tiles_y, int batch)
+{
+    const unsigned p = xcd_chunked_id(bid, nwg);
+    const unsigned S = (unsigned)tiles_x * batch;          // strips
+    const unsigned Q = S / kXcds, R = S % kXcds;
+    const unsigned big = (Q + 1) * tiles_y;                // tiles of an XCD class that owns Q+1 strips
+    unsigned k, rem;
+    if (p < R * big) {
+        k = p / big;
+        rem = p % big;
+    } else {
+        const unsigned pp = p - R * big, small = Q * tiles_y;
+        k = R + pp / small;
+        rem = pp % small;
+    }
+    const unsigned s = k + kXcds * (rem / tiles_y);
+    TileCoord c;
+    c.ty = rem % tiles_y;
+    c.b = s / tiles_x;
+    c.tx = s % tiles_x;
+    return c;
 }
 
 // Streaming accesses: every filter-tap / flow / output element is touched exactly once per launch,

@@ -1,0 +1,168 @@
+// memc_tile.hpp -- LDS tiling machinery shared by the vectorised (16 B per lane) kernels.
+//
+// What MI355X wants from these operators (measured, DESIGN.md "Kernel ladder"): a CU retires roughly one
+// wave-level vector-memory instruction per ~30 clocks whatever its width, so 4-byte-per-lane accesses top out
+// near 2 TB/s while 16-byte ones reach the copy rate.  Hence:
+//   * every streamed tensor (flow, filter taps, outputs, gradients) moves as dwordx4 -- one lane owns FOUR
+//     consecutive sites of a row;
+//   * the data-dependent gathers (and scatters) never touch global memory: the source window of a workgroup's
+//     output tile -- its bounding box under the tile's own flow vectors -- is staged into LDS with coalesced
+//     dwordx4 loads and gathered from there with ds_read_b128 (DS is a separate, much faster pipe);
+//   * sites whose window falls outside the staged region (box larger than the LDS budget: violent or
+//     discontinuous motion) fall back to global gathers lane by lane: slower, never wrong.
+//
+// LDS image layout: one float4 per pixel = up to four channels of that pixel ("pixel quad"), row pitch
+// kPitch pixels, so a single ds_read_b128 returns all (<= 4) channels of one tap.  Columns are XOR-swizzled in
+// their low four bits with bits 2..5 (col ^= (col >> 2) & 15): lanes own 4-pixel-strided sites, which
+// unswizzled would put the 16 lanes of a ds_read_b128 group on 4 bank slots (4-way conflict); the swizzle
+// is a bijection of every aligned 64-column span that spreads them over all 16 slots.
+#pragma once
+
+#include "memc_common.hpp"
+
+namespace memc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld_stream4(const float *p)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+}
+__device__ __forceinline__ void st_stream4(float *p, f32x4 v)
+{
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
+}
+__device__ __forceinline__ f32x4 ld_cached4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+__device__ __forceinline__ int swz_col(int c) { return c ^ ((c >> 2) & 15); }
+
+// 16-B vector path preconditions: width and every stride a multiple of 4 elements, 16-B aligned bases.
+inline bool vec4_ok(int w, std::initializer_list<long> strides, std::initializer_list<const void *> ptrs)
+{
+    if (w % 4) return false;
+    for (long s : strides)
+        if (s % 4) return false;
+    for (const void *p : ptrs)
+        if (reinterpret_cast<uintptr_t>(p) % 16) return false;
+    return true;
+}
+
+// Tile geometry: 256 threads, LX lanes per tile row, 4 sites per lane.
+template <int LX>
+struct TileGeom {
+    static constexpr int kThreads = 256;
+    static constexpr int kTW = 4 * LX;                 // tile width  (sites)
+    static constexpr int kTH = kThreads / LX;          // tile height (sites)
+    static constexpr int kPitch = kTW + 32;            // LDS row pitch in pixels; multiple of 16 (swizzle span)
+    static constexpr int kCapPx = 3072;                // LDS budget: 3072 px * 16 B = 48 KiB -> 3 workgroups / CU
+    static constexpr int kRows = kCapPx / kPitch;      // staged rows that fit
+    static_assert(kPitch % 16 == 0, "swizzle needs a pitch that is a multiple of 16 pixels");
+    static_assert(kPitch / 4 <= 32, "staging uses 32 lanes per region row");
+};
+
+// LDS carve: [0, kCapPx*16) pixel quads, then 16 ints of per-wave bounding boxes.
+template <int LX>
+constexpr int tile_lds_bytes() { return TileGeom<LX>::kCapPx * 16 + 64; }
+
+struct Region {
+    int x0, y0;      // image coordinates of LDS pixel (0,0); x0 % 4 == 0
+    int w, h;        // staged extent (w % 4 == 0); 0 when nothing is staged
+    __device__ __forceinline__ bool covers(int cmin, int cmax, int rmin, int rmax) const
+    {
+        return cmin >= x0 && cmax < x0 + w && rmin >= y0 && rmax < y0 + h;
+    }
+};
+
+// Workgroup-wide bounding box of the clamped source windows [cmin,cmax] x [rmin,rmax] of all valid sites,
+// fitted to the LDS budget.  Each lane passes the box of its own (up to four) valid sites, or an empty box
+// (cmin > cmax).  One __syncthreads.
+template <int LX>
+__device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int rmax, int tile_x0, int tile_y0,
+                                              int *bb /* 16 ints in LDS */)
+{
+    using G = TileGeom<LX>;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cmin = min(cmin, __shfl_xor(cmin, off));
+        cmax = max(cmax, __shfl_xor(cmax, off));
+        rmin = min(rmin, __shfl_xor(rmin, off));
+        rmax = max(rmax, __shfl_xor(rmax, off));
+    }
+    const int wave = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        bb[wave * 4 + 0] = cmin;
+        bb[wave * 4 + 1] = cmax;
+        bb[wave * 4 + 2] = rmin;
+        bb[wave * 4 + 3] = rmax;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < G::kThreads / kWave; w++) {
+        cmin = min(cmin, bb[w * 4 + 0]);
+        cmax = max(cmax, bb[w * 4 + 1]);
+        rmin = min(rmin, bb[w * 4 + 2]);
+        rmax = max(rmax, bb[w * 4 + 3]);
+    }
+    Region r;
+    if (cmin > cmax) {          // no valid site in this tile
+        r.x0 = r.y0 = r.w = r.h = 0;
+        return r;
+    }
+    int x0 = cmin & ~3, w = (cmax | 3) + 1 - x0;
+    int y0 = rmin, h = rmax + 1 - y0;
+    if (w > G::kPitch) {        // clip around the tile centre, keep 4-alignment
+        const int lo = x0, hi = x0 + w - G::kPitch;
+        x0 = min(max((tile_x0 + G::kTW / 2 - G::kPitch / 2) & ~3, lo), hi);
+        w = G::kPitch;
+    }
+    if (h > G::kRows) {
+        const int lo = y0, hi = y0 + h - G::kRows;
+        y0 = min(max(tile_y0 + G::kTH / 2 - G::kRows / 2, lo), hi);
+        h = G::kRows;
+    }
+    r.x0 = x0; r.y0 = y0; r.w = w; r.h = h;
+    return r;
+}
+
+// Stage NCH (1..4) channel planes of the region into LDS pixel quads (missing channels -> 0).
+// Thread layout: 8 region rows x 32 lanes per pass; lane q loads the float4 at columns 4q..4q+3 of every
+// channel (coalesced: a region row is one contiguous run) and writes four swizzled pixel quads.
+// Rows are handled in batches of 32 (4 passes): all loads of a batch are issued before the first LDS write,
+// and they are unconditional -- lanes/rows outside the region read the plane's first element instead -- so
+// that no load result becomes a phi (see the note in fi_fwd_tiled_fs4) and one latency covers the batch.
+template <int LX, int NCH>
+__device__ __forceinline__ void tile_stage(const Region &r, const float *plane0, int64_t cstride, int hstride,
+                                           f32x4 *tile)
+{
+    using G = TileGeom<LX>;
+    const int q = threadIdx.x & 31, row0 = threadIdx.x >> 5;
+    const bool lane_on = 4 * q < r.w;
+    const float *src = plane0 + (int64_t)r.y0 * hstride + r.x0 + 4 * q;
+#pragma unroll
+    for (int base = 0; base < G::kRows; base += 32) {
+        f32x4 v[4][NCH];
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int row = base + row0 + 8 * it;
+            const float *p = (lane_on && row < r.h) ? src + (int64_t)row * hstride : plane0;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) v[it][c] = ld_cached4(p + c * cstride);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int row = base + row0 + 8 * it;
+            if (lane_on && row < r.h) {
+                f32x4 *dst = tile + row * G::kPitch;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    f32x4 px = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) px[c] = v[it][c][i];
+                    dst[swz_col(4 * q + i)] = px;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace memc

@@ -54,6 +54,13 @@ CASES = [
     (2, 3, 64, 192, "smooth", 12.0, 5),    # large smooth motion
     (1, 3, 40, 40, "iid", 30.0, 6),        # mostly out of range: passthrough / |f| < W/2 guard paths
     (2, 5, 33, 65, "zero", None, 7),
+    # vector (16 B per lane, LDS-tiled) path: W % 4 == 0
+    (2, 3, 64, 256, "iid", 20.0, 8),       # source box far larger than the LDS budget: per-site global fallback
+    (1, 5, 16, 32, "iid", 2.0, 9),         # channel chunks 4 + 1
+    (1, 6, 20, 64, "smooth", 4.0, 10),     # 4 + 2
+    (1, 7, 20, 64, "smooth", 4.0, 11),     # 4 + 3
+    (2, 3, 100, 132, "smooth", 8.0, 12),   # ragged tiles (132 = 2 * 64 + 4, 100 = 6 * 16 + 4)
+    (1, 8, 48, 96, "iid", 3.0, 13),        # two full chunks
 ]
 IDS = ["%dx%dx%dx%d-%s" % c[:5] for c in CASES]
 

@@ -148,9 +148,10 @@ def bench_copy(rows, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="fi_fwd: only the 720p batch-32 smooth-flow row")
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "bench_ops.json"))
-    ap.add_argument("--variants", default="1,0,2,3")
+    ap.add_argument("--variants", default="4,5,6,7,1")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     only = set(filter(None, args.only.split(",")))
@@ -164,9 +165,10 @@ def main():
         bench_copy(rows, dev)
     if want("fi_fwd"):
         bench_fi_fwd(rows, dev, 32, 3, 720, 1280, "smooth", variants, "c_headline")
-        bench_fi_fwd(rows, dev, 32, 3, 720, 1280, "iid", variants[:1], "c_headline")
-        bench_fi_fwd(rows, dev, 8, 3, 256, 448, "smooth", variants[:1], "c2")
-        if not args.quick:
+        if not args.headline_only:
+            bench_fi_fwd(rows, dev, 32, 3, 720, 1280, "iid", variants[:1], "c_headline")
+            bench_fi_fwd(rows, dev, 8, 3, 256, 448, "smooth", variants[:1], "c2")
+        if not args.quick and not args.headline_only:
             bench_fi_fwd(rows, dev, 8, 64, 720, 1280, "smooth", variants[:1], "ctx64")
             bench_fi_fwd(rows, dev, 8, 3, 2160, 3840, "smooth", variants[:1], "c5_4k")
     if want("fi_bwd"):

@@ -1,0 +1,102 @@
+// io_skeleton.hip -- measurement probe, NOT part of libmemc_hip.so.
+//
+// The streaming skeleton of the adaptive-warp forward with all data-dependent work removed: per output site
+// read 2 flow + 16 tap values + C image values at the site's own position, write C outputs -- exactly the
+// kernel's ALGORITHMIC traffic (96 B/site at C=3) with no gathers, no LDS and no barriers.  Its time is the
+// ceiling any real kernel with this I/O pattern can reach on the device; variants change only the tile shape,
+// the cache policy of the streams and the residency.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ f32x4 ld4(const float *p)
+{
+    if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return *reinterpret_cast<const f32x4 *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float *p, f32x4 v)
+{
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p));
+    else *reinterpret_cast<f32x4 *>(p) = v;
+}
+
+__device__ __forceinline__ unsigned xcd_chunked_id(unsigned bid, unsigned nwg)
+{
+    const unsigned q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// LX lanes per tile row (4 sites each); 256 threads; MINW = min waves per SIMD for the register allocator
+template <int LX, bool NT, bool XCD, int MINW>
+__global__ __launch_bounds__(256, MINW) void skeleton(int W, int H, int64_t plane, const float *__restrict__ in1,
+                                                      const float *__restrict__ flow, const float *__restrict__ filt,
+                                                      float *__restrict__ out, int tiles_x, int tiles_y)
+{
+    const unsigned t = XCD ? xcd_chunked_id(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, b = t / (tiles_x * tiles_y);
+    const int x = tx * 4 * LX + 4 * (threadIdx.x % LX), y = ty * (256 / LX) + threadIdx.x / LX;
+    if (x >= W || y >= H) return;
+    const int64_t o = (int64_t)y * W + x;
+    f32x4 acc = ld4<NT>(flow + (b * 2 + 0) * plane + o) + ld4<NT>(flow + (b * 2 + 1) * plane + o);
+    f32x4 tp[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) tp[k] = ld4<NT>(filt + (b * 16 + k) * plane + o);
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc += tp[k];
+#pragma unroll
+    for (int c = 0; c < 3; c++) st4<NT>(out + (b * 3 + c) * plane + o, acc * ld4<false>(in1 + (b * 3 + c) * plane + o));
+}
+
+// flat grid-stride float4 copy of n4 float4s (the classic bandwidth test), for calibration
+template <bool NT>
+__global__ __launch_bounds__(256) void copy4(const f32x4 *__restrict__ a, f32x4 *__restrict__ b, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = NT ? __builtin_nontemporal_load(a + i) : a[i];
+        if (NT) __builtin_nontemporal_store(v, b + i); else b[i] = v;
+    }
+}
+// read-only: sums into a tiny output (tests pure read bandwidth)
+__global__ __launch_bounds__(256) void read4(const f32x4 *__restrict__ a, float *__restrict__ sink, int64_t n4)
+{
+    f32x4 acc = {0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+        acc += __builtin_nontemporal_load(a + i);
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
+}
+
+#define LAUNCH(LX, NT, XCD, MINW)                                                                            \
+    do {                                                                                                     \
+        const int tx = (W + 4 * LX - 1) / (4 * LX), ty = (H + 256 / LX - 1) / (256 / LX);                    \
+        hipLaunchKernelGGL((skeleton<LX, NT, XCD, MINW>), dim3((unsigned)tx * ty * B), dim3(256), 0,         \
+                           (hipStream_t)stream, W, H, (int64_t)W * H, in1, flow, filt, out, tx, ty);         \
+    } while (0)
+
+extern "C" int probe_skeleton(void *stream, int variant, int B, int H, int W, const float *in1, const float *flow,
+                              const float *filt, float *out)
+{
+    switch (variant) {
+    case 0: LAUNCH(16, true, true, 1); break;     // 64x16 tile, nt streams, XCD-chunked
+    case 1: LAUNCH(8, true, true, 1); break;      // 32x32
+    case 2: LAUNCH(64, true, true, 1); break;     // 256x4: one wave = 1 KiB contiguous per plane
+    case 3: LAUNCH(32, true, true, 1); break;     // 128x8
+    case 4: LAUNCH(16, false, true, 1); break;    // default cache policy
+    case 5: LAUNCH(16, true, false, 1); break;    // blockIdx order (round-robin over XCDs)
+    case 6: LAUNCH(64, true, false, 1); break;
+    case 7: LAUNCH(16, true, true, 2); break;     // register cap as the real kernel (2 waves / SIMD)
+    case 8: LAUNCH(64, false, false, 1); break;
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int probe_copy(void *stream, int variant, int blocks, const float *a, float *b, int64_t n4)
+{
+    if (variant == 0) hipLaunchKernelGGL(copy4<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)a, (f32x4 *)b, n4);
+    else if (variant == 1) hipLaunchKernelGGL(copy4<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)a, (f32x4 *)b, n4);
+    else hipLaunchKernelGGL(read4, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)a, b, n4);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

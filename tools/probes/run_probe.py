@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Builds (hipcc, in-tree) and runs tools/probes/io_skeleton.hip on cuda:0; prints achieved bandwidth."""
+import ctypes, os, statistics, subprocess, sys
+import torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libio_skeleton.so")
+
+
+def build():
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                    "-o", SO, os.path.join(HERE, "io_skeleton.hip")], check=True)
+
+
+def timeit(fn, iters=15, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); b.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3)
+    return statistics.median(ts)
+
+
+def main():
+    if not os.path.exists(SO):
+        build()
+    if not torch.cuda.is_available():
+        print("built", SO); return
+    lib = ctypes.CDLL(SO)
+    dev = torch.device("cuda:0")
+    B, H, W = 32, 720, 1280
+    x = torch.rand(B, 3, H, W, device=dev); f = torch.randn(B, 2, H, W, device=dev)
+    k = torch.rand(B, 16, H, W, device=dev); o = torch.zeros_like(x)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    nbytes = B * H * W * 96
+    names = {0: "64x16 nt xcd", 1: "32x32 nt xcd", 2: "256x4 nt xcd", 3: "128x8 nt xcd", 4: "64x16 cached xcd",
+             5: "64x16 nt blockIdx-order", 6: "256x4 nt blockIdx-order", 7: "64x16 nt xcd minw2", 8: "256x4 cached blockIdx-order"}
+    for v in range(9):
+        t = timeit(lambda: lib.probe_skeleton(st, v, B, H, W, P(x), P(f), P(k), P(o)))
+        print("skeleton %-28s %8.1f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (names[v], t * 1e6, nbytes / t / 1e9, 100 * nbytes / t / 8e12), flush=True)
+    n4 = nbytes // 32
+    a = torch.rand(n4 * 4, device=dev); b = torch.empty_like(a)
+    lib.probe_copy.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    for blocks in (2048, 8192, 65536):
+        for v, nm in ((0, "copy cached"), (1, "copy nt"), (2, "read-only nt")):
+            t = timeit(lambda: lib.probe_copy(st, v, blocks, P(a), P(b), n4))
+            moved = n4 * 16 * (1 if v == 2 else 2)
+            print("%-14s blocks=%-6d %8.1f us  %7.1f GB/s" % (nm, blocks, t * 1e6, moved / t / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        build()
+    else:
+        main()
