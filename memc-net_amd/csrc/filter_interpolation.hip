@@ -617,6 +617,202 @@ __global__ __launch_bounds__(64 * ROWS) void fi_bwd_direct_fs4(
     st_stream(g2 + s2c, boty);
 }
 
+// --------------------------------------------------------------------------------------------------
+// Backward, fs == 4, RGB, LDS-tiled and vectorised.  Same tile / box machinery as the forward kernel:
+//   * streams (flow, 16 tap planes, 3 gradoutput planes) as dwordx4;
+//   * the image box is staged into LDS pixel quads (needed for the tap and flow gradients);
+//   * the image gradient -- 48 scattered adds per site -- goes into LDS accumulator planes (ds_add_f32) and is
+//     flushed once per cell with row-coalesced global atomics (memc_tile.hpp);
+//   * gradinput3 (each site owns its taps) is accumulated in registers and read-modify-written as dwordx4;
+//     gradinput2 is assigned.
+// Sites whose window is not staged are redone by fi_bwd_site_scalar with global atomics.
+// --------------------------------------------------------------------------------------------------
+__device__ __noinline__ void fi_bwd_site_scalar(int x, int y, int W, int H, int C, int fs,
+                                                const float *in_b, float *gin1_b, int64_t s1c, int s1h,
+                                                const float *flow_p, float *g2, int64_t s2c,
+                                                const float *tap_p, float *g3, int64_t s3c, const float *gout_p)
+{
+    const float fx = flow_p[0], fy = flow_p[s2c];
+    const FiSite s = fi_locate(x, y, W, H, fx, fy);
+    if (!s.valid) return;
+    const int L = s.ix + 1 - fs / 2, T = s.iy + 1 - fs / 2, R = L + fs, Bm = T + fs;
+    float botx = 0.0f, boty = 0.0f;
+    const float gam_x = 1.0f - s.b, gam_y = 1.0f - s.a;
+    for (int c = 0; c < C; c++) {
+        const float *p = in_b + c * s1c;
+        float *q = gin1_b + c * s1c;
+        const float g = gout_p[c * s1c];
+        for (int j = T; j < Bm; j++) {
+            const int jj = clampi(j, H - 1) * s1h;
+            for (int i = L; i < R; i++) {
+                const int ii = clampi(i, W - 1);
+                const float wgt = (j <= s.iy) ? ((i <= s.ix) ? g * (1 - s.a) * (1 - s.b) : g * s.a * (1 - s.b))
+                                              : ((i <= s.ix) ? g * (1 - s.a) * s.b : g * s.a * s.b);
+                const int64_t k = ((j - T) * fs + (i - L)) * s3c;
+                atomic_add_f32(q + jj + ii, wgt * tap_p[k]);
+                g3[k] += wgt * p[jj + ii];
+            }
+        }
+        const float TL = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, T, s.iy, L, s.ix);
+        const float TR = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, T, s.iy, s.ix + 1, R - 1);
+        const float BL = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, s.iy + 1, Bm - 1, L, s.ix);
+        const float BR = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, s.iy + 1, Bm - 1, s.ix + 1, R - 1);
+        float tmp = 0.0f;
+        tmp += gam_x * (TR - TL);
+        tmp += (1.0f - gam_x) * (BR - BL);
+        botx += g * tmp;
+        tmp = 0.0f;
+        tmp += gam_y * (BL - TL);
+        tmp += (1.0f - gam_y) * (BR - TR);
+        boty += g * tmp;
+    }
+    g2[0] = botx;
+    g2[s2c] = boty;
+}
+
+__global__ __launch_bounds__(256) void fi_bwd_tiled_c3(
+    int W, int H, int tiles_x, int tiles_y,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
+    const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
+    const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2,
+    float *__restrict__ gin3)
+{
+    constexpr int LX = 16;
+    using G = TileGeom<LX>;
+    using A = AccGeom<LX>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+    float *acc = reinterpret_cast<float *>(smem + G::kCapPx * 16 + 64);
+
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
+    const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
+    const bool inb = x < W && y < H;
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
+    const float *tap_p = filt + b * s3b + (int64_t)ys * s3h + xs;
+    const float *gout_p = gout + b * s1b + (int64_t)ys * s1h + xs;
+    const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s2c);
+    f32x4 go[3], tp[16];
+#pragma unroll
+    for (int c = 0; c < 3; c++) go[c] = ld_stream4(gout_p + c * s1c);
+#pragma unroll
+    for (int k = 0; k < 16; k++) tp[k] = ld_stream4(tap_p + k * s3c);
+
+    acc_zero<LX, 3>(acc);
+    FiSite4 g;
+    g.valid = 0;
+    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
+        g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
+        if (inb && s.valid) {
+            g.valid |= 1u << j;
+            cmin = min(cmin, max(s.ix - 1, 0));  cmax = max(cmax, min(s.ix + 2, W - 1));
+            rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
+        }
+    }
+    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    const float *in_b = in1 + b * s1b;
+    float *gin1_b = gin1 + b * s1b;
+    tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
+    __syncthreads();
+
+    f32x4 gt[16];                          // gt[k][j]: tap-k gradient of site j
+#pragma unroll
+    for (int k = 0; k < 16; k++) gt[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 gx4 = {0.f, 0.f, 0.f, 0.f}, gy4 = gx4;
+    unsigned fast = 0, slow = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int ro[4], co[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ro[k] = clampi(g.iy[j] - 1 + k, H - 1);
+            co[k] = clampi(g.ix[j] - 1 + k, W - 1);
+        }
+        const bool valid = (g.valid >> j) & 1;
+        const bool staged = valid && r.covers(co[0], co[3], ro[0], ro[3]);
+        fast |= (staged ? 1u : 0u) << j;
+        slow |= ((valid && !staged) ? 1u : 0u) << j;
+        if (!staged) continue;
+        const float a = g.a[j], bt = g.b[j];
+        const float w4[4] = {(1 - a) * (1 - bt), a * (1 - bt), (1 - a) * bt, a * bt};   // quadrant weights / g
+        f32x4 v[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) v[k * 4 + m] = tile[(ro[k] - r.y0) * G::kPitch + swz_col(co[m] - r.x0)];
+        float botx = 0.0f, boty = 0.0f;
+        const float gam_x = 1.0f - bt, gam_y = 1.0f - a;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float gv = go[c][j];
+            // reference rounding: g * (1-a) * (1-b) is evaluated left to right
+            const float wq[4] = {gv * (1 - a) * (1 - bt), gv * a * (1 - bt), gv * (1 - a) * bt, gv * a * bt};
+            float *ap = acc + c * A::kPlane;
+            float TL = 0.0f, TR = 0.0f, BL = 0.0f, BR = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int t = k * 4 + m;
+                    const float wgt = wq[(k >> 1) * 2 + (m >> 1)];
+                    lds_add_f32(ap + (ro[k] - r.y0) * A::kPitch + (co[m] - r.x0), wgt * tp[t][j]);
+                    gt[t][j] += wgt * v[t][c];
+                    const float prod = v[t][c] * tp[t][j];
+                    if (k < 2) { if (m < 2) TL += prod; else TR += prod; }
+                    else       { if (m < 2) BL += prod; else BR += prod; }
+                }
+            float tmp = 0.0f;
+            tmp += gam_x * (TR - TL);
+            tmp += (1.0f - gam_x) * (BR - BL);
+            botx += gv * tmp;
+            tmp = 0.0f;
+            tmp += gam_y * (BL - TL);
+            tmp += (1.0f - gam_y) * (BR - TR);
+            boty += gv * tmp;
+        }
+        (void)w4;
+        gx4[j] = botx;
+        gy4[j] = boty;
+    }
+    if (inb) {
+        float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
+        float *g3 = gin3 + b * s3b + (int64_t)y * s3h + x;
+        if (fast == 0xFu) {
+            st_stream4(g2, gx4);
+            st_stream4(g2 + s2c, gy4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((fast >> j) & 1) {
+                    g2[j] = gx4[j];
+                    g2[s2c + j] = gy4[j];
+                }
+        }
+        if (fast) {                          // gradinput3 += (zero for sites that contributed nothing)
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                f32x4 *p = reinterpret_cast<f32x4 *>(g3 + k * s3c);
+                *p = *p + gt[k];
+            }
+        }
+        while (slow) {                        // rare: window outside the staged box
+            const int j = __ffs(slow) - 1;
+            slow &= slow - 1;
+            fi_bwd_site_scalar(x + j, y, W, H, 3, 4, in_b, gin1_b, s1c, s1h, flow_p + j, g2 + j, s2c, tap_p + j,
+                               g3 + j, s3c, gout_p + j);
+        }
+    }
+    __syncthreads();
+    float *const dst[3] = {gin1_b, gin1_b + s1c, gin1_b + 2 * s1c};
+    const int hs[3] = {s1h, s1h, s1h};
+    acc_flush<LX, 3>(r, acc, dst, hs);
+}
+
 // Backward, any filter size (rare path; run-time loops).
 __global__ __launch_bounds__(256) void fi_bwd_generic(
     int W, int H, int C, int fs, int tiles_x, int tiles_y,
@@ -821,6 +1017,17 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput,
                            gradinput1, gradinput2, gradinput3);
+    } else if (channel == 3 && vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
+                                       {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3})) {
+        using G = TileGeom<16>;
+        using A = AccGeom<16>;
+        const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+        const int lds = G::kCapPx * 16 + 64 + 3 * A::kPlane * 4;
+        static const bool once = (allow_big_lds(fi_bwd_tiled_c3, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(fi_bwd_tiled_c3, dim3((unsigned)ntx * nty * batch), dim3(256), lds, stream, w, h, ntx, nty,
+                           (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,
+                           (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3);
     } else if (channel == 3) {
         hipLaunchKernelGGL((fi_bwd_direct_fs4<3, 4>), dim3(nwg), dim3(256), 0, stream, w, h, channel,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,

@@ -10,6 +10,7 @@
 // operator is d == 1.
 #include "memc_common.hpp"
 #include "memc_internal.h"
+#include "memc_tile.hpp"
 
 namespace memc {
 
@@ -172,6 +173,301 @@ __global__ __launch_bounds__(256) void proj_bwd(
     if (DEPTH) gin2[b * sdb + (int64_t)y * sdh + x] = gd;
 }
 
+// ==================================================================================================
+// Vectorised, LDS-tiled production kernels (W % 4 == 0, 16-B aligned geometry); the scalar kernels above
+// remain as the fallback for odd widths / unaligned views and as measurement arms.
+// ==================================================================================================
+
+// Pass 1, tiled: a workgroup owns a 64x16 tile of SOURCE sites (4 per lane, flow read as dwordx4).
+//
+// A site adds the SAME value to its four target cells (L|R) x (T|B), so the splat factors into
+//     P[T][L] += v                                   (one add per plane per site: the "point splat")
+//     out[y][x] += sum_{dy,dx in {0,1}} wy * wx * P[y-dy][x-dx]        (a 2x2 box sum, a pure gather)
+// with wx = 2 for (x == W-1, dx == 0) and 1 otherwise (the clamped right neighbour R = min(L+1, W-1) coincides
+// with L on the last column, which the reference adds twice), likewise wy on the last row.  LDS fp32 atomics
+// are the scarce resource here (ds_add_f32 retires ~0.35 lane-ops per clock per CU, measured), so the point
+// splat goes to LDS planes covering the bounding box of the tile's (T, L) points -- 3 adds per site instead of
+// 12 -- and the box sum is evaluated when the box is flushed, once per cell, with row-coalesced global
+// atomics (neighbouring tiles' boxes overlap).  Sites whose point falls outside the LDS budget scatter their
+// 12 adds straight to global memory.
+// ABL (measurement arms, results WRONG): 2 = no flush, 3 = no LDS adds.
+template <bool DEPTH, int ABL>
+__global__ __launch_bounds__(256) void proj_scatter_tiled(
+    int W, int H, int tiles_x, int tiles_y,
+    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
+    const float *__restrict__ flow, const float *__restrict__ depth,
+    float *__restrict__ count, float *__restrict__ out)
+{
+    constexpr int LX = 16;
+    using G = TileGeom<LX>;
+    using A = AccGeom<LX>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *acc = reinterpret_cast<float *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + 3 * A::kPlane * 4);
+
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
+    const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
+    const bool inb = x < W && y < H;
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const float *flow_p = flow + b * s1b + (int64_t)ys * s1h + xs;
+    const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s1c);
+    f32x4 d4 = {1.f, 1.f, 1.f, 1.f};
+    if (DEPTH) d4 = ld_stream4(depth + b * sdb + (int64_t)ys * sdh + xs);
+
+    acc_zero<LX, 3>(acc);
+    BlSite st[4];
+    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        st[j] = bl_locate<false>(x + j, y, W, H, fx4[j], fy4[j]);
+        st[j].valid = st[j].valid && inb;
+        if (st[j].valid) {                     // box of the (T, L) points only
+            cmin = min(cmin, st[j].L);  cmax = max(cmax, st[j].L);
+            rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].T);
+        }
+    }
+    // the flush also writes column cmax+1 / row rmax+1 (the R / B neighbours), which need no LDS cell
+    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);   // barrier: acc is zero too
+
+    float *ox = out + b * s1b, *oy = ox + s1c, *cn = count + b * scb;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!st[j].valid || ABL == 3) continue;
+        const BlSite &s = st[j];
+        float vx = -fx4[j], vy = -fy4[j], vc = 1.0f;
+        if (DEPTH) {
+            vx = -d4[j] * fx4[j];
+            vy = -d4[j] * fy4[j];
+            vc = d4[j] * 1.0f;
+        }
+        if (r.covers(s.L, s.L, s.T, s.T)) {
+            const int o = (s.T - r.y0) * A::kPitch + (s.L - r.x0);
+            lds_add_f32(acc + o, vx);
+            lds_add_f32(acc + A::kPlane + o, vy);
+            lds_add_f32(acc + 2 * A::kPlane + o, vc);
+        } else {                              // point clipped out of the LDS budget: straight to global
+            const int oT = s.T * s1h, oB = s.Bm * s1h, cT = s.T * sch, cB = s.Bm * sch;
+            atomic_add_f32(ox + oT + s.L, vx);  atomic_add_f32(ox + oT + s.R, vx);
+            atomic_add_f32(ox + oB + s.L, vx);  atomic_add_f32(ox + oB + s.R, vx);
+            atomic_add_f32(oy + oT + s.L, vy);  atomic_add_f32(oy + oT + s.R, vy);
+            atomic_add_f32(oy + oB + s.L, vy);  atomic_add_f32(oy + oB + s.R, vy);
+            atomic_add_f32(cn + cT + s.L, vc);  atomic_add_f32(cn + cT + s.R, vc);
+            atomic_add_f32(cn + cB + s.L, vc);  atomic_add_f32(cn + cB + s.R, vc);
+        }
+    }
+    __syncthreads();
+    if (ABL == 2 || r.w == 0) return;
+
+    // flush: cells [x0, x0 + w] x [y0, y0 + h] (one extra column / row for the R / B neighbours), clipped to
+    // the image; 64 lanes walk a row, 4 waves take rows round-robin.
+    float *const dst[3] = {ox, oy, cn};
+    const int hs[3] = {s1h, s1h, sch};
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int fw = min(r.w + 1, W - r.x0), fh = min(r.h + 1, H - r.y0);
+    for (int row = wave; row < fh; row += G::kThreads / kWave) {
+        const int gy = r.y0 + row;
+        const bool up = row >= 1, here_y = row < r.h;
+        const float wy0 = (gy == H - 1) ? 2.0f : 1.0f;         // dy == 0 term weight
+        for (int col = lane; col < fw; col += kWave) {
+            const int gx = r.x0 + col;
+            const bool left = col >= 1, here_x = col < r.w;
+            const float wx0 = (gx == W - 1) ? 2.0f : 1.0f;
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                const float *p = acc + pl * A::kPlane + row * A::kPitch + col;
+                // reference order of a cell's contributions is arbitrary (atomics); keep a fixed one here
+                float v = 0.0f;
+                if (here_y && here_x) v += wy0 * wx0 * p[0];
+                if (here_y && left) v += wy0 * p[-1];
+                if (up && here_x) v += wx0 * p[-A::kPitch];
+                if (up && left) v += p[-A::kPitch - 1];
+                if (v != 0.0f) atomic_add_f32(dst[pl] + (int64_t)gy * hs[pl] + gx, v);
+            }
+        }
+    }
+}
+
+// Pass 2, vectorised: out /= count where count > 0, four cells per lane.
+__global__ __launch_bounds__(256) void proj_average_v4(
+    int W, int H, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch, int batch,
+    const float *__restrict__ count, float *__restrict__ out)
+{
+    const int w4 = W / 4;
+    const int64_t n = (int64_t)batch * H * w4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % w4) * 4;
+        const int y = (int)((i / w4) % H);
+        const int b = (int)(i / ((int64_t)w4 * H));
+        const f32x4 c = ld_cached4(count + b * scb + (int64_t)y * sch + x);
+        if (!(c[0] > 0.0f || c[1] > 0.0f || c[2] > 0.0f || c[3] > 0.0f)) continue;
+        float *o = out + b * s1b + (int64_t)y * s1h + x;
+        f32x4 vx = ld_cached4(o), vy = ld_cached4(o + s1c);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (c[j] > 0.0f) {
+                vx[j] = vx[j] / c[j];
+                vy[j] = vy[j] / c[j];
+            }
+        *reinterpret_cast<f32x4 *>(o) = vx;
+        *reinterpret_cast<f32x4 *>(o + s1c) = vy;
+    }
+}
+
+// Pass 3, vectorised scan: only lanes that find a hole (count <= 0) do the reference's walk.
+__device__ __forceinline__ void fill_one_hole(int x, int y, int W, int H, int64_t s1c, int s1h, int sch,
+                                              const float *cn, float *o)
+{
+    int lo = x;  float lt = 0.0f;
+    while (lt == 0.0f && lo - 1 >= 0) { lo--; lt = cn[(int64_t)y * sch + lo]; }
+    int ro = x;  float rt = 0.0f;
+    while (rt == 0.0f && ro + 1 <= W - 1) { ro++; rt = cn[(int64_t)y * sch + ro]; }
+    int uo = y;  float ut = 0.0f;
+    while (ut == 0.0f && uo - 1 >= 0) { uo--; ut = cn[(int64_t)uo * sch + x]; }
+    const float dt = 0.0f;                                  // dead downward search (my_lib_kernel.cu:1799)
+    if (lt + rt + ut + dt <= 0.0f) return;
+    const float fl = lt > 0.0f ? 1.0f : 0.0f, fr = rt > 0.0f ? 1.0f : 0.0f;
+    const float fu = ut > 0.0f ? 1.0f : 0.0f, fd = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; k++, o += s1c) {
+        float *self = o + (int64_t)y * s1h + x;
+        *self = (fl * o[(int64_t)y * s1h + lo] + fr * o[(int64_t)y * s1h + ro] +
+                 fu * o[(int64_t)uo * s1h + x] + fd * *self) / (fl + fr + fu + fd);
+    }
+}
+
+__global__ __launch_bounds__(256) void proj_fillhole_v4(
+    int W, int H, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch, int batch,
+    const float *__restrict__ count, float *out)
+{
+    const int w4 = W / 4;
+    const int64_t n = (int64_t)batch * H * w4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % w4) * 4;
+        const int y = (int)((i / w4) % H);
+        const int b = (int)(i / ((int64_t)w4 * H));
+        const float *cn = count + b * scb;
+        const f32x4 c = ld_cached4(cn + (int64_t)y * sch + x);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (c[j] <= 0.0f) fill_one_hole(x + j, y, W, H, s1c, s1h, sch, cn, out + b * s1b);
+    }
+}
+
+// Backward, tiled: the four corner reads of gradoutput / count (/ forward output) come from an LDS image of
+// the tile's target box -- one pixel quad (gx, gy, count, ox) per cell, plus a planar oy for the depth
+// operator -- instead of 8..16 scattered global loads per site.
+template <bool DEPTH>
+__global__ __launch_bounds__(256) void proj_bwd_tiled(
+    int W, int H, int tiles_x, int tiles_y,
+    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
+    const float *__restrict__ flow, const float *__restrict__ depth, const float *__restrict__ count,
+    const float *__restrict__ fwd_out, const float *__restrict__ gout,
+    float *__restrict__ gin1, float *__restrict__ gin2)
+{
+    constexpr int LX = 16;
+    using G = TileGeom<LX>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+    float *oyt = reinterpret_cast<float *>(smem + G::kCapPx * 16 + 64);     // DEPTH only: planar forward out y
+
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
+    const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
+    const bool inb = x < W && y < H;
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const float *flow_p = flow + b * s1b + (int64_t)ys * s1h + xs;
+    const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s1c);
+    f32x4 d4 = {1.f, 1.f, 1.f, 1.f};
+    if (DEPTH) d4 = ld_stream4(depth + b * sdb + (int64_t)ys * sdh + xs);
+    // gradinput buffers are `+=` targets (caller zero-fills them): read them with the other streams
+    float *g1p = gin1 + b * s1b + (int64_t)ys * s1h + xs;
+    f32x4 acc_x = ld_cached4(g1p), acc_y = ld_cached4(g1p + s1c);
+    f32x4 acc_d = {0.f, 0.f, 0.f, 0.f};
+    float *g2p = nullptr;
+    if (DEPTH) {
+        g2p = gin2 + b * sdb + (int64_t)ys * sdh + xs;
+        acc_d = ld_cached4(g2p);
+    }
+
+    BlSite st[4];
+    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        st[j] = bl_locate<false>(x + j, y, W, H, fx4[j], fy4[j]);
+        st[j].valid = st[j].valid && inb;
+        if (st[j].valid) {
+            cmin = min(cmin, st[j].L);  cmax = max(cmax, st[j].R);
+            rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
+        }
+    }
+    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    const float *go = gout + b * s1b, *cn = count + b * scb, *fo = DEPTH ? fwd_out + b * s1b : nullptr;
+    if (DEPTH) {
+        const float *const planes[4] = {go, go + s1c, cn, fo};
+        const int hs[4] = {s1h, s1h, sch, s1h};
+        tile_stage_planes<LX, 4>(r, planes, hs, tile);
+        // planar copy of forward out y
+        const float *foy = fo + s1c;
+        for (int i = threadIdx.x; i < r.h * (r.w / 4); i += G::kThreads) {
+            const int row = i / (r.w / 4), q = i % (r.w / 4);
+            *reinterpret_cast<f32x4 *>(oyt + row * G::kPitch + 4 * q) =
+                ld_cached4(foy + (int64_t)(r.y0 + row) * s1h + r.x0 + 4 * q);
+        }
+    } else {
+        const float *const planes[3] = {go, go + s1c, cn};
+        const int hs[3] = {s1h, s1h, sch};
+        tile_stage_planes<LX, 3>(r, planes, hs, tile);
+    }
+    __syncthreads();
+    if (!inb) return;
+
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!st[j].valid) continue;
+        const BlSite &s = st[j];
+        f32x4 q[4];          // (gx, gy, count, ox) at TL, TR, BL, BR
+        float oyv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r.covers(s.L, s.R, s.T, s.Bm)) {
+            const int rT = (s.T - r.y0) * G::kPitch, rB = (s.Bm - r.y0) * G::kPitch;
+            const int cL = s.L - r.x0, cR = s.R - r.x0;
+            q[0] = tile[rT + swz_col(cL)];  q[1] = tile[rT + swz_col(cR)];
+            q[2] = tile[rB + swz_col(cL)];  q[3] = tile[rB + swz_col(cR)];
+            if (DEPTH) { oyv[0] = oyt[rT + cL]; oyv[1] = oyt[rT + cR]; oyv[2] = oyt[rB + cL]; oyv[3] = oyt[rB + cR]; }
+        } else {
+            const int o[4] = {s.T * s1h + s.L, s.T * s1h + s.R, s.Bm * s1h + s.L, s.Bm * s1h + s.R};
+            const int c[4] = {s.T * sch + s.L, s.T * sch + s.R, s.Bm * sch + s.L, s.Bm * sch + s.R};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                q[k] = f32x4{go[o[k]], go[s1c + o[k]], cn[c[k]], DEPTH ? fo[o[k]] : 0.f};
+                if (DEPTH) oyv[k] = fo[s1c + o[k]];
+            }
+        }
+        float gx = acc_x[j], gy = acc_y[j], gd = acc_d[j];
+        if (DEPTH) {
+            const float d = d4[j];
+#pragma unroll
+            for (int k = 0; k < 4; k++) gx += -q[k][0] * d / q[k][2];
+#pragma unroll
+            for (int k = 0; k < 4; k++) gy += -q[k][1] * d / q[k][2];
+#pragma unroll
+            for (int k = 0; k < 4; k++) gd += -q[k][0] / q[k][2] * (fx4[j] - q[k][3]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) gd += -q[k][1] / q[k][2] * (fy4[j] - oyv[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) gx += -q[k][0] / q[k][2];
+#pragma unroll
+            for (int k = 0; k < 4; k++) gy += -q[k][1] / q[k][2];
+        }
+        acc_x[j] = gx;  acc_y[j] = gy;  acc_d[j] = gd;
+    }
+    *reinterpret_cast<f32x4 *>(g1p) = acc_x;
+    *reinterpret_cast<f32x4 *>(g1p + s1c) = acc_y;
+    if (DEPTH) *reinterpret_cast<f32x4 *>(g2p) = acc_d;
+}
+
 static int g_proj_variant = -1;
 
 template <bool DEPTH>
@@ -180,6 +476,33 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
                            const float *flow, const float *depth, float *count, float *out)
 {
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
+    const bool vec = vec4_ok(w, {s1b, s1c, s1h, sdb, sdh, scb, sch}, {flow, depth, count, out});
+    if (vec && g_proj_variant != 0) {
+        using G = TileGeom<16>;
+        using A = AccGeom<16>;
+        const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+        const unsigned nwg = (unsigned)ntx * nty * batch;
+#define MEMC_PROJ_SCATTER(ABL)                                                                             \
+    hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3(nwg), dim3(256), 3 * A::kPlane * 4 + 64, stream, w, \
+                       h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow,   \
+                       depth, count, out)
+        if (g_proj_variant == 2) MEMC_PROJ_SCATTER(2);
+        else if (g_proj_variant == 3) MEMC_PROJ_SCATTER(3);
+        else MEMC_PROJ_SCATTER(0);
+#undef MEMC_PROJ_SCATTER
+        if (g_proj_variant >= 2) return launch_status();   // ablation arms time the scatter pass alone
+        if (launch_status() != 0) return -1;
+        const unsigned gs = 256 * 8;                      // grid-stride: 8 workgroups per CU
+        hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c, s1h,
+                           (int64_t)scb, sch, batch, count, out);
+        if (launch_status() != 0) return -1;
+        if (fillhole) {
+            hipLaunchKernelGGL(proj_fillhole_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
+                               s1h, (int64_t)scb, sch, batch, count, out);
+            if (launch_status() != 0) return -1;
+        }
+        return 0;
+    }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
     hipLaunchKernelGGL(proj_scatter<DEPTH>, dim3(nwg), dim3(256), 0, stream, w, h, tiles_x, tiles_y,
@@ -203,6 +526,17 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
                            const float *gout, float *gin1, float *gin2)
 {
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
+    const bool vec = vec4_ok(w, {s1b, s1c, s1h, sdb, sdh, scb, sch}, {flow, depth, count, fwd_out, gout, gin1, gin2});
+    if (vec && g_proj_variant != 0) {
+        using G = TileGeom<16>;
+        const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+        const unsigned nwg = (unsigned)ntx * nty * batch;
+        const int lds = G::kCapPx * 16 + 64 + (DEPTH ? G::kCapPx * 4 : 0);
+        hipLaunchKernelGGL(proj_bwd_tiled<DEPTH>, dim3(nwg), dim3(256), lds, stream, w, h, ntx, nty, (int64_t)s1b,
+                           (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, fwd_out,
+                           gout, gin1, gin2);
+        return launch_status();
+    }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
     hipLaunchKernelGGL(proj_bwd<DEPTH>, dim3(nwg), dim3(256), 0, stream, w, h, tiles_x, tiles_y,

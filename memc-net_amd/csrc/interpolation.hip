@@ -11,6 +11,7 @@
 // and output writes); the four corner gathers of neighbouring lanes fall into the same few cache lines.
 #include "memc_common.hpp"
 #include "memc_internal.h"
+#include "memc_tile.hpp"
 
 namespace memc {
 
@@ -106,10 +107,251 @@ __global__ __launch_bounds__(256) void bl_bwd(
     st_stream(g2 + s2c, boty);
 }
 
+// ==================================================================================================
+// Vectorised, LDS-tiled production kernels (W % 4 == 0, 16-B aligned geometry): same machinery as the
+// adaptive warp (memc_tile.hpp) with a 2x2 footprint.  The scalar kernels above stay as the fallback.
+// ==================================================================================================
+struct BlSite4 {
+    int oTL[4], oTR[4], oBL[4], oBR[4];   // LDS pixel indices of the four corners (0 when not staged)
+    float w00[4], w01[4], w10[4], w11[4];
+    unsigned valid, staged;
+};
+
+template <int NCH>
+__device__ __forceinline__ void bl_fwd_chunk(const Region &r, const BlSite4 &g, const BlSite (&st)[4], bool inb,
+                                             const float *__restrict__ plane0, float *__restrict__ out_p,
+                                             int64_t s1c, int s1h, f32x4 *tile)
+{
+    tile_stage<16, NCH>(r, plane0, s1c, s1h, tile);
+    __syncthreads();
+    if (!inb) return;
+    f32x4 res[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        res[j] = g.w00[j] * tile[g.oTL[j]] + g.w01[j] * tile[g.oTR[j]] + g.w10[j] * tile[g.oBL[j]] +
+                 g.w11[j] * tile[g.oBR[j]];
+        const bool valid = (g.valid >> j) & 1, staged = (g.staged >> j) & 1;
+        if (valid && !staged) {               // rare: corners outside the staged box -> global gathers
+            const BlSite &s = st[j];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const float *p = plane0 + c * s1c;
+                res[j][c] = g.w00[j] * p[s.T * s1h + s.L] + g.w01[j] * p[s.T * s1h + s.R] +
+                            g.w10[j] * p[s.Bm * s1h + s.L] + g.w11[j] * p[s.Bm * s1h + s.R];
+            }
+        }
+        if (!valid) res[j] = f32x4{0.f, 0.f, 0.f, 0.f};     // out-of-range site -> 0 (my_lib_kernel.cu:566-570)
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+        st_stream4(out_p + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
+}
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
+    int W, int H, int C, int tiles_x, int tiles_y,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
+    const float *__restrict__ in1, const float *__restrict__ flow, float *__restrict__ out)
+{
+    constexpr int LX = 16;
+    using G = TileGeom<LX>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
+    const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
+    const bool inb = x < W && y < H;
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
+    const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s2c);
+
+    BlSite st[4];
+    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        st[j] = bl_locate<true>(x + j, y, W, H, fx4[j], fy4[j]);
+        st[j].valid = st[j].valid && inb;
+        if (st[j].valid) {
+            cmin = min(cmin, st[j].L);  cmax = max(cmax, st[j].R);
+            rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
+        }
+    }
+    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    BlSite4 g;
+    g.valid = g.staged = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const BlSite &s = st[j];
+        const bool staged = s.valid && r.covers(s.L, s.R, s.T, s.Bm);
+        g.valid |= (s.valid ? 1u : 0u) << j;
+        g.staged |= (staged ? 1u : 0u) << j;
+        const int rT = staged ? (s.T - r.y0) * G::kPitch : 0, rB = staged ? (s.Bm - r.y0) * G::kPitch : 0;
+        const int cL = staged ? swz_col(s.L - r.x0) : 0, cR = staged ? swz_col(s.R - r.x0) : 0;
+        g.oTL[j] = rT + cL;  g.oTR[j] = rT + cR;  g.oBL[j] = rB + cL;  g.oBR[j] = rB + cR;
+        g.w00[j] = (1 - s.a) * (1 - s.b);  g.w01[j] = s.a * (1 - s.b);
+        g.w10[j] = (1 - s.a) * s.b;        g.w11[j] = s.a * s.b;
+    }
+    const float *in_b = in1 + b * s1b;
+    float *out_p = out + b * s1b + (int64_t)y * s1h + x;
+    if (CT == 3) {
+        bl_fwd_chunk<3>(r, g, st, inb, in_b, out_p, s1c, s1h, tile);
+    } else {
+        int c0 = 0;
+#pragma unroll 1
+        for (; c0 + 4 <= C; c0 += 4) {
+            if (c0 > 0) __syncthreads();
+            bl_fwd_chunk<4>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
+        }
+        if (c0 < C) {
+            if (c0 > 0) __syncthreads();
+            const int nch = C - c0;
+            if (nch == 3)      bl_fwd_chunk<3>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
+            else if (nch == 2) bl_fwd_chunk<2>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
+            else               bl_fwd_chunk<1>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
+        }
+    }
+}
+
+// Backward, tiled, RGB: image gradient splatted into LDS accumulators and flushed with coalesced atomics
+// (memc_tile.hpp "LDS-privatised scatter"); the flow gradient needs the four corner values, gathered from a
+// staged LDS image of the same box.
+__global__ __launch_bounds__(256) void bl_bwd_tiled_c3(
+    int W, int H, int tiles_x, int tiles_y,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
+    const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
+    float *__restrict__ gin1, float *__restrict__ gin2)
+{
+    constexpr int LX = 16;
+    using G = TileGeom<LX>;
+    using A = AccGeom<LX>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+    float *acc = reinterpret_cast<float *>(smem + G::kCapPx * 16 + 64);
+
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
+    const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
+    const bool inb = x < W && y < H;
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
+    const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s2c);
+    const float *gout_p = gout + b * s1b + (int64_t)ys * s1h + xs;
+    f32x4 go[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) go[c] = ld_stream4(gout_p + c * s1c);
+
+    acc_zero<LX, 3>(acc);
+    BlSite st[4];
+    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        st[j] = bl_locate<true>(x + j, y, W, H, fx4[j], fy4[j]);
+        st[j].valid = st[j].valid && inb;
+        if (st[j].valid) {
+            cmin = min(cmin, st[j].L);  cmax = max(cmax, st[j].R);
+            rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
+        }
+    }
+    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    const float *in_b = in1 + b * s1b;
+    float *gin1_b = gin1 + b * s1b;
+    tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
+    __syncthreads();
+
+    f32x4 gx4 = {0.f, 0.f, 0.f, 0.f}, gy4 = gx4;
+    unsigned wrote = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!st[j].valid) continue;
+        const BlSite &s = st[j];
+        wrote |= 1u << j;
+        const float x2 = (float)(x + j) + fx4[j], y2 = (float)y + fy4[j];
+        const float gam_x = (float)s.Bm - y2, gam_y = (float)s.R - x2;
+        const bool staged = r.covers(s.L, s.R, s.T, s.Bm);
+        f32x4 vTL, vTR, vBL, vBR;
+        if (staged) {
+            const int rT = (s.T - r.y0) * G::kPitch, rB = (s.Bm - r.y0) * G::kPitch;
+            const int cL = swz_col(s.L - r.x0), cR = swz_col(s.R - r.x0);
+            vTL = tile[rT + cL];  vTR = tile[rT + cR];  vBL = tile[rB + cL];  vBR = tile[rB + cR];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float *p = in_b + c * s1c;
+                vTL[c] = p[s.T * s1h + s.L];   vTR[c] = p[s.T * s1h + s.R];
+                vBL[c] = p[s.Bm * s1h + s.L];  vBR[c] = p[s.Bm * s1h + s.R];
+            }
+        }
+        float botx = 0.0f, boty = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float gv = go[c][j];
+            const float a00 = gv * (1 - s.a) * (1 - s.b), a01 = gv * s.a * (1 - s.b);
+            const float a10 = gv * (1 - s.a) * s.b, a11 = gv * s.a * s.b;
+            if (staged) {
+                float *ap = acc + c * A::kPlane;
+                const int aT = (s.T - r.y0) * A::kPitch, aB = (s.Bm - r.y0) * A::kPitch;
+                const int aL = s.L - r.x0, aR = s.R - r.x0;
+                lds_add_f32(ap + aT + aL, a00);  lds_add_f32(ap + aT + aR, a01);
+                lds_add_f32(ap + aB + aL, a10);  lds_add_f32(ap + aB + aR, a11);
+            } else {
+                float *q = gin1_b + c * s1c;
+                atomic_add_f32(q + s.T * s1h + s.L, a00);   atomic_add_f32(q + s.T * s1h + s.R, a01);
+                atomic_add_f32(q + s.Bm * s1h + s.L, a10);  atomic_add_f32(q + s.Bm * s1h + s.R, a11);
+            }
+            float tmp = 0.0f;
+            tmp += gam_x * (vTR[c] - vTL[c]);
+            tmp += (1 - gam_x) * (vBR[c] - vBL[c]);
+            botx += gv * tmp;
+            tmp = 0.0f;
+            tmp += gam_y * (vBL[c] - vTL[c]);
+            tmp += (1 - gam_y) * (vBR[c] - vTR[c]);
+            boty += gv * tmp;
+        }
+        gx4[j] = botx;
+        gy4[j] = boty;
+    }
+    // gradinput2 is ASSIGNED at valid sites and untouched elsewhere (my_lib_kernel.cu:649,669)
+    if (inb) {
+        float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
+        if (wrote == 0xFu) {
+            st_stream4(g2, gx4);
+            st_stream4(g2 + s2c, gy4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if ((wrote >> j) & 1) {
+                    g2[j] = gx4[j];
+                    g2[s2c + j] = gy4[j];
+                }
+        }
+    }
+    __syncthreads();
+    float *const dst[3] = {gin1_b, gin1_b + s1c, gin1_b + 2 * s1c};
+    const int hs[3] = {s1h, s1h, s1h};
+    acc_flush<LX, 3>(r, acc, dst, hs);
+}
+
 static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batch, int s1b, int s1c, int s1h,
                          int s2b, int s2c, int s2h, const float *input1, const float *input2, float *output)
 {
     if (w <= 0 || h <= 0 || channel <= 0 || batch <= 0) return 0;
+    if (vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, output})) {
+        using G = TileGeom<16>;
+        const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+        const unsigned nwg_t = (unsigned)ntx * nty * batch;
+        if (channel == 3)
+            hipLaunchKernelGGL(bl_fwd_tiled<3>, dim3(nwg_t), dim3(256), tile_lds_bytes<16>(), stream, w, h, channel,
+                               ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1,
+                               input2, output);
+        else
+            hipLaunchKernelGGL(bl_fwd_tiled<0>, dim3(nwg_t), dim3(256), tile_lds_bytes<16>(), stream, w, h, channel,
+                               ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1,
+                               input2, output);
+        return launch_status();
+    }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
     if (channel == 3)
@@ -126,6 +368,17 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
                          const float *gradoutput, float *gradinput1, float *gradinput2)
 {
     if (w <= 0 || h <= 0 || channel <= 0 || batch <= 0) return 0;
+    if (channel == 3 && vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2})) {
+        using G = TileGeom<16>;
+        using A = AccGeom<16>;
+        const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+        const int lds = G::kCapPx * 16 + 64 + 3 * A::kPlane * 4;
+        static const bool once = (allow_big_lds(bl_bwd_tiled_c3, lds), true);
+        (void)once;
+        hipLaunchKernelGGL(bl_bwd_tiled_c3, dim3((unsigned)ntx * nty * batch), dim3(256), lds, stream, w, h, ntx, nty, (int64_t)s1b, (int64_t)s1c,
+                           s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, gradoutput, gradinput1, gradinput2);
+        return launch_status();
+    }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
     if (channel == 3)

@@ -126,4 +126,12 @@ inline int launch_status()
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Kernels that carve more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU) must opt in once.
+template <typename K>
+inline void allow_big_lds(K kernel, int bytes)
+{
+    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
 }  // namespace memc

@@ -131,22 +131,24 @@ __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int 
 // and they are unconditional -- lanes/rows outside the region read the plane's first element instead -- so
 // that no load result becomes a phi (see the note in fi_fwd_tiled_fs4) and one latency covers the batch.
 template <int LX, int NCH>
-__device__ __forceinline__ void tile_stage(const Region &r, const float *plane0, int64_t cstride, int hstride,
-                                           f32x4 *tile)
+__device__ __forceinline__ void tile_stage_planes(const Region &r, const float *const (&plane)[NCH],
+                                                  const int (&hstride)[NCH], f32x4 *tile)
 {
     using G = TileGeom<LX>;
     const int q = threadIdx.x & 31, row0 = threadIdx.x >> 5;
     const bool lane_on = 4 * q < r.w;
-    const float *src = plane0 + (int64_t)r.y0 * hstride + r.x0 + 4 * q;
 #pragma unroll
     for (int base = 0; base < G::kRows; base += 32) {
         f32x4 v[4][NCH];
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             const int row = base + row0 + 8 * it;
-            const float *p = (lane_on && row < r.h) ? src + (int64_t)row * hstride : plane0;
+            const bool on = lane_on && row < r.h;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) v[it][c] = ld_cached4(p + c * cstride);
+            for (int c = 0; c < NCH; c++) {
+                const float *p = on ? plane[c] + (int64_t)(r.y0 + row) * hstride[c] + r.x0 + 4 * q : plane[c];
+                v[it][c] = ld_cached4(p);
+            }
         }
 #pragma unroll
         for (int it = 0; it < 4; it++) {
@@ -163,6 +165,68 @@ __device__ __forceinline__ void tile_stage(const Region &r, const float *plane0,
             }
         }
     }
+}
+
+// channel planes of ONE tensor: plane c = plane0 + c * cstride, common row stride
+template <int LX, int NCH>
+__device__ __forceinline__ void tile_stage(const Region &r, const float *plane0, int64_t cstride, int hstride,
+                                           f32x4 *tile)
+{
+    const float *plane[NCH];
+    int hs[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        plane[c] = plane0 + c * cstride;
+        hs[c] = hstride;
+    }
+    tile_stage_planes<LX, NCH>(r, plane, hs, tile);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-privatised scatter.  The forward splat and every backward pass scatter fp32 adds to data-dependent
+// cells.  Issued straight to global memory those atomics arrive in ragged, misaligned runs and the chip
+// retires only ~50 G of them per second (measured on the reference-shaped kernels); fully coalesced ones run
+// at ~300 G/s (tools/probes).  So a workgroup accumulates its tile's contributions in LDS planes covering the
+// bounding box of its targets (ds_add_f32), then flushes each non-zero cell once with row-coalesced global
+// atomics -- still atomics, because neighbouring tiles' boxes overlap.  Targets outside the box (clipped to
+// the LDS budget) go to global memory directly.
+//
+// Accumulator layout: NP planes of kAccRows x kAccPitch floats; the odd pitch staggers rows over the banks.
+// ---------------------------------------------------------------------------------------------------------
+template <int LX>
+struct AccGeom {
+    using G = TileGeom<LX>;
+    static constexpr int kPitch = G::kPitch + 1;
+    static constexpr int kRows = G::kRows;
+    static constexpr int kPlane = kPitch * kRows;      // floats per plane
+};
+
+template <int LX, int NP>
+__device__ __forceinline__ void acc_zero(float *acc)
+{
+    using A = AccGeom<LX>;
+    for (int i = threadIdx.x; i < NP * A::kPlane; i += TileGeom<LX>::kThreads) acc[i] = 0.0f;
+}
+
+__device__ __forceinline__ void lds_add_f32(float *p, float v) { (void)unsafeAtomicAdd(p, v); }   // ds_add_f32
+
+// dst[pl] points at image pixel (0,0) of plane pl; hstride in elements.  Zero cells are skipped: adding +-0 to
+// the caller's buffer changes nothing.
+template <int LX, int NP>
+__device__ __forceinline__ void acc_flush(const Region &r, const float *acc, float *const (&dst)[NP],
+                                          const int (&hstride)[NP])
+{
+    using A = AccGeom<LX>;
+    // 64 lanes walk a region row (pitch <= 97 -> two passes), 4 waves take rows round-robin
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (int row = wave; row < r.h; row += TileGeom<LX>::kThreads / kWave)
+        for (int col = lane; col < r.w; col += kWave) {
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) {
+                const float v = acc[pl * A::kPlane + row * A::kPitch + col];
+                if (v != 0.0f) atomic_add_f32(dst[pl] + (int64_t)(r.y0 + row) * hstride[pl] + r.x0 + col, v);
+            }
+        }
 }
 
 }  // namespace memc

@@ -91,7 +91,7 @@ def bench_fi_bwd(rows, dev, B, C, H, W, flow_kind, tag):
            4 * (3 * C + 2 * (2 + 16)), med, mn)
 
 
-def bench_projection(rows, dev, B, H, W, flow_kind, tag):
+def bench_projection(rows, dev, B, H, W, flow_kind, tag, proj_variants=()):
     t = synth.torch_inputs(dev, B, 3, H, W, flow_kind=flow_kind, with_depth=True)
     f, d = t["flow"], t["depth"]
     cnt = f.new_zeros((B, 1, H, W))
@@ -102,6 +102,12 @@ def bench_projection(rows, dev, B, H, W, flow_kind, tag):
 
     def pre():
         cnt.zero_(); out.zero_()
+    for pv in proj_variants:
+        L._debug_set_variant("projection", pv)
+        med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0), pre)
+        report(rows, "flow_projection_fwd %s %dx%dx%d flow=%s ABLATION variant=%d" % (tag, B, H, W, flow_kind, pv),
+               B * H * W, 20, med, mn)
+    L._debug_set_variant("projection", -1)
     for fh in (0, 1):
         med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, fh), pre)
         report(rows, "flow_projection_fwd %s %dx%dx%d flow=%s fillhole=%d" % (tag, B, H, W, flow_kind, fh),
@@ -152,6 +158,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "bench_ops.json"))
     ap.add_argument("--variants", default="4,5,6,7,1")
+    ap.add_argument("--proj-variants", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     only = set(filter(None, args.only.split(",")))
@@ -176,7 +183,8 @@ def main():
         if not args.quick:
             bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "smooth", "720p")
     if want("proj"):
-        bench_projection(rows, dev, 32, 720, 1280, "smooth", "c3")
+        bench_projection(rows, dev, 32, 720, 1280, "smooth", "c3",
+                         [int(v) for v in args.proj_variants.split(",") if v])
         if not args.quick:
             bench_projection(rows, dev, 32, 720, 1280, "iid", "c3")
     if want("interp"):

@@ -68,6 +68,26 @@ __global__ __launch_bounds__(256) void read4(const f32x4 *__restrict__ a, float 
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;
 }
 
+// fp32 global atomic-add throughput: every lane adds to its own element (n elements, each exactly once per pass),
+// REP passes shifted by `shift` elements (shift 0: same lines again back to back; 1: the neighbouring element,
+// i.e. the same cache lines, as the 4-neighbour splat does).
+__global__ __launch_bounds__(256) void atomics(float *__restrict__ dst, int64_t n, int rep, int shift)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        for (int r = 0; r < rep; r++) (void)unsafeAtomicAdd(dst + ((i + (int64_t)r * shift) % n), 1.0f);
+}
+// the same update done as plain read-modify-write (no atomicity): what a non-atomic owner would pay
+__global__ __launch_bounds__(256) void rmw(f32x4 *__restrict__ dst, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] += 1.0f;
+}
+extern "C" int probe_atomics(void *stream, int variant, int blocks, float *dst, int64_t n, int rep, int shift)
+{
+    if (variant == 0) hipLaunchKernelGGL(atomics, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, n, rep, shift);
+    else hipLaunchKernelGGL(rmw, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (f32x4 *)dst, n / 4);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 #define LAUNCH(LX, NT, XCD, MINW)                                                                            \
     do {                                                                                                     \
         const int tx = (W + 4 * LX - 1) / (4 * LX), ty = (H + 256 / LX - 1) / (256 / LX);                    \

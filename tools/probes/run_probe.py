@@ -51,8 +51,24 @@ def main():
             print("%-14s blocks=%-6d %8.1f us  %7.1f GB/s" % (nm, blocks, t * 1e6, moved / t / 1e9), flush=True)
 
 
+def atomics_main():
+    lib = ctypes.CDLL(SO)
+    dev = torch.device("cuda:0")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lib.probe_atomics.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    n = 32 * 720 * 1280 * 3
+    d = torch.zeros(n, device=dev)
+    for rep, shift in ((1, 0), (4, 0), (4, 1), (4, 1280), (2, 1)):
+        t = timeit(lambda: lib.probe_atomics(st, 0, 16384, ctypes.c_void_p(d.data_ptr()), n, rep, shift))
+        print("atomics n=%d rep=%d shift=%-5d %9.1f us  %7.2f G atomics/s" % (n, rep, shift, t * 1e6, n * rep / t / 1e9), flush=True)
+    t = timeit(lambda: lib.probe_atomics(st, 1, 16384, ctypes.c_void_p(d.data_ptr()), n, 1, 0))
+    print("plain float4 += over the same %d elements %9.1f us  %7.1f GB/s (read+write)" % (n, t * 1e6, n * 8 / t / 1e9))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "build":
         build()
+    elif len(sys.argv) > 1 and sys.argv[1] == "atomics":
+        atomics_main()
     else:
         main()

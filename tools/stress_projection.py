@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Race screen: the tiled projection forward vs the scalar reference-shaped kernels on the same GPU, many
+random inputs; count must match bit-for-bit, out within 1e-4."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "memc-net_amd")):
+    sys.path.insert(0, p)
+import torch
+import my_package._ext.my_lib as L
+
+dev = torch.device("cuda:0")
+bad = 0
+for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
+    g = torch.Generator(device=dev); g.manual_seed(it)
+    B, H, W = 1 + it % 3, 16 * (1 + it % 9) + (it % 5), 64 * (1 + it % 4) + 4 * (it % 7)
+    sig = [1.0, 3.0, 8.0, 20.0][it % 4]
+    f = torch.randn(B, 2, H, W, device=dev, generator=g) * sig
+    d = torch.rand(B, 1, H, W, device=dev, generator=g) + 0.1
+    res = {}
+    for v in (0, -1):
+        L._debug_set_variant("projection", v)
+        for fh in (0, 1):
+            c = f.new_zeros(B, 1, H, W); o = torch.zeros_like(f)
+            assert L.FlowProjectionLayer_gpu_forward(f, c, o, fh) == 0
+            c2 = f.new_zeros(B, 1, H, W); o2 = torch.zeros_like(f)
+            assert L.DepthFlowProjectionLayer_gpu_forward(f, d, c2, o2, fh) == 0
+            res[(v, fh)] = (c, o, c2, o2)
+    torch.cuda.synchronize()
+    for fh in (0, 1):
+        a, b = res[(0, fh)], res[(-1, fh)]
+        ok = torch.equal(a[0], b[0]) and (a[1] - b[1]).abs().max().item() <= 1e-4 and \
+            (a[2] - b[2]).abs().max().item() <= 1e-4 and (a[3] - b[3]).abs().max().item() <= 2e-4
+        if not ok:
+            bad += 1
+            print("MISMATCH it=%d B=%d H=%d W=%d sig=%g fh=%d: count eq %s, out err %.3g, dcount err %.3g, dout err %.3g" % (
+                it, B, H, W, sig, fh, torch.equal(a[0], b[0]), (a[1] - b[1]).abs().max().item(),
+                (a[2] - b[2]).abs().max().item(), (a[3] - b[3]).abs().max().item()))
+            if not torch.equal(a[0], b[0]):
+                idx = (a[0] != b[0]).nonzero()
+                print("   count diffs:", idx.shape[0], idx[:5].tolist(), a[0][a[0] != b[0]][:5].tolist(), b[0][a[0] != b[0]][:5].tolist())
+L._debug_set_variant("projection", -1)
+print("stress done, mismatches:", bad)
