@@ -14,16 +14,12 @@ echo "== smoke";   timeout 600 python -c "import __graft_entry__ as g; g.smoke()
 echo "== pytest";  timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee "$OUT/pytest_gpu.log"
 echo "== sweep";   timeout 900 python tools/bench_ops.py ${QUICK:+--quick} --json "$OUT/bench_ops.json" 2>&1 | tee "$OUT/bench_ops.log"
 echo "== bench";   timeout 600 python bench.py 2>&1 | tail -3 | tee "$OUT/bench.log"
+echo "== race screen"; timeout 600 python tools/stress_projection.py 60 2>&1 | tail -3 | tee "$OUT/stress.log"
 cd /tmp && export TMPDIR=/tmp
-echo "== rocprof kernel trace"
+echo "== rocprof kernel trace of bench.py (same command as the bench line above, fewer steps)"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_trace" -o bench -- python "$REPO/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/prof_trace.log" 2>&1
-tail -2 "$OUT/prof_trace.log"
-for CTR in FETCH_SIZE WRITE_SIZE; do
-  echo "== rocprof pmc $CTR"
-  timeout 600 rocprofv3 --pmc $CTR --kernel-trace -d "$OUT/prof_pmc_$CTR" -o bench -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/prof_pmc_$CTR.log" 2>&1
-  tail -2 "$OUT/prof_pmc_$CTR.log"
-done
-cd "$REPO"
-# keep only the summaries (the raw traces can be large)
-find "$OUT" -name "*.csv" -size +8M -delete
-ls -R "$OUT" | head -50
+python "$REPO/tools/prof_summary.py" stats "$OUT/prof_trace/bench_results.db" --out "$OUT/bench_kernel_stats.txt" | head -6
+rm -rf "$OUT/prof_trace"
+echo "== PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a known copy)"
+cd "$REPO" && timeout 900 python tools/pmc_traffic.py --out "$OUT" 2>&1 | tail -30
+ls "$OUT"

@@ -65,8 +65,23 @@ def atomics_main():
     print("plain float4 += over the same %d elements %9.1f us  %7.1f GB/s (read+write)" % (n, t * 1e6, n * 8 / t / 1e9))
 
 
+def copy_only():
+    """a few launches of the float4 copy of known size (calibration source for tools/pmc_traffic.py)"""
+    lib = ctypes.CDLL(SO)
+    dev = torch.device("cuda:0")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lib.probe_copy.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    n4 = 32 * 720 * 1280 * 96 // 32
+    a = torch.rand(n4 * 4, device=dev); b = torch.empty_like(a)
+    for _ in range(6):
+        lib.probe_copy(st, 1, 65536, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n4)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "build":
+    if len(sys.argv) > 1 and sys.argv[1] == "copyonly":
+        copy_only()
+    elif len(sys.argv) > 1 and sys.argv[1] == "build":
         build()
     elif len(sys.argv) > 1 and sys.argv[1] == "atomics":
         atomics_main()
