@@ -106,7 +106,7 @@ __device__ __forceinline__ void fi_gather_store(
         const bool staged = valid && r.covers(co[0], co[3], ro[0], ro[3]);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            ro[k] = staged ? (ro[k] - r.y0) * G::kPitch : 0;
+            ro[k] = staged ? (ro[k] - r.y0) * r.pitch : 0;
             co[k] = staged ? swz_col(co[k] - r.x0) : 0;
         }
         // quadrant sums, row-major inside each quadrant as in the reference (rows 0,1 top; 2,3 bottom)
@@ -152,125 +152,83 @@ __device__ __forceinline__ void fi_fwd_chunk(
 }
 
 // --------------------------------------------------------------------------------------------------
-// Forward, fs == 4, RGB: PERSISTENT variant of the tiled kernel.  One workgroup walks many tiles and
-// requests the NEXT tile's flow while it works on the current one, so that a tile's source box is known
-// the moment the workgroup gets to it and the staging loads, the 16 tap planes and the next flow all go
-// out together: one exposed memory latency per tile instead of two (flow -> box -> staging).
-// Workgroup b is observed on XCD b % 8; it takes every (blocks-per-XCD)-th tile of that XCD's contiguous
-// chunk, so the tiles in flight on one XCD are neighbours and share halo rows in its L2 (measured:
-// FETCH_SIZE equals the algorithmic read bytes with this order, 1.3x with blockIdx order).
+// Forward, fs == 4, channel count a multiple of 4 (the 64-channel context warp, MEMC_Net_star.py:281-285):
+// software-pipelined over chunks of four channels.  The chunk loop of fi_fwd_tiled_fs4<.., 0, ..> exposes one
+// L2/HBM round trip per chunk (stage -> barrier -> gather -> barrier); here the NEXT chunk's rows are already
+// on their way to registers while the current chunk is gathered from LDS, so the round trip hides behind
+// ~1 us of FMA work per chunk (at C = 64 the operator is about as VALU-bound as it is HBM-bound).
 // --------------------------------------------------------------------------------------------------
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void fi_fwd_persist_c3(
-    int W, int H, int tiles_x, int tiles_y, unsigned ntiles,
+__global__ __launch_bounds__(256, 2) void fi_fwd_tiled_c4n(
+    int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
     float *__restrict__ out)
 {
     constexpr int LX = 16;
     using G = TileGeom<LX>;
-    static_assert(G::kRows <= 32, "staging below keeps at most 4 rows per lane in registers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
 
-    // this workgroup's tile sequence: t0, t0 + step, ... inside its XCD's chunk [cbeg, cend)
-    const unsigned xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds;
-    const unsigned step = gridDim.x / kXcds + (xcd < gridDim.x % kXcds ? 1u : 0u);
-    const unsigned q = ntiles / kXcds, rem = ntiles % kXcds;
-    const unsigned cbeg = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-    const unsigned cend = cbeg + q + (xcd < rem ? 1u : 0u);
-    unsigned t = cbeg + slot;
-    if (t >= cend) return;
-
-    const int lx4 = 4 * (threadIdx.x % LX), ly = threadIdx.x / LX;
-    const unsigned per_img = (unsigned)tiles_x * tiles_y;
-    int b = t / per_img, tile_x0 = (t % per_img % tiles_x) * G::kTW, tile_y0 = (t % per_img / tiles_x) * G::kTH;
-    int x = tile_x0 + lx4, y = tile_y0 + ly;
-    bool inb = x < W && y < H;
-    // all loads are unconditional at clamped addresses (see fi_fwd_tiled_fs4)
-    const float *fp0 = flow + b * s2b + (int64_t)min(y, H - 1) * s2h + min(x, W - 4);
-    f32x4 fx4 = ld_stream4(fp0), fy4 = ld_stream4(fp0 + s2c);
-    for (;;) {
-        // site geometry, source box (one barrier; it also fences the previous tile's LDS gathers)
-        FiSite4 g;
-        g.valid = 0;
-        int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
+    const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
+    const bool inb = x < W && y < H;
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
+    const float *tap_p = filt + b * s3b + (int64_t)ys * s3h + xs;
+    const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s2c);
+    f32x4 tp[16];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
-            g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
-            if (inb && s.valid) {
-                g.valid |= 1u << j;
-                cmin = min(cmin, max(s.ix - 1, 0));  cmax = max(cmax, min(s.ix + 2, W - 1));
-                rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
-            }
+    for (int k = 0; k < 16; k++) tp[k] = ld_stream4(tap_p + k * s3c);
+
+    FiSite4 g;
+    g.valid = 0;
+    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
+        g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
+        if (inb && s.valid) {
+            g.valid |= 1u << j;
+            cmin = min(cmin, max(s.ix - 1, 0));  cmax = max(cmax, min(s.ix + 2, W - 1));
+            rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
         }
-        const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
-        unsigned slow = 0;
+    }
+    const Region r = tile_region<LX, true>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    unsigned slow = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (((g.valid >> j) & 1) &&
-                !r.covers(max(g.ix[j] - 1, 0), min(g.ix[j] + 2, W - 1), max(g.iy[j] - 1, 0), min(g.iy[j] + 2, H - 1)))
-                slow |= 1u << j;
+    for (int j = 0; j < 4; j++)
+        if (((g.valid >> j) & 1) &&
+            !r.covers(max(g.ix[j] - 1, 0), min(g.ix[j] + 2, W - 1), max(g.iy[j] - 1, 0), min(g.iy[j] + 2, H - 1)))
+            slow |= 1u << j;
 
-        // all of this tile's loads go out back to back: staging (to registers), taps, next tile's flow
-        const float *in_b = in1 + b * s1b;
-        const int sq = threadIdx.x & 31, srow0 = threadIdx.x >> 5;
-        const bool sact = 4 * sq < r.w;
-        const float *src = in_b + (int64_t)r.y0 * s1h + r.x0 + 4 * sq;
-        f32x4 sv[4][3];
-#pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int row = srow0 + 8 * it;
-            const float *p = (sact && row < r.h) ? src + (int64_t)row * s1h : in_b;
-#pragma unroll
-            for (int c = 0; c < 3; c++) sv[it][c] = ld_cached4(p + c * s1c);
-        }
-        const int xs = min(x, W - 4), ys = min(y, H - 1);
-        const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
-        const float *tap_p = filt + b * s3b + (int64_t)ys * s3h + xs;
-        f32x4 tp[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) tp[k] = ld_stream4(tap_p + k * s3c);
-        float *out_p = out + b * s1b + (int64_t)y * s1h + x;
-        const int cur_x = x, cur_y = y;
-        const bool cur_inb = inb;
-
-        // next tile (the last iteration re-reads its own flow: harmless, keeps the load unconditional)
-        const unsigned tn = t + step;
-        const unsigned tl = tn < cend ? tn : t;
-        b = tl / per_img;
-        tile_x0 = (tl % per_img % tiles_x) * G::kTW;
-        tile_y0 = (tl % per_img / tiles_x) * G::kTH;
-        x = tile_x0 + lx4;
-        y = tile_y0 + ly;
-        inb = x < W && y < H;
-        const float *fpn = flow + b * s2b + (int64_t)min(y, H - 1) * s2h + min(x, W - 4);
-        const f32x4 nfx = ld_stream4(fpn), nfy = ld_stream4(fpn + s2c);
-
-        // staged rows -> LDS pixel quads
-#pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int row = srow0 + 8 * it;
-            if (sact && row < r.h) {
-                f32x4 *dst = tile + row * G::kPitch;
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    dst[swz_col(4 * sq + i)] = f32x4{sv[it][0][i], sv[it][1][i], sv[it][2][i], 0.f};
-            }
-        }
+    const float *in_b = in1 + b * s1b;
+    float *out_p = out + b * s1b + (int64_t)y * s1h + x;
+    const StageSlot sl = stage_slots(r);
+    StageRegs<4> sr;
+    tile_stage_load<4>(r, sl, in_b, s1c, s1h, sr);
+#pragma unroll 1
+    for (int c0 = 0; c0 < C; c0 += 4) {
+        tile_stage_store<4>(r, sl, sr, tile);
         __syncthreads();
-        fi_gather_store<LX, 3>(r, g, tp, cur_inb, cur_x, cur_y, W, H, in_b, out_p, s1c, s1h, tile);
-        while (slow) {                        // rare: windows outside the staged region, redone from global
-            const int j = __ffs(slow) - 1;
-            slow &= slow - 1;
-            fi_site_scalar(cur_x + j, cur_y, W, H, 3, 4, in_b, s1c, s1h, flow_p + j, s2c, tap_p + j, s3c, out_p + j);
-        }
-        if (tn >= cend) break;
-        t = tn;
-        fx4 = nfx;
-        fy4 = nfy;
+        // next chunk's rows: in flight while this chunk is gathered (the last iteration re-reads its own
+        // chunk -- harmless, keeps the loads unconditional)
+        const int cn = c0 + 4 < C ? c0 + 4 : c0;
+        tile_stage_load<4>(r, sl, in_b + cn * s1c, s1c, s1h, sr);
+        // keep the loop-invariant tap splats / LDS addresses inside the loop (see fi_fwd_tiled_fs4)
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
+#pragma unroll
+        for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
+        fi_gather_store<LX, 4>(r, g, tp, inb, x, y, W, H, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
+        __syncthreads();
+    }
+    while (slow) {
+        const int j = __ffs(slow) - 1;
+        slow &= slow - 1;
+        fi_site_scalar(x + j, y, W, H, C, 4, in_b, s1c, s1h, flow_p + j, s2c, tap_p + j, s3c, out_p + j);
     }
 }
 
@@ -297,6 +255,11 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     } else if (ABL == 1) {                                 // hardware order (measurement arm)
         const unsigned t = blockIdx.x;
         tx = t % tiles_x;  ty = (t / tiles_x) % tiles_y;  b = t / (tiles_x * tiles_y);
+    } else if (ABL == 5 || ABL == 6) {                     // stripes 2 / 4 tile columns wide
+        const TileCoord tc = ABL == 5 ? stripe_walk<2>(blockIdx.x, gridDim.x, tiles_x, tiles_y)
+                                      : stripe_walk<4>(blockIdx.x, gridDim.x, tiles_x, tiles_y);
+        tx = tc.tx;  ty = tc.ty;  b = tc.b;
+        if (tx >= tiles_x) return;
     } else {
         const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
         tx = tc.tx;  ty = tc.ty;  b = tc.b;
@@ -314,9 +277,32 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     const float *tap_p = filt + b * s3b + (int64_t)ys * s3h + xs;
     const f32x4 fx4 = ld_stream4(flow_p);
     const f32x4 fy4 = ld_stream4(flow_p + s2c);
+    // ABL == 11 (and the production RGB path once measured): only the first 8 tap planes go out now; the
+    // other 8 are issued AFTER the staging loads, so that the wait for the staged rows (vmcnt counts in issue
+    // order) leaves half of the tap stream in flight under the LDS writes and the barrier.
+    constexpr bool kSplitTaps = (ABL == 11) && CT == 3 && LX == 16;
     f32x4 tp[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) tp[k] = ld_stream4(tap_p + k * s3c);
+    for (int k = 0; k < (kSplitTaps ? 8 : 16); k++) tp[k] = ld_stream4(tap_p + k * s3c);
+
+    // L2 prefetch of a FUTURE tile's flow (measurement arms ABL 7/9/10 only -- see DESIGN.md: it LOSES).  The flow -> box -> staging chain is the only
+    // serial dependency of a tile; its first link is a full HBM miss.  The tile that this XCD will start
+    // ~kAhead workgroups from now gets its 8 KiB of flow pulled into the XCD's L2 here, behind this tile's own
+    // loads (no extra traffic: the bytes are read from HBM exactly once, just earlier).
+    // One dword per 128-B line is enough to fetch the line: the tile's flow is 16 rows x 2 components x 256 B
+    // = 64 lines = one dword per lane of one wave-instruction (every wave issues the same one; 1 VGPR).
+    float pf = 0.0f;
+    if (ABL == 7 || ABL == 9 || ABL == 10) {
+        constexpr unsigned kAhead = ABL == 7 ? 32 : (ABL == 9 ? 64 : 96);
+        const int pa = strip_ahead(blockIdx.x, gridDim.x, kAhead);
+        const TileCoord fc = strip_at(pa < 0 ? 0 : pa, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+        const int l = threadIdx.x & (kWave - 1);
+        const int px = min(fc.tx * G::kTW + (l & 1) * 32, W - 4);
+        const int py = min(fc.ty * G::kTH + ((l & 31) >> 1), H - 1);
+        // past the end of the walk: re-read this tile's own flow (harmless; keeps the load unconditional)
+        const float *pp = pa < 0 ? flow_p : flow + fc.b * s2b + (l >> 5) * s2c + (int64_t)py * s2h + px;
+        pf = *pp;
+    }
 
     // 2. site geometry and this lane's source box
     FiSite4 g;
@@ -332,7 +318,7 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
             rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
         }
     }
-    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    const Region r = tile_region<LX, true>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
     unsigned slow = 0;                        // valid sites whose window is not inside the staged region
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -343,7 +329,18 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     // 3./4. channels, four at a time
     const float *in_b = in1 + b * s1b;
     float *out_p = out + b * s1b + (int64_t)y * s1h + x;
-    if (CT == 3) {
+    if constexpr (kSplitTaps) {
+        const StageSlot sl = stage_slots(r);
+        StageRegs<3> sr;
+        tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);
+        // the address depends (vacuously) on the region so that the scheduler cannot hoist these loads
+        const float *tap_late = tap_p + (r.w < 0 ? 1 : 0);
+#pragma unroll
+        for (int k = 8; k < 16; k++) tp[k] = ld_stream4(tap_late + k * s3c);
+        tile_stage_store<3>(r, sl, sr, tile);
+        __syncthreads();
+        fi_gather_store<LX, 3, ABL>(r, g, tp, inb, x, y, W, H, in_b, out_p, s1c, s1h, tile);
+    } else if (CT == 3) {
         fi_fwd_chunk<LX, 3, ABL>(r, g, tp, inb, x, y, W, H, in_b, out_p, s1c, s1h, tile);
     } else {
         int c0 = 0;
@@ -376,6 +373,7 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
         slow &= slow - 1;
         fi_site_scalar(x + j, y, W, H, C, 4, in_b, s1c, s1h, flow_p + j, s2c, tap_p + j, s3c, out_p + j);
     }
+    asm volatile("" ::"v"(pf));               // the prefetch load must be issued; its value is unused
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -744,7 +742,7 @@ __global__ __launch_bounds__(256) void fi_bwd_tiled_c3(
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int m = 0; m < 4; m++) v[k * 4 + m] = tile[(ro[k] - r.y0) * G::kPitch + swz_col(co[m] - r.x0)];
+            for (int m = 0; m < 4; m++) v[k * 4 + m] = tile[(ro[k] - r.y0) * r.pitch + swz_col(co[m] - r.x0)];
         float botx = 0.0f, boty = 0.0f;
         const float gam_x = 1.0f - bt, gam_y = 1.0f - a;
 #pragma unroll
@@ -938,24 +936,33 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             MEMC_FI_TILED_A(16, 3, 2, 3);
         } else if (variant == 11 && channel == 3) {
             MEMC_FI_TILED_A(16, 3, 3, 4);
-        } else if ((variant == 12 || variant == 13 || variant == 14) && channel == 3) {
+        } else if ((variant == 15 || variant == 16 || variant == 17) && channel == 3) {
             using G = TileGeom<16>;
             const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-            const unsigned ntiles = (unsigned)ntx * nty * batch;
-            const unsigned per_cu = variant == 14 ? 3 : 2;
-            const unsigned grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
-            if (variant == 13)
-                hipLaunchKernelGGL(fi_fwd_persist_c3<1>, dim3(grid), dim3(256), tile_lds_bytes<16>(), stream, w, h,
-                                   ntx, nty, ntiles, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
-                                   (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
-            else if (variant == 14)
-                hipLaunchKernelGGL(fi_fwd_persist_c3<3>, dim3(grid), dim3(256), tile_lds_bytes<16>(), stream, w, h,
-                                   ntx, nty, ntiles, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
-                                   (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
-            else
-                hipLaunchKernelGGL(fi_fwd_persist_c3<2>, dim3(grid), dim3(256), tile_lds_bytes<16>(), stream, w, h,
-                                   ntx, nty, ntiles, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
-                                   (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
+            const int sw = variant == 15 ? 2 : 4;
+            const unsigned grid = (unsigned)((ntx + sw - 1) / sw * sw) * nty * batch;
+#define MEMC_FI_STRIPE(ABL, MINW)                                                                              \
+            hipLaunchKernelGGL((fi_fwd_tiled_fs4<16, 3, MINW, ABL>), dim3(grid), dim3(256), tile_lds_bytes<16>(),  \
+                               stream, w, h, channel, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,     \
+                               (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output)
+            if (variant == 15) MEMC_FI_STRIPE(5, 2);
+            else if (variant == 16) MEMC_FI_STRIPE(6, 2);
+            else MEMC_FI_STRIPE(4, 2);                     // 17: row-major chunk per XCD at 2 waves/SIMD
+        } else if (variant == 18 && channel == 3) {
+            MEMC_FI_TILED_A(16, 3, 2, 7);                  // flow prefetch 32 / 64 / 96 positions ahead (18/19/20)
+        } else if (variant == 19 && channel == 3) {
+            MEMC_FI_TILED_A(16, 3, 2, 9);
+        } else if (variant == 20 && channel == 3) {
+            MEMC_FI_TILED_A(16, 3, 2, 10);
+        } else if (variant == 21 && channel == 3) {
+            MEMC_FI_TILED_A(16, 3, 2, 11);                 // split tap stream around the staging loads
+#undef MEMC_FI_STRIPE
+        } else if (channel % 4 == 0 && channel >= 8 && variant != 4 && variant != 6) {
+            using G = TileGeom<16>;
+            const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+            hipLaunchKernelGGL(fi_fwd_tiled_c4n, dim3((unsigned)ntx * nty * batch), dim3(256), tile_lds_bytes<16>(),
+                               stream, w, h, channel, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,
+                               (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
         } else if (variant == 4) {
             if (channel == 3) MEMC_FI_TILED(16, 3, 3); else MEMC_FI_TILED(16, 0, 3);
         } else {                                           // default: 64x16 tiles, strip walk

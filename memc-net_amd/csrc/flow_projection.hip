@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
             rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
         }
     }
-    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    const Region r = tile_region<LX, true>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
     const float *go = gout + b * s1b, *cn = count + b * scb, *fo = DEPTH ? fwd_out + b * s1b : nullptr;
     if (DEPTH) {
         const float *const planes[4] = {go, go + s1c, cn, fo};
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
         const float *foy = fo + s1c;
         for (int i = threadIdx.x; i < r.h * (r.w / 4); i += G::kThreads) {
             const int row = i / (r.w / 4), q = i % (r.w / 4);
-            *reinterpret_cast<f32x4 *>(oyt + row * G::kPitch + 4 * q) =
+            *reinterpret_cast<f32x4 *>(oyt + row * r.pitch + 4 * q) =
                 ld_cached4(foy + (int64_t)(r.y0 + row) * s1h + r.x0 + 4 * q);
         }
     } else {
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
         f32x4 q[4];          // (gx, gy, count, ox) at TL, TR, BL, BR
         float oyv[4] = {0.f, 0.f, 0.f, 0.f};
         if (r.covers(s.L, s.R, s.T, s.Bm)) {
-            const int rT = (s.T - r.y0) * G::kPitch, rB = (s.Bm - r.y0) * G::kPitch;
+            const int rT = (s.T - r.y0) * r.pitch, rB = (s.Bm - r.y0) * r.pitch;
             const int cL = s.L - r.x0, cR = s.R - r.x0;
             q[0] = tile[rT + swz_col(cL)];  q[1] = tile[rT + swz_col(cR)];
             q[2] = tile[rB + swz_col(cL)];  q[3] = tile[rB + swz_col(cR)];

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
             rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
         }
     }
-    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    const Region r = tile_region<LX, true>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
     BlSite4 g;
     g.valid = g.staged = 0;
 #pragma unroll
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
         const bool staged = s.valid && r.covers(s.L, s.R, s.T, s.Bm);
         g.valid |= (s.valid ? 1u : 0u) << j;
         g.staged |= (staged ? 1u : 0u) << j;
-        const int rT = staged ? (s.T - r.y0) * G::kPitch : 0, rB = staged ? (s.Bm - r.y0) * G::kPitch : 0;
+        const int rT = staged ? (s.T - r.y0) * r.pitch : 0, rB = staged ? (s.Bm - r.y0) * r.pitch : 0;
         const int cL = staged ? swz_col(s.L - r.x0) : 0, cR = staged ? swz_col(s.R - r.x0) : 0;
         g.oTL[j] = rT + cL;  g.oTR[j] = rT + cR;  g.oBL[j] = rB + cL;  g.oBR[j] = rB + cR;
         g.w00[j] = (1 - s.a) * (1 - s.b);  g.w01[j] = s.a * (1 - s.b);
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void bl_bwd_tiled_c3(
         const bool staged = r.covers(s.L, s.R, s.T, s.Bm);
         f32x4 vTL, vTR, vBL, vBR;
         if (staged) {
-            const int rT = (s.T - r.y0) * G::kPitch, rB = (s.Bm - r.y0) * G::kPitch;
+            const int rT = (s.T - r.y0) * r.pitch, rB = (s.Bm - r.y0) * r.pitch;
             const int cL = swz_col(s.L - r.x0), cR = swz_col(s.R - r.x0);
             vTL = tile[rT + cL];  vTR = tile[rT + cR];  vBL = tile[rB + cL];  vBR = tile[rB + cR];
         } else {

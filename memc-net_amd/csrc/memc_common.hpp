@@ -40,9 +40,9 @@ struct TileCoord {
     int b, tx, ty;
 };
 
-__device__ __forceinline__ TileCoord strip_walk(unsigned bid, unsigned nwg, int tiles_x, int tiles_y, int batch)
+// tile at position p of the XCD-major order
+__device__ __forceinline__ TileCoord strip_at(unsigned p, int tiles_x, int tiles_y, int batch)
 {
-    const unsigned p = xcd_chunked_id(bid, nwg);
     const unsigned S = (unsigned)tiles_x * batch;          // strips
     const unsigned Q = S / kXcds, R = S % kXcds;
     const unsigned big = (Q + 1) * tiles_y;                // tiles of an XCD class that owns Q+1 strips
@@ -60,6 +60,55 @@ __device__ __forceinline__ TileCoord strip_walk(unsigned bid, unsigned nwg, int 
     c.ty = rem % tiles_y;
     c.b = s / tiles_x;
     c.tx = s % tiles_x;
+    return c;
+}
+
+__device__ __forceinline__ TileCoord strip_walk(unsigned bid, unsigned nwg, int tiles_x, int tiles_y, int batch)
+{
+    return strip_at(xcd_chunked_id(bid, nwg), tiles_x, tiles_y, batch);
+}
+
+// Position `ahead` places later in the SAME XCD's part of the walk (what a workgroup dispatched ~`ahead`/8 slots
+// later on this XCD will process), or -1 past the end of this XCD's chunk.  Used to pull that tile's flow into
+// this XCD's L2 before its workgroup starts.
+__device__ __forceinline__ int strip_ahead(unsigned bid, unsigned nwg, unsigned ahead)
+{
+    const unsigned q = nwg / kXcds, r = nwg % kXcds, xcd = bid % kXcds;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const unsigned end = base + q + (xcd < r ? 1u : 0u);
+    const unsigned p = base + bid / kXcds + ahead;
+    return p < end ? (int)p : -1;
+}
+
+// Same idea with stripes SW tile columns wide, walked row-major inside the stripe: horizontal neighbours then
+// also share an XCD (and are in flight together).  The grid is launched over ceil(tiles_x / SW) * SW virtual
+// columns per image; tiles with tx >= tiles_x do not exist (the caller returns at once).
+template <int SW>
+__device__ __forceinline__ TileCoord stripe_walk(unsigned bid, unsigned nwg, int tiles_x, int tiles_y)
+{
+    const int stripes_x = (tiles_x + SW - 1) / SW;
+    const int batch = nwg / (stripes_x * SW * tiles_y);
+    // position in XCD-major order, in units of tiles; a stripe holds SW * tiles_y tiles
+    const unsigned p = xcd_chunked_id(bid, nwg);
+    const unsigned per = SW * tiles_y;
+    const unsigned S = (unsigned)stripes_x * batch;        // stripes
+    const unsigned Q = S / kXcds, R = S % kXcds;
+    const unsigned big = (Q + 1) * per;
+    unsigned k, rem;
+    if (p < R * big) {
+        k = p / big;
+        rem = p % big;
+    } else {
+        const unsigned pp = p - R * big, small = Q * per;
+        k = R + pp / small;
+        rem = pp % small;
+    }
+    const unsigned s = k + kXcds * (rem / per);
+    const unsigned in_stripe = rem % per;
+    TileCoord c;
+    c.b = s / stripes_x;
+    c.tx = (s % stripes_x) * SW + in_stripe % SW;
+    c.ty = in_stripe / SW;
     return c;
 }
 

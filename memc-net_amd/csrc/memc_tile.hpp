@@ -64,9 +64,24 @@ struct TileGeom {
 template <int LX>
 constexpr int tile_lds_bytes() { return TileGeom<LX>::kCapPx * 16 + 64; }
 
+// min over the 64 lanes of a wave, returned in every lane (wave-uniform)
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    // row_shr:1,2,4,8 inside each row of 16 lanes; lanes without a source keep their own value
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    // lane 15 of every row now holds the row minimum
+    const int a = __builtin_amdgcn_readlane(v, 15), b = __builtin_amdgcn_readlane(v, 31);
+    const int c = __builtin_amdgcn_readlane(v, 47), d = __builtin_amdgcn_readlane(v, 63);
+    return min(min(a, b), min(c, d));
+}
+
 struct Region {
     int x0, y0;      // image coordinates of LDS pixel (0,0); x0 % 4 == 0
     int w, h;        // staged extent (w % 4 == 0); 0 when nothing is staged
+    int pitch;       // LDS row pitch of the pixel-quad image, a multiple of 16 pixels (swizzle span)
     __device__ __forceinline__ bool covers(int cmin, int cmax, int rmin, int rmax) const
     {
         return cmin >= x0 && cmax < x0 + w && rmin >= y0 && rmax < y0 + h;
@@ -76,18 +91,19 @@ struct Region {
 // Workgroup-wide bounding box of the clamped source windows [cmin,cmax] x [rmin,rmax] of all valid sites,
 // fitted to the LDS budget.  Each lane passes the box of its own (up to four) valid sites, or an empty box
 // (cmin > cmax).  One __syncthreads.
-template <int LX>
+// DYN: the pixel-quad image uses the narrowest pitch (multiple of 16) that holds the box, which buys rows:
+// 96 -> 32 rows, 80 -> 38, 64 -> 48.  Kernels that also keep fixed-shape accumulator planes pass DYN = false.
+template <int LX, bool DYN = false>
 __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int rmax, int tile_x0, int tile_y0,
                                               int *bb /* 16 ints in LDS */)
 {
     using G = TileGeom<LX>;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        cmin = min(cmin, __shfl_xor(cmin, off));
-        cmax = max(cmax, __shfl_xor(cmax, off));
-        rmin = min(rmin, __shfl_xor(rmin, off));
-        rmax = max(rmax, __shfl_xor(rmax, off));
-    }
+    // wave-level reduction on the VALU/SALU only (DPP row shifts, then the four row leaders through readlane);
+    // ds_bpermute-based shuffles would put ~700 clocks of LDS round trips on the tile's critical chain
+    cmin = wave_min_i32(cmin);
+    cmax = -wave_min_i32(-cmax);
+    rmin = wave_min_i32(rmin);
+    rmax = -wave_min_i32(-rmax);
     const int wave = threadIdx.x / kWave;
     if ((threadIdx.x & (kWave - 1)) == 0) {
         bb[wave * 4 + 0] = cmin;
@@ -106,6 +122,7 @@ __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int 
     Region r;
     if (cmin > cmax) {          // no valid site in this tile
         r.x0 = r.y0 = r.w = r.h = 0;
+        r.pitch = G::kPitch;
         return r;
     }
     int x0 = cmin & ~3, w = (cmax | 3) + 1 - x0;
@@ -115,12 +132,14 @@ __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int 
         x0 = min(max((tile_x0 + G::kTW / 2 - G::kPitch / 2) & ~3, lo), hi);
         w = G::kPitch;
     }
-    if (h > G::kRows) {
-        const int lo = y0, hi = y0 + h - G::kRows;
-        y0 = min(max(tile_y0 + G::kTH / 2 - G::kRows / 2, lo), hi);
-        h = G::kRows;
+    const int pitch = DYN ? ((w + 15) & ~15) : G::kPitch;
+    const int rows = DYN ? G::kCapPx / pitch : G::kRows;
+    if (h > rows) {
+        const int lo = y0, hi = y0 + h - rows;
+        y0 = min(max(tile_y0 + G::kTH / 2 - rows / 2, lo), hi);
+        h = rows;
     }
-    r.x0 = x0; r.y0 = y0; r.w = w; r.h = h;
+    r.x0 = x0; r.y0 = y0; r.w = w; r.h = h; r.pitch = pitch;
     return r;
 }
 
@@ -130,41 +149,96 @@ __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int 
 // Rows are handled in batches of 32 (4 passes): all loads of a batch are issued before the first LDS write,
 // and they are unconditional -- lanes/rows outside the region read the plane's first element instead -- so
 // that no load result becomes a phi (see the note in fi_fwd_tiled_fs4) and one latency covers the batch.
+// Work split of the staging: the box is r.h rows of r.w / 4 float4 columns; the 256 lanes take float4 slots
+// round-robin in row-major order, kStageIts = 3 slots each (3 * 256 * 4 px = the whole 3072-pixel budget).
+// All loads are issued before the first LDS write and are unconditional -- slots past the end of the box read
+// the plane's first element -- so that no load result becomes a phi (see fi_fwd_tiled_fs4).
+constexpr int kStageIts = 3;
+
+struct StageSlot {
+    int row[kStageIts], q[kStageIts];      // q = float4 column; row >= r.h marks an empty slot
+};
+
+__device__ __forceinline__ StageSlot stage_slots(const Region &r)
+{
+    StageSlot s;
+    const int wq = max(r.w >> 2, 1);
+    int row = threadIdx.x / wq, q = threadIdx.x % wq;          // one run-time division per kernel
+    const int drow = 256 / wq, dq = 256 % wq;
+#pragma unroll
+    for (int it = 0; it < kStageIts; it++) {
+        s.row[it] = r.w > 0 ? row : r.h;
+        s.q[it] = q;
+        q += dq;
+        row += drow + (q >= wq ? 1 : 0);
+        q -= q >= wq ? wq : 0;
+    }
+    return s;
+}
+
+template <int NCH>
+struct StageRegs {
+    f32x4 v[kStageIts][NCH];
+};
+
+template <int NCH>
+__device__ __forceinline__ void tile_stage_load_planes(const Region &r, const StageSlot &sl,
+                                                       const float *const (&plane)[NCH], const int (&hstride)[NCH],
+                                                       StageRegs<NCH> &sr)
+{
+#pragma unroll
+    for (int it = 0; it < kStageIts; it++) {
+        const bool on = sl.row[it] < r.h;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const float *p = on ? plane[c] + (int64_t)(r.y0 + sl.row[it]) * hstride[c] + r.x0 + 4 * sl.q[it] : plane[c];
+            sr.v[it][c] = ld_cached4(p);
+        }
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void tile_stage_store(const Region &r, const StageSlot &sl, const StageRegs<NCH> &sr,
+                                                 f32x4 *tile)
+{
+#pragma unroll
+    for (int it = 0; it < kStageIts; it++) {
+        if (sl.row[it] < r.h) {
+            f32x4 *dst = tile + sl.row[it] * r.pitch;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                f32x4 px = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NCH; c++) px[c] = sr.v[it][c][i];
+                dst[swz_col(4 * sl.q[it] + i)] = px;
+            }
+        }
+    }
+}
+
+template <int NCH>
+__device__ __forceinline__ void tile_stage_load(const Region &r, const StageSlot &sl, const float *plane0,
+                                                int64_t cstride, int hstride, StageRegs<NCH> &sr)
+{
+    const float *plane[NCH];
+    int hs[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        plane[c] = plane0 + c * cstride;
+        hs[c] = hstride;
+    }
+    tile_stage_load_planes<NCH>(r, sl, plane, hs, sr);
+}
+
 template <int LX, int NCH>
 __device__ __forceinline__ void tile_stage_planes(const Region &r, const float *const (&plane)[NCH],
                                                   const int (&hstride)[NCH], f32x4 *tile)
 {
-    using G = TileGeom<LX>;
-    const int q = threadIdx.x & 31, row0 = threadIdx.x >> 5;
-    const bool lane_on = 4 * q < r.w;
-#pragma unroll
-    for (int base = 0; base < G::kRows; base += 32) {
-        f32x4 v[4][NCH];
-#pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int row = base + row0 + 8 * it;
-            const bool on = lane_on && row < r.h;
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const float *p = on ? plane[c] + (int64_t)(r.y0 + row) * hstride[c] + r.x0 + 4 * q : plane[c];
-                v[it][c] = ld_cached4(p);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 4; it++) {
-            const int row = base + row0 + 8 * it;
-            if (lane_on && row < r.h) {
-                f32x4 *dst = tile + row * G::kPitch;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    f32x4 px = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) px[c] = v[it][c][i];
-                    dst[swz_col(4 * q + i)] = px;
-                }
-            }
-        }
-    }
+    static_assert(TileGeom<LX>::kCapPx <= kStageIts * 256 * 4, "three float4 slots per lane cover the budget");
+    const StageSlot sl = stage_slots(r);
+    StageRegs<NCH> sr;
+    tile_stage_load_planes<NCH>(r, sl, plane, hstride, sr);
+    tile_stage_store<NCH>(r, sl, sr, tile);
 }
 
 // channel planes of ONE tensor: plane c = plane0 + c * cstride, common row stride
