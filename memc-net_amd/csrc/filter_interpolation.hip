@@ -86,6 +86,54 @@ __device__ __noinline__ void fi_site_scalar(int x, int y, int W, int H, int nch,
 // afterwards by fi_site_scalar (at the end of the kernel, once for all channels).
 __device__ __forceinline__ float a_dummy(int v) { return __int_as_float(v); }   // ablation arm only
 
+// Gather + blend of the sites selected by `sel` (bit j) from the staged band; other sites keep their `res`.
+// Branch-free: unselected sites still issue their 16 LDS reads (at pixel 0, harmless).
+template <int LX, int NCH>
+__device__ __forceinline__ void fi_gather(const Region &r, const FiSite4 &g, const f32x4 (&tp)[16], unsigned sel,
+                                          int W, int H, const f32x4 *tile, f32x4 (&res)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool on = (sel >> j) & 1;
+        int ro[4], co[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ro[k] = on ? (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch : 0;
+            co[k] = on ? swz_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0) : 0;
+        }
+        // quadrant sums, row-major inside each quadrant as in the reference (rows 0,1 top; 2,3 bottom)
+        f32x4 TL = {0.f, 0.f, 0.f, 0.f}, TR = TL, BL = TL, BR = TL;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            f32x4 v[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) v[m] = tile[ro[k] + co[m]];
+            if (k < 2) {
+                TL += v[0] * tp[k * 4 + 0][j];  TL += v[1] * tp[k * 4 + 1][j];
+                TR += v[2] * tp[k * 4 + 2][j];  TR += v[3] * tp[k * 4 + 3][j];
+            } else {
+                BL += v[0] * tp[k * 4 + 0][j];  BL += v[1] * tp[k * 4 + 1][j];
+                BR += v[2] * tp[k * 4 + 2][j];  BR += v[3] * tp[k * 4 + 3][j];
+            }
+        }
+        const float a = g.a[j], bt = g.b[j];
+        const f32x4 val = ((1 - a) * (1 - bt)) * TL + (a * (1 - bt)) * TR + ((1 - a) * bt) * BL + (a * bt) * BR;
+        res[j] = on ? val : res[j];
+    }
+}
+
+// sites of this lane whose (clamped) window lies inside the band
+__device__ __forceinline__ unsigned fi_covered(const Region &r, const FiSite4 &g, int W, int H)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (((g.valid >> j) & 1) &&
+            r.covers(max(g.ix[j] - 1, 0), min(g.ix[j] + 2, W - 1), max(g.iy[j] - 1, 0), min(g.iy[j] + 2, H - 1)))
+            m |= 1u << j;
+    return m;
+}
+
 template <int LX, int NCH, int ABL = 0>
 __device__ __forceinline__ void fi_gather_store(
     const Region &r, const FiSite4 &g, const f32x4 (&tp)[16], bool inb, int x, int y, int W, int H,
@@ -195,36 +243,67 @@ __global__ __launch_bounds__(256, 2) void fi_fwd_tiled_c4n(
             rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
         }
     }
-    const Region r = tile_region<LX, true>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
-    unsigned slow = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-        if (((g.valid >> j) & 1) &&
-            !r.covers(max(g.ix[j] - 1, 0), min(g.ix[j] + 2, W - 1), max(g.iy[j] - 1, 0), min(g.iy[j] + 2, H - 1)))
-            slow |= 1u << j;
-
+    const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
+    const Bands bands = make_bands<LX>(box);
     const float *in_b = in1 + b * s1b;
     float *out_p = out + b * s1b + (int64_t)y * s1h + x;
-    const StageSlot sl = stage_slots(r);
-    StageRegs<4> sr;
-    tile_stage_load<4>(r, sl, in_b, s1c, s1h, sr);
+    unsigned done = 0;
 #pragma unroll 1
-    for (int c0 = 0; c0 < C; c0 += 4) {
-        tile_stage_store<4>(r, sl, sr, tile);
-        __syncthreads();
-        // next chunk's rows: in flight while this chunk is gathered (the last iteration re-reads its own
-        // chunk -- harmless, keeps the loads unconditional)
-        const int cn = c0 + 4 < C ? c0 + 4 : c0;
-        tile_stage_load<4>(r, sl, in_b + cn * s1c, s1c, s1h, sr);
-        // keep the loop-invariant tap splats / LDS addresses inside the loop (see fi_fwd_tiled_fs4)
+    for (int bi = 0; bi < bands.n; bi++) {
+        const Region r = band_region(box, bands, bi);
+        const unsigned sel = inb ? fi_covered(r, g, W, H) & ~done : 0u;
+        // later bands only run when somebody still needs them; the vote is also the barrier that frees the LDS
+        if (bi > 0 && !__syncthreads_or(sel != 0)) continue;
+        done |= sel;
+        // band 0 also writes the out-of-range sites (they copy the input pixel)
+        const unsigned wr = sel | (bi == 0 && inb ? ~g.valid & 0xFu : 0u);
+        const StageSlot sl = stage_slots(r);
+        StageRegs<4> sr;
+        tile_stage_load<4>(r, sl, in_b, s1c, s1h, sr);
+#pragma unroll 1
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            tile_stage_store<4>(r, sl, sr, tile);
+            __syncthreads();
+            // next chunk's rows: in flight while this chunk is gathered (the last iteration re-reads its own
+            // chunk -- harmless, keeps the loads unconditional)
+            const int cn = c0 + 4 < C ? c0 + 4 : c0;
+            tile_stage_load<4>(r, sl, in_b + cn * s1c, s1c, s1h, sr);
+            // keep the loop-invariant tap splats / LDS addresses inside the loop (see fi_fwd_tiled_fs4)
 #pragma unroll
-        for (int k = 0; k < 16; k++)
-            asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
+            for (int k = 0; k < 16; k++)
+                asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
 #pragma unroll
-        for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
-        fi_gather_store<LX, 4>(r, g, tp, inb, x, y, W, H, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
-        __syncthreads();
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
+            f32x4 res[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) res[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            fi_gather<LX, 4>(r, g, tp, sel, W, H, tile, res);
+            const float *plane0 = in_b + c0 * s1c;
+            float *o = out_p + c0 * s1c;
+            if (wr & ~g.valid) {                           // out-of-range sites copy the input pixel
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const f32x4 own = ld_cached4(plane0 + c * s1c + (int64_t)y * s1h + x);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (!((g.valid >> j) & 1)) res[j][c] = own[j];
+                }
+            }
+            if (wr == 0xFu) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) st_stream4(o + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
+            } else if (wr) {                               // a lane whose sites are split over bands
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((wr >> j) & 1) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) o[c * s1c + j] = res[j][c];
+                    }
+            }
+            __syncthreads();
+        }
     }
+    unsigned slow = inb ? g.valid & ~done : 0u;            // not coverable within kMaxBands bands
     while (slow) {
         const int j = __ffs(slow) - 1;
         slow &= slow - 1;
@@ -318,13 +397,11 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
             rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
         }
     }
-    const Region r = tile_region<LX, true>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
-    unsigned slow = 0;                        // valid sites whose window is not inside the staged region
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-        if (((g.valid >> j) & 1) &&
-            !r.covers(max(g.ix[j] - 1, 0), min(g.ix[j] + 2, W - 1), max(g.iy[j] - 1, 0), min(g.iy[j] + 2, H - 1)))
-            slow |= 1u << j;
+    // 3. source box, swept in bands when it does not fit the LDS budget (memc_tile.hpp)
+    const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
+    const Bands bands = make_bands<LX>(box);
+    const Region r = band_region(box, bands, 0);
+    unsigned slow = inb ? g.valid & ~fi_covered(r, g, W, H) : 0u;   // sites outside the first band
 
     // 3./4. channels, four at a time
     const float *in_b = in1 + b * s1b;
@@ -340,6 +417,43 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
         tile_stage_store<3>(r, sl, sr, tile);
         __syncthreads();
         fi_gather_store<LX, 3, ABL>(r, g, tp, inb, x, y, W, H, in_b, out_p, s1c, s1h, tile);
+    } else if (CT == 3 && ABL == 0) {
+        // production RGB path: band loop, results kept in registers until every band has run
+        f32x4 res[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) res[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned done = 0;
+#pragma unroll 1
+        for (int bi = 0; bi < bands.n; bi++) {
+            const Region rb = band_region(box, bands, bi);
+            const unsigned sel = inb ? fi_covered(rb, g, W, H) & ~done : 0u;
+            if (bi > 0 && !__syncthreads_or(sel != 0)) continue;
+            done |= sel;
+            tile_stage<LX, 3>(rb, in_b, s1c, s1h, tile);
+            __syncthreads();
+            // keep tap splats / blend weights inside the loop (hoisted, they spill: see the chunk loop below)
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
+            fi_gather<LX, 3>(rb, g, tp, sel, W, H, tile, res);
+        }
+        slow = inb ? g.valid & ~done : 0u;
+        if (inb) {
+            if (g.valid != 0xFu) {                         // out-of-range sites copy the input pixel
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const f32x4 own = ld_cached4(in_b + c * s1c + (int64_t)y * s1h + x);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (!((g.valid >> j) & 1)) res[j][c] = own[j];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                st_stream4(out_p + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
+        }
     } else if (CT == 3) {
         fi_fwd_chunk<LX, 3, ABL>(r, g, tp, inb, x, y, W, H, in_b, out_p, s1c, s1h, tile);
     } else {

@@ -119,6 +119,10 @@ __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int 
         rmin = min(rmin, bb[w * 4 + 2]);
         rmax = max(rmax, bb[w * 4 + 3]);
     }
+    cmin = __builtin_amdgcn_readfirstlane(cmin);
+    cmax = __builtin_amdgcn_readfirstlane(cmax);
+    rmin = __builtin_amdgcn_readfirstlane(rmin);
+    rmax = __builtin_amdgcn_readfirstlane(rmax);
     Region r;
     if (cmin > cmax) {          // no valid site in this tile
         r.x0 = r.y0 = r.w = r.h = 0;
@@ -149,6 +153,95 @@ __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int 
 // Rows are handled in batches of 32 (4 passes): all loads of a batch are issued before the first LDS write,
 // and they are unconditional -- lanes/rows outside the region read the plane's first element instead -- so
 // that no load result becomes a phi (see the note in fi_fwd_tiled_fs4) and one latency covers the batch.
+// ---------------------------------------------------------------------------------------------------------
+// Bands: when a tile's source box does not fit the LDS budget (large or discontinuous motion) the pure-gather
+// kernels do not drop to scalar code; they sweep the box in overlapping sub-boxes ("bands"), one stage ->
+// gather round per band.  Bands overlap by >= 3 rows / columns, so every 4x4 (or 2x2) window lies wholly inside
+// at least one band.  At most kMaxBands rounds; what is still uncovered after that (pathological motion) goes
+// to the scalar path.  Ordinary tiles have exactly one band and pay nothing for this.
+// ---------------------------------------------------------------------------------------------------------
+struct BBox {
+    int x0, w, y0, h;          // unclipped box, x0 % 4 == 0, w % 4 == 0; w == 0: no valid site
+};
+
+constexpr int kMaxBands = 6;
+
+struct Bands {
+    int nbx, nby, n;           // band grid, n = min(nbx * nby, kMaxBands)
+    int bw, bh, pitch;         // band extent and LDS pitch
+    int sx, sy;                // band steps
+};
+
+// Workgroup-wide box of the lanes' boxes (DPP / readlane reduction + one barrier), not clipped.
+template <int LX>
+__device__ __forceinline__ BBox tile_bbox(int cmin, int cmax, int rmin, int rmax, int *bb /* 16 ints in LDS */)
+{
+    using G = TileGeom<LX>;
+    cmin = wave_min_i32(cmin);
+    cmax = -wave_min_i32(-cmax);
+    rmin = wave_min_i32(rmin);
+    rmax = -wave_min_i32(-rmax);
+    const int wave = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        bb[wave * 4 + 0] = cmin;
+        bb[wave * 4 + 1] = cmax;
+        bb[wave * 4 + 2] = rmin;
+        bb[wave * 4 + 3] = rmax;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < G::kThreads / kWave; w++) {
+        cmin = min(cmin, bb[w * 4 + 0]);
+        cmax = max(cmax, bb[w * 4 + 1]);
+        rmin = min(rmin, bb[w * 4 + 2]);
+        rmax = max(rmax, bb[w * 4 + 3]);
+    }
+    // the box is workgroup-uniform: keep it (and everything derived from it) in scalar registers
+    cmin = __builtin_amdgcn_readfirstlane(cmin);
+    cmax = __builtin_amdgcn_readfirstlane(cmax);
+    rmin = __builtin_amdgcn_readfirstlane(rmin);
+    rmax = __builtin_amdgcn_readfirstlane(rmax);
+    BBox b;
+    if (cmin > cmax) {
+        b.x0 = b.y0 = b.w = b.h = 0;
+    } else {
+        b.x0 = cmin & ~3;
+        b.w = (cmax | 3) + 1 - b.x0;
+        b.y0 = rmin;
+        b.h = rmax + 1 - rmin;
+    }
+    return b;
+}
+
+template <int LX>
+__device__ __forceinline__ Bands make_bands(const BBox &b)
+{
+    using G = TileGeom<LX>;
+    Bands d;
+    d.bw = min(b.w, G::kPitch);
+    d.pitch = max((d.bw + 15) & ~15, 16);
+    const int rows = G::kCapPx / d.pitch;
+    d.bh = min(b.h, rows);
+    d.sx = (G::kPitch - 4) & ~3;                               // 92: overlap 4 columns
+    d.sy = rows - 3;                                           // overlap 3 rows
+    d.nbx = b.w > d.bw ? (b.w - d.bw + d.sx - 1) / d.sx + 1 : 1;
+    d.nby = b.h > d.bh ? (b.h - d.bh + d.sy - 1) / d.sy + 1 : 1;
+    d.n = b.w == 0 ? 1 : min(d.nbx * d.nby, kMaxBands);
+    return d;
+}
+
+__device__ __forceinline__ Region band_region(const BBox &b, const Bands &d, int i)
+{
+    Region r;
+    const int bi = i % d.nbx, bj = i / d.nbx;
+    r.x0 = min(b.x0 + bi * d.sx, b.x0 + b.w - d.bw);
+    r.y0 = min(b.y0 + bj * d.sy, b.y0 + b.h - d.bh);
+    r.w = d.bw;
+    r.h = d.bh;
+    r.pitch = d.pitch;
+    return r;
+}
+
 // Work split of the staging: the box is r.h rows of r.w / 4 float4 columns; the 256 lanes take float4 slots
 // round-robin in row-major order, kStageIts = 3 slots each (3 * 256 * 4 px = the whole 3072-pixel budget).
 // All loads are issued before the first LDS write and are unconditional -- slots past the end of the box read
