@@ -336,22 +336,71 @@ __device__ __forceinline__ void fill_one_hole(int x, int y, int W, int H, int64_
     }
 }
 
+// count-plane reader for the walks: LDS copy of the workgroup's neighbourhood when the cell is inside it,
+// global memory otherwise (a walk that leaves the neighbourhood is rare and simply continues there)
+struct CountView {
+    const float *lds;      // [kFhRows][kFhPitch] floats
+    const float *glob;     // count plane of this image
+    int x0, y0, w, h, sch; // staged neighbourhood (image coordinates) and the global row stride
+    __device__ __forceinline__ float at(int y, int x) const
+    {
+        const int ly = y - y0, lx = x - x0;
+        if ((unsigned)ly < (unsigned)h && (unsigned)lx < (unsigned)w) return lds[ly * 80 + lx];
+        return glob[(int64_t)y * sch + x];
+    }
+};
+constexpr int kFhPitch = 80, kFhRows = 24;     // 64x16 tile + 8 columns left/right, 8 rows above (no downward search)
+
+__device__ __forceinline__ void fill_one_hole_lds(int x, int y, int W, int H, int64_t s1c, int s1h,
+                                                  const CountView &cv, float *o)
+{
+    int lo = x;  float lt = 0.0f;
+    while (lt == 0.0f && lo - 1 >= 0) { lo--; lt = cv.at(y, lo); }
+    int ro = x;  float rt = 0.0f;
+    while (rt == 0.0f && ro + 1 <= W - 1) { ro++; rt = cv.at(y, ro); }
+    int uo = y;  float ut = 0.0f;
+    while (ut == 0.0f && uo - 1 >= 0) { uo--; ut = cv.at(uo, x); }
+    const float dt = 0.0f;                                  // dead downward search (my_lib_kernel.cu:1799)
+    if (lt + rt + ut + dt <= 0.0f) return;
+    const float fl = lt > 0.0f ? 1.0f : 0.0f, fr = rt > 0.0f ? 1.0f : 0.0f;
+    const float fu = ut > 0.0f ? 1.0f : 0.0f, fd = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; k++, o += s1c) {
+        float *self = o + (int64_t)y * s1h + x;
+        *self = (fl * o[(int64_t)y * s1h + lo] + fr * o[(int64_t)y * s1h + ro] +
+                 fu * o[(int64_t)uo * s1h + x] + fd * *self) / (fl + fr + fu + fd);
+    }
+}
+
+// Pass 3, tiled: every hole's walk is a chain of DEPENDENT reads of `count` (each an L2 round trip from global
+// memory); the workgroup therefore copies the count cells around its 64x16 tile into LDS first and walks there.
 __global__ __launch_bounds__(256) void proj_fillhole_v4(
-    int W, int H, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch, int batch,
+    int W, int H, int tiles_x, int tiles_y, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch,
     const float *__restrict__ count, float *out)
 {
-    const int w4 = W / 4;
-    const int64_t n = (int64_t)batch * H * w4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int x = (int)(i % w4) * 4;
-        const int y = (int)((i / w4) % H);
-        const int b = (int)(i / ((int64_t)w4 * H));
-        const float *cn = count + b * scb;
-        const f32x4 c = ld_cached4(cn + (int64_t)y * sch + x);
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (c[j] <= 0.0f) fill_one_hole(x + j, y, W, H, s1c, s1h, sch, cn, out + b * s1b);
+    __shared__ __attribute__((aligned(16))) float cnt_lds[kFhRows * kFhPitch];
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const int b = tc.b, tile_x0 = tc.tx * 64, tile_y0 = tc.ty * 16;
+    const float *cn = count + b * scb;
+    CountView cv;
+    cv.lds = cnt_lds;  cv.glob = cn;  cv.sch = sch;
+    cv.x0 = max(tile_x0 - 8, 0);
+    cv.y0 = max(tile_y0 - 8, 0);
+    cv.w = min(tile_x0 + 64 + 8, W) - cv.x0;                // multiple of 4 (W % 4 == 0)
+    cv.h = min(tile_y0 + 16, H) - cv.y0;
+    const int wq = cv.w / 4;
+    for (int i = threadIdx.x; i < cv.h * wq; i += 256) {
+        const int row = i / wq, q = i % wq;
+        *reinterpret_cast<f32x4 *>(cnt_lds + row * kFhPitch + 4 * q) =
+            ld_cached4(cn + (int64_t)(cv.y0 + row) * sch + cv.x0 + 4 * q);
     }
+    __syncthreads();
+    const int x = tile_x0 + 4 * (threadIdx.x % 16), y = tile_y0 + threadIdx.x / 16;
+    if (x >= W || y >= H) return;
+    const float *own = cnt_lds + (y - cv.y0) * kFhPitch + (x - cv.x0);
+#pragma unroll 1
+    for (int j = 0; j < 4; j++)
+        if (own[j] <= 0.0f) fill_one_hole_lds(x + j, y, W, H, s1c, s1h, cv, out + b * s1b);
 }
 
 // Backward, tiled: the four corner reads of gradoutput / count (/ forward output) come from an LDS image of
@@ -497,8 +546,8 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
                            (int64_t)scb, sch, batch, count, out);
         if (launch_status() != 0) return -1;
         if (fillhole) {
-            hipLaunchKernelGGL(proj_fillhole_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
-                               s1h, (int64_t)scb, sch, batch, count, out);
+            hipLaunchKernelGGL(proj_fillhole_v4, dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
+                               (int64_t)s1c, s1h, (int64_t)scb, sch, count, out);
             if (launch_status() != 0) return -1;
         }
         return 0;

@@ -61,6 +61,10 @@ CASES = [
     (1, 7, 20, 64, "smooth", 4.0, 11),     # 4 + 3
     (2, 3, 100, 132, "smooth", 8.0, 12),   # ragged tiles (132 = 2 * 64 + 4, 100 = 6 * 16 + 4)
     (1, 8, 48, 96, "iid", 3.0, 13),        # two full chunks
+    # source boxes beyond the LDS budget: band sweep (and, past 6 bands, the scalar path)
+    (1, 8, 64, 128, "smooth", 14.0, 14),   # pipelined multi-chunk kernel, several bands, lanes split over bands
+    (1, 12, 40, 128, "iid", 8.0, 15),
+    (1, 3, 96, 256, "smooth", 25.0, 16),
 ]
 IDS = ["%dx%dx%dx%d-%s" % c[:5] for c in CASES]
 
