@@ -184,12 +184,12 @@ __global__ __launch_bounds__(256) void proj_bwd(
 //     P[T][L] += v                                   (one add per plane per site: the "point splat")
 //     out[y][x] += sum_{dy,dx in {0,1}} wy * wx * P[y-dy][x-dx]        (a 2x2 box sum, a pure gather)
 // with wx = 2 for (x == W-1, dx == 0) and 1 otherwise (the clamped right neighbour R = min(L+1, W-1) coincides
-// with L on the last column, which the reference adds twice), likewise wy on the last row.  LDS fp32 atomics
-// are the scarce resource here (ds_add_f32 retires ~0.35 lane-ops per clock per CU, measured), so the point
-// splat goes to LDS planes covering the bounding box of the tile's (T, L) points -- 3 adds per site instead of
-// 12 -- and the box sum is evaluated when the box is flushed, once per cell, with row-coalesced global
-// atomics (neighbouring tiles' boxes overlap).  Sites whose point falls outside the LDS budget scatter their
-// 12 adds straight to global memory.
+// with L on the last column, which the reference adds twice), likewise wy on the last row.  The point splat goes
+// to LDS planes covering the bounding box of the tile's (T, L) points -- WITHOUT LDS atomics (ds_add_f32
+// retires only ~0.35 lane-ops per clock per CU, measured): sites sharing a cell are serialised by tag
+// arbitration (see below) -- and the box sum is evaluated when the box is flushed, once per cell, with
+// row-coalesced global atomics (neighbouring tiles' boxes overlap).  Sites whose point falls outside the LDS
+// budget scatter their 12 adds straight to global memory.
 // ABL (measurement arms, results WRONG): 2 = no flush, 3 = no LDS adds.
 template <bool DEPTH, int ABL>
 __global__ __launch_bounds__(256) void proj_scatter_tiled(
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
     using A = AccGeom<LX>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *acc = reinterpret_cast<float *>(smem);
-    int *bb = reinterpret_cast<int *>(smem + 3 * A::kPlane * 4);
+    int *bb = reinterpret_cast<int *>(smem + 4 * A::kPlane * 4);
 
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
@@ -215,7 +215,13 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
     f32x4 d4 = {1.f, 1.f, 1.f, 1.f};
     if (DEPTH) d4 = ld_stream4(depth + b * sdb + (int64_t)ys * sdh + xs);
 
-    acc_zero<LX, 3>(acc);
+    // zero the three value planes and set the tag plane to "free" (vector stores)
+    {
+        f32x4 *a4 = reinterpret_cast<f32x4 *>(acc);
+        for (int i = threadIdx.x; i < 3 * A::kPlane / 4; i += G::kThreads) a4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int *tag0 = reinterpret_cast<int *>(acc + 3 * A::kPlane);
+        for (int i = threadIdx.x; i < A::kPlane; i += G::kThreads) tag0[i] = -1;
+    }
     BlSite st[4];
     int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
 #pragma unroll
@@ -228,34 +234,68 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
         }
     }
     // the flush also writes column cmax+1 / row rmax+1 (the R / B neighbours), which need no LDS cell
-    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);   // barrier: acc is zero too
+    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);   // barrier: planes are ready
 
     float *ox = out + b * s1b, *oy = ox + s1c, *cn = count + b * scb;
+    int *tag = reinterpret_cast<int *>(acc + 3 * A::kPlane);
+    float vx[4], vy[4], vc[4];
+    int cell[4];
+    unsigned pending = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        if (!st[j].valid || ABL == 3) continue;
         const BlSite &s = st[j];
-        float vx = -fx4[j], vy = -fy4[j], vc = 1.0f;
+        vx[j] = -fx4[j];  vy[j] = -fy4[j];  vc[j] = 1.0f;
         if (DEPTH) {
-            vx = -d4[j] * fx4[j];
-            vy = -d4[j] * fy4[j];
-            vc = d4[j] * 1.0f;
+            vx[j] = -d4[j] * fx4[j];
+            vy[j] = -d4[j] * fy4[j];
+            vc[j] = d4[j] * 1.0f;
         }
+        cell[j] = 0;
+        if (!s.valid || ABL == 3) continue;
         if (r.covers(s.L, s.L, s.T, s.T)) {
-            const int o = (s.T - r.y0) * A::kPitch + (s.L - r.x0);
-            lds_add_f32(acc + o, vx);
-            lds_add_f32(acc + A::kPlane + o, vy);
-            lds_add_f32(acc + 2 * A::kPlane + o, vc);
+            cell[j] = (s.T - r.y0) * A::kPitch + (s.L - r.x0);
+            pending |= 1u << j;
         } else {                              // point clipped out of the LDS budget: straight to global
             const int oT = s.T * s1h, oB = s.Bm * s1h, cT = s.T * sch, cB = s.Bm * sch;
-            atomic_add_f32(ox + oT + s.L, vx);  atomic_add_f32(ox + oT + s.R, vx);
-            atomic_add_f32(ox + oB + s.L, vx);  atomic_add_f32(ox + oB + s.R, vx);
-            atomic_add_f32(oy + oT + s.L, vy);  atomic_add_f32(oy + oT + s.R, vy);
-            atomic_add_f32(oy + oB + s.L, vy);  atomic_add_f32(oy + oB + s.R, vy);
-            atomic_add_f32(cn + cT + s.L, vc);  atomic_add_f32(cn + cT + s.R, vc);
-            atomic_add_f32(cn + cB + s.L, vc);  atomic_add_f32(cn + cB + s.R, vc);
+            atomic_add_f32(ox + oT + s.L, vx[j]);  atomic_add_f32(ox + oT + s.R, vx[j]);
+            atomic_add_f32(ox + oB + s.L, vx[j]);  atomic_add_f32(ox + oB + s.R, vx[j]);
+            atomic_add_f32(oy + oT + s.L, vy[j]);  atomic_add_f32(oy + oT + s.R, vy[j]);
+            atomic_add_f32(oy + oB + s.L, vy[j]);  atomic_add_f32(oy + oB + s.R, vy[j]);
+            atomic_add_f32(cn + cT + s.L, vc[j]);  atomic_add_f32(cn + cT + s.R, vc[j]);
+            atomic_add_f32(cn + cB + s.L, vc[j]);  atomic_add_f32(cn + cB + s.R, vc[j]);
         }
     }
+    // Point splat WITHOUT LDS atomics (ds_add_f32 retires ~0.35 lane-ops per clock per CU): sites that share a
+    // cell are serialised by tag arbitration.  Per round every pending site writes its id into the cell's tag;
+    // after a barrier exactly one of them reads its own id back -- the winner -- and does a plain
+    // read-modify-write of the three value planes; the others stay pending.  Unique targets (the bulk) finish
+    // in round 0; a cell hit by m sites takes m rounds.  After kRounds rounds the stragglers use atomics.
+    constexpr int kRounds = 4;
+    const int uid0 = threadIdx.x * 4;
+#pragma unroll 1
+    for (int round = 0; round < kRounds; round++) {
+        if (round > 0 && !__syncthreads_or(pending != 0)) break;   // also orders the previous winners' writes
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((pending >> j) & 1) tag[cell[j]] = uid0 + j;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (((pending >> j) & 1) && tag[cell[j]] == uid0 + j) {
+                acc[cell[j]] += vx[j];
+                acc[A::kPlane + cell[j]] += vy[j];
+                acc[2 * A::kPlane + cell[j]] += vc[j];
+                pending &= ~(1u << j);
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if ((pending >> j) & 1) {             // more than kRounds sites on one cell (strongly compressive flow)
+            lds_add_f32(acc + cell[j], vx[j]);
+            lds_add_f32(acc + A::kPlane + cell[j], vy[j]);
+            lds_add_f32(acc + 2 * A::kPlane + cell[j], vc[j]);
+        }
     __syncthreads();
     if (ABL == 2 || r.w == 0) return;
 
@@ -532,7 +572,7 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const unsigned nwg = (unsigned)ntx * nty * batch;
 #define MEMC_PROJ_SCATTER(ABL)                                                                             \
-    hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3(nwg), dim3(256), 3 * A::kPlane * 4 + 64, stream, w, \
+    hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3(nwg), dim3(256), 4 * A::kPlane * 4 + 64, stream, w, \
                        h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow,   \
                        depth, count, out)
         if (g_proj_variant == 2) MEMC_PROJ_SCATTER(2);
