@@ -207,7 +207,7 @@ def main():
     ap.add_argument("--ctx-only", action="store_true", help="fi_fwd: only the C=64 context-warp row")
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "bench_ops.json"))
-    ap.add_argument("--variants", default="4,5,6,7,1")
+    ap.add_argument("--variants", default="-1,1,0")
     ap.add_argument("--proj-variants", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
