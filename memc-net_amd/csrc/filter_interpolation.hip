@@ -733,8 +733,9 @@ __global__ __launch_bounds__(64 * ROWS) void fi_bwd_direct_fs4(
 // Backward, fs == 4, RGB, LDS-tiled and vectorised.  Same tile / box machinery as the forward kernel:
 //   * streams (flow, 16 tap planes, 3 gradoutput planes) as dwordx4;
 //   * the image box is staged into LDS pixel quads (needed for the tap and flow gradients);
-//   * the image gradient -- 48 scattered adds per site -- goes into LDS accumulator planes (ds_add_f32) and is
-//     flushed once per cell with row-coalesced global atomics (memc_tile.hpp);
+//   * the image gradient -- 48 scattered adds per site -- goes into fp64 LDS accumulator planes (ds_add_f64:
+//     twenty times the rate of ds_add_f32 on this chip) and is flushed once per cell, rounded to fp32, with
+//     row-coalesced global atomics (memc_tile.hpp);
 //   * gradinput3 (each site owns its taps) is accumulated in registers and read-modify-written as dwordx4;
 //     gradinput2 is assigned.
 // Sites whose window is not staged are redone by fi_bwd_site_scalar with global atomics.
@@ -782,7 +783,7 @@ __device__ __noinline__ void fi_bwd_site_scalar(int x, int y, int W, int H, int 
     g2[s2c] = boty;
 }
 
-__global__ __launch_bounds__(256) void fi_bwd_tiled_c3(
+__global__ __launch_bounds__(256, 2) void fi_bwd_tiled_c3(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
@@ -791,11 +792,13 @@ __global__ __launch_bounds__(256) void fi_bwd_tiled_c3(
 {
     constexpr int LX = 16;
     using G = TileGeom<LX>;
-    using A = AccGeom<LX>;
+    using A = Acc64Geom<LX>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // phase 1 uses the LDS as the staged image (pixel quads, 48 KiB), phase 2 re-uses the SAME bytes as the
+    // fp64 accumulator planes (73 KiB): the image gradient needs taps and weights only, not the image
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
-    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
-    float *acc = reinterpret_cast<float *>(smem + G::kCapPx * 16 + 64);
+    double *acc = reinterpret_cast<double *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + 3 * A::kPlane * 8);
 
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
@@ -812,7 +815,6 @@ __global__ __launch_bounds__(256) void fi_bwd_tiled_c3(
 #pragma unroll
     for (int k = 0; k < 16; k++) tp[k] = ld_stream4(tap_p + k * s3c);
 
-    acc_zero<LX, 3>(acc);
     FiSite4 g;
     g.valid = 0;
     int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
@@ -826,74 +828,77 @@ __global__ __launch_bounds__(256) void fi_bwd_tiled_c3(
             rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
         }
     }
-    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
+    const Bands bands = make_bands<LX, false>(box);
     const float *in_b = in1 + b * s1b;
     float *gin1_b = gin1 + b * s1b;
+    float *g2 = gin2 + b * s2b + (int64_t)ys * s2h + xs;
+    float *g3 = gin3 + b * s3b + (int64_t)ys * s3h + xs;
+    unsigned done = 0;
+#pragma unroll 1
+    for (int bi = 0; bi < bands.n; bi++) {
+    const Region r = band_region(box, bands, bi);
+    const unsigned fast = inb ? fi_covered(r, g, W, H) & ~done : 0u;
+    // later bands run only if some site still needs them; the vote is also the barrier that frees the LDS
+    if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
+    done |= fast;
     tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
     __syncthreads();
+    // keep tap splats / weights inside the band loop (hoisted, they spill)
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
+#pragma unroll
+    for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
 
-    f32x4 gt[16];                          // gt[k][j]: tap-k gradient of site j
-#pragma unroll
-    for (int k = 0; k < 16; k++) gt[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- phase 1: tap and flow gradients from the staged image.
+    // With s = sum_c g_c * in_c(tap cell) (3 FMAs per tap), and q the tap's quadrant:
+    //     gradinput3[tap] = wq * s,   gradinput2.x = sum_taps cx[q] * s * tap,   gradinput2.y likewise,
+    // where wq = {(1-a)(1-b), a(1-b), (1-a)b, ab}, cx = {-(1-b), (1-b), -b, b}, cy = {-(1-a), -a, (1-a), a}.
+    // (The reference sums per channel first -- same value up to fp32 re-association, ~1e-7 relative.)
+    // Tap rows are the outer loop so that only one row of tap gradients (4 float4) is live at a time.
     f32x4 gx4 = {0.f, 0.f, 0.f, 0.f}, gy4 = gx4;
-    unsigned fast = 0, slow = 0;
+    int ro[4][4], co[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int ro[4], co[4];
+    for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            ro[k] = clampi(g.iy[j] - 1 + k, H - 1);
-            co[k] = clampi(g.ix[j] - 1 + k, W - 1);
+            const bool on = (fast >> j) & 1;
+            ro[j][k] = on ? (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch : 0;
+            co[j][k] = on ? swz_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0) : 0;
         }
-        const bool valid = (g.valid >> j) & 1;
-        const bool staged = valid && r.covers(co[0], co[3], ro[0], ro[3]);
-        fast |= (staged ? 1u : 0u) << j;
-        slow |= ((valid && !staged) ? 1u : 0u) << j;
-        if (!staged) continue;
-        const float a = g.a[j], bt = g.b[j];
-        const float w4[4] = {(1 - a) * (1 - bt), a * (1 - bt), (1 - a) * bt, a * bt};   // quadrant weights / g
-        f32x4 v[16];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 4; k++) {
+        f32x4 gt[4];                           // gt[m][j]: gradient of tap (k, m) of site j
 #pragma unroll
-            for (int m = 0; m < 4; m++) v[k * 4 + m] = tile[(ro[k] - r.y0) * r.pitch + swz_col(co[m] - r.x0)];
-        float botx = 0.0f, boty = 0.0f;
-        const float gam_x = 1.0f - bt, gam_y = 1.0f - a;
+        for (int m = 0; m < 4; m++) gt[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float gv = go[c][j];
-            // reference rounding: g * (1-a) * (1-b) is evaluated left to right
-            const float wq[4] = {gv * (1 - a) * (1 - bt), gv * a * (1 - bt), gv * (1 - a) * bt, gv * a * bt};
-            float *ap = acc + c * A::kPlane;
-            float TL = 0.0f, TR = 0.0f, BL = 0.0f, BR = 0.0f;
+        for (int j = 0; j < 4; j++) {
+            const float a = g.a[j], bt = g.b[j];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const int t = k * 4 + m;
-                    const float wgt = wq[(k >> 1) * 2 + (m >> 1)];
-                    lds_add_f32(ap + (ro[k] - r.y0) * A::kPitch + (co[m] - r.x0), wgt * tp[t][j]);
-                    gt[t][j] += wgt * v[t][c];
-                    const float prod = v[t][c] * tp[t][j];
-                    if (k < 2) { if (m < 2) TL += prod; else TR += prod; }
-                    else       { if (m < 2) BL += prod; else BR += prod; }
-                }
-            float tmp = 0.0f;
-            tmp += gam_x * (TR - TL);
-            tmp += (1.0f - gam_x) * (BR - BL);
-            botx += gv * tmp;
-            tmp = 0.0f;
-            tmp += gam_y * (BL - TL);
-            tmp += (1.0f - gam_y) * (BR - TR);
-            boty += gv * tmp;
+            for (int m = 0; m < 4; m++) {
+                const f32x4 v = tile[ro[j][k] + co[j][m]];
+                float sv = 0.0f;
+                sv += go[0][j] * v[0];  sv += go[1][j] * v[1];  sv += go[2][j] * v[2];
+                const float wa = m < 2 ? (1 - a) : a, wb = k < 2 ? (1 - bt) : bt;
+                gt[m][j] = (wa * wb) * sv;
+                const float st = sv * tp[k * 4 + m][j];
+                gx4[j] += (m < 2 ? -wb : wb) * st;
+                gy4[j] += (k < 2 ? -wa : wa) * st;
+            }
         }
-        (void)w4;
-        gx4[j] = botx;
-        gy4[j] = boty;
+        if (fast) {                            // gradinput3 += (lanes of sites outside this band add zero)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                f32x4 val = gt[m];
+#pragma unroll
+                for (int j = 0; j < 4; j++) val[j] = ((fast >> j) & 1) ? val[j] : 0.0f;
+                f32x4 *p = reinterpret_cast<f32x4 *>(g3 + (k * 4 + m) * s3c);
+                *p = *p + val;
+            }
+        }
     }
-    if (inb) {
-        float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
-        float *g3 = gin3 + b * s3b + (int64_t)y * s3h + x;
+    if (fast) {                                // gradinput2 is ASSIGNED at the sites of this band
         if (fast == 0xFu) {
             st_stream4(g2, gx4);
             st_stream4(g2 + s2c, gy4);
@@ -905,24 +910,46 @@ __global__ __launch_bounds__(256) void fi_bwd_tiled_c3(
                     g2[s2c + j] = gy4[j];
                 }
         }
-        if (fast) {                          // gradinput3 += (zero for sites that contributed nothing)
+    }
+    __syncthreads();                           // everybody is done reading the image: the LDS becomes `acc`
+
+    // ---- phase 2: image gradient, 48 fp64 LDS adds per site
+    acc64_zero<LX, 3>(acc);
+    __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                f32x4 *p = reinterpret_cast<f32x4 *>(g3 + k * s3c);
-                *p = *p + gt[k];
-            }
+    for (int j = 0; j < 4; j++) {
+        if (!((fast >> j) & 1)) continue;
+        int ro[4], co[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ro[k] = (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * A::kPitch;
+            co[k] = acc64_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0);
         }
-        while (slow) {                        // rare: window outside the staged box
-            const int j = __ffs(slow) - 1;
-            slow &= slow - 1;
-            fi_bwd_site_scalar(x + j, y, W, H, 3, 4, in_b, gin1_b, s1c, s1h, flow_p + j, g2 + j, s2c, tap_p + j,
-                               g3 + j, s3c, gout_p + j);
+        const float a = g.a[j], bt = g.b[j];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float gv = go[c][j];
+            const float wq[4] = {gv * (1 - a) * (1 - bt), gv * a * (1 - bt), gv * (1 - a) * bt, gv * a * bt};
+            double *ap = acc + c * A::kPlane;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+                    lds_add_f64(ap + ro[k] + co[m], (double)(wq[(k >> 1) * 2 + (m >> 1)] * tp[k * 4 + m][j]));
         }
     }
     __syncthreads();
     float *const dst[3] = {gin1_b, gin1_b + s1c, gin1_b + 2 * s1c};
     const int hs[3] = {s1h, s1h, s1h};
-    acc_flush<LX, 3>(r, acc, dst, hs);
+    acc64_flush<LX, 3>(r, acc, dst, hs);
+    }   // bands
+    unsigned slow = inb ? g.valid & ~done : 0u;            // not coverable within kMaxBands bands
+    while (slow) {                            // rare: redone from global memory with global atomics
+        const int j = __ffs(slow) - 1;
+        slow &= slow - 1;
+        fi_bwd_site_scalar(x + j, y, W, H, 3, 4, in_b, gin1_b, s1c, s1h, flow_p + j, g2 + j, s2c, tap_p + j,
+                           g3 + j, s3c, gout_p + j);
+    }
 }
 
 // Backward, any filter size (rare path; run-time loops).
@@ -1141,9 +1168,9 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
     } else if (channel == 3 && vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
                                        {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3})) {
         using G = TileGeom<16>;
-        using A = AccGeom<16>;
+        using A = Acc64Geom<16>;
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-        const int lds = G::kCapPx * 16 + 64 + 3 * A::kPlane * 4;
+        const int lds = 3 * A::kPlane * 8 + 64;            // >= the 48 KiB image it aliases
         static const bool once = (allow_big_lds(fi_bwd_tiled_c3, lds), true);
         (void)once;
         hipLaunchKernelGGL(fi_bwd_tiled_c3, dim3((unsigned)ntx * nty * batch), dim3(256), lds, stream, w, h, ntx, nty,

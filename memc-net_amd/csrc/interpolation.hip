@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
 // Backward, tiled, RGB: image gradient splatted into LDS accumulators and flushed with coalesced atomics
 // (memc_tile.hpp "LDS-privatised scatter"); the flow gradient needs the four corner values, gathered from a
 // staged LDS image of the same box.
-__global__ __launch_bounds__(256) void bl_bwd_tiled_c3(
+__global__ __launch_bounds__(256, 2) void bl_bwd_tiled_c3(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
@@ -225,11 +225,13 @@ __global__ __launch_bounds__(256) void bl_bwd_tiled_c3(
 {
     constexpr int LX = 16;
     using G = TileGeom<LX>;
-    using A = AccGeom<LX>;
+    using A = Acc64Geom<LX>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // phase 1 uses the LDS as the staged image (48 KiB of pixel quads), phase 2 re-uses the same bytes as the
+    // fp64 accumulator planes (73 KiB): two workgroups per CU instead of one
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
-    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
-    float *acc = reinterpret_cast<float *>(smem + G::kCapPx * 16 + 64);
+    double *acc = reinterpret_cast<double *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + 3 * A::kPlane * 8);
 
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
@@ -243,7 +245,6 @@ __global__ __launch_bounds__(256) void bl_bwd_tiled_c3(
 #pragma unroll
     for (int c = 0; c < 3; c++) go[c] = ld_stream4(gout_p + c * s1c);
 
-    acc_zero<LX, 3>(acc);
     BlSite st[4];
     int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
 #pragma unroll
@@ -261,16 +262,18 @@ __global__ __launch_bounds__(256) void bl_bwd_tiled_c3(
     tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
     __syncthreads();
 
+    // ---- phase 1: flow gradient from the four corner values
     f32x4 gx4 = {0.f, 0.f, 0.f, 0.f}, gy4 = gx4;
-    unsigned wrote = 0;
+    unsigned wrote = 0, staged_mask = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (!st[j].valid) continue;
         const BlSite &s = st[j];
         wrote |= 1u << j;
         const float x2 = (float)(x + j) + fx4[j], y2 = (float)y + fy4[j];
-        const float gam_x = (float)s.Bm - y2, gam_y = (float)s.R - x2;
+        const float gam_x = (float)s.Bm - y2, gam_y = (float)s.R - x2;   // clamped corners, my_lib_kernel.cu:634,652
         const bool staged = r.covers(s.L, s.R, s.T, s.Bm);
+        staged_mask |= (staged ? 1u : 0u) << j;
         f32x4 vTL, vTR, vBL, vBR;
         if (staged) {
             const int rT = (s.T - r.y0) * r.pitch, rB = (s.Bm - r.y0) * r.pitch;
@@ -288,19 +291,6 @@ __global__ __launch_bounds__(256) void bl_bwd_tiled_c3(
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float gv = go[c][j];
-            const float a00 = gv * (1 - s.a) * (1 - s.b), a01 = gv * s.a * (1 - s.b);
-            const float a10 = gv * (1 - s.a) * s.b, a11 = gv * s.a * s.b;
-            if (staged) {
-                float *ap = acc + c * A::kPlane;
-                const int aT = (s.T - r.y0) * A::kPitch, aB = (s.Bm - r.y0) * A::kPitch;
-                const int aL = s.L - r.x0, aR = s.R - r.x0;
-                lds_add_f32(ap + aT + aL, a00);  lds_add_f32(ap + aT + aR, a01);
-                lds_add_f32(ap + aB + aL, a10);  lds_add_f32(ap + aB + aR, a11);
-            } else {
-                float *q = gin1_b + c * s1c;
-                atomic_add_f32(q + s.T * s1h + s.L, a00);   atomic_add_f32(q + s.T * s1h + s.R, a01);
-                atomic_add_f32(q + s.Bm * s1h + s.L, a10);  atomic_add_f32(q + s.Bm * s1h + s.R, a11);
-            }
             float tmp = 0.0f;
             tmp += gam_x * (vTR[c] - vTL[c]);
             tmp += (1 - gam_x) * (vBR[c] - vBL[c]);
@@ -328,10 +318,38 @@ __global__ __launch_bounds__(256) void bl_bwd_tiled_c3(
                 }
         }
     }
+    __syncthreads();                           // the image has been read: the LDS becomes the accumulators
+
+    // ---- phase 2: image gradient, 12 fp64 LDS adds per site
+    acc64_zero<LX, 3>(acc);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!st[j].valid) continue;
+        const BlSite &s = st[j];
+        const bool staged = (staged_mask >> j) & 1;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float gv = go[c][j];
+            const float a00 = gv * (1 - s.a) * (1 - s.b), a01 = gv * s.a * (1 - s.b);
+            const float a10 = gv * (1 - s.a) * s.b, a11 = gv * s.a * s.b;
+            if (staged) {
+                double *ap = acc + c * A::kPlane;
+                const int aT = (s.T - r.y0) * A::kPitch, aB = (s.Bm - r.y0) * A::kPitch;
+                const int aL = acc64_col(s.L - r.x0), aR = acc64_col(s.R - r.x0);
+                lds_add_f64(ap + aT + aL, (double)a00);  lds_add_f64(ap + aT + aR, (double)a01);
+                lds_add_f64(ap + aB + aL, (double)a10);  lds_add_f64(ap + aB + aR, (double)a11);
+            } else {
+                float *q = gin1_b + c * s1c;
+                atomic_add_f32(q + s.T * s1h + s.L, a00);   atomic_add_f32(q + s.T * s1h + s.R, a01);
+                atomic_add_f32(q + s.Bm * s1h + s.L, a10);  atomic_add_f32(q + s.Bm * s1h + s.R, a11);
+            }
+        }
+    }
     __syncthreads();
     float *const dst[3] = {gin1_b, gin1_b + s1c, gin1_b + 2 * s1c};
     const int hs[3] = {s1h, s1h, s1h};
-    acc_flush<LX, 3>(r, acc, dst, hs);
+    acc64_flush<LX, 3>(r, acc, dst, hs);
 }
 
 static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batch, int s1b, int s1c, int s1h,
@@ -370,9 +388,9 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
     if (w <= 0 || h <= 0 || channel <= 0 || batch <= 0) return 0;
     if (channel == 3 && vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2})) {
         using G = TileGeom<16>;
-        using A = AccGeom<16>;
+        using A = Acc64Geom<16>;
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-        const int lds = G::kCapPx * 16 + 64 + 3 * A::kPlane * 4;
+        const int lds = 3 * A::kPlane * 8 + 64;            // >= the 48 KiB image it aliases
         static const bool once = (allow_big_lds(bl_bwd_tiled_c3, lds), true);
         (void)once;
         hipLaunchKernelGGL(bl_bwd_tiled_c3, dim3((unsigned)ntx * nty * batch), dim3(256), lds, stream, w, h, ntx, nty, (int64_t)s1b, (int64_t)s1c,

@@ -88,6 +88,46 @@ extern "C" int probe_atomics(void *stream, int variant, int blocks, float *dst, 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// LDS fp32 atomic throughput: every lane does REP ds_add_f32 to address (lane * stride + r * rstep) % 8192.
+__global__ __launch_bounds__(256) void lds_atomics(float *__restrict__ sink, int rep, int stride, int rstep, int mode)
+{
+    __shared__ float buf[8192];
+    for (int i = threadIdx.x; i < 8192; i += 256) buf[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x;
+    for (int r = 0; r < rep; r++) {
+        const int a = (lane * stride + r * rstep) & 8191;
+        if (mode == 0) (void)unsafeAtomicAdd(buf + a, 1.0f);                 // ds_add_f32
+        else if (mode == 1) (void)atomicAdd(reinterpret_cast<unsigned *>(buf) + a, 1u);   // ds_add_u32
+        else buf[a] += 1.0f;                                                  // plain read-modify-write
+    }
+    __syncthreads();
+    if (buf[threadIdx.x] == 12345.f) sink[0] = 1.f;
+}
+__global__ __launch_bounds__(256) void lds_atomics64(float *__restrict__ sink, int rep, int stride, int rstep, int mode)
+{
+    __shared__ double buf[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) buf[i] = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x;
+    for (int r = 0; r < rep; r++) {
+        const int a = (lane * stride + r * rstep) & 4095;
+        if (mode == 3) (void)unsafeAtomicAdd(buf + a, 1.0);                                            // ds_add_f64
+        else (void)atomicAdd(reinterpret_cast<unsigned long long *>(buf) + a, 1ull);                   // ds_add_u64
+    }
+    __syncthreads();
+    if (buf[threadIdx.x] == 12345.0) sink[0] = 1.f;
+}
+extern "C" int probe_lds_atomics(void *stream, int blocks, float *sink, int rep, int stride, int rstep, int mode)
+{
+    if (mode >= 3) {
+        hipLaunchKernelGGL(lds_atomics64, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sink, rep, stride, rstep, mode);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    hipLaunchKernelGGL(lds_atomics, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sink, rep, stride, rstep, mode);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 #define LAUNCH(LX, NT, XCD, MINW)                                                                            \
     do {                                                                                                     \
         const int tx = (W + 4 * LX - 1) / (4 * LX), ty = (H + 256 / LX - 1) / (256 / LX);                    \

@@ -65,6 +65,20 @@ def atomics_main():
     print("plain float4 += over the same %d elements %9.1f us  %7.1f GB/s (read+write)" % (n, t * 1e6, n * 8 / t / 1e9))
 
 
+def lds_main():
+    lib = ctypes.CDLL(SO)
+    dev = torch.device("cuda:0")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sink = torch.zeros(4, device=dev)
+    blocks, rep = 256 * 8, 4096
+    for mode, nm in ((3, "ds_add_f64"), (4, "ds_add_u64"), (0, "ds_add_f32"), (1, "ds_add_u32")):
+        for stride, rstep in ((1, 256), (4, 1), (4, 97)):
+            t = timeit(lambda: lib.probe_lds_atomics(st, blocks, ctypes.c_void_p(sink.data_ptr()), rep, stride, rstep, mode), iters=5, warmup=2)
+            ops = blocks * 256 * rep
+            print("%-11s stride=%-3d rstep=%-4d %8.1f us  %8.1f G lane-ops/s  (%.2f per clk per CU at 2.4 GHz)" % (
+                nm, stride, rstep, t * 1e6, ops / t / 1e9, ops / t / 256 / 2.4e9), flush=True)
+
+
 def copy_only():
     """a few launches of the float4 copy of known size (calibration source for tools/pmc_traffic.py)"""
     lib = ctypes.CDLL(SO)
@@ -83,6 +97,8 @@ if __name__ == "__main__":
         copy_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "build":
         build()
+    elif len(sys.argv) > 1 and sys.argv[1] == "lds":
+        lds_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "atomics":
         atomics_main()
     else:
