@@ -21,7 +21,11 @@
  *     (my_package/functions/FilterInterpolationLayer.py:26-29,46-48; FlowProjectionLayer.py:27-29,54);
  *   - `output`, `gradoutput` and `gradinput1` are indexed with input1's b/c/h strides
  *     (my_lib_kernel.cu:1184,1276-1283), `gradinput2`/`gradinput3` with input2's/input3's;
- *   - work is enqueued asynchronously on `stream`; no host synchronisation, no allocation, no global state;
+ *   - work is enqueued asynchronously on `stream`; no host synchronisation and no state carried from one call
+ *     to the next.  One exception to "never allocates": the first (Depth)FlowProjection FORWARD call on a
+ *     device allocates 40 KiB of device scratch (per-image "far source" flags of its fast path) and keeps it
+ *     for the life of the process; every call clears its slice on its own stream.  Make that first call
+ *     outside a stream capture (inside one the library silently uses its general path instead);
  *   - return 0 on success, -1 on a failed shape/stride check or a launch error (my_lib_cuda.c:611-646,
  *     my_lib_kernel.cu:1559-1566).
  *

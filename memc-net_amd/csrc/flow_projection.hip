@@ -12,7 +12,11 @@
 #include "memc_internal.h"
 #include "memc_tile.hpp"
 
+#include <mutex>
+
 namespace memc {
+
+constexpr int kFlagWords = 256;               // far flags of the fast path: image b -> word b % 256, + 1 summary word
 
 // --------------------------------------------------------------------------------------------------
 // Pass 1: scatter.  One lane = one source site; 12 fp32 atomics per valid site (8 flow + 4 count) into
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth,
-    float *__restrict__ count, float *__restrict__ out)
+    float *__restrict__ count, float *__restrict__ out, const int *__restrict__ far_flag)
 {
     constexpr int LX = 16;
     using G = TileGeom<LX>;
@@ -204,9 +208,11 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *acc = reinterpret_cast<float *>(smem);
     int *bb = reinterpret_cast<int *>(smem + 4 * A::kPlane * 4);
+    if (far_flag && far_flag[kFlagWords] == 0) return;   // queued behind proj_owner: nothing to redo at all
 
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
+    if (far_flag && far_flag[b % kFlagWords] == 0) return;   // this image was complete on the fast path
     const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
     const bool inb = x < W && y < H;
     const int xs = min(x, W - 4), ys = min(y, H - 1);
@@ -328,17 +334,165 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
     }
 }
 
+// ==================================================================================================
+// OWNER-COMPUTES forward (the fast path).  The splat is a scatter only because the reference walks SOURCE
+// sites; flow is cheap to re-read (8 B per site), so here a workgroup owns a 64x16 tile of OUTPUT cells and
+// scans every source that can reach it:
+//   * sources in the tile dilated by kReach (+ alignment) are read as dwordx4 (the halo comes out of L2);
+//   * a source whose point (T, L) falls into the tile's point window [ty0-1, ty0+15] x [tx0-1, tx0+63] is
+//     splatted into fp64 LDS planes (ds_add_f64: fast on this chip, and more accurate than fp32 atomics);
+//   * then every lane owns four cells: 2x2 box sum of the points (border duplicates as weights 2, see
+//     proj_scatter_tiled), normalisation by the count, one dwordx4 STORE per plane.
+// No global atomics, no separate averaging pass, no dependence on the caller's zero fill; HBM traffic is the
+// algorithmic 20 B per site (24 with depth).
+//
+// Reach: a source with |fx| >= kReach or |fy| >= kReach is invisible to the owners of its targets.  Such "far"
+// sources are skipped consistently by every owner, and the workgroup that is HOME to one raises a device flag.
+// The launcher then queues the general path (zero, scatter with atomics, average), whose kernels return at
+// once when the flag is clear: correctness never depends on the motion being small, only speed does.
+// ==================================================================================================
+constexpr int kPtW = 68, kPtH = 17;           // point window 65 x 17, pitch 68
+
+// kReach = supported |flow| on the fast path (pixels)
+template <bool DEPTH, int kReach>
+__global__ __launch_bounds__(256) void proj_owner(
+    int W, int H, int tiles_x, int tiles_y,
+    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
+    const float *__restrict__ flow, const float *__restrict__ depth,
+    float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag)
+{
+    constexpr int kScanPadX = kReach + 4;         // dilated tile: columns, kept 4-aligned
+    constexpr int kScanW = 64 + 2 * kScanPadX;    // source columns
+    constexpr int kScanH = 16 + 2 * kReach + 1;   // source rows: [ty0 - kReach - 1, ty0 + 16 + kReach)
+    __shared__ double P[3 * kPtH * kPtW];
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
+    for (int i = threadIdx.x; i < 3 * kPtH * kPtW; i += 256) P[i] = 0.0;
+
+    // scan: kScanW / 4 = 26 float4 columns x kScanH rows = 1274 slots, 5 per lane; all loads first
+    constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + 255) / 256;
+    const float *flow_b = flow + b * s1b;
+    const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
+    f32x4 fx[kIts], fy[kIts], dd[kIts];
+    int sx[kIts], sy[kIts];
+    bool live[kIts];
+#pragma unroll
+    for (int it = 0; it < kIts; it++) {
+        const int slot = threadIdx.x + 256 * it;
+        const int row = slot / kCols4, c4 = slot % kCols4;
+        sx[it] = tx0 - kScanPadX + 4 * c4;
+        sy[it] = ty0 - kReach - 1 + row;
+        live[it] = slot < kSlots && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
+        const float *p = live[it] ? flow_b + (int64_t)sy[it] * s1h + sx[it] : flow_b;
+        // sources of the tile itself are read once in the whole launch: stream them; the halo is shared
+        fx[it] = ld_cached4(p);
+        fy[it] = ld_cached4(p + s1c);
+        if (DEPTH) dd[it] = ld_cached4(live[it] ? depth_b + (int64_t)sy[it] * sdh + sx[it] : depth_b);
+    }
+    __syncthreads();                           // P is zero
+    bool far = false;
+#pragma unroll
+    for (int it = 0; it < kIts; it++) {
+        if (!live[it]) continue;
+        const bool home_row = sy[it] >= ty0 && sy[it] < ty0 + 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = sx[it] + j, y = sy[it];
+            const float fxv = fx[it][j], fyv = fy[it][j];
+            const BlSite s = bl_locate<false>(x, y, W, H, fxv, fyv);
+            if (!s.valid) continue;
+            const bool near = fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach;
+            if (!near) {
+                far = far || (home_row && x >= tx0 && x < tx0 + 64);
+                continue;
+            }
+            const int py = s.T - (ty0 - 1), px = s.L - (tx0 - 1);
+            if ((unsigned)py < (unsigned)kPtH && (unsigned)px < 65u) {
+                float vx = -fxv, vy = -fyv, vc = 1.0f;
+                if (DEPTH) {
+                    vx = -dd[it][j] * fxv;
+                    vy = -dd[it][j] * fyv;
+                    vc = dd[it][j] * 1.0f;
+                }
+                double *q = P + py * kPtW + px;
+                lds_add_f64(q, (double)vx);
+                lds_add_f64(q + kPtH * kPtW, (double)vy);
+                lds_add_f64(q + 2 * kPtH * kPtW, (double)vc);
+            }
+        }
+    }
+    if (far) {                                 // this image needs the general path
+        far_flag[b % kFlagWords] = 1;
+        far_flag[kFlagWords] = 1;
+    }
+    __syncthreads();
+
+    // every lane owns four cells of a row
+    const int cx = tx0 + 4 * (threadIdx.x % 16), cy = ty0 + threadIdx.x / 16;
+    if (cx >= W || cy >= H) return;
+    const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
+    f32x4 ox, oy, oc;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
+        const double *q = P + (cy - (ty0 - 1)) * kPtW + (cx + j - (tx0 - 1));
+        float v[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const double *qq = q + pl * kPtH * kPtW;
+            // the four contributions are rounded to fp32 one by one and added in a fixed order (the
+            // reference's order is arbitrary: fp32 atomics)
+            float t = 0.0f;
+            t += wy0 * wx0 * (float)qq[0];
+            t += wy0 * (float)qq[-1];
+            t += wx0 * (float)qq[-kPtW];
+            t += (float)qq[-kPtW - 1];
+            v[pl] = t;
+        }
+        if (v[2] > 0.0f) {                     // my_lib_kernel.cu:1730-1735
+            v[0] = v[0] / v[2];
+            v[1] = v[1] / v[2];
+        }
+        ox[j] = v[0];  oy[j] = v[1];  oc[j] = v[2];
+    }
+    float *o = out + b * s1b + (int64_t)cy * s1h + cx;
+    *reinterpret_cast<f32x4 *>(o) = ox;        // plain stores: pass 3 (hole fill) re-reads them
+    *reinterpret_cast<f32x4 *>(o + s1c) = oy;
+    *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
+}
+
+// general path, queued behind proj_owner: each kernel returns at once unless a far source was seen
+__global__ __launch_bounds__(256) void proj_redo_zero(int W, int H, int64_t s1b, int64_t s1c, int s1h, int64_t scb,
+                                                      int sch, int batch, float *__restrict__ count,
+                                                      float *__restrict__ out, const int *__restrict__ far_flag)
+{
+    if (far_flag[kFlagWords] == 0) return;
+    const int w4 = W / 4;
+    const int64_t n = (int64_t)batch * H * w4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % w4) * 4, y = (int)((i / w4) % H), b = (int)(i / ((int64_t)w4 * H));
+        if (far_flag[b % kFlagWords] == 0) continue;
+        float *o = out + b * s1b + (int64_t)y * s1h + x;
+        *reinterpret_cast<f32x4 *>(o) = z;
+        *reinterpret_cast<f32x4 *>(o + s1c) = z;
+        *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)y * sch + x) = z;
+    }
+}
+
 // Pass 2, vectorised: out /= count where count > 0, four cells per lane.
 __global__ __launch_bounds__(256) void proj_average_v4(
     int W, int H, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch, int batch,
-    const float *__restrict__ count, float *__restrict__ out)
+    const float *__restrict__ count, float *__restrict__ out, const int *__restrict__ far_flag)
 {
+    if (far_flag && far_flag[kFlagWords] == 0) return;
     const int w4 = W / 4;
     const int64_t n = (int64_t)batch * H * w4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int x = (int)(i % w4) * 4;
         const int y = (int)((i / w4) % H);
         const int b = (int)(i / ((int64_t)w4 * H));
+        if (far_flag && far_flag[b % kFlagWords] == 0) continue;
         const f32x4 c = ld_cached4(count + b * scb + (int64_t)y * sch + x);
         if (!(c[0] > 0.0f || c[1] > 0.0f || c[2] > 0.0f || c[3] > 0.0f)) continue;
         float *o = out + b * s1b + (int64_t)y * s1h + x;
@@ -559,6 +713,30 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
 
 static int g_proj_variant = -1;
 
+// The fast path needs a few device words (per-image far flags) that outlive a kernel: 40 KiB per device,
+// allocated on first use and kept for the life of the process (the only state in the library; it carries no
+// information from one call to the next -- every call clears it on its own stream first).  Returns nullptr if
+// the allocation is impossible (e.g. inside a stream capture): the caller then uses the general path.
+static int *far_flag_for_current_device()
+{
+    static std::mutex mu;
+    static int *flags[64] = {nullptr};
+    static unsigned next[64] = {0};
+    constexpr unsigned kSlots = 32, kSlotWords = 320;   // calls rotate over 32 flag blocks (concurrent streams)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!flags[dev]) {
+        void *p = nullptr;
+        if (hipMalloc(&p, kSlots * kSlotWords * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        flags[dev] = static_cast<int *>(p);
+    }
+    return flags[dev] + (next[dev]++ % kSlots) * kSlotWords;
+}
+
 template <bool DEPTH>
 static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fillhole,
                            int s1b, int s1c, int s1h, int sdb, int sdh, int scb, int sch,
@@ -571,20 +749,40 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
         using A = AccGeom<16>;
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const unsigned nwg = (unsigned)ntx * nty * batch;
-#define MEMC_PROJ_SCATTER(ABL)                                                                             \
+        const unsigned gs = 256 * 8;                      // grid-stride: 8 workgroups per CU
+#define MEMC_PROJ_SCATTER(ABL, FLAG)                                                                        \
     hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3(nwg), dim3(256), 4 * A::kPlane * 4 + 64, stream, w, \
                        h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow,   \
-                       depth, count, out)
-        if (g_proj_variant == 2) MEMC_PROJ_SCATTER(2);
-        else if (g_proj_variant == 3) MEMC_PROJ_SCATTER(3);
-        else MEMC_PROJ_SCATTER(0);
+                       depth, count, out, FLAG)
+        int *flag = (g_proj_variant == 1 || g_proj_variant >= 2) ? nullptr : far_flag_for_current_device();   // -1, -5: fast path
+        if (flag) {
+            // fast path: owner-computes (no atomics, fused averaging) + the general path behind a device flag
+            if (hipMemsetAsync(flag, 0, (kFlagWords + 1) * sizeof(int), stream) != hipSuccess) return -1;
+            if (g_proj_variant == -6)
+                hipLaunchKernelGGL((proj_owner<DEPTH, 16>), dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
+                                   (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, flag);
+            else
+                hipLaunchKernelGGL((proj_owner<DEPTH, 24>), dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
+                                   (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, flag);
+            if (launch_status() != 0) return -1;
+            if (g_proj_variant == -5) return 0;            // measurement arm: owner kernel alone
+            hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c, s1h,
+                               (int64_t)scb, sch, batch, count, out, flag);
+            MEMC_PROJ_SCATTER(0, flag);
+            hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
+                               s1h, (int64_t)scb, sch, batch, count, out, flag);
+            if (launch_status() != 0) return -1;
+        } else {
+            if (g_proj_variant == 2) MEMC_PROJ_SCATTER(2, nullptr);
+            else if (g_proj_variant == 3) MEMC_PROJ_SCATTER(3, nullptr);
+            else MEMC_PROJ_SCATTER(0, nullptr);
+            if (g_proj_variant >= 2) return launch_status();   // ablation arms time the scatter pass alone
+            if (launch_status() != 0) return -1;
+            hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
+                               s1h, (int64_t)scb, sch, batch, count, out, nullptr);
+            if (launch_status() != 0) return -1;
+        }
 #undef MEMC_PROJ_SCATTER
-        if (g_proj_variant >= 2) return launch_status();   // ablation arms time the scatter pass alone
-        if (launch_status() != 0) return -1;
-        const unsigned gs = 256 * 8;                      // grid-stride: 8 workgroups per CU
-        hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c, s1h,
-                           (int64_t)scb, sch, batch, count, out);
-        if (launch_status() != 0) return -1;
         if (fillhole) {
             hipLaunchKernelGGL(proj_fillhole_v4, dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
                                (int64_t)s1c, s1h, (int64_t)scb, sch, count, out);

@@ -17,7 +17,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     f = torch.randn(B, 2, H, W, device=dev, generator=g) * sig
     d = torch.rand(B, 1, H, W, device=dev, generator=g) + 0.1
     res = {}
-    for v in (0, -1):
+    for v in (0, -1, 1):
         L._debug_set_variant("projection", v)
         for fh in (0, 1):
             c = f.new_zeros(B, 1, H, W); o = torch.zeros_like(f)
@@ -26,14 +26,14 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
             assert L.DepthFlowProjectionLayer_gpu_forward(f, d, c2, o2, fh) == 0
             res[(v, fh)] = (c, o, c2, o2)
     torch.cuda.synchronize()
-    for fh in (0, 1):
-        a, b = res[(0, fh)], res[(-1, fh)]
+    for fh, other in ((0, -1), (1, -1), (0, 1), (1, 1)):
+        a, b = res[(0, fh)], res[(other, fh)]
         ok = torch.equal(a[0], b[0]) and (a[1] - b[1]).abs().max().item() <= 1e-4 and \
             (a[2] - b[2]).abs().max().item() <= 1e-4 and (a[3] - b[3]).abs().max().item() <= 2e-4
         if not ok:
             bad += 1
-            print("MISMATCH it=%d B=%d H=%d W=%d sig=%g fh=%d: count eq %s, out err %.3g, dcount err %.3g, dout err %.3g" % (
-                it, B, H, W, sig, fh, torch.equal(a[0], b[0]), (a[1] - b[1]).abs().max().item(),
+            print("MISMATCH variant=%d it=%d B=%d H=%d W=%d sig=%g fh=%d: count eq %s, out err %.3g, dcount err %.3g, dout err %.3g" % (
+                other, it, B, H, W, sig, fh, torch.equal(a[0], b[0]), (a[1] - b[1]).abs().max().item(),
                 (a[2] - b[2]).abs().max().item(), (a[3] - b[3]).abs().max().item()))
             if not torch.equal(a[0], b[0]):
                 idx = (a[0] != b[0]).nonzero()
