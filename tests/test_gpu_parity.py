@@ -287,3 +287,80 @@ def test_full_size_properties():
         got = float((out[:, k] * count[:, 0]).sum(dtype=torch.float64))
         want = -4.0 * float((flow[:, k] * valid).sum(dtype=torch.float64))
         assert abs(got - want) <= 1e-3 * max(1.0, abs(want))
+
+
+def test_stream_capture_and_replay(oracle):
+    """The launchers allocate nothing and synchronise nothing, so a forward can be captured into a HIP graph and
+    replayed (FlowProjection's one-time scratch allocation happens at its first call, made before capture)."""
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    import my_package._ext.my_lib as my_lib
+    d = make(CASES[0])
+    x, f, k = T(d["x"]), T(d["flow"]), T(d["filt"])
+    flow = T(d["flow"])
+    cnt = flow.new_zeros((flow.size(0), 1, flow.size(2), flow.size(3)))
+    pout = torch.zeros_like(flow)
+    assert my_lib.FlowProjectionLayer_gpu_forward(flow, cnt, pout, 1) == 0      # first call: allocates scratch
+    out = torch.zeros_like(x)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out.zero_(); cnt.zero_(); pout.zero_()
+            assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+            assert my_lib.FlowProjectionLayer_gpu_forward(flow, cnt, pout, 1) == 0
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    close(N(out), oracle.filter_interpolation_forward(d["x"], d["flow"], d["filt"]), "captured FI forward")
+    close(N(pout), oracle.flow_projection_forward(d["flow"], 1)[0], "captured projection")
+
+
+def test_concurrent_streams_projection(oracle):
+    """Two streams running the projection fast path at the same time must not share far-source flags."""
+    import my_package._ext.my_lib as my_lib
+    rng = np.random.default_rng(31)
+    near = synth.np_flow(rng, 2, 64, 128, "smooth", 3.0)            # stays on the fast path
+    far = synth.np_flow(rng, 2, 64, 128, "iid", 40.0)               # every image needs the general path
+    want_near = oracle.flow_projection_forward(near, 1)[0]
+    want_far = oracle.flow_projection_forward(far, 1)[0]
+    tn, tf = T(near), T(far)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for it in range(20):
+        cn, on = tn.new_zeros(2, 1, 64, 128), torch.zeros_like(tn)
+        cf, of = tf.new_zeros(2, 1, 64, 128), torch.zeros_like(tf)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            assert my_lib.FlowProjectionLayer_gpu_forward(tn, cn, on, 1) == 0
+        with torch.cuda.stream(s2):
+            assert my_lib.FlowProjectionLayer_gpu_forward(tf, cf, of, 1) == 0
+        outs.append((on, of))
+    torch.cuda.synchronize()
+    for on, of in outs:
+        close(N(on), want_near, "near-flow stream")
+        close(N(of), want_far, "far-flow stream")
+
+
+def test_4k_frame_properties():
+    """BASELINE configs[4] size (3840x2160): offsets beyond 2^31 bytes per tensor, identity and linearity."""
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    B, C, H, W = 2, 3, 2160, 3840
+    t = synth.torch_inputs(dev(), B, C, H, W, flow_kind="smooth", seed=5)
+    fi = FilterInterpolationModule()
+    onehot = torch.zeros_like(t["filt"]); onehot[:, 5] = 1
+    assert torch.equal(fi(t["x"], torch.zeros_like(t["flow"]), onehot), t["x"])
+    x2 = torch.rand_like(t["x"])
+    lhs = fi(0.5 * t["x"] + x2, t["flow"], t["filt"])
+    rhs = 0.5 * fi(t["x"], t["flow"], t["filt"]) + fi(x2, t["flow"], t["filt"])
+    assert float((lhs - rhs).abs().max()) <= ATOL
+
+
+def test_large_channel_count_offsets(oracle):
+    """64 channels at 720p: the per-batch stride exceeds 2^25 elements; compare a strip against the oracle."""
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    rng = np.random.default_rng(41)
+    B, C, H, W = 1, 64, 96, 1280
+    xn, fn, kn = synth.np_image(rng, B, C, H, W), synth.np_flow(rng, B, H, W, "smooth"), synth.np_filter(rng, B, H, W)
+    out = FilterInterpolationModule()(T(xn), T(fn), T(kn))
+    close(N(out), oracle.filter_interpolation_forward(xn, fn, kn), "C=64 forward")
