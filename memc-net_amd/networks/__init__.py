@@ -1,10 +1,12 @@
 """Build-owned network definitions that sit on top of the hot path.
 
-Only `MEMC_Net_star` so far: same constructor, forward signature, return structure and state-dict keys as the
+`MEMC_Net_star` and `MEMC_Net`: same constructor, forward signature, return structure and state-dict keys as the
 reference's `networks.MEMC_Net_star` (so its checkpoints load), written from scratch on stock `torch.nn` layers
 plus this repository's `my_package` operators.  Needed because the reference's files cannot travel to the GPU
 box; validated against the reference network itself in `tests/test_network_star.py` (CPU, this container).
 """
+from .MEMC_Net import MEMC_Net
 from .MEMC_Net_star import MEMC_Net_star
+from .replicate import broadcast_module_state, shard_pairs
 
-__all__ = ("MEMC_Net_star",)
+__all__ = ("MEMC_Net", "MEMC_Net_star", "broadcast_module_state", "shard_pairs")

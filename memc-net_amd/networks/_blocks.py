@@ -125,11 +125,14 @@ _TRUNK = ("c32 c32 c32 p  c64 c64 p  c128 c128 p  c256 c256 p  c512 c512 p  c512
           "c512 u c256  c256 u c128  c128 u c64  c64 u c32  c32 u c16").split()
 
 
-def unet_trunk(cin, align_corners):
+def unet_trunk(cin, align_corners, batch_norm=False):
     """Flat list of modules (the reference extends a python list with Sequential objects, which flattens them:
-    state-dict keys are indices into that flat list)."""
+    state-dict keys are indices into that flat list).  `batch_norm`: MEMC_Net normalises in front of every
+    pooling and upsampling layer (MEMC_Net.py:293-320); MEMC_Net_star has those lines commented out."""
     mods, ch = [], cin
     for tok in _TRUNK:
+        if tok in ("p", "u") and batch_norm:
+            mods.append(nn.BatchNorm2d(ch))
         if tok == "p":
             mods.append(nn.MaxPool2d((2, 2)))
         elif tok == "u":

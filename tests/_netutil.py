@@ -21,7 +21,13 @@ def named_weights(state_dict):
             fan_in = max(1, int(torch.tensor(t.shape[1:]).prod()))
             gain = 1.0                          # keeps the random flow within a few pixels and outputs O(1)
             v = torch.randn(t.shape, generator=g) * (gain / math.sqrt(fan_in))
-        else:
+        elif name.endswith("num_batches_tracked"):
+            v = torch.zeros(t.shape)
+        elif name.endswith("running_var"):
+            v = 0.5 + torch.rand(t.shape, generator=g)
+        elif name.endswith(".weight"):                                   # 1-D weight: a batch-norm scale
+            v = 1.0 + 0.1 * torch.randn(t.shape, generator=g)
+        else:                                                            # biases, running means
             v = torch.randn(t.shape, generator=g) * 0.01
         out[name] = v.to(t.dtype)
     return out

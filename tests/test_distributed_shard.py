@@ -74,3 +74,46 @@ def test_single_rank_plan():
     plan = bench.shard_plan(0, 1, 32, 1234)
     assert plan["global_batch"] == 32 and plan["items"] == 32 and plan["seed"] == 1234
     assert bench.BYTES_PER_SITE["fi_fwd"](3, 4) == 96 and bench.BYTES_PER_SITE["fi_fwd"](64, 4) == 584
+
+
+def _bcast_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "memc-net_amd"))
+    import importlib.util
+    import torch
+    import torch.distributed as dist
+    # load replicate.py on its own: `import networks` would pull in my_package (needs the HIP library + a GPU)
+    spec = importlib.util.spec_from_file_location(
+        "replicate", os.path.join(ROOT, "memc-net_amd", "networks", "replicate.py"))
+    rep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rep)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                                   # ranks start with DIFFERENT weights
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 4, 1))
+    before = torch.cat([t.double().reshape(-1) for t in net.state_dict().values()]).sum().item()
+    msgs, nbytes = rep.broadcast_module_state(net, src=0, bucket_bytes=512)   # tiny buckets: several messages
+    after = torch.cat([t.double().reshape(-1) for t in net.state_dict().values()]).sum().item()
+    live = sum(p.double().sum().item() for p in net.parameters())   # the LIVE parameters changed, not copies
+    pairs = list(rep.shard_pairs(rank, world, 4))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, before, after, live, msgs, nbytes, pairs))
+
+
+def test_weight_broadcast_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, a0, l0, m0, n0, p0), (_, b1, a1, l1, m1, n1, p1) = res
+    assert b0 != b1                       # different before
+    assert a0 == a1 == b0                 # rank 0's weights everywhere after (bit-exact: it is a copy)
+    assert l0 == l1
+    assert m0 == m1 and m0 >= 3 and n0 == n1          # fp32 buckets of <= 512 B + one int64 (num_batches_tracked)
+    assert p0 == [0, 1, 2, 3] and p1 == [4, 5, 6, 7]  # disjoint, contiguous, complete

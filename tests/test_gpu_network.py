@@ -15,12 +15,12 @@ sys.path.insert(0, HERE)
 import _netutil      # noqa: E402
 
 pytestmark = pytest.mark.gpu
-GOLD = os.path.join(HERE, "golden", "network_star_128.npz")
+MODELS = {"MEMC_Net_star": ("network_star_128.npz", 128), "MEMC_Net": ("network_base_64.npz", 64)}
 REL_TOL = 2e-3          # of each output's max magnitude; 70 M-parameter fp32 net, two different conv libraries
 
 
-@pytest.fixture(scope="module")
-def net():
+@pytest.fixture(scope="module", params=sorted(MODELS))
+def net(request):
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
     _netutil.purge_networks()
@@ -28,14 +28,17 @@ def net():
     assert hasattr(my_lib, "FilterInterpolationLayer_gpu_forward")
     import networks
     assert "memc-net_amd" in networks.__file__
-    m = networks.MEMC_Net_star(channel=3, filter_size=4, training=False)
+    m = getattr(networks, request.param)(channel=3, filter_size=4, training=False)
     m.load_state_dict(_netutil.named_weights(m.state_dict()), strict=True)
-    return m.cuda().eval()
+    m = m.cuda().eval()
+    m.gold = np.load(os.path.join(HERE, "golden", MODELS[request.param][0]))
+    m.size = MODELS[request.param][1]
+    return m
 
 
 def test_inference_matches_reference_vectors(net):
-    gold = np.load(GOLD)
-    x = _netutil.frames(7, 1, 128, 128).cuda()
+    gold = net.gold
+    x = _netutil.frames(7, 1, net.size, net.size).cuda()
     with torch.no_grad():
         frames_out, flows, filters, occl = net(x)
     got = {"blended": frames_out[0], "rectified": frames_out[1], "flow0": flows[0], "flow1": flows[1],
@@ -50,16 +53,18 @@ def test_inference_matches_reference_vectors(net):
 
 
 def test_training_step_matches_reference_fingerprint(net):
-    gold = np.load(GOLD)
+    gold = net.gold
+    weights = {k: v.clone() for k, v in net.state_dict().items()}       # batch-norm statistics move in train()
     net.train()
     net.zero_grad()
     try:
-        losses, _f, _k, _o = net(_netutil.training_frames(5, 1, 128, 128).cuda())
+        losses, _f, _k, _o = net(_netutil.training_frames(5, 1, net.size, net.size).cuda())
         total = sum(l.abs().mean() for l in losses)
         total.backward()
         torch.cuda.synchronize()
     finally:
         net.eval()
+        net.load_state_dict(weights)
     assert abs(float(total) - float(gold["train_loss"])) <= 1e-3 * float(gold["train_loss"])
     got = _netutil.grad_l1_by_module(net)
     want = {k[len("grad_l1/"):]: float(gold[k]) for k in gold.files if k.startswith("grad_l1/")}

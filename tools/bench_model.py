@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""tools/bench_model.py -- BASELINE.json config 4: full MEMC_Net_star inference (random weights) on 1280x720
+frame pairs, sharded as independent pairs over the GPUs of one node.  NOT the headline metric (bench.py is);
+this is the end-to-end context for it: how much of a frame interpolation is spent in the hot-path operators.
+
+    python tools/bench_model.py [--pairs 4 --steps 5 --warmup 2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        tools/bench_model.py --gpus N ...
+
+Rank 0 builds the weights, all other ranks receive them through ONE bucketed RCCL broadcast
+(networks/replicate.py); after that the ranks never communicate on the data path.  Frames are padded to
+multiples of 128 by replication exactly like the reference demo (demo_HD720p.py:88-113) and the output is cropped
+back.  Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "memc-net_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+
+def pad_to_128(h, w):
+    def one(n):
+        if n != ((n >> 7) << 7):
+            full = ((n >> 7) + 1) << 7
+            a = (full - n) // 2
+            return a, full - n - a
+        return 32, 32
+    top, bottom = one(h)
+    left, right = one(w)
+    return left, right, top, bottom
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=4, help="frame pairs per GPU per step (32 / 8 GPUs)")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--json", default="")
+    a = ap.parse_args(argv)
+
+    import torch
+    import torch.nn.functional as F
+    import bench
+    rank, local_rank, world = bench.dist_env()
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("needs a GPU: the HIP operators have no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import my_package._ext.my_lib as my_lib
+    import networks
+    torch.manual_seed(1234 + rank)                     # deliberately different: only the broadcast makes them equal
+    net = networks.MEMC_Net_star(channel=3, filter_size=4, training=False).to(dev).eval()
+    t0 = time.perf_counter()
+    msgs, nbytes = networks.broadcast_module_state(net, src=0)
+    torch.cuda.synchronize(dev)
+    bcast_s = time.perf_counter() - t0
+
+    g = torch.Generator(device=dev).manual_seed(99 + rank)
+    frames = torch.rand((2, a.pairs, 3, a.height, a.width), device=dev, generator=g)
+    pl, pr, pt, pb = pad_to_128(a.height, a.width)
+
+    def interpolate_batch():
+        x = torch.stack([F.pad(frames[i], (pl, pr, pt, pb), mode="replicate") for i in range(2)])
+        (blended, rectified), flows, filters, occl = net(x)
+        return rectified[:, :, pt:pt + a.height, pl:pl + a.width]
+
+    with torch.no_grad():
+        worst, _ = bench.timed_steps(lambda i: interpolate_batch(), a.steps, a.warmup, world, dev)
+
+        # share of the step spent inside the hot-path operators: one extra untimed pass with events around them
+        spans, originals = [], {}
+        for name in [n for n in dir(my_lib) if n.endswith(("_gpu_forward", "_gpu_backward"))]:
+            fn = originals[name] = getattr(my_lib, name)
+
+            def wrapped(*args, _fn=fn, _name=name):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = _fn(*args)
+                e.record()
+                spans.append((_name, s, e))
+                return r
+            setattr(my_lib, name, wrapped)
+        # (my_package.functions.* look the entry points up on the my_lib module at call time)
+        s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        interpolate_batch()
+        e0.record()
+        torch.cuda.synchronize(dev)
+        for name, fn in originals.items():
+            setattr(my_lib, name, fn)
+        per_op = {}
+        for name, s, e in spans:
+            per_op[name] = per_op.get(name, 0.0) + s.elapsed_time(e)
+        pass_ms = s0.elapsed_time(e0)
+
+    if rank == 0:
+        pairs = world * a.pairs * a.steps
+        line = {"metric": "MEMC_Net_star inference, interpolated 1280x720 frames/s", "value": round(pairs / worst, 3),
+                "unit": "frames/s", "mpixels_per_s": round(pairs * a.height * a.width / worst / 1e6, 2),
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(worst / a.steps * 1e3, 2),
+                "scaling": "weak", "dtype": "f32", "data": "synthetic, random weights",
+                "config": {"workload": "MEMC_Net_star inference %dx%d (padded %dx%d), %d pairs/GPU" % (
+                    a.width, a.height, a.width + pl + pr, a.height + pt + pb, a.pairs),
+                    "global_pairs_per_step": world * a.pairs,
+                    "weights": "rank 0 -> all, %d RCCL broadcast message(s), %.1f MB, %.3f s" % (msgs, nbytes / 1e6, bcast_s)},
+                "hot_path_ops_ms": {k: round(v, 3) for k, v in sorted(per_op.items())},
+                "hot_path_ops_calls": len(spans),
+                "hot_path_share_of_step": round(sum(per_op.values()) / pass_ms, 4), "instrumented_pass_ms": round(pass_ms, 2)}
+        print(json.dumps(line), flush=True)
+        if a.json:
+            json.dump(line, open(a.json, "w"), indent=1)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
