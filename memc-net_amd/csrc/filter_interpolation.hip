@@ -733,10 +733,10 @@ __global__ __launch_bounds__(64 * ROWS) void fi_bwd_direct_fs4(
 // Backward, fs == 4, RGB, LDS-tiled and vectorised.  Same tile / box machinery as the forward kernel:
 //   * streams (flow, 16 tap planes, 3 gradoutput planes) as dwordx4;
 //   * the image box is staged into LDS pixel quads (needed for the tap and flow gradients);
-//   * the image gradient -- 48 scattered adds per site -- goes into fp64 LDS accumulator planes (ds_add_f64:
-//     twenty times the rate of ds_add_f32 on this chip) and is flushed once per cell, rounded to fp32, with
-//     row-coalesced global atomics (memc_tile.hpp);
-//   * gradinput3 (each site owns its taps) is accumulated in registers and read-modify-written as dwordx4;
+//   * the image gradient -- 48 scattered adds per site -- goes, one colour channel at a time, into transposed fp64
+//     LDS accumulator planes (ds_add_f64: twenty times the rate of ds_add_f32 on this chip; AccT in
+//     memc_tile.hpp) and is flushed once per cell, rounded to fp32, with row-coalesced global atomics;
+//   * gradinput3 (each site owns its taps) is stored once per site as dwordx4 (the caller zero-fills it);
 //     gradinput2 is assigned.
 // Sites whose window is not staged are redone by fi_bwd_site_scalar with global atomics.
 // --------------------------------------------------------------------------------------------------
@@ -783,44 +783,97 @@ __device__ __noinline__ void fi_bwd_site_scalar(int x, int y, int W, int H, int 
     g2[s2c] = boty;
 }
 
+// Per-workgroup phase timestamps (shader clock) for tools/trace_kernel.py; written by the ABL == 9 arm only.
+__device__ unsigned long long *g_trace_buf = nullptr;
+constexpr int kTraceSlots = 16;
+template <bool ON>
+__device__ __forceinline__ void trace_mark(int slot)
+{
+    if (ON && threadIdx.x == 0) g_trace_buf[(size_t)blockIdx.x * kTraceSlots + slot] = __builtin_readcyclecounter();
+}
+
+// ABL != 0 are MEASUREMENT arms (tools/bench_ops.py --bwd-variants; their results are wrong by construction):
+//   1 no fp64 LDS adds (zero + flush kept; zero cells are not flushed)   2 no phase 2 at all
+//   3 phase 1 without its LDS reads                                      5 flush with plain stores
+//   6 no prefetch of the next tile (loads issued at the top of the iteration)
+//   9 production + phase timestamps of the second tile of every workgroup
+//
+// Persistent: the grid is 2 workgroups per CU (what 256 VGPRs + 64 KiB of LDS allow); workgroup w walks the tiles
+// w, w + grid, w + 2 grid, ... of the XCD-major strip order (grid % 8 == 0, so a workgroup stays on its XCD's
+// chunk).  The 21 float4 of per-site inputs of the NEXT tile are requested between the two phases of the current
+// one and arrive while phase 2 runs on the LDS (no global loads there; barriers wait on lgkmcnt only).
+struct FiBwdIn {
+    f32x4 fx, fy, go[3], tp[16];
+};
+
+template <int ABL>
 __global__ __launch_bounds__(256, 2) void fi_bwd_tiled_c3(
-    int W, int H, int tiles_x, int tiles_y,
+    int W, int H, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
     const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2,
     float *__restrict__ gin3)
 {
     constexpr int LX = 16;
+    constexpr bool TR = ABL == 9;
     using G = TileGeom<LX>;
-    using A = Acc64Geom<LX>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // phase 1 uses the LDS as the staged image (pixel quads, 48 KiB), phase 2 re-uses the SAME bytes as the
-    // fp64 accumulator planes (73 KiB): the image gradient needs taps and weights only, not the image
+    // phase 1 uses the LDS as the staged image (pixel quads, 48 KiB); phase 2 re-uses the same bytes (and 16 KiB
+    // more) as TWO transposed fp64 accumulator planes that the three colour channels take in turn: while plane A
+    // is flushed to gradinput1, the next channel is already being accumulated in plane B
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
-    double *acc = reinterpret_cast<double *>(smem);
-    int *bb = reinterpret_cast<int *>(smem + 3 * A::kPlane * 8);
+    double *const plane0 = reinterpret_cast<double *>(smem);     // plane i at plane0 + i * AccT::kPlane
+    int *bb = reinterpret_cast<int *>(smem + 2 * AccT::kPlane * 8);
 
-    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
-    const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
-    const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
+    const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
+    const int lx4 = 4 * (threadIdx.x % LX), ly = threadIdx.x / LX;
+
+    // requests the per-site inputs of tile `v` (always a valid tile: loads stay unconditional)
+    auto request = [&](unsigned v, FiBwdIn &in) {
+        const TileCoord tc = strip_walk(v, ntiles, tiles_x, tiles_y, batch);
+        const int xs = min(tc.tx * G::kTW + lx4, W - 4), ys = min(tc.ty * G::kTH + ly, H - 1);
+        const float *flow_b = flow + tc.b * s2b, *filt_b = filt + tc.b * s3b, *gout_b = gout + tc.b * s1b;
+        const unsigned o1 = 4u * (unsigned)(ys * s1h + xs), o2 = 4u * (unsigned)(ys * s2h + xs),
+                       o3 = 4u * (unsigned)(ys * s3h + xs);
+        in.fx = ld_stream4_u(flow_b, o2);
+        in.fy = ld_stream4_u(flow_b + s2c, o2);
+#pragma unroll
+        for (int c = 0; c < 3; c++) in.go[c] = ld_stream4_u(gout_b + c * s1c, o1);
+#pragma unroll
+        for (int k = 0; k < 16; k++) in.tp[k] = ld_stream4_u(filt_b + k * s3c, o3);
+    };
+
+    unsigned v = blockIdx.x;
+    int iter = 0;
+    FiBwdIn nx;
+    request(v, nx);
+#pragma unroll 1
+    for (;; iter++) {
+    const bool tr = TR && iter == 1;
+    if (tr) trace_mark<TR>(0);
+    FiBwdIn in = nx;
+    f32x4 (&tp)[16] = in.tp;
+    f32x4 (&go)[3] = in.go;
+    const TileCoord tc = strip_walk(v, ntiles, tiles_x, tiles_y, batch);
+    const int b = tc.b;
+    const int x = tc.tx * G::kTW + lx4, y = tc.ty * G::kTH + ly;
     const bool inb = x < W && y < H;
     const int xs = min(x, W - 4), ys = min(y, H - 1);
-    const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
-    const float *tap_p = filt + b * s3b + (int64_t)ys * s3h + xs;
-    const float *gout_p = gout + b * s1b + (int64_t)ys * s1h + xs;
-    const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s2c);
-    f32x4 go[3], tp[16];
-#pragma unroll
-    for (int c = 0; c < 3; c++) go[c] = ld_stream4(gout_p + c * s1c);
-#pragma unroll
-    for (int k = 0; k < 16; k++) tp[k] = ld_stream4(tap_p + k * s3c);
+    // wave-uniform plane bases + one 32-bit byte offset per tensor (see ld_stream4_u)
+    const float *flow_b = flow + b * s2b, *filt_b = filt + b * s3b, *gout_b = gout + b * s1b;
+    float *gin2_b = gin2 + b * s2b, *gin3_b = gin3 + b * s3b;
+    const unsigned o1 = 4u * (unsigned)(ys * s1h + xs), o2 = 4u * (unsigned)(ys * s2h + xs),
+                   o3 = 4u * (unsigned)(ys * s3h + xs);
+    if (ABL == 6) request(v, in);
+    if (TR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tr) trace_mark<TR>(1);                                 // inputs have arrived
 
     FiSite4 g;
     g.valid = 0;
     int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
+        const FiSite s = fi_locate(x + j, y, W, H, in.fx[j], in.fy[j]);
         g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
         if (inb && s.valid) {
             g.valid |= 1u << j;
@@ -832,9 +885,10 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_tiled_c3(
     const Bands bands = make_bands<LX, false>(box);
     const float *in_b = in1 + b * s1b;
     float *gin1_b = gin1 + b * s1b;
-    float *g2 = gin2 + b * s2b + (int64_t)ys * s2h + xs;
-    float *g3 = gin3 + b * s3b + (int64_t)ys * s3h + xs;
-    unsigned done = 0;
+    unsigned done = 0, fastbits = 0;                           // fastbits: 4 bits per band, the sites it owns
+    if (tr) trace_mark<TR>(2);                                 // bounding box known
+
+    // ================= phase 1, band by band: tap and flow gradients from the staged image =================
 #pragma unroll 1
     for (int bi = 0; bi < bands.n; bi++) {
     const Region r = band_region(box, bands, bi);
@@ -842,8 +896,10 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_tiled_c3(
     // later bands run only if some site still needs them; the vote is also the barrier that frees the LDS
     if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
     done |= fast;
+    fastbits |= fast << (4 * bi);
     tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
     __syncthreads();
+    if (tr && bi == 0) trace_mark<TR>(3);                      // image staged
     // keep tap splats / weights inside the band loop (hoisted, they spill)
 #pragma unroll
     for (int k = 0; k < 16; k++)
@@ -851,24 +907,24 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_tiled_c3(
 #pragma unroll
     for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
 
-    // ---- phase 1: tap and flow gradients from the staged image.
     // With s = sum_c g_c * in_c(tap cell) (3 FMAs per tap), and q the tap's quadrant:
     //     gradinput3[tap] = wq * s,   gradinput2.x = sum_taps cx[q] * s * tap,   gradinput2.y likewise,
     // where wq = {(1-a)(1-b), a(1-b), (1-a)b, ab}, cx = {-(1-b), (1-b), -b, b}, cy = {-(1-a), -a, (1-a), a}.
     // (The reference sums per channel first -- same value up to fp32 re-association, ~1e-7 relative.)
     // Tap rows are the outer loop so that only one row of tap gradients (4 float4) is live at a time.
     f32x4 gx4 = {0.f, 0.f, 0.f, 0.f}, gy4 = gx4;
-    int ro[4][4], co[4][4];
+    int co[4][4];
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const bool on = (fast >> j) & 1;
-            ro[j][k] = on ? (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch : 0;
-            co[j][k] = on ? swz_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0) : 0;
-        }
+        for (int m = 0; m < 4; m++)
+            co[j][m] = ((fast >> j) & 1) ? swz_col(clampi(g.ix[j] - 1 + m, W - 1) - r.x0) : 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+        int ro[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            ro[j] = ((fast >> j) & 1) ? (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch : 0;
         f32x4 gt[4];                           // gt[m][j]: gradient of tap (k, m) of site j
 #pragma unroll
         for (int m = 0; m < 4; m++) gt[m] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -877,9 +933,9 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_tiled_c3(
             const float a = g.a[j], bt = g.b[j];
 #pragma unroll
             for (int m = 0; m < 4; m++) {
-                const f32x4 v = tile[ro[j][k] + co[j][m]];
+                const f32x4 pix = ABL == 3 ? f32x4{a, bt, a, bt} : tile[ro[j] + co[j][m]];
                 float sv = 0.0f;
-                sv += go[0][j] * v[0];  sv += go[1][j] * v[1];  sv += go[2][j] * v[2];
+                sv += go[0][j] * pix[0];  sv += go[1][j] * pix[1];  sv += go[2][j] * pix[2];
                 const float wa = m < 2 ? (1 - a) : a, wb = k < 2 ? (1 - bt) : bt;
                 gt[m][j] = (wa * wb) * sv;
                 const float st = sv * tp[k * 4 + m][j];
@@ -887,69 +943,95 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_tiled_c3(
                 gy4[j] += (k < 2 ? -wa : wa) * st;
             }
         }
-        if (fast) {                            // gradinput3 += (lanes of sites outside this band add zero)
+        if (fast == 0xFu) {                    // the common case: this band owns the whole quad -> plain stores
+#pragma unroll                                 // (the buffer is zero-filled by the caller: 0 + g == g)
+            for (int m = 0; m < 4; m++) st_stream4_u(gin3_b + (k * 4 + m) * s3c, o3, gt[m]);
+        } else if (fast) {                     // mixed quad: lanes of sites outside this band add zero
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 f32x4 val = gt[m];
 #pragma unroll
                 for (int j = 0; j < 4; j++) val[j] = ((fast >> j) & 1) ? val[j] : 0.0f;
-                f32x4 *p = reinterpret_cast<f32x4 *>(g3 + (k * 4 + m) * s3c);
+                MEMC_GLOBAL f32x4 *p = reinterpret_cast<MEMC_GLOBAL f32x4 *>(at_u(gin3_b + (k * 4 + m) * s3c, o3));
                 *p = *p + val;
             }
         }
     }
     if (fast) {                                // gradinput2 is ASSIGNED at the sites of this band
         if (fast == 0xFu) {
-            st_stream4(g2, gx4);
-            st_stream4(g2 + s2c, gy4);
+            st_stream4_u(gin2_b, o2, gx4);
+            st_stream4_u(gin2_b + s2c, o2, gy4);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if ((fast >> j) & 1) {
-                    g2[j] = gx4[j];
-                    g2[s2c + j] = gy4[j];
+                    at_u(gin2_b, o2)[j] = gx4[j];
+                    at_u(gin2_b + s2c, o2)[j] = gy4[j];
                 }
         }
     }
-    __syncthreads();                           // everybody is done reading the image: the LDS becomes `acc`
+    __syncthreads();                           // everybody is done reading the image
+    }   // phase-1 bands
+    if (tr) trace_mark<TR>(4);                                 // phase 1 done
 
-    // ---- phase 2: image gradient, 48 fp64 LDS adds per site
-    acc64_zero<LX, 3>(acc);
+    // next tile's inputs: in flight during phase 2 (the last iteration re-requests its own tile: unconditional)
+    const unsigned vn = v + gridDim.x;
+    if (ABL != 6) request(vn < ntiles ? vn : v, nx);
+
+    // ================= phase 2, band by band: image gradient through the LDS planes =========================
+    // 16 ds_add_f64 per site and channel; channel c accumulates in plane c & 1 while the previous channel's plane
+    // is flushed (row-coalesced global atomics), so the LDS atomics and the global atomics overlap.
+    if (ABL != 2) {
+    acct_zero<2>(plane0);                      // the image was here; every flush below leaves its plane zeroed again
     __syncthreads();
+    if (tr) trace_mark<TR>(5);                                 // planes zeroed
+#pragma unroll 1
+    for (int bi = 0; bi < bands.n; bi++) {
+    const unsigned fast = (fastbits >> (4 * bi)) & 0xFu;
+    if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
+    const Region r = band_region(box, bands, bi);
+#pragma unroll 1
+    for (int c = 0; c < 4; c++) {
+        if (c > 0) acct_flush_zero<ABL == 5>(r, plane0 + ((c - 1) & 1) * AccT::kPlane, gin1_b + (c - 1) * s1c, s1h);
+        if (c < 3) {
+            double *acc = plane0 + (c & 1) * AccT::kPlane;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (!((fast >> j) & 1)) continue;
-        int ro[4], co[4];
+            for (int j = 0; j < 4; j++) {
+                if (ABL == 1 || !((fast >> j) & 1)) continue;
+                // keep the cell addresses and weights inside the loop (hoisted, they spill)
+                asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
+                int ro[4], co[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            ro[k] = (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * A::kPitch;
-            co[k] = acc64_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0);
+                for (int k = 0; k < 4; k++) {
+                    ro[k] = (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * AccT::kPitch;
+                    co[k] = acct_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0);
+                }
+                const float a = g.a[j], bt = g.b[j];
+                const float gv = c == 0 ? go[0][j] : (c == 1 ? go[1][j] : go[2][j]);
+                const float wq[4] = {gv * (1 - a) * (1 - bt), gv * a * (1 - bt), gv * (1 - a) * bt, gv * a * bt};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int m = 0; m < 4; m++)
+                        lds_add_f64(acc + ro[k] + co[m], (double)(wq[(k >> 1) * 2 + (m >> 1)] * tp[k * 4 + m][j]));
+            }
         }
-        const float a = g.a[j], bt = g.b[j];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float gv = go[c][j];
-            const float wq[4] = {gv * (1 - a) * (1 - bt), gv * a * (1 - bt), gv * (1 - a) * bt, gv * a * bt};
-            double *ap = acc + c * A::kPlane;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-#pragma unroll
-                for (int m = 0; m < 4; m++)
-                    lds_add_f64(ap + ro[k] + co[m], (double)(wq[(k >> 1) * 2 + (m >> 1)] * tp[k * 4 + m][j]));
-        }
+        __syncthreads();
+        if (tr && bi == 0) trace_mark<TR>(6 + c);              // channel c accumulated, channel c-1 flushed
     }
-    __syncthreads();
-    float *const dst[3] = {gin1_b, gin1_b + s1c, gin1_b + 2 * s1c};
-    const int hs[3] = {s1h, s1h, s1h};
-    acc64_flush<LX, 3>(r, acc, dst, hs);
-    }   // bands
+    }   // phase-2 bands
+    }
+    if (tr) trace_mark<TR>(12);                                // bands done
     unsigned slow = inb ? g.valid & ~done : 0u;            // not coverable within kMaxBands bands
     while (slow) {                            // rare: redone from global memory with global atomics
         const int j = __ffs(slow) - 1;
         slow &= slow - 1;
-        fi_bwd_site_scalar(x + j, y, W, H, 3, 4, in_b, gin1_b, s1c, s1h, flow_p + j, g2 + j, s2c, tap_p + j,
-                           g3 + j, s3c, gout_p + j);
+        fi_bwd_site_scalar(x + j, y, W, H, 3, 4, in_b, gin1_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j,
+                           s2c, filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
     }
+    if (vn >= ntiles) break;
+    v = vn;
+    }   // tiles
 }
 
 // Backward, any filter size (rare path; run-time loops).
@@ -1019,6 +1101,14 @@ using namespace memc;
 // Variant selection for A/B measurement (memc_internal.h); -1 = automatic.
 static int g_fi_fwd_variant = -1;
 extern "C" void memc_debug_set_fi_fwd_variant(int v) { g_fi_fwd_variant = v; }
+static int g_fi_bwd_variant = -1;
+extern "C" void memc_debug_set_fi_bwd_variant(int v) { g_fi_bwd_variant = v; }
+// device buffer of gridDim.x * 16 uint64 for the timestamp arm (fi_bwd variant 9); tools/trace_kernel.py
+extern "C" int memc_debug_set_trace_buffer(void *p)
+{
+    unsigned long long *q = (unsigned long long *)p;
+    return hipMemcpyToSymbol(HIP_SYMBOL(memc::g_trace_buf), &q, sizeof(q)) == hipSuccess ? 0 : -1;
+}
 // MEMC_FI_FWD_VARIANT=<n> in the environment forces a kernel variant (measurement / test matrix only).
 static int fi_fwd_variant()
 {
@@ -1168,14 +1258,32 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
     } else if (channel == 3 && vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
                                        {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3})) {
         using G = TileGeom<16>;
-        using A = Acc64Geom<16>;
+        static_assert(2 * AccT::kPlane * 8 >= G::kCapPx * 16 && G::kPitch <= AccT::kMaxW && G::kRows <= AccT::kRows,
+                      "the two accumulator planes alias (and extend) the staged image");
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-        const int lds = 3 * A::kPlane * 8 + 64;            // >= the 48 KiB image it aliases
-        static const bool once = (allow_big_lds(fi_bwd_tiled_c3, lds), true);
-        (void)once;
-        hipLaunchKernelGGL(fi_bwd_tiled_c3, dim3((unsigned)ntx * nty * batch), dim3(256), lds, stream, w, h, ntx, nty,
-                           (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,
-                           (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3);
+        const int lds = 2 * AccT::kPlane * 8 + 64;
+        // persistent: two workgroups per CU, a multiple of 8 so that a workgroup keeps its XCD
+        const unsigned ntiles = (unsigned)ntx * nty * batch;
+        const unsigned grid = ntiles < persistent_grid(2) ? ntiles : persistent_grid(2);
+#define MEMC_FI_BWD(ABL)                                                                                           \
+        do {                                                                                                       \
+            static const bool once = (allow_big_lds(fi_bwd_tiled_c3<ABL>, lds), true);                             \
+            (void)once;                                                                                            \
+            hipLaunchKernelGGL(fi_bwd_tiled_c3<ABL>, dim3(grid), dim3(256), lds, stream, w, h, ntx, nty, batch,    \
+                               (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,     \
+                               (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2,      \
+                               gradinput3);                                                                        \
+        } while (0)
+        switch (g_fi_bwd_variant) {
+        case 1: MEMC_FI_BWD(1); break;
+        case 2: MEMC_FI_BWD(2); break;
+        case 3: MEMC_FI_BWD(3); break;
+        case 5: MEMC_FI_BWD(5); break;
+        case 6: MEMC_FI_BWD(6); break;
+        case 9: MEMC_FI_BWD(9); break;
+        default: MEMC_FI_BWD(0);
+        }
+#undef MEMC_FI_BWD
     } else if (channel == 3) {
         hipLaunchKernelGGL((fi_bwd_direct_fs4<3, 4>), dim3(nwg), dim3(256), 0, stream, w, h, channel,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,

@@ -183,4 +183,20 @@ inline void allow_big_lds(K kernel, int bytes)
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// Grid of a persistent kernel: `per_cu` workgroups on every CU of the current device, rounded down to a
+// multiple of the XCD count so that workgroup w and w + grid sit on the same XCD.
+inline unsigned persistent_grid(int per_cu)
+{
+    static unsigned cus[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = (unsigned)n;
+    }
+    const unsigned g = (unsigned)per_cu * cus[dev] / kXcds * kXcds;
+    return g ? g : kXcds;
+}
+
 }  // namespace memc

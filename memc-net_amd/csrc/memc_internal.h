@@ -8,9 +8,12 @@ extern "C" {
 #endif
 
 // A/B measurement hooks (tools/bench_ops.py).  variant < 0 restores automatic selection.
-// They change which of several equivalent kernels a launcher picks -- never the results.
+// The fi_fwd / projection hooks change which of several equivalent kernels a launcher picks (ablation arms,
+// documented at each kernel, excepted).
 void memc_debug_set_fi_fwd_variant(int variant);
 void memc_debug_set_projection_variant(int variant);
+void memc_debug_set_fi_bwd_variant(int variant);
+int memc_debug_set_trace_buffer(void *device_u64_buffer);   // gridDim.x * 16 slots, written by fi_bwd variant 9      // > 0: ablation arms, results deliberately wrong
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,34 @@ __device__ __forceinline__ void st_stream4(float *p, f32x4 v)
 }
 __device__ __forceinline__ f32x4 ld_cached4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
+// Wave-uniform base + 32-bit per-lane BYTE offset: compiles to the saddr form (global_load ... v_off, s[base]),
+// so a kernel that touches many planes at the same site keeps ONE offset register instead of a 64-bit pointer
+// per plane (sixteen tap planes = 32 VGPRs of addresses, which the big kernels then spill).
+// (the empty asm pins the base in an SGPR pair at the point of use: otherwise LLVM re-associates
+// (base + k * plane) + offset into per-lane 64-bit pointers again and hoists them out of loops.  The pointer
+// is rebuilt in the GLOBAL address space: an inline asm hides where it came from, and a generic pointer would
+// compile to flat_load/flat_store, which also count on lgkmcnt -- every LDS barrier would then wait for them.)
+#define MEMC_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ uintptr_t pin_sgpr(const void *ubase)
+{
+    uintptr_t u = reinterpret_cast<uintptr_t>(ubase);
+    asm volatile("" : "+s"(u));
+    return u;
+}
+__device__ __forceinline__ f32x4 ld_stream4_u(const float *ubase, unsigned byte_off)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const MEMC_GLOBAL f32x4 *>(pin_sgpr(ubase) + byte_off));
+}
+__device__ __forceinline__ void st_stream4_u(float *ubase, unsigned byte_off, f32x4 v)
+{
+    __builtin_nontemporal_store(v, reinterpret_cast<MEMC_GLOBAL f32x4 *>(pin_sgpr(ubase) + byte_off));
+}
+// plain (cached) accesses through the same addressing
+__device__ __forceinline__ MEMC_GLOBAL float *at_u(float *ubase, unsigned byte_off)
+{
+    return reinterpret_cast<MEMC_GLOBAL float *>(pin_sgpr(ubase) + byte_off);
+}
+
 __device__ __forceinline__ int swz_col(int c) { return c ^ ((c >> 2) & 15); }
 
 // 16-B vector path preconditions: width and every stride a multiple of 4 elements, 16-B aligned bases.
@@ -425,7 +453,7 @@ __device__ __forceinline__ void acc64_zero(double *acc)
 
 __device__ __forceinline__ void lds_add_f64(double *p, double v) { (void)unsafeAtomicAdd(p, v); }   // ds_add_f64
 
-template <int LX, int NP>
+template <int LX, int NP, bool PLAIN_STORE = false>      // PLAIN_STORE: measurement only (wrong results)
 __device__ __forceinline__ void acc64_flush(const Region &r, const double *acc, float *const (&dst)[NP],
                                             const int (&hstride)[NP])
 {
@@ -436,9 +464,69 @@ __device__ __forceinline__ void acc64_flush(const Region &r, const double *acc, 
 #pragma unroll
             for (int pl = 0; pl < NP; pl++) {
                 const float v = (float)acc[pl * A::kPlane + row * A::kPitch + acc64_col(col)];
-                if (v != 0.0f) atomic_add_f32(dst[pl] + (int64_t)(r.y0 + row) * hstride[pl] + r.x0 + col, v);
+                float *q = dst[pl] + (int64_t)(r.y0 + row) * hstride[pl] + r.x0 + col;
+                if (v != 0.0f) {
+                    if (PLAIN_STORE) *q = v; else atomic_add_f32(q, v);
+                }
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Transposed fp64 accumulator plane.  Measured (tools/probes/run_probe.py ldspat): a ds_add_f64 costs ~8.8 clk
+// per wave-instruction whatever the number of active lanes, and the LDS serialises it over groups of 16 lanes
+// that must hit 16 different 8-byte slots (mod 128 B) to stay at that cost -- with one lane per pixel quad a
+// group is 16 quads of one tile row, i.e. cells 4 apart (+ flow), which in a row-major plane is 2..4 passes
+// (16 / 28 clk measured).  Here column c of a row is stored at (c & 3) * 32 + (c >> 2): cells 4 apart are
+// adjacent, rows are 128 cells (a multiple of 16 slots) apart, so lane i of a group lands in slot
+// (i + (offset >> 2)) mod 16 -- distinct unless the flow folds over itself.
+// ---------------------------------------------------------------------------------------------------------
+struct AccT {
+    static constexpr int kPitch = 128, kRows = 32, kPlane = kPitch * kRows;      // 32 KiB of doubles
+    static constexpr int kMaxW = 128;
+};
+__device__ __forceinline__ int acct_col(int c) { return ((c & 3) << 5) | (c >> 2); }
+
+template <int NPLANES = 1>
+__device__ __forceinline__ void acct_zero(double *acc)
+{
+    f32x4 *p = reinterpret_cast<f32x4 *>(acc);
+#pragma unroll
+    for (int i = 0; i < NPLANES * AccT::kPlane / 2 / 256; i++) p[threadIdx.x + i * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// Adds every non-zero cell of the region to dst (row-coalesced global atomics) and leaves the plane zeroed.
+// A wave takes rows wave, wave + 4, ...; four rows (eight cells per lane) are read before any is consumed so
+// that the LDS latency is paid once per batch, not once per cell.
+template <bool PLAIN_STORE = false>
+__device__ __forceinline__ void acct_flush_zero(const Region &r, double *acc, float *dst, int hstride)
+{
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int c0 = acct_col(lane), c1 = acct_col(lane + kWave);
+    const bool ok0 = lane < r.w, ok1 = lane + kWave < r.w;
+#pragma unroll 1
+    for (int row0 = wave; row0 < r.h; row0 += 16) {
+        double val[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int row = min(row0 + 4 * u, AccT::kRows - 1);
+            val[u][0] = acc[row * AccT::kPitch + c0];
+            val[u][1] = acc[row * AccT::kPitch + c1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int row = row0 + 4 * u;
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const float f = (float)val[u][hh];
+                if (row < r.h && (hh ? ok1 : ok0) && f != 0.0f) {
+                    acc[row * AccT::kPitch + (hh ? c1 : c0)] = 0.0;
+                    float *q = dst + (int64_t)(r.y0 + row) * hstride + r.x0 + lane + hh * kWave;
+                    if (PLAIN_STORE) *q = f; else atomic_add_f32(q, f);
+                }
+            }
+        }
+    }
 }
 
 }  // namespace memc

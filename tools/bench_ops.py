@@ -93,13 +93,19 @@ def bench_fi_fwd(rows, dev, B, C, H, W, flow_kind, variants, tag, rounds=4):
     L._debug_set_variant("fi_fwd", -1)
 
 
-def bench_fi_bwd(rows, dev, B, C, H, W, flow_kind, tag):
+def bench_fi_bwd(rows, dev, B, C, H, W, flow_kind, tag, variants=()):
     t = synth.torch_inputs(dev, B, C, H, W, flow_kind=flow_kind, with_grad=True)
     x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
     g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
 
     def pre():
         g1.zero_(); g2.zero_(); g3.zero_()
+    for v in variants:
+        L._debug_set_variant("fi_bwd", v)
+        med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre)
+        report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s ABLATION variant=%d" % (tag, C, B, H, W, flow_kind, v),
+               B * H * W, 4 * (3 * C + 2 * (2 + 16)), med, mn)
+    L._debug_set_variant("fi_bwd", -1)
     med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre)
     report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s" % (tag, C, B, H, W, flow_kind), B * H * W,
            4 * (3 * C + 2 * (2 + 16)), med, mn)
@@ -209,6 +215,7 @@ def main():
     ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "bench_ops.json"))
     ap.add_argument("--variants", default="-1,1,0")
     ap.add_argument("--proj-variants", default="")
+    ap.add_argument("--bwd-variants", default="", help="fi_bwd ablation arms (timing only, wrong results)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     only = set(filter(None, args.only.split(",")))
@@ -233,7 +240,8 @@ def main():
     if want("fi_bwd"):
         bench_fi_bwd(rows, dev, 8, 3, 256, 448, "smooth", "c2")
         if not args.quick:
-            bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "smooth", "720p")
+            bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "smooth", "720p",
+                         [int(v) for v in args.bwd_variants.split(",") if v])
     if want("proj"):
         bench_projection(rows, dev, 32, 720, 1280, "smooth", "c3",
                          [int(v) for v in args.proj_variants.split(",") if v])

@@ -118,6 +118,47 @@ __global__ __launch_bounds__(256) void lds_atomics64(float *__restrict__ sink, i
     __syncthreads();
     if (buf[threadIdx.x] == 12345.0) sink[0] = 1.f;
 }
+// ds_add_f64 under the access patterns of the tiled backward kernels.  pattern:
+//   0 consecutive cells, all lanes          1 consecutive, every 4th lane active      2 consecutive, every 8th
+//   3 kernel layout (row = lane/16, col = 4*(lane%16), pitch 97, bit-1 swizzle), no flow noise
+//   4 kernel layout with +-2 cells of per-lane noise     5 as 4 without the swizzle / with pitch 96
+//   6 as 3 with half of the lanes inactive (lane%2)      7 kernel layout, col = lane%16 * 4 + (lane/16) (rows share a line)
+__global__ __launch_bounds__(256) void lds_atomics_pattern(float *__restrict__ sink, int rep, int pattern)
+{
+    __shared__ double buf[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) buf[i] = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned h = (lane * 2654435761u) >> 13;
+    bool active = true;
+    int base;
+    if (pattern <= 2) {
+        base = wave * 64 + lane;
+        if (pattern == 1) { active = (lane & 3) == 0; base = wave * 64 + (lane >> 2); }
+        if (pattern == 2) { active = (lane & 7) == 0; base = wave * 64 + (lane >> 3); }
+    } else if (pattern == 7) {
+        base = wave * 4 * 97 + (lane & 15) * 4 + (lane >> 4);
+    } else {
+        const int row = wave * 4 + (lane >> 4);
+        int col = 4 * (lane & 15) + ((pattern == 4 || pattern == 5) ? (int)(h % 5) : 0);
+        const int pitch = pattern == 5 ? 96 : 97;
+        if (pattern != 5) col ^= (col >> 4) & 2;
+        base = row * pitch + col;
+        if (pattern == 6) active = (lane & 1) == 0;
+    }
+    for (int r = 0; r < rep; r++) {
+        const int a = (base + (r & 15) * 194 + (r >> 4)) & 4095;
+        if (active) (void)unsafeAtomicAdd(buf + a, 1.0);
+    }
+    __syncthreads();
+    if (buf[threadIdx.x] == 12345.0) sink[0] = 1.f;
+}
+extern "C" int probe_lds_pattern(void *stream, int blocks, float *sink, int rep, int pattern)
+{
+    hipLaunchKernelGGL(lds_atomics_pattern, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sink, rep, pattern);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" int probe_lds_atomics(void *stream, int blocks, float *sink, int rep, int stride, int rstep, int mode)
 {
     if (mode >= 3) {

@@ -79,6 +79,22 @@ def lds_main():
                 nm, stride, rstep, t * 1e6, ops / t / 1e9, ops / t / 256 / 2.4e9), flush=True)
 
 
+def lds_pattern_main():
+    lib = ctypes.CDLL(SO)
+    dev = torch.device("cuda:0")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sink = torch.zeros(4, device=dev)
+    blocks, rep = 256 * 8, 4096
+    names = {0: "consecutive, 64 lanes", 1: "consecutive, 16 of 64 lanes", 2: "consecutive, 8 of 64 lanes",
+             3: "kernel layout, no noise", 4: "kernel layout, noise 0..4 cells", 5: "pitch 96, no swizzle, noise",
+             6: "kernel layout, 32 of 64 lanes", 7: "rows interleaved in one line"}
+    for pat in sorted(names):
+        t = timeit(lambda: lib.probe_lds_pattern(st, blocks, ctypes.c_void_p(sink.data_ptr()), rep, pat), iters=5, warmup=2)
+        instr = blocks * 4 * rep                       # wave-instructions
+        print("ds_add_f64 %-34s %8.1f us  %6.1f clk per wave-instruction per CU (2.4 GHz)" % (
+            names[pat], t * 1e6, t * 2.4e9 * 256 / instr), flush=True)
+
+
 def copy_only():
     """a few launches of the float4 copy of known size (calibration source for tools/pmc_traffic.py)"""
     lib = ctypes.CDLL(SO)
@@ -97,6 +113,8 @@ if __name__ == "__main__":
         copy_only()
     elif len(sys.argv) > 1 and sys.argv[1] == "build":
         build()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ldspat":
+        lds_pattern_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "lds":
         lds_main()
     elif len(sys.argv) > 1 and sys.argv[1] == "atomics":
