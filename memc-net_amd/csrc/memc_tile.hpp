@@ -24,6 +24,16 @@ namespace memc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// threadIdx.x through an opaque asm: values derived from it are recomputed where they are used instead of
+// being hoisted out of a persistent kernel's tile loop and kept (or spilled) for the whole kernel -- a spill
+// reload is a scratch LOAD, and waiting for it means waiting for every store and atomic issued before it.
+__device__ __forceinline__ unsigned tid_now()
+{
+    unsigned t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 __device__ __forceinline__ f32x4 ld_stream4(const float *p)
 {
     return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
@@ -48,18 +58,26 @@ __device__ __forceinline__ uintptr_t pin_sgpr(const void *ubase)
     asm volatile("" : "+s"(u));
     return u;
 }
+// The offset goes through an asm as well so that its zero-extension sits in the SAME basic block as the access
+// (instruction selection is per block: a zext CSE'd into an earlier block is just a 64-bit VGPR pair to it, and
+// the access falls back to v_lshl_add_u64 + a 64-bit vaddr).
+__device__ __forceinline__ uintptr_t addr_u(const void *ubase, unsigned byte_off)
+{
+    asm volatile("" : "+v"(byte_off));
+    return pin_sgpr(ubase) + byte_off;
+}
 __device__ __forceinline__ f32x4 ld_stream4_u(const float *ubase, unsigned byte_off)
 {
-    return __builtin_nontemporal_load(reinterpret_cast<const MEMC_GLOBAL f32x4 *>(pin_sgpr(ubase) + byte_off));
+    return __builtin_nontemporal_load(reinterpret_cast<const MEMC_GLOBAL f32x4 *>(addr_u(ubase, byte_off)));
 }
 __device__ __forceinline__ void st_stream4_u(float *ubase, unsigned byte_off, f32x4 v)
 {
-    __builtin_nontemporal_store(v, reinterpret_cast<MEMC_GLOBAL f32x4 *>(pin_sgpr(ubase) + byte_off));
+    __builtin_nontemporal_store(v, reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(ubase, byte_off)));
 }
 // plain (cached) accesses through the same addressing
 __device__ __forceinline__ MEMC_GLOBAL float *at_u(float *ubase, unsigned byte_off)
 {
-    return reinterpret_cast<MEMC_GLOBAL float *>(pin_sgpr(ubase) + byte_off);
+    return reinterpret_cast<MEMC_GLOBAL float *>(addr_u(ubase, byte_off));
 }
 
 __device__ __forceinline__ int swz_col(int c) { return c ^ ((c >> 2) & 15); }
@@ -132,8 +150,9 @@ __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int 
     cmax = -wave_min_i32(-cmax);
     rmin = wave_min_i32(rmin);
     rmax = -wave_min_i32(-rmax);
-    const int wave = threadIdx.x / kWave;
-    if ((threadIdx.x & (kWave - 1)) == 0) {
+    const unsigned tid = tid_now();
+    const int wave = tid / kWave;
+    if ((tid & (kWave - 1)) == 0) {
         bb[wave * 4 + 0] = cmin;
         bb[wave * 4 + 1] = cmax;
         bb[wave * 4 + 2] = rmin;
@@ -209,8 +228,9 @@ __device__ __forceinline__ BBox tile_bbox(int cmin, int cmax, int rmin, int rmax
     cmax = -wave_min_i32(-cmax);
     rmin = wave_min_i32(rmin);
     rmax = -wave_min_i32(-rmax);
-    const int wave = threadIdx.x / kWave;
-    if ((threadIdx.x & (kWave - 1)) == 0) {
+    const unsigned tid = tid_now();
+    const int wave = tid / kWave;
+    if ((tid & (kWave - 1)) == 0) {
         bb[wave * 4 + 0] = cmin;
         bb[wave * 4 + 1] = cmax;
         bb[wave * 4 + 2] = rmin;
@@ -285,7 +305,8 @@ __device__ __forceinline__ StageSlot stage_slots(const Region &r)
 {
     StageSlot s;
     const int wq = max(r.w >> 2, 1);
-    int row = threadIdx.x / wq, q = threadIdx.x % wq;          // one run-time division per kernel
+    const unsigned tid = tid_now();
+    int row = tid / wq, q = tid % wq;          // one run-time division per kernel
     const int drow = 256 / wq, dq = 256 % wq;
 #pragma unroll
     for (int it = 0; it < kStageIts; it++) {
@@ -401,7 +422,7 @@ template <int LX, int NP>
 __device__ __forceinline__ void acc_zero(float *acc)
 {
     using A = AccGeom<LX>;
-    for (int i = threadIdx.x; i < NP * A::kPlane; i += TileGeom<LX>::kThreads) acc[i] = 0.0f;
+    for (int i = tid_now(); i < NP * A::kPlane; i += TileGeom<LX>::kThreads) acc[i] = 0.0f;
 }
 
 __device__ __forceinline__ void lds_add_f32(float *p, float v) { (void)unsafeAtomicAdd(p, v); }   // ds_add_f32
@@ -414,7 +435,8 @@ __device__ __forceinline__ void acc_flush(const Region &r, const float *acc, flo
 {
     using A = AccGeom<LX>;
     // 64 lanes walk a region row (pitch <= 97 -> two passes), 4 waves take rows round-robin
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const unsigned tid = tid_now();
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
     for (int row = wave; row < r.h; row += TileGeom<LX>::kThreads / kWave)
         for (int col = lane; col < r.w; col += kWave) {
 #pragma unroll
@@ -448,7 +470,7 @@ template <int LX, int NP>
 __device__ __forceinline__ void acc64_zero(double *acc)
 {
     using A = Acc64Geom<LX>;
-    for (int i = threadIdx.x; i < NP * A::kPlane; i += TileGeom<LX>::kThreads) acc[i] = 0.0;
+    for (int i = tid_now(); i < NP * A::kPlane; i += TileGeom<LX>::kThreads) acc[i] = 0.0;
 }
 
 __device__ __forceinline__ void lds_add_f64(double *p, double v) { (void)unsafeAtomicAdd(p, v); }   // ds_add_f64
@@ -458,7 +480,8 @@ __device__ __forceinline__ void acc64_flush(const Region &r, const double *acc, 
                                             const int (&hstride)[NP])
 {
     using A = Acc64Geom<LX>;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const unsigned tid = tid_now();
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
     for (int row = wave; row < r.h; row += TileGeom<LX>::kThreads / kWave)
         for (int col = lane; col < r.w; col += kWave) {
 #pragma unroll
@@ -491,8 +514,9 @@ template <int NPLANES = 1>
 __device__ __forceinline__ void acct_zero(double *acc)
 {
     f32x4 *p = reinterpret_cast<f32x4 *>(acc);
+    const unsigned tid = tid_now();
 #pragma unroll
-    for (int i = 0; i < NPLANES * AccT::kPlane / 2 / 256; i++) p[threadIdx.x + i * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NPLANES * AccT::kPlane / 2 / 256; i++) p[tid + i * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // Adds every non-zero cell of the region to dst (row-coalesced global atomics) and leaves the plane zeroed.
@@ -501,7 +525,8 @@ __device__ __forceinline__ void acct_zero(double *acc)
 template <bool PLAIN_STORE = false>
 __device__ __forceinline__ void acct_flush_zero(const Region &r, double *acc, float *dst, int hstride)
 {
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const unsigned tid = tid_now();
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
     const int c0 = acct_col(lane), c1 = acct_col(lane + kWave);
     const bool ok0 = lane < r.w, ok1 = lane + kWave < r.w;
 #pragma unroll 1

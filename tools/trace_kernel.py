@@ -14,10 +14,10 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "memc-net_amd"))
 import my_package._ext.my_lib as L      # noqa: E402
 from tools import synth                 # noqa: E402
 
-# slot i -> what ended there (persistent kernel; the SECOND tile of every workgroup is the one traced)
-MARKS = [(1, "wait for (prefetched) inputs"), (2, "locate + bbox"), (3, "stage image"),
-         (4, "phase 1 (taps/flow grads)"), (5, "request next tile + zero planes"), (6, "adds c0"),
-         (7, "flush c0 + adds c1"), (8, "flush c1 + adds c2"), (9, "flush c2"), (12, "later bands / tail")]
+# slot i -> what ended there
+MARKS = [(1, "load inputs"), (2, "locate + bbox"), (3, "stage image"), (4, "phase 1 (taps/flow grads)"),
+         (5, "zero plane"), (6, "adds c0"), (7, "flush c0"), (8, "adds c1"), (9, "flush c1"), (10, "adds c2"),
+         (11, "flush c2"), (12, "later bands / tail")]
 
 
 def main():
@@ -27,7 +27,7 @@ def main():
     x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
     g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
     ntiles = ((W + 63) // 64) * ((H + 15) // 16) * B
-    nblk = min(ntiles, 2 * torch.cuda.get_device_properties(0).multi_processor_count // 8 * 8)
+    nblk = ntiles
     buf = torch.zeros(nblk * 16, dtype=torch.int64, device=dev)
     lib = L._lib
     lib.memc_debug_set_trace_buffer.argtypes = [ctypes.c_void_p]
@@ -41,11 +41,12 @@ def main():
     L._debug_set_variant("fi_bwd", -1)
     ts = buf.cpu().numpy().reshape(nblk, 16).astype(np.int64)
     us = a.elapsed_time(b) * 1e3
-    per_tile = us / (ntiles / nblk)
-    print("kernel %.1f us by events (timestamp arm); %d persistent workgroups x %.1f tiles -> %.2f us per tile" % (
-        us, nblk, ntiles / nblk, per_tile))
+    slots = 2 * torch.cuda.get_device_properties(0).multi_processor_count
+    per_tile = us / (ntiles / slots)
+    print("kernel %.1f us by events (timestamp arm); %d workgroups, %d resident -> %.2f us per tile" % (
+        us, nblk, slots, per_tile))
     tot = (ts[:, 12] - ts[:, 0]).astype(np.float64)
-    print("%-34s %9s %9s" % ("phase (tile 2 of each workgroup)", "share", "~us"))
+    print("%-34s %9s %9s" % ("phase", "share", "~us"))
     prev = 0
     for slot, nm in MARKS:
         d = (ts[:, slot] - ts[:, prev]).astype(np.float64)
