@@ -919,7 +919,7 @@ __device__ __forceinline__ void fi_bwd_adds(const Region &r, unsigned fast, FiSi
 //   MINW = 3: 3 workgroups / CU at 168 VGPRs (152 B of spills)        (arm 16)  1.93 ms
 //   persistent, 2 / CU, next tile's inputs prefetched during phase 2  (arm 10)  1.83 ms (2.09 with this phase 1)
 //   persistent without the prefetch                                   (arm 11)  1.83 ms (1.98)
-//   second workgroup of every CU delayed by half a tile                          no change
+//   second workgroup of every CU delayed by half a tile; wave priority rising through phase 2      no change
 //   no phase 2 at all                                                 (arm 2)   1.05 - 1.3 ms (the HBM floor)
 // i.e. the time is phase 1 (HBM bound) PLUS the LDS-atomic work of phase 2, however the two are arranged: what
 // is left to gain is in the number and the conflict rate of the ds_add_f64 (768 wave-instructions per tile at

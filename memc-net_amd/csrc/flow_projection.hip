@@ -354,7 +354,15 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
 constexpr int kPtW = 68, kPtH = 17;           // point window 65 x 17, pitch 68
 
 // kReach = supported |flow| on the fast path (pixels)
-template <bool DEPTH, int kReach>
+// Per-workgroup phase timestamps (shader clock) for tools/trace_kernel.py; written by the TRACE instance only.
+__device__ unsigned long long *g_trace_buf_proj = nullptr;
+template <bool ON>
+__device__ __forceinline__ void trace_mark_proj(int slot)
+{
+    if (ON && threadIdx.x == 0) g_trace_buf_proj[(size_t)blockIdx.x * 16 + slot] = __builtin_readcyclecounter();
+}
+
+template <bool DEPTH, int kReach, bool TRACE = false>
 __global__ __launch_bounds__(256) void proj_owner(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
@@ -367,6 +375,7 @@ __global__ __launch_bounds__(256) void proj_owner(
     __shared__ double P[3 * kPtH * kPtW];
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
     const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
+    trace_mark_proj<TRACE>(0);
     for (int i = threadIdx.x; i < 3 * kPtH * kPtW; i += 256) P[i] = 0.0;
 
     // scan: kScanW / 4 = 26 float4 columns x kScanH rows = 1274 slots, 5 per lane; all loads first
@@ -390,6 +399,9 @@ __global__ __launch_bounds__(256) void proj_owner(
         if (DEPTH) dd[it] = ld_cached4(live[it] ? depth_b + (int64_t)sy[it] * sdh + sx[it] : depth_b);
     }
     __syncthreads();                           // P is zero
+    trace_mark_proj<TRACE>(1);                 // loads issued, P zeroed
+    if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    trace_mark_proj<TRACE>(2);                 // loads arrived
     bool far = false;
 #pragma unroll
     for (int it = 0; it < kIts; it++) {
@@ -425,7 +437,9 @@ __global__ __launch_bounds__(256) void proj_owner(
         far_flag[b % kFlagWords] = 1;
         far_flag[kFlagWords] = 1;
     }
+    trace_mark_proj<TRACE>(3);                 // scan + splat done (wave 0)
     __syncthreads();
+    trace_mark_proj<TRACE>(4);                 // all waves done
 
     // every lane owns four cells of a row
     const int cx = tx0 + 4 * (threadIdx.x % 16), cy = ty0 + threadIdx.x / 16;
@@ -459,6 +473,7 @@ __global__ __launch_bounds__(256) void proj_owner(
     *reinterpret_cast<f32x4 *>(o) = ox;        // plain stores: pass 3 (hole fill) re-reads them
     *reinterpret_cast<f32x4 *>(o + s1c) = oy;
     *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
+    trace_mark_proj<TRACE>(5);                 // outputs stored (issued)
 }
 
 // general path, queued behind proj_owner: each kernel returns at once unless a far source was seen
@@ -758,14 +773,17 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
         if (flag) {
             // fast path: owner-computes (no atomics, fused averaging) + the general path behind a device flag
             if (hipMemsetAsync(flag, 0, (kFlagWords + 1) * sizeof(int), stream) != hipSuccess) return -1;
-            if (g_proj_variant == -6)
+            if (g_proj_variant == -7)
+                hipLaunchKernelGGL((proj_owner<DEPTH, 24, true>), dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
+                                   (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, flag);
+            else if (g_proj_variant == -6)
                 hipLaunchKernelGGL((proj_owner<DEPTH, 16>), dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
                                    (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, flag);
             else
                 hipLaunchKernelGGL((proj_owner<DEPTH, 24>), dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
                                    (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, flag);
             if (launch_status() != 0) return -1;
-            if (g_proj_variant == -5) return 0;            // measurement arm: owner kernel alone
+            if (g_proj_variant == -5 || g_proj_variant == -7) return 0;     // measurement arms: owner kernel alone
             hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c, s1h,
                                (int64_t)scb, sch, batch, count, out, flag);
             MEMC_PROJ_SCATTER(0, flag);
@@ -837,6 +855,11 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
 using namespace memc;
 
 extern "C" void memc_debug_set_projection_variant(int v) { g_proj_variant = v; }
+extern "C" int memc_debug_set_trace_buffer_proj(void *p)
+{
+    unsigned long long *q = (unsigned long long *)p;
+    return hipMemcpyToSymbol(HIP_SYMBOL(memc::g_trace_buf_proj), &q, sizeof(q)) == hipSuccess ? 0 : -1;
+}
 
 extern "C" int FlowProjection_gpu_forward_kernel(
     memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
 // Backward, tiled, RGB: image gradient splatted into LDS accumulators and flushed with coalesced atomics
 // (memc_tile.hpp "LDS-privatised scatter"); the flow gradient needs the four corner values, gathered from a
 // staged LDS image of the same box.
-__global__ __launch_bounds__(256, 2) void bl_bwd_tiled_c3(
+__global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
@@ -225,13 +225,13 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_tiled_c3(
 {
     constexpr int LX = 16;
     using G = TileGeom<LX>;
-    using A = Acc64Geom<LX>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // phase 1 uses the LDS as the staged image (48 KiB of pixel quads), phase 2 re-uses the same bytes as the
-    // fp64 accumulator planes (73 KiB): two workgroups per CU instead of one
+    // phase 1 uses the LDS as the staged image (48 KiB of pixel quads), phase 2 re-uses the same bytes as ONE
+    // transposed fp64 accumulator plane (AccT, 32 KiB) that the colour channels take in turn: three workgroups
+    // per CU, and the 16-lane groups of a ds_add_f64 hit adjacent slots (see memc_tile.hpp)
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     double *acc = reinterpret_cast<double *>(smem);
-    int *bb = reinterpret_cast<int *>(smem + 3 * A::kPlane * 8);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
 
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
@@ -320,36 +320,34 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_tiled_c3(
     }
     __syncthreads();                           // the image has been read: the LDS becomes the accumulators
 
-    // ---- phase 2: image gradient, 12 fp64 LDS adds per site
-    acc64_zero<LX, 3>(acc);
+    // ---- phase 2: image gradient, 4 fp64 LDS adds per site and channel
+    acct_zero<1>(acc);
     __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (!st[j].valid) continue;
-        const BlSite &s = st[j];
-        const bool staged = (staged_mask >> j) & 1;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float gv = go[c][j];
+        for (int j = 0; j < 4; j++) {
+            if (!st[j].valid) continue;
+            const BlSite &s = st[j];
+            const bool staged = (staged_mask >> j) & 1;
+            const float gv = c == 0 ? go[0][j] : (c == 1 ? go[1][j] : go[2][j]);
             const float a00 = gv * (1 - s.a) * (1 - s.b), a01 = gv * s.a * (1 - s.b);
             const float a10 = gv * (1 - s.a) * s.b, a11 = gv * s.a * s.b;
             if (staged) {
-                double *ap = acc + c * A::kPlane;
-                const int aT = (s.T - r.y0) * A::kPitch, aB = (s.Bm - r.y0) * A::kPitch;
-                const int aL = acc64_col(s.L - r.x0), aR = acc64_col(s.R - r.x0);
-                lds_add_f64(ap + aT + aL, (double)a00);  lds_add_f64(ap + aT + aR, (double)a01);
-                lds_add_f64(ap + aB + aL, (double)a10);  lds_add_f64(ap + aB + aR, (double)a11);
+                const int aT = (s.T - r.y0) * AccT::kPitch, aB = (s.Bm - r.y0) * AccT::kPitch;
+                const int aL = acct_col(s.L - r.x0), aR = acct_col(s.R - r.x0);
+                lds_add_f64(acc + aT + aL, (double)a00);  lds_add_f64(acc + aT + aR, (double)a01);
+                lds_add_f64(acc + aB + aL, (double)a10);  lds_add_f64(acc + aB + aR, (double)a11);
             } else {
                 float *q = gin1_b + c * s1c;
                 atomic_add_f32(q + s.T * s1h + s.L, a00);   atomic_add_f32(q + s.T * s1h + s.R, a01);
                 atomic_add_f32(q + s.Bm * s1h + s.L, a10);  atomic_add_f32(q + s.Bm * s1h + s.R, a11);
             }
         }
+        __syncthreads();
+        acct_flush_zero(r, acc, gin1_b + c * s1c, s1h);        // leaves the plane zeroed for the next channel
+        __syncthreads();
     }
-    __syncthreads();
-    float *const dst[3] = {gin1_b, gin1_b + s1c, gin1_b + 2 * s1c};
-    const int hs[3] = {s1h, s1h, s1h};
-    acc64_flush<LX, 3>(r, acc, dst, hs);
 }
 
 static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batch, int s1b, int s1c, int s1h,
@@ -388,11 +386,10 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
     if (w <= 0 || h <= 0 || channel <= 0 || batch <= 0) return 0;
     if (channel == 3 && vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2})) {
         using G = TileGeom<16>;
-        using A = Acc64Geom<16>;
+        static_assert(AccT::kPlane * 8 <= G::kCapPx * 16 && G::kPitch <= AccT::kMaxW && G::kRows <= AccT::kRows,
+                      "the accumulator plane aliases the staged image");
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-        const int lds = 3 * A::kPlane * 8 + 64;            // >= the 48 KiB image it aliases
-        static const bool once = (allow_big_lds(bl_bwd_tiled_c3, lds), true);
-        (void)once;
+        const int lds = tile_lds_bytes<16>();
         hipLaunchKernelGGL(bl_bwd_tiled_c3, dim3((unsigned)ntx * nty * batch), dim3(256), lds, stream, w, h, ntx, nty, (int64_t)s1b, (int64_t)s1c,
                            s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, gradoutput, gradinput1, gradinput2);
         return launch_status();

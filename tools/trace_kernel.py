@@ -1,7 +1,11 @@
 #!/usr/bin/env python
-"""tools/trace_kernel.py -- per-phase timeline of fi_bwd_tiled_c3 from in-kernel shader-clock timestamps
-(measurement arm 9).  Run on the GPU box:  python tools/trace_kernel.py
-Prints the mean / median duration of every phase of a workgroup and how many workgroups overlap on a CU."""
+"""tools/trace_kernel.py -- per-phase timeline of a tiled kernel from in-kernel shader-clock timestamps
+(measurement arms: fi_bwd variant 9, projection variant -7).  Run on the GPU box:
+
+    python tools/trace_kernel.py [fi_bwd|proj]
+
+Prints the share of a workgroup's life spent in every phase (thread 0's view; barriers fold the slowest wave's
+time into the phase that ends with them)."""
 import ctypes
 import os
 import sys
@@ -14,43 +18,54 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "memc-net_amd"))
 import my_package._ext.my_lib as L      # noqa: E402
 from tools import synth                 # noqa: E402
 
-# slot i -> what ended there
-MARKS = [(1, "load inputs"), (2, "locate + bbox"), (3, "stage image"), (4, "phase 1 (taps/flow grads)"),
-         (5, "zero plane"), (6, "adds c0"), (7, "flush c0"), (8, "adds c1"), (9, "flush c1"), (10, "adds c2"),
-         (11, "flush c2"), (12, "later bands / tail")]
+KERNELS = {
+    "fi_bwd": dict(setter="memc_debug_set_trace_buffer", op="fi_bwd", variant=9, last=12,
+                   marks=[(1, "load inputs"), (2, "locate + bbox"), (3, "stage image"),
+                          (4, "phase 1 (taps/flow grads)"), (5, "zero plane"), (6, "adds c0"), (7, "flush c0"),
+                          (8, "adds c1"), (9, "flush c1"), (10, "adds c2"), (11, "flush c2"),
+                          (12, "later bands / tail")]),
+    "proj": dict(setter="memc_debug_set_trace_buffer_proj", op="projection", variant=-7, last=5,
+                 marks=[(1, "issue scan loads + zero P + barrier"), (2, "wait for the loads"),
+                        (3, "scan: locate + fp64 splat (wave 0)"), (4, "barrier (slowest wave)"),
+                        (5, "box sum + normalise + store")]),
+}
 
 
 def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "fi_bwd"
+    K = KERNELS[which]
     dev = torch.device("cuda:0")
     B, C, H, W = 32, 3, 720, 1280
     t = synth.torch_inputs(dev, B, C, H, W, flow_kind="smooth", with_grad=True)
     x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
-    g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
+    if which == "fi_bwd":
+        g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
+        fn = lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3)     # noqa: E731
+    else:
+        cnt, out = f.new_zeros((B, 1, H, W)), torch.zeros_like(f)
+        fn = lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0)                   # noqa: E731
     ntiles = ((W + 63) // 64) * ((H + 15) // 16) * B
-    nblk = ntiles
-    buf = torch.zeros(nblk * 16, dtype=torch.int64, device=dev)
-    lib = L._lib
-    lib.memc_debug_set_trace_buffer.argtypes = [ctypes.c_void_p]
-    assert lib.memc_debug_set_trace_buffer(ctypes.c_void_p(buf.data_ptr())) == 0
+    buf = torch.zeros(ntiles * 16, dtype=torch.int64, device=dev)
+    setter = getattr(L._lib, K["setter"])
+    setter.argtypes = [ctypes.c_void_p]
+    assert setter(ctypes.c_void_p(buf.data_ptr())) == 0
     for _ in range(30):
-        L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3)
-    L._debug_set_variant("fi_bwd", 9)
+        fn()
+    L._debug_set_variant(K["op"], K["variant"])
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(); L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3); b.record(); b.synchronize()
-    L._debug_set_variant("fi_bwd", -1)
-    ts = buf.cpu().numpy().reshape(nblk, 16).astype(np.int64)
+    a.record(); fn(); b.record(); b.synchronize()
+    L._debug_set_variant(K["op"], -1)
+    ts = buf.cpu().numpy().reshape(ntiles, 16).astype(np.int64)
     us = a.elapsed_time(b) * 1e3
-    slots = 2 * torch.cuda.get_device_properties(0).multi_processor_count
-    per_tile = us / (ntiles / slots)
-    print("kernel %.1f us by events (timestamp arm); %d workgroups, %d resident -> %.2f us per tile" % (
-        us, nblk, slots, per_tile))
-    tot = (ts[:, 12] - ts[:, 0]).astype(np.float64)
-    print("%-34s %9s %9s" % ("phase", "share", "~us"))
+    tot = (ts[:, K["last"]] - ts[:, 0]).astype(np.float64)
+    print("%s: %.1f us by events (timestamp arm), %d workgroups, mean workgroup life %.0f shader clocks" % (
+        which, us, ntiles, tot.mean()))
+    print("%-40s %8s %12s" % ("phase", "share", "mean clocks"))
     prev = 0
-    for slot, nm in MARKS:
+    for slot, nm in K["marks"]:
         d = (ts[:, slot] - ts[:, prev]).astype(np.float64)
-        print("%-34s %8.1f%% %9.2f" % (nm, 100 * d.mean() / tot.mean(), per_tile * d.mean() / tot.mean()))
+        print("%-40s %7.1f%% %12.0f" % (nm, 100 * d.mean() / tot.mean(), d.mean()))
         prev = slot
 
 
