@@ -18,7 +18,10 @@
  * Contract (identical to the reference):
  *   - fp32, NCHW, strides in ELEMENTS, w-stride must be 1;
  *   - every output / gradient buffer is borrowed: allocated AND zero-filled by the caller
- *     (my_package/functions/FilterInterpolationLayer.py:26-29,46-48; FlowProjectionLayer.py:27-29,54);
+ *     (my_package/functions/FilterInterpolationLayer.py:26-29,46-48; FlowProjectionLayer.py:27-29,54).
+ *     With zero-filled buffers the results are the reference's.  With anything else they are unspecified,
+ *     and in one place differ from the reference's `+=`: the FilterInterpolation backward STORES gradinput3
+ *     (each site owns its taps) instead of adding to it; gradinput1 is added to, gradinput2 assigned, as there;
  *   - `output`, `gradoutput` and `gradinput1` are indexed with input1's b/c/h strides
  *     (my_lib_kernel.cu:1184,1276-1283), `gradinput2`/`gradinput3` with input2's/input3's;
  *   - work is enqueued asynchronously on `stream`; no host synchronisation and no state carried from one call
