@@ -197,6 +197,34 @@ int DepthFlowProjection_gpu_backward_kernel(
     const float *input1, const float *input2, const float *count, const float *output,
     const float *gradoutput, float *gradinput1, float *gradinput2);
 
+/* ------------------------------------------------------------------------------------------------------
+ * EXTENSION -- no reference counterpart.  The two adaptive warps of a frame pair and
+ * their occlusion-weighted blend, networks/MEMC_Net_star.py:266-277 (`FilterInterpolate`), in one pass:
+ *
+ *     output = occlusion0 * FilterInterpolation(input0, flow0, filter0)
+ *            + occlusion1 * FilterInterpolation(input2, flow1, filter1)
+ *
+ * so that the two warped frames never exist in memory (188 instead of 236 bytes per site).  Forward only (the
+ * shipped Python layer differentiates it through the reference-API entry points above).  RGB inputs,
+ * filter_size 4, 16-byte aligned geometry: anything else returns -1 and the caller composes the result from two
+ * FilterInterpolationLayer_gpu_forward calls.  input0 / input2 / output share one layout, flow0 / flow1 another,
+ * filter0 / filter1 another, the occlusions ([B, 1, H, W]) another.  `output` need not be zero-filled.
+ * ------------------------------------------------------------------------------------------------------ */
+int FilterInterpolationBlendLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input0,
+                                              const memc_tensor4 *input2, const memc_tensor4 *flow0,
+                                              const memc_tensor4 *flow1, const memc_tensor4 *filter0,
+                                              const memc_tensor4 *filter1, const memc_tensor4 *occlusion0,
+                                              const memc_tensor4 *occlusion1, const memc_tensor4 *output);
+
+int FilterInterpolationBlend_gpu_forward_kernel(
+    memc_stream_t stream, const int w, const int h, const int channel, const int batch, const int filter_size,
+    const int input_b_stride, const int input_c_stride, const int input_h_stride,
+    const int flow_b_stride, const int flow_c_stride, const int flow_h_stride,
+    const int filter_b_stride, const int filter_c_stride, const int filter_h_stride,
+    const int occlusion_b_stride, const int occlusion_h_stride,
+    const float *input0, const float *input2, const float *flow0, const float *flow1,
+    const float *filter0, const float *filter1, const float *occlusion0, const float *occlusion1, float *output);
+
 #ifdef __cplusplus
 }
 #endif

@@ -491,6 +491,146 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
 }
 
 // --------------------------------------------------------------------------------------------------
+// EXTENSION (no reference counterpart): the two adaptive warps of a frame pair and
+// their occlusion-weighted blend in one pass,
+//     out = occ0 * FI(in0, flow0, filt0) + occ1 * FI(in2, flow1, filt1)          (MEMC_Net_star.py:266-277)
+// RGB, fs == 4.  Per site this moves 2 * (12 + 8 + 64) + 8 + 12 = 188 B instead of the 2 * 96 + 44 = 236 B of two
+// warps and a separate blend: the two warped frames never exist in memory.  Same tile machinery as
+// fi_fwd_tiled_fs4: both directions' streams are requested up front, then each direction runs its own
+// box -> stage -> gather round on the same LDS bytes.
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 fi_site_vals3(int x, int y, int W, int H, const float *plane0, int64_t s1c,
+                                               int s1h, float fx, float fy, const float *tap_p, int64_t s3c)
+{
+    const FiSite s = fi_locate(x, y, W, H, fx, fy);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!s.valid) return v;                                // (callers only pass valid sites)
+    const int L = s.ix - 1, T = s.iy - 1, R = L + 4, Bm = T + 4;
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+        const float *p = plane0 + c * s1c;
+        const float TL = fi_quad_sum(p, s1h, W, H, tap_p, s3c, 4, L, T, T, s.iy, L, s.ix);
+        const float TR = fi_quad_sum(p, s1h, W, H, tap_p, s3c, 4, L, T, T, s.iy, s.ix + 1, R - 1);
+        const float BL = fi_quad_sum(p, s1h, W, H, tap_p, s3c, 4, L, T, s.iy + 1, Bm - 1, L, s.ix);
+        const float BR = fi_quad_sum(p, s1h, W, H, tap_p, s3c, 4, L, T, s.iy + 1, Bm - 1, s.ix + 1, R - 1);
+        v[c] = (1 - s.a) * (1 - s.b) * TL + s.a * (1 - s.b) * TR + (1 - s.a) * s.b * BL + s.a * s.b * BR;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void fi_fwd_blend_c3(
+    int W, int H, int tiles_x, int tiles_y,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
+    int64_t sob, int soh,
+    const float *__restrict__ in0, const float *__restrict__ in2, const float *__restrict__ flow0,
+    const float *__restrict__ flow1, const float *__restrict__ filt0, const float *__restrict__ filt1,
+    const float *__restrict__ occ0, const float *__restrict__ occ1, float *__restrict__ out)
+{
+    constexpr int LX = 16;
+    using G = TileGeom<LX>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const int b = tc.b;
+    const unsigned tid = tid_now();
+    const int x = tc.tx * G::kTW + 4 * (int)(tid % LX), y = tc.ty * G::kTH + (int)(tid / LX);
+    const bool inb = x < W && y < H;
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const unsigned o2 = 4u * (unsigned)(ys * s2h + xs), o3 = 4u * (unsigned)(ys * s3h + xs),
+                   oo = 4u * (unsigned)(ys * soh + xs);
+    // (pinned in SGPRs here: after the divergent exits below the compiler refuses to move it there)
+    const uintptr_t out_u = pin_sgpr(out + b * s1b);
+    // all streams of both directions first: 2 * 18 + 2 float4 per lane in flight
+    f32x4 fx[2], fy[2], oc[2], tp0[16], tp1[16];
+    fx[0] = ld_stream4_u(flow0 + b * s2b, o2);  fy[0] = ld_stream4_u(flow0 + b * s2b + s2c, o2);
+    fx[1] = ld_stream4_u(flow1 + b * s2b, o2);  fy[1] = ld_stream4_u(flow1 + b * s2b + s2c, o2);
+#pragma unroll
+    for (int k = 0; k < 16; k++) tp0[k] = ld_stream4_u(filt0 + b * s3b + k * s3c, o3);
+#pragma unroll
+    for (int k = 0; k < 16; k++) tp1[k] = ld_stream4_u(filt1 + b * s3b + k * s3c, o3);
+    oc[0] = ld_stream4_u(occ0 + b * sob, oo);
+    oc[1] = ld_stream4_u(occ1 + b * sob, oo);
+
+    // one direction: box -> (bands of) stage -> gather; returns the warped RGB of the lane's four sites
+    auto warp = [&](const float *in_b, const float *flow_b, const float *filt_b, const f32x4 &fx4, const f32x4 &fy4,
+                    f32x4 (&tp)[16], f32x4 (&res)[4]) {
+        FiSite4 g;
+        g.valid = 0;
+        int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
+            g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
+            if (inb && s.valid) {
+                g.valid |= 1u << j;
+                cmin = min(cmin, max(s.ix - 1, 0));  cmax = max(cmax, min(s.ix + 2, W - 1));
+                rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
+            }
+        }
+        const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
+        const Bands bands = make_bands<LX>(box);
+#pragma unroll
+        for (int j = 0; j < 4; j++) res[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned done = 0;
+#pragma unroll 1
+        for (int bi = 0; bi < bands.n; bi++) {
+            const Region rb = band_region(box, bands, bi);
+            const unsigned sel = inb ? fi_covered(rb, g, W, H) & ~done : 0u;
+            if (bi > 0 && !__syncthreads_or(sel != 0)) continue;
+            done |= sel;
+            tile_stage<LX, 3>(rb, in_b, s1c, s1h, tile);
+            __syncthreads();
+            // keep tap splats / blend weights inside the loop (hoisted, they spill)
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
+            fi_gather<LX, 3>(rb, g, tp, sel, W, H, tile, res);
+        }
+        if (!inb) return;
+        unsigned slow = g.valid & ~done;                   // rare: not coverable within kMaxBands bands
+        while (slow) {
+            const int j = __ffs(slow) - 1;
+            slow &= slow - 1;
+            const f32x4 v = fi_site_vals3(x + j, y, W, H, in_b, s1c, s1h, flow_b[(int64_t)y * s2h + x + j],
+                                          flow_b[s2c + (int64_t)y * s2h + x + j],
+                                          filt_b + (int64_t)y * s3h + x + j, s3c);
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) res[jj] = jj == j ? v : res[jj];
+        }
+        if (g.valid != 0xFu) {                             // out-of-range sites copy the input pixel
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const f32x4 own = ld_cached4(in_b + c * s1c + (int64_t)y * s1h + x);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (!((g.valid >> j) & 1)) res[j][c] = own[j];
+            }
+        }
+    };
+
+    f32x4 w0[4], w2[4];
+    warp(in0 + b * s1b, flow0 + b * s2b, filt0 + b * s3b, fx[0], fy[0], tp0, w0);
+    __syncthreads();                                       // direction 0's gathers are done: the LDS is free again
+    warp(in2 + b * s1b, flow1 + b * s2b, filt1 + b * s3b, fx[1], fy[1], tp1, w2);
+    if (!inb) return;
+    const unsigned o1 = 4u * (unsigned)(y * s1h + x);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float p0 = oc[0][j] * w0[j][c], p2 = oc[1][j] * w2[j][c];     // two products, one sum: the
+            v[j] = p0 + p2;                                                      // reference's torch expression
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<MEMC_GLOBAL f32x4 *>(out_u + (uintptr_t)(c * s1c) * 4u + o1));
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // Forward, fs == 4, direct gather from global memory through L1/L2.
 //   ROWS waves per workgroup, one image row each: tile = 64 x ROWS sites.
 //   CT > 0: channel count known at compile time (fully unrolled); CT == 0: run-time channel loop.
@@ -1420,5 +1560,31 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput,
                            gradinput1, gradinput2, gradinput3);
     }
+    return launch_status();
+}
+
+// EXTENSION (no reference counterpart): fused dual warp + occlusion blend, see fi_fwd_blend_c3.
+// Strides: in0 / in2 / out share (s1b, s1c, s1h); flow0 / flow1 (s2b, s2c, s2h); filter0 / filter1 (s3b, s3c, s3h);
+// occlusion0 / occlusion1 are [B, 1, H, W] with (sob, soh).  RGB and fs == 4 only, 16-byte aligned geometry;
+// returns -1 otherwise (the caller composes the result from the two forward calls instead).
+extern "C" int FilterInterpolationBlend_gpu_forward_kernel(
+    memc_stream_t stream_, const int w, const int h, const int channel, const int batch, const int filter_size,
+    const int s1b, const int s1c, const int s1h, const int s2b, const int s2c, const int s2h,
+    const int s3b, const int s3c, const int s3h, const int sob, const int soh,
+    const float *input0, const float *input2, const float *flow0, const float *flow1,
+    const float *filter0, const float *filter1, const float *occlusion0, const float *occlusion1, float *output)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (w <= 0 || h <= 0 || batch <= 0) return 0;
+    if (channel != 3 || filter_size != 4) return -1;
+    if (!vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h, sob, soh},
+                 {input0, input2, flow0, flow1, filter0, filter1, occlusion0, occlusion1, output}))
+        return -1;
+    using G = TileGeom<16>;
+    const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+    hipLaunchKernelGGL(fi_fwd_blend_c3, dim3((unsigned)ntx * nty * batch), dim3(256), tile_lds_bytes<16>(), stream, w,
+                       h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,
+                       (int64_t)s3c, s3h, (int64_t)sob, soh, input0, input2, flow0, flow1, filter0, filter1,
+                       occlusion0, occlusion1, output);
     return launch_status();
 }

@@ -153,6 +153,36 @@ int FilterInterpolationLayer_gpu_backward(memc_stream_t stream, const memc_tenso
         input3->data, gradoutput->data, gradinput1->data, gradinput2->data, gradinput3->data);
 }
 
+// EXTENSION (memc_warp.h): fused dual warp + occlusion blend.  Same checks as two FilterInterpolation forwards,
+// plus pairwise-equal layouts (one set of strides per tensor kind reaches the kernel).
+int FilterInterpolationBlendLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input0,
+                                              const memc_tensor4 *input2, const memc_tensor4 *flow0,
+                                              const memc_tensor4 *flow1, const memc_tensor4 *filter0,
+                                              const memc_tensor4 *filter1, const memc_tensor4 *occlusion0,
+                                              const memc_tensor4 *occlusion1, const memc_tensor4 *output)
+{
+    const memc_tensor4 *all[] = {input0, input2, flow0, flow1, filter0, filter1, occlusion0, occlusion1, output};
+    for (const memc_tensor4 *t : all)
+        if (!ok(t)) return kErr;
+    if (!flow_matches(input0, flow0)) return kErr;
+    if (!same_layout(input0, input2) || !same_layout(input0, output) || !same_layout(flow0, flow1) ||
+        !same_layout(filter0, filter1) || !same_layout(occlusion0, occlusion1))
+        return kErr;
+    if (filter0->size[0] != input0->size[0] || filter0->size[2] != input0->size[2] ||
+        filter0->size[3] != input0->size[3])
+        return kErr;
+    if (occlusion0->size[0] != input0->size[0] || occlusion0->size[1] != 1 ||
+        occlusion0->size[2] != input0->size[2] || occlusion0->size[3] != input0->size[3])
+        return kErr;
+    const int filter_size = (int)sqrt((float)filter0->size[1]);
+    return FilterInterpolationBlend_gpu_forward_kernel(
+        stream, (int)input0->size[3], (int)input0->size[2], (int)input0->size[1], (int)input0->size[0], filter_size,
+        (int)input0->stride[0], (int)input0->stride[1], (int)input0->stride[2], (int)flow0->stride[0],
+        (int)flow0->stride[1], (int)flow0->stride[2], (int)filter0->stride[0], (int)filter0->stride[1],
+        (int)filter0->stride[2], (int)occlusion0->stride[0], (int)occlusion0->stride[2], input0->data, input2->data,
+        flow0->data, flow1->data, filter0->data, filter1->data, occlusion0->data, occlusion1->data, output->data);
+}
+
 // count tensor [N,1,H,W] matching the flow tensor; my_lib_cuda.c:813-817
 static bool count_matches(const memc_tensor4 *flow, const memc_tensor4 *count)
 {

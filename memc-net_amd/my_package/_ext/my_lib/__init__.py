@@ -98,9 +98,13 @@ _SYMBOLS = {
     "DepthFlowProjectionLayer_gpu_forward": (4, True),
     "DepthFlowProjectionLayer_gpu_backward": (7, False),
 }
+# extension without a reference counterpart (include/memc_warp.h, "EXTENSION"): fused dual warp + blend
+_EXTENSIONS = {
+    "FilterInterpolationBlendLayer_gpu_forward": (9, False),
+}
 
 __all__ = ["version", "LIB_PATH"]
-for _name, (_n, _flag) in _SYMBOLS.items():
+for _name, (_n, _flag) in list(_SYMBOLS.items()) + list(_EXTENSIONS.items()):
     globals()[_name] = _bind(_name, _n, _flag)
     __all__.append(_name)
 

@@ -1,0 +1,70 @@
+"""FilterInterpolationBlendLayer -- EXTENSION, no reference counterpart.
+
+    out = occlusion0 * FilterInterpolation(input0, flow0, filter0)
+        + occlusion1 * FilterInterpolation(input2, flow1, filter1)
+
+i.e. `FilterInterpolate` of networks/MEMC_Net_star.py:264-277 as ONE kernel (the two warped frames are never
+written).  Differentiable: the backward pass goes through the reference-API entry points (two forward
+recomputations + two backward launches; nothing but the inputs is kept for it).
+
+The fused kernel covers what the networks use (RGB, 4x4 filters, widths a multiple of 4); any other shape is
+composed from FilterInterpolationLayer calls -- same values, no error.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+import my_package._ext.my_lib as my_lib
+from ._common import check, f32c, require_gpu
+from .FilterInterpolationLayer import FilterInterpolationLayer
+
+
+def fused_supported(input0, filter0):
+    return input0.size(1) == 3 and filter0.size(1) == 16 and input0.size(3) % 4 == 0
+
+
+def _warp(x, flow, filt):
+    out = torch.zeros_like(x)
+    check(my_lib.FilterInterpolationLayer_gpu_forward(x, flow, filt, out), "FilterInterpolationLayer_gpu_forward")
+    return out
+
+
+class _FilterInterpolationBlendFunction(Function):
+    @staticmethod
+    def forward(ctx, input0, input2, flow0, flow1, filter0, filter1, occlusion0, occlusion1):
+        args = (input0, input2, flow0, flow1, filter0, filter1, occlusion0, occlusion1)
+        require_gpu("FilterInterpolationBlendLayer", *args)
+        args = tuple(f32c(t) for t in args)
+        output = torch.empty_like(args[0])                   # every element is written
+        check(my_lib.FilterInterpolationBlendLayer_gpu_forward(*args, output),
+              "FilterInterpolationBlendLayer_gpu_forward")
+        ctx.save_for_backward(*args)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gradoutput):
+        input0, input2, flow0, flow1, filter0, filter1, occ0, occ1 = ctx.saved_tensors
+        gradoutput = f32c(gradoutput)
+        grads = []
+        for x, flow, filt, occ in ((input0, flow0, filter0, occ0), (input2, flow1, filter1, occ1)):
+            warped = _warp(x, flow, filt)                    # recomputed, not stored by the forward pass
+            g_occ = (gradoutput * warped).sum(dim=1, keepdim=True)
+            g_warp = (gradoutput * occ).contiguous()
+            g_x, g_flow, g_filt = torch.zeros_like(x), torch.zeros_like(flow), torch.zeros_like(filt)
+            check(my_lib.FilterInterpolationLayer_gpu_backward(x, flow, filt, g_warp, g_x, g_flow, g_filt),
+                  "FilterInterpolationLayer_gpu_backward")
+            grads.append((g_x, g_flow, g_filt, g_occ))
+        (gx0, gf0, gk0, go0), (gx2, gf1, gk1, go1) = grads
+        return gx0, gx2, gf0, gf1, gk0, gk1, go0, go1
+
+
+class FilterInterpolationBlendLayer(object):
+    """`FilterInterpolationBlendLayer()(input0, input2, flow0, flow1, filter0, filter1, occlusion0, occlusion1)`"""
+
+    def __call__(self, input0, input2, flow0, flow1, filter0, filter1, occlusion0, occlusion1):
+        if fused_supported(input0, filter0):
+            return _FilterInterpolationBlendFunction.apply(input0, input2, flow0, flow1, filter0, filter1,
+                                                           occlusion0, occlusion1)
+        warp = FilterInterpolationLayer()
+        return occlusion0 * warp(input0, flow0, filter0) + occlusion1 * warp(input2, flow1, filter1)

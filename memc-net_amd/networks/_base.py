@@ -10,6 +10,10 @@ import torch.nn.functional as F
 
 from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
 from my_package.modules.FlowProjectionModule import FlowProjectionModule
+try:        # extension of this repository's my_package; absent from the reference's
+    from my_package.modules.FilterInterpolationBlendModule import FilterInterpolationBlendModule
+except ImportError:
+    FilterInterpolationBlendModule = None
 
 from ._blocks import FlowEstimator, run_unet, unet_head, unet_trunk
 
@@ -22,6 +26,7 @@ class MEMCNetBase(nn.Module):
         self.filter_size = filter_size
         self.training = training
         self.align_corners = align_corners
+        self.fused_blend = True             # one kernel for both warps + the blend where my_package offers it
         fs2 = filter_size * filter_size
         self.initScaleNets_filter = unet_trunk(2 * channel, align_corners, batch_norm)
         self.initScaleNets_filter1 = unet_head(fs2)
@@ -80,7 +85,12 @@ class MEMCNetBase(nn.Module):
                                                        self.initScaleNets_occlusion2, both)]
 
         warp = FilterInterpolationModule()
-        blended = occlusions[0] * warp(frame0, flows[0], filters[0]) + occlusions[1] * warp(frame2, flows[1], filters[1])
+        if self.fused_blend and FilterInterpolationBlendModule is not None:
+            blended = FilterInterpolationBlendModule()(frame0, frame2, flows[0], flows[1], filters[0], filters[1],
+                                                       occlusions[0], occlusions[1])
+        else:
+            blended = (occlusions[0] * warp(frame0, flows[0], filters[0])
+                       + occlusions[1] * warp(frame2, flows[1], filters[1]))
         extra = self._context(frame0, frame2, flows, filters, warp)
 
         rect_in = torch.cat((blended, flows[0], flows[1], filters[0], filters[1], occlusions[0], occlusions[1])

@@ -365,3 +365,63 @@ def test_large_channel_count_offsets(oracle):
     xn, fn, kn = synth.np_image(rng, B, C, H, W), synth.np_flow(rng, B, H, W, "smooth"), synth.np_filter(rng, B, H, W)
     out = FilterInterpolationModule()(T(xn), T(fn), T(kn))
     close(N(out), oracle.filter_interpolation_forward(xn, fn, kn), "C=64 forward")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# EXTENSION: fused dual warp + occlusion blend.  Expected value = the composition of two
+# oracle forwards, blended in fp32 exactly as the reference network writes it (MEMC_Net_star.py:277); gradients =
+# the oracle backward of each warp fed with occlusion * gradoutput, occlusion gradients = sum_c gout * warp.
+# ------------------------------------------------------------------------------------------------------------
+BLEND_CASES = [
+    (2, 3, 40, 64, "smooth", 4.0, 31), (1, 3, 100, 132, "iid", 3.0, 32), (2, 3, 64, 256, "iid", 20.0, 33),
+    (1, 3, 96, 256, "smooth", 25.0, 34),        # bands
+    (1, 5, 24, 48, "smooth", 4.0, 35),          # not RGB: composed path of the Python layer
+    (1, 3, 19, 23, "iid", 2.0, 36),             # width not a multiple of 4: composed path
+]
+
+
+@pytest.mark.parametrize("case", BLEND_CASES, ids=["%dx%dx%dx%d-%s" % c[:5] for c in BLEND_CASES])
+def test_filter_interpolation_blend(oracle, case):
+    from my_package.modules.FilterInterpolationBlendModule import FilterInterpolationBlendModule
+    B, C, H, W, kind, sigma, seed = case
+    a, b2 = make(case), make(case[:6] + (seed + 100,))
+    rng = np.random.default_rng(seed + 7)
+    o0 = rng.random((B, 1, H, W), dtype=np.float32)
+    o1 = rng.random((B, 1, H, W), dtype=np.float32)
+    names = ("x0", "x2", "f0", "f1", "k0", "k1", "o0", "o1")
+    host = dict(x0=a["x"], x2=b2["x"], f0=a["flow"], f1=b2["flow"], k0=a["filt"], k1=b2["filt"], o0=o0, o1=o1)
+    t = {n: T(host[n], True) for n in names}
+    out = FilterInterpolationBlendModule()(*[t[n] for n in names])
+    out.backward(T(a["gout"]))
+    w0 = oracle.filter_interpolation_forward(host["x0"], host["f0"], host["k0"])
+    w2 = oracle.filter_interpolation_forward(host["x2"], host["f1"], host["k1"])
+    close(N(out), o0 * w0 + o1 * w2, "blend forward")
+    gout = a["gout"]
+    for x, f, k, o, w in (("x0", "f0", "k0", "o0", w0), ("x2", "f1", "k1", "o1", w2)):
+        g1, g2, g3 = oracle.filter_interpolation_backward(host[x], host[f], host[k], (gout * host[o]).astype(np.float32))
+        close(N(t[x].grad), g1, "grad " + x, RTOL)
+        close(N(t[f].grad), g2, "grad " + f, RTOL)
+        close(N(t[k].grad), g3, "grad " + k, RTOL)
+        close(N(t[o].grad), (gout * w).sum(axis=1, keepdims=True), "grad " + o, RTOL)
+
+
+def test_filter_interpolation_blend_c_abi_checks():
+    """the C entry point: needs no zero-filled output; rejects what the fused kernel does not cover"""
+    import my_package._ext.my_lib as my_lib
+    B, H, W = 1, 32, 64
+    z = lambda c: torch.rand(B, c, H, W, device=dev())          # noqa: E731
+    out = torch.full((B, 3, H, W), 7.0, device=dev())
+    args = [z(3), z(3), z(2) * 4 - 2, z(2) * 4 - 2, z(16) / 16, z(16) / 16, z(1), z(1)]
+    assert my_lib.FilterInterpolationBlendLayer_gpu_forward(*args, out) == 0
+    ref = args[6] * _fi(my_lib, args[0], args[2], args[4]) + args[7] * _fi(my_lib, args[1], args[3], args[5])
+    assert float((out - ref).abs().max()) <= 1e-5
+    bad = list(args); bad[0] = z(4); bad[1] = z(4)
+    assert my_lib.FilterInterpolationBlendLayer_gpu_forward(*bad, torch.zeros(B, 4, H, W, device=dev())) == -1
+    bad = list(args); bad[7] = z(2)
+    assert my_lib.FilterInterpolationBlendLayer_gpu_forward(*bad, out) == -1
+
+
+def _fi(my_lib, x, f, k):
+    o = torch.zeros_like(x)
+    assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, k, o) == 0
+    return o

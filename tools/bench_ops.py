@@ -93,6 +93,25 @@ def bench_fi_fwd(rows, dev, B, C, H, W, flow_kind, variants, tag, rounds=4):
     L._debug_set_variant("fi_fwd", -1)
 
 
+def bench_fi_blend(rows, dev, B, H, W, flow_kind):
+    """fused dual warp + blend (188 B/site) against its composition: two forwards + the torch blend (236 B/site)"""
+    a = synth.torch_inputs(dev, B, 3, H, W, flow_kind=flow_kind, seed=11)
+    b = synth.torch_inputs(dev, B, 3, H, W, flow_kind=flow_kind, seed=12)
+    o0, o1 = torch.rand(B, 1, H, W, device=dev), torch.rand(B, 1, H, W, device=dev)
+    out = torch.empty_like(a["x"])
+    w0, w2 = torch.zeros_like(a["x"]), torch.zeros_like(a["x"])
+    med, mn = time_launches(lambda: L.FilterInterpolationBlendLayer_gpu_forward(
+        a["x"], b["x"], a["flow"], b["flow"], a["filt"], b["filt"], o0, o1, out))
+    report(rows, "fi_blend fused  C=3 %dx%dx%d flow=%s" % (B, H, W, flow_kind), B * H * W, 188, med, mn)
+
+    def composed():
+        L.FilterInterpolationLayer_gpu_forward(a["x"], a["flow"], a["filt"], w0)
+        L.FilterInterpolationLayer_gpu_forward(b["x"], b["flow"], b["filt"], w2)
+        torch.add(o0 * w0, o1 * w2, out=out)
+    med, mn = time_launches(composed)
+    report(rows, "fi_blend composed (2 fwd + torch blend) %dx%dx%d" % (B, H, W), B * H * W, 188, med, mn)
+
+
 def bench_fi_bwd(rows, dev, B, C, H, W, flow_kind, tag, variants=()):
     t = synth.torch_inputs(dev, B, C, H, W, flow_kind=flow_kind, with_grad=True)
     x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
@@ -237,6 +256,8 @@ def main():
         if not args.quick and not args.headline_only:
             bench_fi_fwd(rows, dev, 8, 64, 720, 1280, "smooth", variants[:1], "ctx64")
             bench_fi_fwd(rows, dev, 8, 3, 2160, 3840, "smooth", variants[:1], "c5_4k")
+    if want("fi_blend"):
+        bench_fi_blend(rows, dev, 32, 720, 1280, "smooth")
     if want("fi_bwd"):
         bench_fi_bwd(rows, dev, 8, 3, 256, 448, "smooth", "c2")
         if not args.quick:
