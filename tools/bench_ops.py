@@ -27,8 +27,11 @@ from tools import synth  # noqa: E402
 PEAK = 8.0e12
 
 
-def time_launches(fn, pre=None, warmup=12, iters=15):
-    """median / min launch time in seconds; `pre` (e.g. zero-filling outputs) runs outside the timed span."""
+def time_launches(fn, pre=None, warmup=12, iters=15, burst=1):
+    """median / min launch time in seconds; `pre` (e.g. zero-filling outputs) runs outside the timed span.
+    burst > 1: that many launches back to back between the two events, time divided by it -- for launches of a
+    few tens of microseconds, where one launch between two events mostly measures the host's enqueue latency
+    (the accumulating passes then add into non-zero buffers, which costs the same)."""
     for _ in range(warmup):
         if pre:
             pre()
@@ -41,10 +44,11 @@ def time_launches(fn, pre=None, warmup=12, iters=15):
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()
-        fn()
+        for _ in range(burst):
+            fn()
         b.record()
         b.synchronize()
-        ts.append(a.elapsed_time(b) * 1e-3)
+        ts.append(a.elapsed_time(b) * 1e-3 / burst)
     return statistics.median(ts), min(ts)
 
 
@@ -79,15 +83,20 @@ def bench_fi_fwd(rows, dev, B, C, H, W, flow_kind, variants, tag, rounds=4):
             for _ in range(2):
                 fn()
             torch.cuda.synchronize()
+            burst = 20 if B * H * W < 4e6 else 1           # tiny launches: see time_launches
             for _ in range(8):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); fn(); b.record(); b.synchronize()
-                samples[v].append(a.elapsed_time(b) * 1e-3)
+                a.record()
+                for _ in range(burst):
+                    fn()
+                b.record(); b.synchronize()
+                samples[v].append(a.elapsed_time(b) * 1e-3 / burst)
             if ref is None:
                 ref = out.clone()
             same[v] = bool((out - ref).abs().max().item() <= 1e-5)
     for v in variants:
-        report(rows, "fi_fwd %s C=%d %dx%dx%d flow=%s variant=%d" % (tag, C, B, H, W, flow_kind, v),
+        report(rows, "fi_fwd %s C=%d %dx%dx%d flow=%s variant=%d%s" % (tag, C, B, H, W, flow_kind, v,
+                                                                       " (bursts of 20)" if B * H * W < 4e6 else ""),
                B * H * W, 4 * (2 * C + 2 + 16), statistics.median(samples[v]), min(samples[v]),
                {"variant": v, "matches_first_variant": same[v]})
     L._debug_set_variant("fi_fwd", -1)
@@ -125,9 +134,10 @@ def bench_fi_bwd(rows, dev, B, C, H, W, flow_kind, tag, variants=()):
         report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s ABLATION variant=%d" % (tag, C, B, H, W, flow_kind, v),
                B * H * W, 4 * (3 * C + 2 * (2 + 16)), med, mn)
     L._debug_set_variant("fi_bwd", -1)
-    med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre)
-    report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s" % (tag, C, B, H, W, flow_kind), B * H * W,
-           4 * (3 * C + 2 * (2 + 16)), med, mn)
+    burst = 20 if B * H * W < 4e6 else 1
+    med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre, burst=burst)
+    report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s%s" % (tag, C, B, H, W, flow_kind, " (bursts of 20)" if burst > 1 else ""),
+           B * H * W, 4 * (3 * C + 2 * (2 + 16)), med, mn)
 
 
 def bench_projection(rows, dev, B, H, W, flow_kind, tag, proj_variants=()):

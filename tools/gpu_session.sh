@@ -14,6 +14,7 @@ echo "== smoke";   timeout 600 python -c "import __graft_entry__ as g; g.smoke()
 echo "== pytest";  timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee "$OUT/pytest_gpu.log"
 echo "== sweep";   timeout 900 python tools/bench_ops.py ${QUICK:+--quick} --json "$OUT/bench_ops.json" 2>&1 | tee "$OUT/bench_ops.log"
 echo "== bench";   timeout 600 python bench.py 2>&1 | tail -3 | tee "$OUT/bench.log"
+echo "== model"; timeout 600 python tools/bench_model.py --json "$OUT/bench_model.json" 2>&1 | tail -2 | tee "$OUT/bench_model.log"
 echo "== race screen"; timeout 600 python tools/stress_projection.py 60 2>&1 | tail -3 | tee "$OUT/stress.log"
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprof kernel trace of bench.py (same command as the bench line above, fewer steps)"
