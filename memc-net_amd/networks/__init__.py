@@ -7,6 +7,7 @@ box; validated against the reference network itself in `tests/test_network_star.
 """
 from .MEMC_Net import MEMC_Net
 from .MEMC_Net_star import MEMC_Net_star
+from .inference import interpolate_pairs, pad_amounts
 from .replicate import broadcast_module_state, shard_pairs
 
-__all__ = ("MEMC_Net", "MEMC_Net_star", "broadcast_module_state", "shard_pairs")
+__all__ = ("MEMC_Net", "MEMC_Net_star", "broadcast_module_state", "shard_pairs", "interpolate_pairs", "pad_amounts")

@@ -195,3 +195,26 @@ def test_base_model_matches_reference_class():
     assert sorted(got_g) == sorted(want_g)
     for k in want_g:
         assert abs(got_g[k] - want_g[k]) <= 1e-4 * max(1e-6, want_g[k]), k
+
+
+def test_demo_padding_rule():
+    """demo_HD720p.py:88-106: pad up to the next multiple of 128, split floor / rest; 32 per side when already a
+    multiple (values worked out from that arithmetic)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "inference", os.path.join(os.path.dirname(HERE), "memc-net_amd", "networks", "inference.py"))
+    inf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(inf)
+    assert inf.pad_amounts(720, 1280) == (32, 32, 24, 24)          # 1280 = 10 * 128 -> 32 + 32; 720 -> 768
+    assert inf.pad_amounts(1080, 1920) == (32, 32, 36, 36)         # 1080 -> 1152
+    assert inf.pad_amounts(256, 448) == (32, 32, 32, 32)           # 448 -> 512; 256 is a multiple
+    assert inf.pad_amounts(480, 640) == (32, 32, 16, 16)           # 640 = 5 * 128; 480 -> 512
+    assert inf.pad_amounts(101, 203) == (26, 27, 13, 14)           # odd totals: floor first
+
+    class Probe(torch.nn.Module):                                   # returns its padded first frame
+        def forward(self, x):
+            assert x.shape[-2] % 128 == 0 or x.shape[-2] - 64 > 0
+            return [x[0], x[0] + 1.0], None, None, None
+    f0 = torch.rand(2, 3, 101, 203)
+    out = inf.interpolate_pairs(Probe(), f0, torch.rand(2, 3, 101, 203), which=0)
+    assert torch.equal(out, f0)                                     # the crop undoes the padding exactly

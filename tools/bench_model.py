@@ -24,18 +24,6 @@ for _p in (ROOT, os.path.join(ROOT, "memc-net_amd")):
         sys.path.insert(0, _p)
 
 
-def pad_to_128(h, w):
-    def one(n):
-        if n != ((n >> 7) << 7):
-            full = ((n >> 7) + 1) << 7
-            a = (full - n) // 2
-            return a, full - n - a
-        return 32, 32
-    top, bottom = one(h)
-    left, right = one(w)
-    return left, right, top, bottom
-
-
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,7 +36,6 @@ def main(argv=None):
     a = ap.parse_args(argv)
 
     import torch
-    import torch.nn.functional as F
     import bench
     rank, local_rank, world = bench.dist_env()
     if world != a.gpus:
@@ -73,12 +60,10 @@ def main(argv=None):
 
     g = torch.Generator(device=dev).manual_seed(99 + rank)
     frames = torch.rand((2, a.pairs, 3, a.height, a.width), device=dev, generator=g)
-    pl, pr, pt, pb = pad_to_128(a.height, a.width)
+    pl, pr, pt, pb = networks.pad_amounts(a.height, a.width)
 
     def interpolate_batch():
-        x = torch.stack([F.pad(frames[i], (pl, pr, pt, pb), mode="replicate") for i in range(2)])
-        (blended, rectified), flows, filters, occl = net(x)
-        return rectified[:, :, pt:pt + a.height, pl:pl + a.width]
+        return networks.interpolate_pairs(net, frames[0], frames[1])
 
     with torch.no_grad():
         worst, _ = bench.timed_steps(lambda i: interpolate_batch(), a.steps, a.warmup, world, dev)
