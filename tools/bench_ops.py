@@ -156,6 +156,11 @@ def bench_projection(rows, dev, B, H, W, flow_kind, tag, proj_variants=()):
         med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0), pre)
         report(rows, "flow_projection_fwd %s %dx%dx%d flow=%s ABLATION variant=%d" % (tag, B, H, W, flow_kind, pv),
                B * H * W, 20, med, mn)
+    if proj_variants:
+        L._debug_set_variant("projection", -8)
+        med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 1), pre)
+        report(rows, "flow_projection_fwd %s %dx%dx%d flow=%s fillhole=1 ABLATION holes detected, none filled" % (
+            tag, B, H, W, flow_kind), B * H * W, 20, med, mn)
     L._debug_set_variant("projection", -1)
     for fh in (0, 1):
         med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, fh), pre)
