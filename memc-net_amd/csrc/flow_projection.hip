@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void proj_owner(
     constexpr int kScanPadX = kReach + 4;         // dilated tile: columns, kept 4-aligned
     constexpr int kScanW = 64 + 2 * kScanPadX;    // source columns
     constexpr int kScanH = 16 + 2 * kReach + 1;   // source rows: [ty0 - kReach - 1, ty0 + 16 + kReach)
-    __shared__ double P[3 * kPtH * kPtW];
+    __shared__ __attribute__((aligned(16))) double P[3 * kPtH * kPtW];
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
     const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
     trace_mark_proj<TRACE>(0);
@@ -407,6 +407,16 @@ __global__ __launch_bounds__(256) void proj_owner(
     for (int it = 0; it < kIts; it++) {
         if (!live[it]) continue;
         const bool home_row = sy[it] >= ty0 && sy[it] < ty0 + 16;
+        // conservative row test first (one pixel of slack covers the rounding of y + fy): a wave scans ~2.5 rows
+        // of the dilated tile, and in the rows farther from the tile than the local motion no lane can land --
+        // the whole wave then skips the per-source work (VALU is what bounds this kernel)
+        if (!home_row) {
+            const float lo = (float)(ty0 - 2 - sy[it]), hi = (float)(ty0 + 17 - sy[it]);
+            const f32x4 f = fy[it];
+            if (!((f[0] >= lo && f[0] < hi) || (f[1] >= lo && f[1] < hi) || (f[2] >= lo && f[2] < hi) ||
+                  (f[3] >= lo && f[3] < hi)))
+                continue;
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int x = sx[it] + j, y = sy[it];
@@ -446,21 +456,36 @@ __global__ __launch_bounds__(256) void proj_owner(
     if (cx >= W || cy >= H) return;
     const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
     f32x4 ox, oy, oc;
+    // The lane's four cells need the point sums of columns c-1 .. c+3 of two rows, per plane: read them once as
+    // 2 x (two 16-byte pairs + one double) instead of 16 single doubles -- lanes are four cells apart, which for
+    // 8-byte reads is a 4-way bank conflict, and this read-out was most of the kernel's LDS time.
+    double top[3][5], bot[3][5];               // [plane][column c-1 .. c+3], rows cy-1 and cy
+    {
+        const int col0 = cx - tx0;             // P column of cell cx-1 (a multiple of 4: 16-byte aligned pairs)
+        const double *r0 = P + (cy - ty0) * kPtW + col0, *r1 = r0 + kPtW;
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const double *a = r0 + pl * kPtH * kPtW, *c = r1 + pl * kPtH * kPtW;
+            const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
+            const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
+            top[pl][0] = a01[0]; top[pl][1] = a01[1]; top[pl][2] = a23[0]; top[pl][3] = a23[1]; top[pl][4] = a[4];
+            bot[pl][0] = c01[0]; bot[pl][1] = c01[1]; bot[pl][2] = c23[0]; bot[pl][3] = c23[1]; bot[pl][4] = c[4];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
-        const double *q = P + (cy - (ty0 - 1)) * kPtW + (cx + j - (tx0 - 1));
         float v[3];
 #pragma unroll
         for (int pl = 0; pl < 3; pl++) {
-            const double *qq = q + pl * kPtH * kPtW;
             // the four contributions are rounded to fp32 one by one and added in a fixed order (the
             // reference's order is arbitrary: fp32 atomics)
             float t = 0.0f;
-            t += wy0 * wx0 * (float)qq[0];
-            t += wy0 * (float)qq[-1];
-            t += wx0 * (float)qq[-kPtW];
-            t += (float)qq[-kPtW - 1];
+            t += wy0 * wx0 * (float)bot[pl][j + 1];
+            t += wy0 * (float)bot[pl][j];
+            t += wx0 * (float)top[pl][j + 1];
+            t += (float)top[pl][j];
             v[pl] = t;
         }
         if (v[2] > 0.0f) {                     // my_lib_kernel.cu:1730-1735
