@@ -376,27 +376,38 @@ __global__ __launch_bounds__(256) void proj_owner(
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
     const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
     trace_mark_proj<TRACE>(0);
-    for (int i = threadIdx.x; i < 3 * kPtH * kPtW; i += 256) P[i] = 0.0;
+    {
+        static_assert((3 * kPtH * kPtW) % 2 == 0, "P is zeroed 16 bytes at a time");
+        f32x4 *pz = reinterpret_cast<f32x4 *>(P);
+        for (int i = threadIdx.x; i < 3 * kPtH * kPtW / 2; i += 256) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    // scan: kScanW / 4 = 26 float4 columns x kScanH rows = 1274 slots, 5 per lane; all loads first
+    // scan: kScanW / 4 float4 columns x kScanH rows of slots, kIts per lane; all loads first.  Slot -> (row,
+    // column) by one division and increments, addresses as wave-uniform base + 32-bit lane offset (the address
+    // arithmetic of this prologue was a quarter of the kernel's VALU instructions, and VALU is its bound).
     constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + 255) / 256;
     const float *flow_b = flow + b * s1b;
     const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
     f32x4 fx[kIts], fy[kIts], dd[kIts];
     int sx[kIts], sy[kIts];
     bool live[kIts];
+    int row = (int)threadIdx.x / kCols4, c4 = (int)threadIdx.x % kCols4;
 #pragma unroll
     for (int it = 0; it < kIts; it++) {
-        const int slot = threadIdx.x + 256 * it;
-        const int row = slot / kCols4, c4 = slot % kCols4;
         sx[it] = tx0 - kScanPadX + 4 * c4;
         sy[it] = ty0 - kReach - 1 + row;
-        live[it] = slot < kSlots && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
-        const float *p = live[it] ? flow_b + (int64_t)sy[it] * s1h + sx[it] : flow_b;
-        // sources of the tile itself are read once in the whole launch: stream them; the halo is shared
-        fx[it] = ld_cached4(p);
-        fy[it] = ld_cached4(p + s1c);
-        if (DEPTH) dd[it] = ld_cached4(live[it] ? depth_b + (int64_t)sy[it] * sdh + sx[it] : depth_b);
+        live[it] = row < kScanH && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
+        // dead slots read the plane's first pixels (unconditional loads)
+        const unsigned off = live[it] ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
+        fx[it] = ld_cached4_u(flow_b, off);
+        fy[it] = ld_cached4_u(flow_b + s1c, off);
+        if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+        row += 256 / kCols4;                   // the next slot of this lane is 256 further on
+        c4 += 256 % kCols4;
+        if (c4 >= kCols4) {
+            c4 -= kCols4;
+            row++;
+        }
     }
     __syncthreads();                           // P is zero
     trace_mark_proj<TRACE>(1);                 // loads issued, P zeroed

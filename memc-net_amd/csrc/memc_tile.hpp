@@ -74,6 +74,10 @@ __device__ __forceinline__ void st_stream4_u(float *ubase, unsigned byte_off, f3
 {
     __builtin_nontemporal_store(v, reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(ubase, byte_off)));
 }
+__device__ __forceinline__ f32x4 ld_cached4_u(const float *ubase, unsigned byte_off)
+{
+    return *reinterpret_cast<const MEMC_GLOBAL f32x4 *>(addr_u(ubase, byte_off));
+}
 // plain (cached) accesses through the same addressing
 __device__ __forceinline__ MEMC_GLOBAL float *at_u(float *ubase, unsigned byte_off)
 {
