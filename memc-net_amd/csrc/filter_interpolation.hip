@@ -1510,8 +1510,9 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput,
                            gradinput1, gradinput2, gradinput3);
-    } else if (channel == 3 && vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
-                                       {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3})) {
+    } else if (channel == 3 && plane_fits_u32(w, h, {s1h, s2h, s3h}) &&
+               vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
+                       {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3})) {
         using G = TileGeom<16>;
         static_assert(AccT::kPlane * 8 <= G::kCapPx * 16 && G::kPitch <= AccT::kMaxW && G::kRows <= AccT::kRows,
                       "the accumulator plane aliases the staged image");
@@ -1578,7 +1579,8 @@ extern "C" int FilterInterpolationBlend_gpu_forward_kernel(
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
     if (channel != 3 || filter_size != 4) return -1;
     if (!vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h, sob, soh},
-                 {input0, input2, flow0, flow1, filter0, filter1, occlusion0, occlusion1, output}))
+                 {input0, input2, flow0, flow1, filter0, filter1, occlusion0, occlusion1, output}) ||
+        !plane_fits_u32(w, h, {s1h, s2h, s3h, soh}))
         return -1;
     using G = TileGeom<16>;
     const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;

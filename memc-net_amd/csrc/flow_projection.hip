@@ -824,7 +824,9 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
     hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3(nwg), dim3(256), 4 * A::kPlane * 4 + 64, stream, w, \
                        h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow,   \
                        depth, count, out, FLAG)
-        int *flag = (g_proj_variant == 1 || g_proj_variant >= 2) ? nullptr : far_flag_for_current_device();   // -1, -5, -8: fast path
+        // (the owner kernel addresses the flow / depth planes with 32-bit offsets)
+        int *flag = (g_proj_variant == 1 || g_proj_variant >= 2 || !plane_fits_u32(w, h, {s1h, sdh}))
+                        ? nullptr : far_flag_for_current_device();                  // -1, -5, -8: fast path
         if (flag) {
             // fast path: owner-computes (no atomics, fused averaging) + the general path behind a device flag
             if (hipMemsetAsync(flag, 0, (kFlagWords + 1) * sizeof(int), stream) != hipSuccess) return -1;

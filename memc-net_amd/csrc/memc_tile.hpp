@@ -86,6 +86,15 @@ __device__ __forceinline__ MEMC_GLOBAL float *at_u(float *ubase, unsigned byte_o
 
 __device__ __forceinline__ int swz_col(int c) { return c ^ ((c >> 2) & 15); }
 
+// Kernels that address a plane as wave-uniform base + 32-bit byte offset (ld_stream4_u & co.) need every in-plane
+// byte offset (h - 1) * row_stride + w to fit 32 bits; a view with a gigantic row stride takes the 64-bit kernels.
+inline bool plane_fits_u32(int w, int h, std::initializer_list<long> row_strides)
+{
+    for (long s : row_strides)
+        if (((long long)(h > 0 ? h - 1 : 0) * s + w) * 4LL >= (1LL << 32)) return false;
+    return true;
+}
+
 // 16-B vector path preconditions: width and every stride a multiple of 4 elements, 16-B aligned bases.
 inline bool vec4_ok(int w, std::initializer_list<long> strides, std::initializer_list<const void *> ptrs)
 {

@@ -425,3 +425,26 @@ def _fi(my_lib, x, f, k):
     o = torch.zeros_like(x)
     assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, k, o) == 0
     return o
+
+
+def test_views_with_huge_row_strides(oracle):
+    """The owner-computes projection and the tiled FI backward address a plane with 32-bit byte offsets.  A view
+    whose rows are 2^21 elements (8 MiB) apart spans 4.7 GiB per plane at H = 600: the launcher must route it to
+    the 64-bit kernels -- same numbers as on a dense copy."""
+    from my_package.modules.FlowProjectionModule import FlowProjectionModule  # noqa: F401  (package import check)
+    import my_package._ext.my_lib as my_lib
+    if torch.cuda.get_device_properties(0).total_memory < 64 << 30:
+        pytest.skip("needs ~25 GB of address space on the device")
+    H, W, S = 600, 64, 1 << 21
+    rng = np.random.default_rng(77)
+    fn = synth.np_flow(rng, 1, H, W, "smooth", 4.0)
+
+    def view(c):
+        base = torch.zeros(c * H * S, device=dev())
+        return base.as_strided((1, c, H, W), (0, H * S, S, 1))
+    flow, cnt, out = view(2), view(1), view(2)
+    flow.copy_(T(fn))
+    assert my_lib.FlowProjectionLayer_gpu_forward(flow, cnt, out, 1) == 0
+    want_out, want_cnt = oracle.flow_projection_forward(fn, 1)
+    close(N(out.contiguous()), want_out, "projection through a 4.7 GiB-per-plane view")
+    close(N(cnt.contiguous()), want_cnt, "count")

@@ -2,7 +2,7 @@
 # tools/pmc_sq.sh <tag> <bench_ops --only key> <kernel-name substring> -- shader-core counters of one operator
 # (rocprofv3 --pmc in two passes of <= 8 SQ counters; only --kernel-trace beside them).  Run on the GPU box.
 # Prints per counter the mean per dispatch of the LARGEST grid and a few derived ratios.
-TAG=$1; ONLY=$2; MATCH=$3
+TAG=$1; ONLY=$2; MATCH=$3; EXTRA=${4:-}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -11,7 +11,7 @@ P2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_LDS_ATOMIC SQ_INSTS_VMEM SQ_LDS_DATA_FIF
 i=0
 for CTRS in "$P1" "$P2"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $CTRS --kernel-trace -d $OUT/p$i -o r -- python $REPO/tools/bench_ops.py --only $ONLY --json $OUT/ops$i.json > $OUT/p$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $CTRS --kernel-trace -d $OUT/p$i -o r -- python $REPO/tools/bench_ops.py --only $ONLY $EXTRA --json $OUT/ops$i.json > $OUT/p$i.log 2>&1
   python $REPO/tools/prof_summary.py pmc $OUT/p$i/r_results.db --match "$MATCH" --out $OUT/pmc$i.json > /dev/null
   rm -rf $OUT/p$i
 done
