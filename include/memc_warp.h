@@ -20,8 +20,10 @@
  *   - every output / gradient buffer is borrowed: allocated AND zero-filled by the caller
  *     (my_package/functions/FilterInterpolationLayer.py:26-29,46-48; FlowProjectionLayer.py:27-29,54).
  *     With zero-filled buffers the results are the reference's.  With anything else they are unspecified,
- *     and in one place differ from the reference's `+=`: the FilterInterpolation backward STORES gradinput3
- *     (each site owns its taps) instead of adding to it; gradinput1 is added to, gradinput2 assigned, as there;
+ *     and in two places differ from the reference's `+=`: the FilterInterpolation backward STORES gradinput3
+ *     (each site owns its taps) and the (Depth)FlowProjection backward STORES gradinput1 / gradinput2 (each site
+ *     owns its elements) instead of adding to them; FilterInterpolation gradinput1 is added to and gradinput2
+ *     assigned, as in the reference;
  *   - `output`, `gradoutput` and `gradinput1` are indexed with input1's b/c/h strides
  *     (my_lib_kernel.cu:1184,1276-1283), `gradinput2`/`gradinput3` with input2's/input3's;
  *   - work is enqueued asynchronously on `stream`; no host synchronisation and no state carried from one call

@@ -683,7 +683,6 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
-    float *oyt = reinterpret_cast<float *>(smem + G::kCapPx * 16 + 64);     // DEPTH only: planar forward out y
 
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
@@ -694,15 +693,11 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
     const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s1c);
     f32x4 d4 = {1.f, 1.f, 1.f, 1.f};
     if (DEPTH) d4 = ld_stream4(depth + b * sdb + (int64_t)ys * sdh + xs);
-    // gradinput buffers are `+=` targets (caller zero-fills them): read them with the other streams
+    // every site owns its gradient elements and the caller zero-fills the buffers (FlowProjectionLayer.py:54): they
+    // are STORED once (invalid sites store the zero they already hold) instead of read, added to and written
     float *g1p = gin1 + b * s1b + (int64_t)ys * s1h + xs;
-    f32x4 acc_x = ld_cached4(g1p), acc_y = ld_cached4(g1p + s1c);
-    f32x4 acc_d = {0.f, 0.f, 0.f, 0.f};
-    float *g2p = nullptr;
-    if (DEPTH) {
-        g2p = gin2 + b * sdb + (int64_t)ys * sdh + xs;
-        acc_d = ld_cached4(g2p);
-    }
+    f32x4 acc_x = {0.f, 0.f, 0.f, 0.f}, acc_y = acc_x, acc_d = acc_x;
+    float *g2p = DEPTH ? gin2 + b * sdb + (int64_t)ys * sdh + xs : nullptr;
 
     BlSite st[4];
     int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
@@ -717,21 +712,40 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
     }
     const Region r = tile_region<LX, true>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
     const float *go = gout + b * s1b, *cn = count + b * scb, *fo = DEPTH ? fwd_out + b * s1b : nullptr;
-    if (DEPTH) {
-        const float *const planes[4] = {go, go + s1c, cn, fo};
-        const int hs[4] = {s1h, s1h, sch, s1h};
-        tile_stage_planes<LX, 4>(r, planes, hs, tile);
-        // planar copy of forward out y
-        const float *foy = fo + s1c;
-        for (int i = threadIdx.x; i < r.h * (r.w / 4); i += G::kThreads) {
-            const int row = i / (r.w / 4), q = i % (r.w / 4);
-            *reinterpret_cast<f32x4 *>(oyt + row * r.pitch + 4 * q) =
-                ld_cached4(foy + (int64_t)(r.y0 + row) * s1h + r.x0 + 4 * q);
+    // Every use of a corner is gout / count (times something of the site) or the forward output: the staged pixel
+    // quad is therefore (gout_x / count, gout_y / count, out_x, out_y) -- the divisions (~12 VALU instructions
+    // each; this kernel was VALU-bound on sixteen of them per site) are done once per staged cell, four
+    // components hold everything (no separate plane for out_y: 48 instead of 61 KiB of LDS, 3 workgroups per CU),
+    // and a site is eight or sixteen FMAs.  (g / c) * d differs from the reference's (g * d) / c by <= 1 ulp.
+    {
+        constexpr int NP = DEPTH ? 5 : 3;
+        const StageSlot sl = stage_slots(r);
+        StageRegs<NP> sr;
+        if constexpr (DEPTH) {
+            const float *const planes[5] = {go, go + s1c, cn, fo, fo + s1c};
+            const int hs[5] = {s1h, s1h, sch, s1h, s1h};
+            tile_stage_load_planes<5>(r, sl, planes, hs, sr);
+        } else {
+            const float *const planes[3] = {go, go + s1c, cn};
+            const int hs[3] = {s1h, s1h, sch};
+            tile_stage_load_planes<3>(r, sl, planes, hs, sr);
         }
-    } else {
-        const float *const planes[3] = {go, go + s1c, cn};
-        const int hs[3] = {s1h, s1h, sch};
-        tile_stage_planes<LX, 3>(r, planes, hs, tile);
+#pragma unroll
+        for (int it = 0; it < kStageIts; it++) {
+            if (sl.row[it] < r.h) {
+                f32x4 *dst = tile + sl.row[it] * r.pitch;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float inv = 1.0f / sr.v[it][2][i];       // cells nobody projected to: inf, never read
+                    f32x4 px = {sr.v[it][0][i] * inv, sr.v[it][1][i] * inv, 0.f, 0.f};
+                    if (DEPTH) {
+                        px[2] = sr.v[it][NP - 2][i];
+                        px[3] = sr.v[it][NP - 1][i];
+                    }
+                    dst[swz_col(4 * sl.q[it] + i)] = px;
+                }
+            }
+        }
     }
     __syncthreads();
     if (!inb) return;
@@ -740,39 +754,36 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
     for (int j = 0; j < 4; j++) {
         if (!st[j].valid) continue;
         const BlSite &s = st[j];
-        f32x4 q[4];          // (gx, gy, count, ox) at TL, TR, BL, BR
-        float oyv[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 q[4];          // (gx / count, gy / count, ox, oy) at TL, TR, BL, BR
         if (r.covers(s.L, s.R, s.T, s.Bm)) {
             const int rT = (s.T - r.y0) * r.pitch, rB = (s.Bm - r.y0) * r.pitch;
-            const int cL = s.L - r.x0, cR = s.R - r.x0;
-            q[0] = tile[rT + swz_col(cL)];  q[1] = tile[rT + swz_col(cR)];
-            q[2] = tile[rB + swz_col(cL)];  q[3] = tile[rB + swz_col(cR)];
-            if (DEPTH) { oyv[0] = oyt[rT + cL]; oyv[1] = oyt[rT + cR]; oyv[2] = oyt[rB + cL]; oyv[3] = oyt[rB + cR]; }
-        } else {
+            const int cL = swz_col(s.L - r.x0), cR = swz_col(s.R - r.x0);
+            q[0] = tile[rT + cL];  q[1] = tile[rT + cR];  q[2] = tile[rB + cL];  q[3] = tile[rB + cR];
+        } else {             // rare: the corner is outside the staged box
             const int o[4] = {s.T * s1h + s.L, s.T * s1h + s.R, s.Bm * s1h + s.L, s.Bm * s1h + s.R};
             const int c[4] = {s.T * sch + s.L, s.T * sch + s.R, s.Bm * sch + s.L, s.Bm * sch + s.R};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                q[k] = f32x4{go[o[k]], go[s1c + o[k]], cn[c[k]], DEPTH ? fo[o[k]] : 0.f};
-                if (DEPTH) oyv[k] = fo[s1c + o[k]];
+                const float inv = 1.0f / cn[c[k]];
+                q[k] = f32x4{go[o[k]] * inv, go[s1c + o[k]] * inv, DEPTH ? fo[o[k]] : 0.f, DEPTH ? fo[s1c + o[k]] : 0.f};
             }
         }
-        float gx = acc_x[j], gy = acc_y[j], gd = acc_d[j];
+        float gx = 0.0f, gy = 0.0f, gd = 0.0f;
         if (DEPTH) {
             const float d = d4[j];
 #pragma unroll
-            for (int k = 0; k < 4; k++) gx += -q[k][0] * d / q[k][2];
+            for (int k = 0; k < 4; k++) gx += -q[k][0] * d;
 #pragma unroll
-            for (int k = 0; k < 4; k++) gy += -q[k][1] * d / q[k][2];
+            for (int k = 0; k < 4; k++) gy += -q[k][1] * d;
 #pragma unroll
-            for (int k = 0; k < 4; k++) gd += -q[k][0] / q[k][2] * (fx4[j] - q[k][3]);
+            for (int k = 0; k < 4; k++) gd += -q[k][0] * (fx4[j] - q[k][2]);
 #pragma unroll
-            for (int k = 0; k < 4; k++) gd += -q[k][1] / q[k][2] * (fy4[j] - oyv[k]);
+            for (int k = 0; k < 4; k++) gd += -q[k][1] * (fy4[j] - q[k][3]);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; k++) gx += -q[k][0] / q[k][2];
+            for (int k = 0; k < 4; k++) gx += -q[k][0];
 #pragma unroll
-            for (int k = 0; k < 4; k++) gy += -q[k][1] / q[k][2];
+            for (int k = 0; k < 4; k++) gy += -q[k][1];
         }
         acc_x[j] = gx;  acc_y[j] = gy;  acc_d[j] = gd;
     }
@@ -893,7 +904,7 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
         using G = TileGeom<16>;
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const unsigned nwg = (unsigned)ntx * nty * batch;
-        const int lds = G::kCapPx * 16 + 64 + (DEPTH ? G::kCapPx * 4 : 0);
+        const int lds = tile_lds_bytes<16>();
         hipLaunchKernelGGL(proj_bwd_tiled<DEPTH>, dim3(nwg), dim3(256), lds, stream, w, h, ntx, nty, (int64_t)s1b,
                            (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, fwd_out,
                            gout, gin1, gin2);
