@@ -935,6 +935,7 @@ __device__ __forceinline__ void trace_mark(int slot)
 // ABL != 0 are MEASUREMENT arms (tools/bench_ops.py --bwd-variants; their results are wrong by construction):
 //   1 no fp64 LDS adds (zero + flush kept; zero cells are not flushed)   2 no phase 2 at all
 //   3 phase 1 without its LDS reads                                      5 flush with plain stores
+//   4 accumulate but never flush (plane re-zeroed instead)
 //   9 production + phase timestamps
 // gradinput3 and gradinput2 of ONE site straight from global memory (mixed quads of the tiled backward: some of a
 // lane's four sites belong to another band or are invalid).  Assigns both, like the tiled path; the image
@@ -1151,7 +1152,8 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_tiled_c3(
         fi_bwd_adds<ABL>(r, fast, g, tp, go, c, acc, W, H);
         __syncthreads();
         if (bi == 0) trace_mark<TR>(6 + 2 * c);                // channel c accumulated
-        acct_flush_zero<ABL == 5>(r, acc, gin1_b + c * s1c, s1h);    // leaves the plane zeroed for the next channel
+        if (ABL == 4) acct_zero<1>(acc);                            // measurement: accumulate, never flush
+        else acct_flush_zero<ABL == 5>(r, acc, gin1_b + c * s1c, s1h);    // leaves the plane zeroed for the next channel
         __syncthreads();
         if (bi == 0) trace_mark<TR>(7 + 2 * c);                // channel c flushed
     }
@@ -1537,6 +1539,7 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
         case 1: MEMC_FI_BWD(1); break;
         case 2: MEMC_FI_BWD(2); break;
         case 3: MEMC_FI_BWD(3); break;
+        case 4: MEMC_FI_BWD(4); break;
         case 5: MEMC_FI_BWD(5); break;
         case 9: MEMC_FI_BWD(9); break;
         case 16:                                           // three workgroups per CU: 168 VGPRs, spills

@@ -499,9 +499,10 @@ __global__ __launch_bounds__(256) void proj_owner(
             t += (float)top[pl][j];
             v[pl] = t;
         }
-        if (v[2] > 0.0f) {                     // my_lib_kernel.cu:1730-1735
-            v[0] = v[0] / v[2];
-            v[1] = v[1] / v[2];
+        if (v[2] > 0.0f) {                     // my_lib_kernel.cu:1730-1735; one reciprocal for both components
+            const float inv = 1.0f / v[2];     // (<= 1 ulp from the two divisions; VALU is this kernel's bound)
+            v[0] = v[0] * inv;
+            v[1] = v[1] * inv;
         }
         ox[j] = v[0];  oy[j] = v[1];  oc[j] = v[2];
     }

@@ -384,7 +384,8 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
                          const float *gradoutput, float *gradinput1, float *gradinput2)
 {
     if (w <= 0 || h <= 0 || channel <= 0 || batch <= 0) return 0;
-    if (channel == 3 && vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2})) {
+    if (channel == 3 && plane_fits_u32(w, h, {s1h}) &&
+        vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2})) {
         using G = TileGeom<16>;
         static_assert(AccT::kPlane * 8 <= G::kCapPx * 16 && G::kPitch <= AccT::kMaxW && G::kRows <= AccT::kRows,
                       "the accumulator plane aliases the staged image");

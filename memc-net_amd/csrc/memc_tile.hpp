@@ -535,21 +535,33 @@ __device__ __forceinline__ void acct_zero(double *acc)
 // Adds every non-zero cell of the region to dst (row-coalesced global atomics) and leaves the plane zeroed.
 // A wave takes rows wave, wave + 4, ...; four rows (eight cells per lane) are read before any is consumed so
 // that the LDS latency is paid once per batch, not once per cell.
-template <bool PLAIN_STORE = false>
+// STORAGE_ORDER: lanes walk the plane in the order it is stored (lane l reads slots l and l + 64 of a row, i.e.
+// columns 4 * (slot & 31) + (slot >> 5)): conflict-free LDS reads and zero-writes, global atomics 16 bytes apart
+// (four cache lines per wave-instruction instead of two).  Otherwise lanes walk columns: row-coalesced atomics,
+// 4-way bank conflicts on the 8-byte LDS accesses.  Measured equal (FI backward 1822 vs 1820 us, Interpolation
+// backward 541 vs 544): the flush is bound by neither; the coalesced walk is the default.
+template <bool PLAIN_STORE = false, bool STORAGE_ORDER = false>
 __device__ __forceinline__ void acct_flush_zero(const Region &r, double *acc, float *dst, int hstride)
 {
     const unsigned tid = tid_now();
     const int lane = tid & (kWave - 1), wave = tid / kWave;
-    const int c0 = acct_col(lane), c1 = acct_col(lane + kWave);
-    const bool ok0 = lane < r.w, ok1 = lane + kWave < r.w;
+    const int s0 = STORAGE_ORDER ? lane : acct_col(lane), s1 = STORAGE_ORDER ? lane + kWave : acct_col(lane + kWave);
+    const int col0 = STORAGE_ORDER ? 4 * (lane & 31) + (lane >> 5) : lane;
+    const int col1 = STORAGE_ORDER ? col0 + 2 : lane + kWave;
+    const bool ok0 = col0 < r.w, ok1 = col1 < r.w;
+    // wave-uniform base + 32-bit byte offsets
+    const uintptr_t base = pin_sgpr(dst);
+    unsigned off = 4u * (unsigned)((r.y0 + wave) * hstride + r.x0 + col0);
+    const unsigned step = 16u * (unsigned)hstride;          // four rows down
+    const unsigned dcol = 4u * (unsigned)(col1 - col0);
 #pragma unroll 1
-    for (int row0 = wave; row0 < r.h; row0 += 16) {
+    for (int row0 = wave; row0 < r.h; row0 += 16, off += 4u * step) {
         double val[4][2];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int row = min(row0 + 4 * u, AccT::kRows - 1);
-            val[u][0] = acc[row * AccT::kPitch + c0];
-            val[u][1] = acc[row * AccT::kPitch + c1];
+            val[u][0] = acc[row * AccT::kPitch + s0];
+            val[u][1] = acc[row * AccT::kPitch + s1];
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -558,9 +570,9 @@ __device__ __forceinline__ void acct_flush_zero(const Region &r, double *acc, fl
             for (int hh = 0; hh < 2; hh++) {
                 const float f = (float)val[u][hh];
                 if (row < r.h && (hh ? ok1 : ok0) && f != 0.0f) {
-                    acc[row * AccT::kPitch + (hh ? c1 : c0)] = 0.0;
-                    float *q = dst + (int64_t)(r.y0 + row) * hstride + r.x0 + lane + hh * kWave;
-                    if (PLAIN_STORE) *q = f; else atomic_add_f32(q, f);
+                    acc[row * AccT::kPitch + (hh ? s1 : s0)] = 0.0;
+                    MEMC_GLOBAL float *q = reinterpret_cast<MEMC_GLOBAL float *>(base + (off + u * step + hh * dcol));
+                    if (PLAIN_STORE) *q = f; else (void)__builtin_amdgcn_global_atomic_fadd_f32(q, f);
                 }
             }
         }
