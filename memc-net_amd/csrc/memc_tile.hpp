@@ -461,52 +461,12 @@ __device__ __forceinline__ void acc_flush(const Region &r, const float *acc, flo
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// fp64 accumulator planes.  Measured on MI355X (tools/probes, `run_probe.py lds`): ds_add_f32 retires 0.33
-// lane-ops per clock per CU whatever the access pattern (an emulated path), ds_add_f64 6.7 conflict-free and
-// 2.0 on the 4-strided pattern -- twenty / six times faster.  The backward passes therefore accumulate their
-// scattered image gradient in DOUBLE in LDS (also more accurate than the reference's fp32 atomics) and round
-// to fp32 once, when a cell is flushed.  Layout: odd pitch + a one-bit column swizzle make the 4-strided,
-// two-row access pattern of a wave conflict-free.
+// fp64 accumulation in LDS.  Measured on MI355X (tools/probes, `run_probe.py lds`): ds_add_f32 retires 0.33
+// lane-ops per clock per CU whatever the access pattern (an emulated path), ds_add_f64 6.7 conflict-free --
+// twenty times faster.  The backward passes therefore accumulate their scattered image gradient in DOUBLE in
+// LDS (also more accurate than the reference's fp32 atomics) and round to fp32 once, when a cell is flushed.
 // ---------------------------------------------------------------------------------------------------------
-template <int LX>
-struct Acc64Geom {
-    using G = TileGeom<LX>;
-    static constexpr int kPitch = G::kPitch + 1;       // 97: odd, == 1 (mod 32)
-    static constexpr int kRows = G::kRows;
-    static constexpr int kPlane = kPitch * kRows;      // doubles per plane
-    static_assert(G::kPitch <= 96, "the column swizzle below flips bit 1 of columns 32..63 only");
-};
-
-__device__ __forceinline__ int acc64_col(int c) { return c ^ ((c >> 4) & 2); }
-
-template <int LX, int NP>
-__device__ __forceinline__ void acc64_zero(double *acc)
-{
-    using A = Acc64Geom<LX>;
-    for (int i = tid_now(); i < NP * A::kPlane; i += TileGeom<LX>::kThreads) acc[i] = 0.0;
-}
-
 __device__ __forceinline__ void lds_add_f64(double *p, double v) { (void)unsafeAtomicAdd(p, v); }   // ds_add_f64
-
-template <int LX, int NP, bool PLAIN_STORE = false>      // PLAIN_STORE: measurement only (wrong results)
-__device__ __forceinline__ void acc64_flush(const Region &r, const double *acc, float *const (&dst)[NP],
-                                            const int (&hstride)[NP])
-{
-    using A = Acc64Geom<LX>;
-    const unsigned tid = tid_now();
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
-    for (int row = wave; row < r.h; row += TileGeom<LX>::kThreads / kWave)
-        for (int col = lane; col < r.w; col += kWave) {
-#pragma unroll
-            for (int pl = 0; pl < NP; pl++) {
-                const float v = (float)acc[pl * A::kPlane + row * A::kPitch + acc64_col(col)];
-                float *q = dst[pl] + (int64_t)(r.y0 + row) * hstride[pl] + r.x0 + col;
-                if (v != 0.0f) {
-                    if (PLAIN_STORE) *q = v; else atomic_add_f32(q, v);
-                }
-            }
-        }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // Transposed fp64 accumulator plane.  Measured (tools/probes/run_probe.py ldspat): a ds_add_f64 costs ~8.8 clk
