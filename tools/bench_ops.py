@@ -128,13 +128,14 @@ def bench_fi_bwd(rows, dev, B, C, H, W, flow_kind, tag, variants=()):
 
     def pre():
         g1.zero_(); g2.zero_(); g3.zero_()
+    burst = 20 if B * H * W < 4e6 else 1
     for v in variants:
         L._debug_set_variant("fi_bwd", v)
-        med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre)
+        med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre,
+                                burst=burst)
         report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s ABLATION variant=%d" % (tag, C, B, H, W, flow_kind, v),
                B * H * W, 4 * (3 * C + 2 * (2 + 16)), med, mn)
     L._debug_set_variant("fi_bwd", -1)
-    burst = 20 if B * H * W < 4e6 else 1
     med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre, burst=burst)
     report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s%s" % (tag, C, B, H, W, flow_kind, " (bursts of 20)" if burst > 1 else ""),
            B * H * W, 4 * (3 * C + 2 * (2 + 16)), med, mn)
@@ -274,7 +275,7 @@ def main():
     if want("fi_blend"):
         bench_fi_blend(rows, dev, 32, 720, 1280, "smooth")
     if want("fi_bwd"):
-        bench_fi_bwd(rows, dev, 8, 3, 256, 448, "smooth", "c2")
+        bench_fi_bwd(rows, dev, 8, 3, 256, 448, "smooth", "c2", [int(v) for v in args.bwd_variants.split(",") if v])
         if not args.quick:
             bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "smooth", "720p",
                          [int(v) for v in args.bwd_variants.split(",") if v])
