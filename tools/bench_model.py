@@ -33,6 +33,9 @@ def main(argv=None):
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--json", default="")
+    ap.add_argument("--miopen-search", action="store_true",
+                    help="torch.backends.cudnn.benchmark = True: let MIOpen time its convolution solvers per shape")
+    ap.add_argument("--channels-last", action="store_true", help="NHWC activations / weights for the dense layers")
     a = ap.parse_args(argv)
 
     import torch
@@ -49,10 +52,13 @@ def main(argv=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=dev)
 
+    torch.backends.cudnn.benchmark = bool(a.miopen_search)
     import my_package._ext.my_lib as my_lib
     import networks
     torch.manual_seed(1234 + rank)                     # deliberately different: only the broadcast makes them equal
     net = networks.MEMC_Net_star(channel=3, filter_size=4, training=False).to(dev).eval()
+    if a.channels_last:
+        net = net.to(memory_format=torch.channels_last)
     t0 = time.perf_counter()
     msgs, nbytes = networks.broadcast_module_state(net, src=0)
     torch.cuda.synchronize(dev)
@@ -100,6 +106,7 @@ def main(argv=None):
                 "unit": "frames/s", "mpixels_per_s": round(pairs * a.height * a.width / worst / 1e6, 2),
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(worst / a.steps * 1e3, 2),
                 "scaling": "weak", "dtype": "f32", "data": "synthetic, random weights",
+                "dense_layers": {"miopen_search": bool(a.miopen_search), "channels_last": bool(a.channels_last)},
                 "config": {"workload": "MEMC_Net_star inference %dx%d (padded %dx%d), %d pairs/GPU" % (
                     a.width, a.height, a.width + pl + pr, a.height + pt + pb, a.pairs),
                     "global_pairs_per_step": world * a.pairs,
