@@ -65,7 +65,7 @@ def test_training_step_matches_reference_fingerprint(net):
     finally:
         net.eval()
         net.load_state_dict(weights)
-    assert abs(float(total) - float(gold["train_loss"])) <= 1e-3 * float(gold["train_loss"])
+    assert abs(float(total.detach()) - float(gold["train_loss"])) <= 1e-3 * float(gold["train_loss"])
     got = _netutil.grad_l1_by_module(net)
     want = {k[len("grad_l1/"):]: float(gold[k]) for k in gold.files if k.startswith("grad_l1/")}
     assert sorted(got) == sorted(want)

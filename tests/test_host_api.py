@@ -107,3 +107,22 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), "%s mentions the oracle" % os.path.join(dirpath, f)
+
+
+def test_blend_extension_surface_and_no_cpu_path():
+    """The fused warp + blend extension: module / layer names, argument order, and -- like everything else -- no CPU
+    path, neither on the fused branch (RGB, 16 taps, W % 4 == 0) nor on the composed one."""
+    from my_package.modules.FilterInterpolationBlendModule import FilterInterpolationBlendModule
+    from my_package.functions.FilterInterpolationBlendLayer import FilterInterpolationBlendLayer, fused_supported
+    import my_package._ext.my_lib as my_lib
+    assert list(inspect.signature(FilterInterpolationBlendModule.forward).parameters) == [
+        "self", "input0", "input2", "flow0", "flow1", "filter0", "filter1", "occlusion0", "occlusion1"]
+    assert callable(FilterInterpolationBlendLayer()) and callable(my_lib.FilterInterpolationBlendLayer_gpu_forward)
+    z = torch.zeros
+    assert fused_supported(z(1, 3, 8, 8), z(1, 16, 8, 8))
+    assert not fused_supported(z(1, 4, 8, 8), z(1, 16, 8, 8)) and not fused_supported(z(1, 3, 8, 6), z(1, 16, 8, 6))
+    assert not fused_supported(z(1, 3, 8, 8), z(1, 9, 8, 8))
+    for c, w in ((3, 8), (5, 8), (3, 6)):
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            FilterInterpolationBlendModule()(z(1, c, 8, w), z(1, c, 8, w), z(1, 2, 8, w), z(1, 2, 8, w),
+                                             z(1, 16, 8, w), z(1, 16, 8, w), z(1, 1, 8, w), z(1, 1, 8, w))
