@@ -17,9 +17,9 @@ echo "== bench";   timeout 600 python bench.py 2>&1 | tail -3 | tee "$OUT/bench.
 echo "== model"; timeout 600 python tools/bench_model.py --json "$OUT/bench_model.json" 2>&1 | tail -2 | tee "$OUT/bench_model.log"
 echo "== race screen"; timeout 600 python tools/stress_projection.py 60 2>&1 | tail -3 | tee "$OUT/stress.log"
 cd /tmp && export TMPDIR=/tmp
-echo "== rocprof kernel trace of bench.py (same command as the bench line above, fewer steps)"
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_trace" -o bench -- python "$REPO/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/prof_trace.log" 2>&1
-python "$REPO/tools/prof_summary.py" stats "$OUT/prof_trace/bench_results.db" --out "$OUT/bench_kernel_stats.txt" | head -6
+echo "== rocprof kernel trace of bench.py (the same command as the bench line above, minus the CPU baseline)"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_trace" -o bench -- python "$REPO/bench.py" --no-cpu-baseline > "$OUT/prof_trace.log" 2>&1
+python "$REPO/tools/prof_summary.py" stats "$OUT/prof_trace/bench_results.db" --tail 300 --out "$OUT/bench_kernel_stats.txt" | grep -v "^at::\|^$" | head -6
 rm -rf "$OUT/prof_trace"
 echo "== PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a known copy)"
 cd "$REPO" && timeout 900 python tools/pmc_traffic.py --out "$OUT" 2>&1 | tail -30

@@ -27,7 +27,7 @@ def short(name, n=70):
     return name if len(name) <= n else name[:n - 3] + "..."
 
 
-def stats(db):
+def stats(db, tail=0):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute(
         "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
@@ -35,6 +35,15 @@ def stats(db):
     out = ["%-72s %7s %14s %12s %12s %12s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us")]
     for name, calls, tot, avg, mn, mx in rows:
         out.append("%-72s %7d %14.1f %12.2f %12.2f %12.2f" % (short(name), calls, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3))
+    if tail and rows:
+        # the dominant kernel's LAST `tail` dispatches = the timed steps of bench.py (its untimed pre-warm and
+        # warm-up launches come first and run at lower clocks, tools/timeline.py)
+        top = rows[0][0]
+        d = [r[0] for r in cur.execute("select duration from kernels where name = ? order by start", (top,)).fetchall()]
+        d = d[-tail:]
+        out.append("")
+        out.append("%s: last %d dispatches (the timed steps): avg %.2f us, min %.2f, max %.2f" % (
+            short(top), len(d), sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3))
     return "\n".join(out) + "\n"
 
 
@@ -65,8 +74,9 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--match", default="")
     ap.add_argument("--out", default="")
+    ap.add_argument("--tail", type=int, default=0, help="stats: also average the dominant kernel's last N dispatches")
     a = ap.parse_args()
-    text = stats(a.db) if a.mode == "stats" else json.dumps(pmc(a.db, a.match), indent=1) + "\n"
+    text = stats(a.db, a.tail) if a.mode == "stats" else json.dumps(pmc(a.db, a.match), indent=1) + "\n"
     if a.out:
         open(a.out, "w").write(text)
     sys.stdout.write(text)
