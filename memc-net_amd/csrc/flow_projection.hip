@@ -386,6 +386,13 @@ __global__ __launch_bounds__(256) void proj_owner(
     // column) by one division and increments, addresses as wave-uniform base + 32-bit lane offset (the address
     // arithmetic of this prologue was a quarter of the kernel's VALU instructions, and VALU is its bound).
     constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + 255) / 256;
+    // slot `it` of the 256 lanes covers scan rows [256 it / kCols4, (256 it + 255) / kCols4]; the tile is rows
+    // [kReach + 1, kReach + 17): the slot is "far" when all of its rows are at least kNearRows away from the tile
+    constexpr int kNearRows = 8;
+    auto far_it = [](int it) {
+        const int first = 256 * it / kCols4, last = (256 * it + 255) / kCols4;
+        return last <= kReach + 1 - kNearRows || first >= kReach + 17 + kNearRows;
+    };
     const float *flow_b = flow + b * s1b;
     const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
     f32x4 fx[kIts], fy[kIts], dd[kIts];
@@ -399,9 +406,14 @@ __global__ __launch_bounds__(256) void proj_owner(
         live[it] = row < kScanH && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
         // dead slots read the plane's first pixels (unconditional loads)
         const unsigned off = live[it] ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
-        fx[it] = ld_cached4_u(flow_b, off);
         fy[it] = ld_cached4_u(flow_b + s1c, off);
-        if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+        // Rows more than ~8 px from the tile (the first and last two slots of a lane) almost never pass the row
+        // test below: only their fy is requested here, fx / depth follow inside the branch if they do.  The scan
+        // moves 7.6x the tile's own bytes through the CU's 64 B/clk L1 path, which is a bound of its own.
+        if (!far_it(it)) {
+            fx[it] = ld_cached4_u(flow_b, off);
+            if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+        }
         row += 256 / kCols4;                   // the next slot of this lane is 256 further on
         c4 += 256 % kCols4;
         if (c4 >= kCols4) {
@@ -428,10 +440,16 @@ __global__ __launch_bounds__(256) void proj_owner(
                   (f[3] >= lo && f[3] < hi)))
                 continue;
         }
+        f32x4 fxq = fx[it], ddq = dd[it];
+        if (far_it(it)) {                      // rare: requested only now (and consumed inside this branch)
+            const unsigned off = 4u * (unsigned)(sy[it] * s1h + sx[it]);
+            fxq = ld_cached4_u(flow_b, off);
+            if (DEPTH) ddq = ld_cached4_u(depth_b, 4u * (unsigned)(sy[it] * sdh + sx[it]));
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int x = sx[it] + j, y = sy[it];
-            const float fxv = fx[it][j], fyv = fy[it][j];
+            const float fxv = fxq[j], fyv = fy[it][j];
             const BlSite s = bl_locate<false>(x, y, W, H, fxv, fyv);
             if (!s.valid) continue;
             const bool near = fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach;
@@ -443,9 +461,9 @@ __global__ __launch_bounds__(256) void proj_owner(
             if ((unsigned)py < (unsigned)kPtH && (unsigned)px < 65u) {
                 float vx = -fxv, vy = -fyv, vc = 1.0f;
                 if (DEPTH) {
-                    vx = -dd[it][j] * fxv;
-                    vy = -dd[it][j] * fyv;
-                    vc = dd[it][j] * 1.0f;
+                    vx = -ddq[j] * fxv;
+                    vy = -ddq[j] * fyv;
+                    vc = ddq[j] * 1.0f;
                 }
                 double *q = P + py * kPtW + px;
                 lds_add_f64(q, (double)vx);
