@@ -5,11 +5,17 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The shipped path is the HIP
  * library under memc-net_amd/csrc and it has no CPU fallback.
  *
- * PARITY UNPINNED (see DESIGN.md "Oracle"): the reference holds no tests, golden vectors or fixtures for
- * this path, its Python wrappers cannot be imported (torch.utils.ffi is gone) and its
- * C file needs TH.h from PyTorch 0.2's TH library, which this image lacks, so no admissible reference
- * build exists here.  The restatement is anchored on the reference source line by line (citations below)
- * and on the known answers SURVEY.md appendix A.7 recorded from the reference (tests/test_oracle_kat.py).
+ * PARITY PINNED against outputs of the reference itself (see DESIGN.md "Oracle").  The reference holds no
+ * tests, golden vectors or fixtures for this path, its Python wrappers cannot be imported
+ * (torch.utils.ffi is gone) and its CPU file needs TH.h from PyTorch 0.2's TH library, which this image lacks --
+ * but its GPU file, my_package/src/my_lib_kernel.cu, is self-contained and builds for gfx950 with the image's own
+ * hipify-perl + hipcc (`make -C oracle ref` -> oracle/_ref/libmemc_ref_gpu.so).  Those kernels, run on an MI355X:
+ *   - tests/golden/ref_gpu_*.npz hold their outputs for every entry point of the path (forward, backward,
+ *     with and without hole filling); tests/test_golden_reference.py holds this file to them, on any machine;
+ *   - tests/test_gpu_reference.py repeats the comparison live on the GPU box, and compares the HIP path with
+ *     the reference kernels directly.
+ * Also: the known answers SURVEY.md appendix A.7 recorded from the reference's C code (tests/test_oracle_kat.py)
+ * and an independent pure-Python restatement (tests/test_oracle_vs_spec.py).
  *
  * Every function restates one reference function; citations are file:line under /root/reference.
  * Float arithmetic follows the reference's C expression order exactly (build with -ffp-contract=off:

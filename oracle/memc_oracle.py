@@ -1,6 +1,7 @@
 """numpy front-end of the CPU checker (oracle/memc_oracle.c).
 
-TEST INFRASTRUCTURE ONLY -- PARITY UNPINNED (see the header of memc_oracle.c and DESIGN.md "Oracle").
+TEST INFRASTRUCTURE ONLY -- parity pinned against the reference's own GPU kernels (see the header of
+memc_oracle.c, oracle/ref_gpu.py and DESIGN.md "Oracle").
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
 path (memc-net_amd/my_package) never does and has no CPU fallback.
 
