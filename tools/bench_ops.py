@@ -197,41 +197,6 @@ def bench_interp(rows, dev, B, C, H, W, flow_kind, tag):
            4 * (3 * C + 4), med, mn)
 
 
-def cpu_rows(rows):
-    """The oracle (port of the reference's CPU code) timed per operator on a bounded 720p sample, same box:
-    a baseline beside the GPU rows -- says nothing about kernel quality (that is the roofline fraction)."""
-    import time
-    import numpy as np
-    from oracle import memc_oracle as O          # baseline only
-    O.build()
-    rng = np.random.default_rng(0)
-    B, C, H, W = 4, 3, 720, 1280
-    x = synth.np_image(rng, B, C, H, W); f = synth.np_flow(rng, B, H, W, "smooth"); k = synth.np_filter(rng, B, H, W)
-    g = synth.np_image(rng, B, C, H, W); d = synth.np_depth(rng, B, H, W); gf = rng.random((B, 2, H, W), dtype=np.float32)
-    _, cnt = O.flow_projection_forward(f, 0)
-    do, dc = O.depth_flow_projection_forward(f, d, 0)
-    cases = [
-        ("fi_fwd", lambda: O.filter_interpolation_forward(x, f, k)),
-        ("fi_bwd", lambda: O.filter_interpolation_backward(x, f, k, g)),
-        ("flow_projection_fwd (no fill: the reference CPU code has none)", lambda: O.flow_projection_forward(f, 0)),
-        ("flow_projection_fwd + restated fill-hole", lambda: O.flow_projection_forward(f, 1)),
-        ("depth_flow_projection_fwd", lambda: O.depth_flow_projection_forward(f, d, 0)),
-        ("flow_projection_bwd", lambda: O.flow_projection_backward(f, cnt, gf)),
-        ("depth_flow_projection_bwd", lambda: O.depth_flow_projection_backward(f, d, dc, do, gf)),
-        ("interpolation_fwd", lambda: O.interpolation_ch_forward(x, f)),
-        ("interpolation_bwd", lambda: O.interpolation_ch_backward(x, f, g)),
-    ]
-    for name, fn in cases:
-        fn()
-        reps, spent = 0, 0.0
-        while spent < 2.0 and reps < 50:
-            t0 = time.perf_counter(); fn(); spent += time.perf_counter() - t0; reps += 1
-        mp = B * H * W * reps / spent / 1e6
-        rows.append({"op": "cpu_baseline " + name, "mpix_s": round(mp, 2), "threads": O.num_threads(),
-                     "sample": "%dx%dx%dx%d, %d reps" % (B, C, H, W, reps)})
-        print("%-72s %10.2f Mpix/s  (oracle, %d threads)" % ("cpu_baseline " + name, mp, O.num_threads()), flush=True)
-
-
 def bench_copy(rows, dev):
     """calibration: a plain device copy of the same byte volume as the headline launch"""
     n = 2831155200 // 8
@@ -286,8 +251,7 @@ def main():
             bench_projection(rows, dev, 32, 720, 1280, "iid", "c3")
     if want("interp"):
         bench_interp(rows, dev, 32, 3, 720, 1280, "smooth", "720p")
-    if want("cpu"):
-        cpu_rows(rows)
+    # baselines (the CPU oracle, the reference's own kernels on this GPU) live under tests/: tests/bench_baselines.py
     os.makedirs(os.path.dirname(args.json), exist_ok=True)
     json.dump({"device": torch.cuda.get_device_name(0), "lib": L.version(), "rows": rows}, open(args.json, "w"),
               indent=1)

@@ -13,6 +13,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 echo "== smoke";   timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee "$OUT/smoke.log"
 echo "== pytest";  timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee "$OUT/pytest_gpu.log"
 echo "== sweep";   timeout 900 python tools/bench_ops.py ${QUICK:+--quick} --json "$OUT/bench_ops.json" 2>&1 | tee "$OUT/bench_ops.log"
+echo "== baselines (reference kernels on this GPU, CPU oracle)"; timeout 900 python tests/bench_baselines.py --json "$OUT/baselines.json" 2>&1 | grep -v amdgpu.ids | tee "$OUT/baselines.log"
 echo "== bench";   timeout 600 python bench.py 2>&1 | tail -3 | tee "$OUT/bench.log"
 echo "== model"; timeout 600 python tools/bench_model.py --json "$OUT/bench_model.json" 2>&1 | tail -2 | tee "$OUT/bench_model.log"
 echo "== race screen"; timeout 600 python tools/stress_projection.py 60 2>&1 | tail -3 | tee "$OUT/stress.log"
