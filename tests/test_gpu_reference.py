@@ -88,3 +88,34 @@ def test_interpolation_rgb_entry_point():
     assert L.InterpolationLayer_gpu_backward(x, f, g, g1, g2) == 0
     w1, w2 = R.interpolation_backward(x, f, g)
     close(N(g1), N(w1), "bl_g1"); close(N(g2), N(w2), "bl_g2")
+
+
+@pytest.mark.parametrize("kind", ["smooth", "iid"])
+def test_benchmark_size_against_reference_kernels(kind):
+    """BASELINE's 1280x720 frames (batch 2, device-generated like bench.py): the HIP path against the reference
+    kernels themselves -- real parity at full size, where the CPU oracle would take minutes."""
+    import my_package._ext.my_lib as L
+    from tools import synth
+    B, C, H, W = 2, 3, 720, 1280
+    t = synth.torch_inputs(torch.device("cuda:0"), B, C, H, W, flow_kind=kind, seed=5, with_grad=True, with_depth=True)
+    x, f, k, g, dep = t["x"], t["flow"], t["filt"], t["gout"], t["depth"]
+    z = torch.zeros_like
+    out = z(x); assert L.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+    close(N(out), N(R.filter_interpolation_forward(x, f, k)), "fi_fwd 720p")
+    g1, g2, g3 = z(x), z(f), z(k)
+    assert L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+    w1, w2, w3 = R.filter_interpolation_backward(x, f, k, g)
+    close(N(g1), N(w1), "fi_g1 720p"); close(N(g2), N(w2), "fi_g2 720p"); close(N(g3), N(w3), "fi_g3 720p")
+    cnt, o = z(dep), z(f); assert L.FlowProjectionLayer_gpu_forward(f, cnt, o, 1) == 0
+    wo, wc = R.flow_projection_forward(f, 1)
+    assert torch.equal(cnt, wc); close(N(o), N(wo), "fp + fill 720p")
+    cnt, o = z(dep), z(f); assert L.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, o, 1) == 0
+    wo, wc = R.depth_flow_projection_forward(f, dep, 1)
+    close(N(cnt), N(wc), "dfp count 720p"); close(N(o), N(wo), "dfp + fill 720p")
+    gf = torch.rand_like(f)
+    cnt0, o0 = z(dep), z(f); assert L.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt0, o0, 0) == 0
+    g1, g2 = z(f), z(dep); assert L.DepthFlowProjectionLayer_gpu_backward(f, dep, cnt0, o0, gf, g1, g2) == 0
+    w1, w2 = R.depth_flow_projection_backward(f, dep, cnt0, o0, gf)
+    close(N(g1), N(w1), "dfp_g1 720p"); close(N(g2), N(w2), "dfp_g2 720p")
+    o = z(x); assert L.InterpolationLayer_gpu_forward(x, f, o) == 0
+    close(N(o), N(R.interpolation_forward(x, f)), "bl_fwd 720p")
