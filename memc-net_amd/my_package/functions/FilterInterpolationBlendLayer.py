@@ -24,7 +24,7 @@ def fused_supported(input0, filter0):
 
 
 def _warp(x, flow, filt):
-    out = torch.zeros_like(x)
+    out = torch.empty_like(x)                                # every element is written
     check(my_lib.FilterInterpolationLayer_gpu_forward(x, flow, filt, out), "FilterInterpolationLayer_gpu_forward")
     return out
 

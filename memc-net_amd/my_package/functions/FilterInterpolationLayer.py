@@ -25,7 +25,10 @@ class _FilterInterpolationFunction(Function):
     def forward(ctx, input1, input2, input3):
         require_gpu("FilterInterpolationLayer", input1, input2, input3)
         input1, input2, input3 = f32c(input1), f32c(input2), f32c(input3)
-        output = torch.zeros_like(input1)                      # reference: .resize_(...).zero_() (:26)
+        # the reference zero-fills (:26); the forward kernels write EVERY element (invalid sites copy the input,
+        # tests/test_gpu_parity.py::test_forward_outputs_need_no_zero_fill), so the memset -- a quarter of the
+        # call's time at 720p -- is skipped.  The C entry point still accepts zero-filled buffers, of course.
+        output = torch.empty_like(input1)
         err = my_lib.FilterInterpolationLayer_gpu_forward(input1, input2, input3, output)
         check(err, "FilterInterpolationLayer_gpu_forward")
         ctx.save_for_backward(input1, input2, input3)

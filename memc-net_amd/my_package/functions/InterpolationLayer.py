@@ -20,7 +20,7 @@ def _make_bilinear_function(label, fwd_name, bwd_name):
         def forward(ctx, input1, input2):
             require_gpu(label, input1, input2)
             input1, input2 = f32c(input1), f32c(input2)
-            output = torch.zeros_like(input1)                   # reference :25
+            output = torch.empty_like(input1)     # reference zero-fills (:25); every element is written (invalid: 0)
             check(fwd(input1, input2, output), fwd_name)
             ctx.save_for_backward(input1, input2)
             return output

@@ -448,3 +448,26 @@ def test_views_with_huge_row_strides(oracle):
     want_out, want_cnt = oracle.flow_projection_forward(fn, 1)
     close(N(out.contiguous()), want_out, "projection through a 4.7 GiB-per-plane view")
     close(N(cnt.contiguous()), want_cnt, "count")
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_forward_outputs_need_no_zero_fill(oracle, case):
+    """The Python layer hands FilterInterpolation / Interpolation(Ch) forward an UNINITIALISED output (no memset):
+    every element must be written by the kernels -- valid sites, invalid sites (copy / zero), every channel, every
+    kernel variant the shapes of CASES select.  Checked with a NaN-filled buffer through the C ABI."""
+    import my_package._ext.my_lib as my_lib
+    d = make(case)
+    x, f, k = T(d["x"]), T(d["flow"]), T(d["filt"])
+    out = torch.full_like(x, float("nan"))
+    assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+    assert not torch.isnan(out).any()
+    close(N(out), oracle.filter_interpolation_forward(d["x"], d["flow"], d["filt"]), "FI forward into a NaN buffer")
+    out = torch.full_like(x, float("nan"))
+    assert my_lib.InterpolationChLayer_gpu_forward(x, f, out) == 0
+    assert not torch.isnan(out).any()
+    close(N(out), oracle.interpolation_ch_forward(d["x"], d["flow"]), "InterpolationCh forward into a NaN buffer")
+    for fs in (2, 3):                                            # the any-filter-size kernel
+        kk = T(d["filt"][:, :fs * fs])
+        out = torch.full_like(x, float("nan"))
+        assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, kk, out) == 0
+        assert not torch.isnan(out).any()
