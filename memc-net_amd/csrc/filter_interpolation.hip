@@ -782,7 +782,8 @@ __global__ __launch_bounds__(512) void fi_fwd_refshape(
 //                                               reference issues 16*C atomics for this)
 //   gradinput2  = flow gradients from the quadrant sums (assignment; the sums are computed once, the
 //                 reference recomputes them twice more)
-// Invalid sites write nothing: the buffers keep the caller's zeros.
+// Invalid sites store zeros to gradinput2 / gradinput3 (which are therefore fully defined by the kernel) and
+// leave gradinput1, an accumulation target, alone.
 // --------------------------------------------------------------------------------------------------
 template <int CT, int ROWS>
 __global__ __launch_bounds__(64 * ROWS) void fi_bwd_direct_fs4(
@@ -804,7 +805,15 @@ __global__ __launch_bounds__(64 * ROWS) void fi_bwd_direct_fs4(
     const float fx = ld_stream(flow_b);
     const float fy = ld_stream(flow_b + s2c);
     const FiSite s = fi_locate(x, y, W, H, fx, fy);
-    if (!s.valid) return;
+    if (!s.valid) {                            // gradinput2 / gradinput3 are fully DEFINED by the kernels: an
+        float *z3 = gin3 + b * s3b + (int64_t)y * s3h + x;    // invalid site stores the zeros the reference's
+#pragma unroll                                                  // caller-side memset would have left there
+        for (int k = 0; k < 16; k++) z3[k * s3c] = 0.0f;
+        float *z2 = gin2 + b * s2b + (int64_t)y * s2h + x;
+        z2[0] = 0.0f;
+        z2[s2c] = 0.0f;
+        return;
+    }
 
     const float *tap_p = filt + b * s3b + (int64_t)y * s3h + x;
     float t[16], gt[16];
@@ -863,7 +872,7 @@ __global__ __launch_bounds__(64 * ROWS) void fi_bwd_direct_fs4(
     }
     float *g3 = gin3 + b * s3b + (int64_t)y * s3h + x;
 #pragma unroll
-    for (int k = 0; k < 16; k++) g3[k * s3c] += gt[k];
+    for (int k = 0; k < 16; k++) g3[k * s3c] = gt[k];         // stored: the site owns its taps
     float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
     st_stream(g2, botx);
     st_stream(g2 + s2c, boty);
@@ -903,7 +912,7 @@ __device__ __noinline__ void fi_bwd_site_scalar(int x, int y, int W, int H, int 
                                               : ((i <= s.ix) ? g * (1 - s.a) * s.b : g * s.a * s.b);
                 const int64_t k = ((j - T) * fs + (i - L)) * s3c;
                 atomic_add_f32(q + jj + ii, wgt * tap_p[k]);
-                g3[k] += wgt * p[jj + ii];
+                if (c == 0) g3[k] = wgt * p[jj + ii]; else g3[k] += wgt * p[jj + ii];
             }
         }
         const float TL = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, T, s.iy, L, s.ix);
@@ -975,6 +984,22 @@ struct FiBwdIn {
 // where wq = {(1-a)(1-b), a(1-b), (1-a)b, ab}, cx = {-(1-b), (1-b), -b, b}, cy = {-(1-a), -a, (1-a), a}.
 // (The reference sums per channel first -- same value up to fp32 re-association, ~1e-7 relative.)
 // Tap rows are the outer loop so that only one row of tap gradients (4 float4) is live at a time.
+// gradinput2 / gradinput3 are fully DEFINED by the backward kernels (the Python layer hands them over
+// uninitialised -- their memsets were 72 B/site, a seventh of the call): a quad that contains an invalid site
+// first stores zeros to its 16 + 2 float4; its valid sites are then stored site by site (fi_bwd_site_taps), by the
+// same lane and therefore after these.  Quads of four valid sites are stored by phase 1 or by fi_bwd_site_taps.
+__device__ __forceinline__ void fi_bwd_zero_invalid(bool inb, unsigned valid, float *gin2_b, int64_t s2c, unsigned o2,
+                                                    float *gin3_b, int64_t s3c, unsigned o3)
+{
+    if (!inb || valid == 0xFu) return;         // rare (image borders, |flow| guard): ordinary 64-bit addressing
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    float *q3 = gin3_b + (o3 >> 2), *q2 = gin2_b + (o2 >> 2);
+#pragma unroll 1
+    for (int k = 0; k < 16; k++) *reinterpret_cast<f32x4 *>(q3 + k * s3c) = z;
+    *reinterpret_cast<f32x4 *>(q2) = z;
+    *reinterpret_cast<f32x4 *>(q2 + s2c) = z;
+}
+
 template <int ABL>
 __device__ __forceinline__ void fi_bwd_phase1(const Region &r, unsigned fast, FiSite4 &g, f32x4 (&tp)[16],
                                               const f32x4 (&go)[3], const f32x4 *tile, int W, int H,
@@ -1121,6 +1146,7 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_tiled_c3(
     float *gin1_b = gin1 + b * s1b;
     unsigned done = 0;
     trace_mark<TR>(2);                                         // bounding box known
+    fi_bwd_zero_invalid(inb, g.valid, gin2_b, s2c, o2, gin3_b, s3c, o3);
 #pragma unroll 1
     for (int bi = 0; bi < bands.n; bi++) {
     const Region r = band_region(box, bands, bi);
@@ -1240,6 +1266,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_tiled_c3_persistent(
     const Bands bands = make_bands<LX, false>(box);
     const float *in_b = in1 + b * s1b;
     float *gin1_b = gin1 + b * s1b;
+    fi_bwd_zero_invalid(inb, g.valid, gin2_b, s2c, o2, gin3_b, s3c, o3);
     unsigned done = 0, fastbits = 0;                           // fastbits: 4 bits per band, the sites it owns
 #pragma unroll 1
     for (int bi = 0; bi < bands.n; bi++) {
@@ -1309,10 +1336,16 @@ __global__ __launch_bounds__(256) void fi_bwd_generic(
     const float *flow_b = flow + b * s2b + (int64_t)y * s2h + x;
     const float fx = flow_b[0], fy = flow_b[s2c];
     const FiSite s = fi_locate(x, y, W, H, fx, fy);
-    if (!s.valid) return;
+    float *g3 = gin3 + b * s3b + (int64_t)y * s3h + x;
+    if (!s.valid) {                            // gradinput2 / gradinput3 are fully defined by the kernels
+        for (int k = 0; k < fs * fs; k++) g3[k * s3c] = 0.0f;
+        float *z2 = gin2 + b * s2b + (int64_t)y * s2h + x;
+        z2[0] = 0.0f;
+        z2[s2c] = 0.0f;
+        return;
+    }
     const int L = s.ix + 1 - fs / 2, T = s.iy + 1 - fs / 2, R = L + fs, Bm = T + fs;
     const float *tap_p = filt + b * s3b + (int64_t)y * s3h + x;
-    float *g3 = gin3 + b * s3b + (int64_t)y * s3h + x;
     const float *in_b = in1 + b * s1b;
     float *gin1_b = gin1 + b * s1b;
     const float *gout_p = gout + b * s1b + (int64_t)y * s1h + x;
@@ -1330,7 +1363,8 @@ __global__ __launch_bounds__(256) void fi_bwd_generic(
                                               : ((i <= s.ix) ? g * (1 - s.a) * s.b : g * s.a * s.b);
                 const int64_t k = ((j - T) * fs + (i - L)) * s3c;
                 atomic_add_f32(q + jj + ii, wgt * tap_p[k]);
-                g3[k] += wgt * p[jj + ii];     // this site owns its taps: plain read-modify-write
+                // this site owns its taps: stored by the first channel, accumulated by the others
+                if (c == 0) g3[k] = wgt * p[jj + ii]; else g3[k] += wgt * p[jj + ii];
             }
         }
         const float TL = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, T, s.iy, L, s.ix);

@@ -51,7 +51,7 @@ class _FilterInterpolationBlendFunction(Function):
             warped = _warp(x, flow, filt)                    # recomputed, not stored by the forward pass
             g_occ = (gradoutput * warped).sum(dim=1, keepdim=True)
             g_warp = (gradoutput * occ).contiguous()
-            g_x, g_flow, g_filt = torch.zeros_like(x), torch.zeros_like(flow), torch.zeros_like(filt)
+            g_x, g_flow, g_filt = torch.zeros_like(x), torch.empty_like(flow), torch.empty_like(filt)
             check(my_lib.FilterInterpolationLayer_gpu_backward(x, flow, filt, g_warp, g_x, g_flow, g_filt),
                   "FilterInterpolationLayer_gpu_backward")
             grads.append((g_x, g_flow, g_filt, g_occ))

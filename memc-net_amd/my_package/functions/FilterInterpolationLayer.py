@@ -39,9 +39,12 @@ class _FilterInterpolationFunction(Function):
     def backward(ctx, gradoutput):
         input1, input2, input3 = ctx.saved_tensors
         gradoutput = f32c(gradoutput)
-        gradinput1 = torch.zeros_like(input1)                   # reference :46-48
-        gradinput2 = torch.zeros_like(input2)
-        gradinput3 = torch.zeros_like(input3)
+        gradinput1 = torch.zeros_like(input1)                   # accumulation target: zero-filled (reference :46)
+        # the reference zero-fills these two as well (:47-48); the backward kernels DEFINE every element of them
+        # (invalid sites store zero; tests/test_gpu_parity.py::test_backward_defines_flow_and_tap_gradients), so
+        # 72 B/site of memsets -- a seventh of the call at 720p -- are skipped
+        gradinput2 = torch.empty_like(input2)
+        gradinput3 = torch.empty_like(input3)
         err = my_lib.FilterInterpolationLayer_gpu_backward(
             input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)
         check(err, "FilterInterpolationLayer_gpu_backward")

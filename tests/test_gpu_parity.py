@@ -181,7 +181,7 @@ def test_depth_flow_projection(oracle, case):
 
 
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
-                if not os.path.basename(p).startswith("network_"))      # operator fixtures only
+                if os.path.basename(p).startswith(("small_", "config1_")))   # the oracle-made operator fixtures
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
@@ -471,3 +471,22 @@ def test_forward_outputs_need_no_zero_fill(oracle, case):
         out = torch.full_like(x, float("nan"))
         assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, kk, out) == 0
         assert not torch.isnan(out).any()
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_backward_defines_flow_and_tap_gradients(oracle, case):
+    """The Python layer hands the FilterInterpolation backward UNINITIALISED gradinput2 / gradinput3: every element
+    must be stored by the kernels (invalid sites: zero), whatever kernel the shape selects (tiled RGB, direct,
+    any filter size; quads split between bands, sites only the scalar path can reach).  NaN-filled buffers."""
+    import my_package._ext.my_lib as my_lib
+    d = make(case)
+    x, f, k, g = T(d["x"]), T(d["flow"]), T(d["filt"]), T(d["gout"])
+    for kk, fs in ((k, 4), (T(d["filt"][:, :9]), 3)):
+        g1 = torch.zeros_like(x)
+        g2, g3 = torch.full_like(f, float("nan")), torch.full_like(kk, float("nan"))
+        assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, kk, g, g1, g2, g3) == 0
+        assert not torch.isnan(g2).any() and not torch.isnan(g3).any(), "fs=%d" % fs
+        w1, w2, w3 = oracle.filter_interpolation_backward(d["x"], d["flow"], N(kk), d["gout"])
+        close(N(g1), w1, "gradinput1 fs=%d" % fs, RTOL)
+        close(N(g2), w2, "gradinput2 fs=%d" % fs, RTOL)
+        close(N(g3), w3, "gradinput3 fs=%d" % fs, RTOL)
