@@ -19,10 +19,11 @@
  *   - fp32, NCHW, strides in ELEMENTS, w-stride must be 1;
  *   - every output / gradient buffer is borrowed: allocated AND zero-filled by the caller
  *     (my_package/functions/FilterInterpolationLayer.py:26-29,46-48; FlowProjectionLayer.py:27-29,54).
- *     (Of these, the library itself only RELIES on zeros in the accumulation targets -- FilterInterpolation /
- *     Interpolation gradinput1 and the projection forward's count / output: forward warp outputs and the
- *     FilterInterpolation gradinput2 / gradinput3 are fully defined by the kernels, which is what lets the
- *     shipped Python layer skip those memsets.)
+ *     (Of these, the library itself only RELIES on zeros in the scattered-into gradients -- FilterInterpolation /
+ *     Interpolation gradinput1, Interpolation gradinput2, the projection backward's gradients on its scalar
+ *     path: the forward outputs of every operator (projection count / output included) and the FilterInterpolation
+ *     gradinput2 / gradinput3 are fully defined by the kernels, which is what lets the shipped Python layer skip
+ *     those memsets.)
  *     With zero-filled buffers the results are the reference's.  With anything else they are unspecified,
  *     and in two places differ from the reference's `+=`: the FilterInterpolation backward STORES gradinput3
  *     (each site owns its taps) and the (Depth)FlowProjection backward STORES gradinput1 / gradinput2 (each site

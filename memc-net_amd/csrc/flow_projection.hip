@@ -536,17 +536,34 @@ __global__ __launch_bounds__(256) void proj_redo_zero(int W, int H, int64_t s1b,
                                                       int sch, int batch, float *__restrict__ count,
                                                       float *__restrict__ out, const int *__restrict__ far_flag)
 {
-    if (far_flag[kFlagWords] == 0) return;
+    // far_flag == nullptr: unconditional (the general path when it runs on its own: the forward pass DEFINES count
+    // and output, it does not rely on the caller's zero fill)
+    if (far_flag && far_flag[kFlagWords] == 0) return;
     const int w4 = W / 4;
     const int64_t n = (int64_t)batch * H * w4;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int x = (int)(i % w4) * 4, y = (int)((i / w4) % H), b = (int)(i / ((int64_t)w4 * H));
-        if (far_flag[b % kFlagWords] == 0) continue;
+        if (far_flag && far_flag[b % kFlagWords] == 0) continue;
         float *o = out + b * s1b + (int64_t)y * s1h + x;
         *reinterpret_cast<f32x4 *>(o) = z;
         *reinterpret_cast<f32x4 *>(o + s1c) = z;
         *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)y * sch + x) = z;
+    }
+}
+
+// the same for the scalar path (odd widths, unaligned views)
+__global__ __launch_bounds__(256) void proj_zero_scalar(int W, int H, int batch, int64_t s1b, int64_t s1c, int s1h,
+                                                        int64_t scb, int sch, float *__restrict__ count,
+                                                        float *__restrict__ out)
+{
+    const int64_t n = (int64_t)batch * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((int64_t)W * H));
+        float *o = out + b * s1b + (int64_t)y * s1h + x;
+        o[0] = 0.0f;
+        o[s1c] = 0.0f;
+        count[b * scb + (int64_t)y * sch + x] = 0.0f;
     }
 }
 
@@ -878,6 +895,9 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
                                s1h, (int64_t)scb, sch, batch, count, out, flag);
             if (launch_status() != 0) return -1;
         } else {
+            if (g_proj_variant < 2)             // (the ablation arms 2 / 3 time the scatter pass alone)
+                hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
+                                   s1h, (int64_t)scb, sch, batch, count, out, (const int *)nullptr);
             if (g_proj_variant == 2) MEMC_PROJ_SCATTER(2, nullptr);
             else if (g_proj_variant == 3) MEMC_PROJ_SCATTER(3, nullptr);
             else MEMC_PROJ_SCATTER(0, nullptr);
@@ -897,6 +917,8 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
+    hipLaunchKernelGGL(proj_zero_scalar, dim3(256 * 8), dim3(256), 0, stream, w, h, batch, (int64_t)s1b, (int64_t)s1c, s1h,
+                       (int64_t)scb, sch, count, out);
     hipLaunchKernelGGL(proj_scatter<DEPTH>, dim3(nwg), dim3(256), 0, stream, w, h, tiles_x, tiles_y,
                        (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out);
     if (launch_status() != 0) return -1;

@@ -19,8 +19,8 @@ class _DepthFlowProjectionFunction(Function):
     def forward(ctx, input1, input2, fillhole):
         require_gpu("DepthFlowProjectionLayer", input1, input2)
         input1, input2 = f32c(input1), f32c(input2)
-        count = input1.new_zeros((input1.size(0), 1, input1.size(2), input1.size(3)))
-        output = torch.zeros_like(input1)
+        count = input1.new_empty((input1.size(0), 1, input1.size(2), input1.size(3)))   # defined by the forward pass
+        output = torch.empty_like(input1)                                               # (see FlowProjectionLayer)
         err = my_lib.DepthFlowProjectionLayer_gpu_forward(input1, input2, count, output, int(fillhole))
         check(err, "DepthFlowProjectionLayer_gpu_forward")
         ctx.save_for_backward(input1, input2, count, output)

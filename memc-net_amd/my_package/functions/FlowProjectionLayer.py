@@ -19,8 +19,10 @@ class _FlowProjectionFunction(Function):
     def forward(ctx, input1, fillhole):
         require_gpu("FlowProjectionLayer", input1)
         input1 = f32c(input1)
-        count = input1.new_zeros((input1.size(0), 1, input1.size(2), input1.size(3)))   # reference :27
-        output = torch.zeros_like(input1)                                               # reference :28
+        # the reference zero-fills both (:27-28); the forward pass here DEFINES every element of them on every
+        # path (tests/test_gpu_parity.py::test_projection_forward_needs_no_zero_fill): no memsets
+        count = input1.new_empty((input1.size(0), 1, input1.size(2), input1.size(3)))
+        output = torch.empty_like(input1)
         err = my_lib.FlowProjectionLayer_gpu_forward(input1, count, output, int(fillhole))
         check(err, "FlowProjectionLayer_gpu_forward")
         ctx.save_for_backward(input1, count)

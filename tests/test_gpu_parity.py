@@ -490,3 +490,31 @@ def test_backward_defines_flow_and_tap_gradients(oracle, case):
         close(N(g1), w1, "gradinput1 fs=%d" % fs, RTOL)
         close(N(g2), w2, "gradinput2 fs=%d" % fs, RTOL)
         close(N(g3), w3, "gradinput3 fs=%d" % fs, RTOL)
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_projection_forward_needs_no_zero_fill(oracle, case):
+    """(Depth)FlowProjection forward DEFINES count and output on every path (owner-computes fast path, the general
+    path behind its far flag or on its own, the scalar kernels of odd widths): the Python layer passes
+    uninitialised buffers.  NaN-filled buffers through the C ABI, every path forced in turn."""
+    import my_package._ext.my_lib as my_lib
+    d = make(case)
+    f, dep = T(d["flow"]), T(d["depth"])
+    want = {fh: oracle.flow_projection_forward(d["flow"], fh) for fh in (0, 1)}
+    dwant = oracle.depth_flow_projection_forward(d["flow"], d["depth"], 1)
+    try:
+        for variant in (-1, 1, 0):                       # automatic (fast path where it applies), general, scalar
+            my_lib._debug_set_variant("projection", variant)
+            for fh in (0, 1):
+                cnt = torch.full((f.shape[0], 1, f.shape[2], f.shape[3]), float("nan"), device=dev())
+                out = torch.full_like(f, float("nan"))
+                assert my_lib.FlowProjectionLayer_gpu_forward(f, cnt, out, fh) == 0
+                assert not torch.isnan(cnt).any() and not torch.isnan(out).any(), (variant, fh)
+                assert np.array_equal(N(cnt), want[fh][1])
+                close(N(out), want[fh][0], "projection variant %d fillhole %d" % (variant, fh))
+            cnt, out = torch.full_like(dep, float("nan")), torch.full_like(f, float("nan"))
+            assert my_lib.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, out, 1) == 0
+            close(N(cnt), dwant[1], "depth count variant %d" % variant, RTOL)
+            close(N(out), dwant[0], "depth out variant %d" % variant)
+    finally:
+        my_lib._debug_set_variant("projection", -1)
