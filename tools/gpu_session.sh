@@ -20,6 +20,7 @@ echo "== race screen"; timeout 600 python tools/stress_projection.py 60 2>&1 | t
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprof kernel trace of bench.py (the same command as the bench line above, minus the CPU baseline)"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_trace" -o bench -- python "$REPO/bench.py" --no-cpu-baseline > "$OUT/prof_trace.log" 2>&1
+grep '^{"metric"' "$OUT/prof_trace.log" | tail -1 > "$OUT/bench_line_profiled_run.json"    # the bench line of THIS process
 python "$REPO/tools/prof_summary.py" stats "$OUT/prof_trace/bench_results.db" --tail 300 --out "$OUT/bench_kernel_stats.txt" | grep -v "^at::\|^$" | head -6
 rm -rf "$OUT/prof_trace"
 echo "== PMC traffic (FETCH_SIZE / WRITE_SIZE in separate passes, calibrated on a known copy)"
