@@ -431,34 +431,7 @@ struct AccGeom {
     static constexpr int kPlane = kPitch * kRows;      // floats per plane
 };
 
-template <int LX, int NP>
-__device__ __forceinline__ void acc_zero(float *acc)
-{
-    using A = AccGeom<LX>;
-    for (int i = tid_now(); i < NP * A::kPlane; i += TileGeom<LX>::kThreads) acc[i] = 0.0f;
-}
-
 __device__ __forceinline__ void lds_add_f32(float *p, float v) { (void)unsafeAtomicAdd(p, v); }   // ds_add_f32
-
-// dst[pl] points at image pixel (0,0) of plane pl; hstride in elements.  Zero cells are skipped: adding +-0 to
-// the caller's buffer changes nothing.
-template <int LX, int NP>
-__device__ __forceinline__ void acc_flush(const Region &r, const float *acc, float *const (&dst)[NP],
-                                          const int (&hstride)[NP])
-{
-    using A = AccGeom<LX>;
-    // 64 lanes walk a region row (pitch <= 97 -> two passes), 4 waves take rows round-robin
-    const unsigned tid = tid_now();
-    const int lane = tid & (kWave - 1), wave = tid / kWave;
-    for (int row = wave; row < r.h; row += TileGeom<LX>::kThreads / kWave)
-        for (int col = lane; col < r.w; col += kWave) {
-#pragma unroll
-            for (int pl = 0; pl < NP; pl++) {
-                const float v = acc[pl * A::kPlane + row * A::kPitch + col];
-                if (v != 0.0f) atomic_add_f32(dst[pl] + (int64_t)(r.y0 + row) * hstride[pl] + r.x0 + col, v);
-            }
-        }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // fp64 accumulation in LDS.  Measured on MI355X (tools/probes, `run_probe.py lds`): ds_add_f32 retires 0.33
