@@ -1,12 +1,16 @@
-# modules/DepthFlowProjectionModule.py -- wrapper the reference lacks for its DepthFlowProjectionLayer_* C entry points
-from torch.nn import Module
+"""`DepthFlowProjectionModule(requires_grad=True)(input1, input2)` -- flow projection weighted by a depth map
+[B,1,H,W].  The reference ships the C entry points (`DepthFlowProjectionLayer_*`, my_lib.h:92-108) but no Python
+wrapper; this is that wrapper, with FlowProjectionModule's constructor."""
 from my_package.functions.DepthFlowProjectionLayer import DepthFlowProjectionLayer
+from ._operator_module import OperatorModule
 
 
-class DepthFlowProjectionModule(Module):
+class DepthFlowProjectionModule(OperatorModule):
+    layer = DepthFlowProjectionLayer
+
     def __init__(self, requires_grad=True):
-        super(DepthFlowProjectionModule, self).__init__()
-        self.f = DepthFlowProjectionLayer(requires_grad)
+        OperatorModule.__init__(self)
+        self._bind(requires_grad)
 
     def forward(self, input1, input2):
         return self.f(input1, input2)

@@ -1,12 +1,15 @@
-# modules/FilterInterpolationModule.py -- same surface as the reference's module of this name
-from torch.nn import Module
+"""`FilterInterpolationModule()(input1, input2, input3)` -- image [B,C,H,W], flow [B,2,H,W], taps [B,fs*fs,H,W];
+the surface of the reference's module of this name."""
 from my_package.functions.FilterInterpolationLayer import FilterInterpolationLayer
+from ._operator_module import OperatorModule
 
 
-class FilterInterpolationModule(Module):
+class FilterInterpolationModule(OperatorModule):
+    layer = FilterInterpolationLayer
+
     def __init__(self):
-        super(FilterInterpolationModule, self).__init__()
-        self.f = FilterInterpolationLayer()
+        OperatorModule.__init__(self)
+        self._bind()
 
     def forward(self, input1, input2, input3):
         return self.f(input1, input2, input3)

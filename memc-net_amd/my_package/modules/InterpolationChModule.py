@@ -1,12 +1,15 @@
-# modules/InterpolationChModule.py -- wrapper the reference lacks for its InterpolationChLayer_* C entry points
-from torch.nn import Module
+"""`InterpolationChModule()(input1, input2)` -- bilinear warp, any channel count.  The reference ships the C entry
+points (`InterpolationChLayer_*`, my_lib.h:49-61) but no Python wrapper for them; this is that wrapper."""
 from my_package.functions.InterpolationChLayer import InterpolationChLayer
+from ._operator_module import OperatorModule
 
 
-class InterpolationChModule(Module):
+class InterpolationChModule(OperatorModule):
+    layer = InterpolationChLayer
+
     def __init__(self):
-        super(InterpolationChModule, self).__init__()
-        self.f = InterpolationChLayer()
+        OperatorModule.__init__(self)
+        self._bind()
 
     def forward(self, input1, input2):
         return self.f(input1, input2)

@@ -1,12 +1,21 @@
-# modules/InterpolationModule.py -- same surface as the reference's module of this name
-from torch.nn import Module
+"""`InterpolationModule()(input1, input2)` -- bilinear warp of an RGB image by a flow field.
+
+    input1  [B, 3, H, W]  image (the reference's C layer rejects any other channel count, my_lib.c:450;
+                          InterpolationChModule is the any-channel sibling)
+    input2  [B, 2, H, W]  flow, channel 0 = dx, channel 1 = dy
+    returns [B, 3, H, W]  out(y, x) = bilinear(image, (x + dx, y + dy)); 0 where that point leaves the image
+
+Surface of the reference's module of this name (used by networks/MEMC_Net_VE.py:454-497)."""
 from my_package.functions.InterpolationLayer import InterpolationLayer
+from ._operator_module import OperatorModule
 
 
-class InterpolationModule(Module):
+class InterpolationModule(OperatorModule):
+    layer = InterpolationLayer
+
     def __init__(self):
-        super(InterpolationModule, self).__init__()
-        self.f = InterpolationLayer()
+        OperatorModule.__init__(self)
+        self._bind()
 
     def forward(self, input1, input2):
         return self.f(input1, input2)
