@@ -244,6 +244,7 @@ def main():
         if not args.quick:
             bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "smooth", "720p",
                          [int(v) for v in args.bwd_variants.split(",") if v])
+            bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "iid", "720p")
     if want("proj"):
         bench_projection(rows, dev, 32, 720, 1280, "smooth", "c3",
                          [int(v) for v in args.proj_variants.split(",") if v])
