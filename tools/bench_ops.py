@@ -233,6 +233,7 @@ def main():
         bench_fi_fwd(rows, dev, 32, 3, 720, 1280, "smooth", variants, "c_headline")
         if not args.headline_only:
             bench_fi_fwd(rows, dev, 32, 3, 720, 1280, "iid", variants[:1], "c_headline")
+            bench_fi_fwd(rows, dev, 32, 3, 720, 1280, "video", variants[:1], "c_headline")
             bench_fi_fwd(rows, dev, 8, 3, 256, 448, "smooth", variants[:1], "c2")
         if not args.quick and not args.headline_only:
             bench_fi_fwd(rows, dev, 8, 64, 720, 1280, "smooth", variants[:1], "ctx64")
@@ -245,11 +246,13 @@ def main():
             bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "smooth", "720p",
                          [int(v) for v in args.bwd_variants.split(",") if v])
             bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "iid", "720p")
+            bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "video", "720p")
     if want("proj"):
         bench_projection(rows, dev, 32, 720, 1280, "smooth", "c3",
                          [int(v) for v in args.proj_variants.split(",") if v])
         if not args.quick:
             bench_projection(rows, dev, 32, 720, 1280, "iid", "c3")
+            bench_projection(rows, dev, 32, 720, 1280, "video", "c3")
     if want("interp"):
         bench_interp(rows, dev, 32, 3, 720, 1280, "smooth", "720p")
     # baselines (the CPU oracle, the reference's own kernels on this GPU) live under tests/: tests/bench_baselines.py

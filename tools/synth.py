@@ -6,7 +6,8 @@ host-side 2.8 GB batch would only measure PCIe).
 
   image   x    ~ U[0,1)
   flow    smooth: bilinear x16 upsample of N(0, 4^2) low-resolution noise (|f| mostly < 12 px -- what a flow
-               field looks like after FlowProjection); iid: N(0, sigma^2) per pixel (defeats any tiling)
+               field looks like after FlowProjection); iid: N(0, sigma^2) per pixel (defeats any tiling);
+               video (device generator only): as smooth with a x64 upsample, i.e. four times smoother
   filter  k    ~ U[0,1) / fs^2   (taps sum to about 1/2: outputs stay O(1))
   depth   d    ~ U[0.1, 1.1)
   grad    g    ~ U[0,1)
@@ -64,6 +65,12 @@ def torch_inputs(device, B, C, H, W, fs=4, flow_kind="smooth", seed=1234, with_g
     out["x"] = torch.rand((B, C, H, W), device=device, generator=g, dtype=torch.float32)
     if flow_kind == "smooth":
         h, w = (H + 15) // 16 + 1, (W + 15) // 16 + 1
+        lo = torch.randn((B, 2, h, w), device=device, generator=g, dtype=torch.float32) * 4.0
+        out["flow"] = F.interpolate(lo, size=(H, W), mode="bilinear", align_corners=True).contiguous()
+    elif flow_kind == "video":
+        # same magnitude as "smooth", four times smoother (x64 upsample: ~0.09 px of flow change per pixel instead
+        # of ~0.35) -- closer to what a flow network produces inside moving objects; secondary bench rows only
+        h, w = (H + 63) // 64 + 1, (W + 63) // 64 + 1
         lo = torch.randn((B, 2, h, w), device=device, generator=g, dtype=torch.float32) * 4.0
         out["flow"] = F.interpolate(lo, size=(H, W), mode="bilinear", align_corners=True).contiguous()
     elif flow_kind == "iid":
