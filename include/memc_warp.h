@@ -35,7 +35,11 @@
  *     to the next.  One exception to "never allocates": the first (Depth)FlowProjection FORWARD call on a
  *     device allocates 40 KiB of device scratch (per-image "far source" flags of its fast path) and keeps it
  *     for the life of the process; every call clears its slice on its own stream.  Make that first call
- *     outside a stream capture (inside one the library silently uses its general path instead);
+ *     outside a stream capture (inside one the library silently uses its general path instead).  A second one:
+ *     a (Depth)FlowProjection forward call WITH hole filling takes a workspace of about 0.4 bytes per pixel from
+ *     the device's default memory pool (hipMallocAsync, released in stream order by hipFreeAsync; the pool's
+ *     release threshold is raised once so that it keeps the memory).  Inside a stream capture, or if the
+ *     allocation fails, the hole filler falls back to a variant that needs none;
  *   - return 0 on success, -1 on a failed shape/stride check or a launch error (my_lib_cuda.c:611-646,
  *     my_lib_kernel.cu:1559-1566).
  *

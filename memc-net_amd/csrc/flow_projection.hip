@@ -354,6 +354,69 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
 constexpr int kPtW = 68, kPtH = 17;           // point window 65 x 17, pitch 68
 
 // kReach = supported |flow| on the fast path (pixels)
+// ---- carry-based hole filling (pass 3), shared pieces; the scheme is described at proj_fillhole_carry ----------
+struct FillWs {
+    int *up, *left, *right;       // left starts out as "last non-zero column in the tile", right as "first"
+    int *n_list, *list;           // tiles that contain a hole, in kListSegs segments of `cap` entries: fill counts,
+    int cap;                      // then tile positions (strip order).  Segmented so that 30 000 workgroups do not
+};                                // all bump ONE counter (same-address atomics serialise: +150 us when every tile
+constexpr int kListSegs = 256;    // has a hole).
+
+struct TileSummary {              // LDS
+    int col_last[64], row_first[16], row_last[16];
+};
+
+__device__ __forceinline__ void summary_init(TileSummary &t)
+{
+    if (threadIdx.x < 64) t.col_last[threadIdx.x] = -1;
+    if (threadIdx.x < 16) {
+        t.row_first[threadIdx.x] = INT_MAX;
+        t.row_last[threadIdx.x] = -1;
+    }
+}
+
+// the lane's four counts at (x .. x+3, y), local coordinates (lx .. lx+3, ly); returns "one of them is a hole".
+// A barrier must separate summary_init from this, and this from summary_store.
+__device__ __forceinline__ bool summary_add(TileSummary &t, bool inb, const f32x4 &c4, int lx, int ly, int x, int y)
+{
+    bool hole = false;
+    int first = INT_MAX, last = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!inb) continue;
+        hole = hole || c4[j] <= 0.0f;                      // what pass 3 fills (my_lib_kernel.cu:1757)
+        if (c4[j] != 0.0f) {                               // what stops a walk (:1778-1797)
+            atomicMax(&t.col_last[lx + j], y);
+            first = min(first, x + j);
+            last = max(last, x + j);
+        }
+    }
+    if (last >= 0) {
+        atomicMin(&t.row_first[ly], first);
+        atomicMax(&t.row_last[ly], last);
+    }
+    return hole;
+}
+
+__device__ __forceinline__ void summary_store(const TileSummary &t, int any_hole, const FillWs &ws, unsigned tile, int b,
+                                              int tx, int ty, int W, int H, int ntx, int nty)
+{
+    const int tx0 = tx * 64, ty0 = ty * 16;
+    if (threadIdx.x < 64 && tx0 + (int)threadIdx.x < W)
+        ws.up[((int64_t)b * nty + ty) * W + tx0 + threadIdx.x] = t.col_last[threadIdx.x];
+    if (threadIdx.x < 16 && ty0 + (int)threadIdx.x < H) {
+        const int64_t i = ((int64_t)b * H + ty0 + threadIdx.x) * ntx + tx;
+        ws.right[i] = t.row_first[threadIdx.x] == INT_MAX ? -1 : t.row_first[threadIdx.x];
+        ws.left[i] = t.row_last[threadIdx.x];
+    }
+    // (a tile may be listed twice -- by proj_owner and again after the general path redid its image: the filler
+    // re-reads the counts and filling is idempotent)
+    if (threadIdx.x == 0 && any_hole) {
+        const int seg = tile % kListSegs, slot = atomicAdd(ws.n_list + seg, 1);
+        if (slot < ws.cap) ws.list[(int64_t)seg * ws.cap + slot] = (int)tile;      // (cap holds every tile twice)
+    }
+}
+
 // Per-workgroup phase timestamps (shader clock) for tools/trace_kernel.py; written by the TRACE instance only.
 __device__ unsigned long long *g_trace_buf_proj = nullptr;
 template <bool ON>
@@ -367,7 +430,7 @@ __global__ __launch_bounds__(256) void proj_owner(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth,
-    float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag)
+    float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, FillWs ws)
 {
     constexpr int kScanPadX = kReach + 4;         // dilated tile: columns, kept 4-aligned
     constexpr int kScanW = 64 + 2 * kScanPadX;    // source columns
@@ -376,6 +439,8 @@ __global__ __launch_bounds__(256) void proj_owner(
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
     const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
     trace_mark_proj<TRACE>(0);
+    __shared__ TileSummary sm;                   // for the hole filler, when one follows (ws.up != nullptr)
+    summary_init(sm);
     {
         static_assert((3 * kPtH * kPtW) % 2 == 0, "P is zeroed 16 bytes at a time");
         f32x4 *pz = reinterpret_cast<f32x4 *>(P);
@@ -482,7 +547,7 @@ __global__ __launch_bounds__(256) void proj_owner(
 
     // every lane owns four cells of a row
     const int cx = tx0 + 4 * (threadIdx.x % 16), cy = ty0 + threadIdx.x / 16;
-    if (cx >= W || cy >= H) return;
+    const bool inb = cx < W && cy < H;            // (no early exit: the summary below has a barrier)
     const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
     f32x4 ox, oy, oc;
     // The lane's four cells need the point sums of columns c-1 .. c+3 of two rows, per plane: read them once as
@@ -524,11 +589,18 @@ __global__ __launch_bounds__(256) void proj_owner(
         }
         ox[j] = v[0];  oy[j] = v[1];  oc[j] = v[2];
     }
-    float *o = out + b * s1b + (int64_t)cy * s1h + cx;
-    *reinterpret_cast<f32x4 *>(o) = ox;        // plain stores: pass 3 (hole fill) re-reads them
-    *reinterpret_cast<f32x4 *>(o + s1c) = oy;
-    *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
+    if (inb) {
+        float *o = out + b * s1b + (int64_t)cy * s1h + cx;
+        *reinterpret_cast<f32x4 *>(o) = ox;    // plain stores: pass 3 (hole fill) re-reads them
+        *reinterpret_cast<f32x4 *>(o + s1c) = oy;
+        *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
+    }
     trace_mark_proj<TRACE>(5);                 // outputs stored (issued)
+    if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
+        const bool hole = summary_add(sm, inb, oc, 4 * (threadIdx.x % 16), threadIdx.x / 16, cx, cy);
+        const int any_hole = __syncthreads_or(hole);
+        summary_store(sm, any_hole, ws, xcd_chunked_id(blockIdx.x, gridDim.x), b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
+    }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -541,103 +613,86 @@ __global__ __launch_bounds__(256) void proj_owner(
 //   up   [b][ty][x]   nearest row above band ty  whose cell in column x has a non-zero count   (-1: none)
 //   left [b][y ][tx]  nearest column left of tile column tx with a non-zero count in row y      (-1: none)
 //   right[b][y ][tx]  likewise to the right
-// plus one byte per tile: "has a hole" (tiles without one leave after reading that byte).
+// plus the list of the tiles that contain a hole (the filler is launched over that list only).
 // Same cells, same flags, same arithmetic as the walks -- identical results.  The tables (0.4 B per pixel) live in
 // a stream-ordered allocation made and released by the launcher (hipMallocAsync / hipFreeAsync).
 // --------------------------------------------------------------------------------------------------
-struct FillWs {
-    int *up, *left, *right;       // left starts out as "last non-zero column in the tile", right as "first"
-    unsigned char *hole;
-};
-
+// Summaries from the count plane, for the paths on which proj_owner did not write them: the general path on its
+// own (far_flag == nullptr: every tile) or behind the far flag (only the images it redid; returns at once when
+// no image was flagged).  Grid-stride over tiles.
 __global__ __launch_bounds__(256) void proj_fill_summary(
-    int W, int H, int tiles_x, int tiles_y, int64_t scb, int sch, const float *__restrict__ count, FillWs ws)
+    int W, int H, int tiles_x, int tiles_y, int batch, int64_t scb, int sch, const float *__restrict__ count,
+    FillWs ws, const int *__restrict__ far_flag)
 {
-    __shared__ int col_last[64], row_first[16], row_last[16];
-    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
-    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
-    const int lx = 4 * (threadIdx.x % 16), ly = threadIdx.x / 16;
-    const int x = tx0 + lx, y = ty0 + ly;
-    const bool inb = x < W && y < H;
-    if (threadIdx.x < 64) col_last[threadIdx.x] = -1;
-    if (threadIdx.x < 16) {
-        row_first[threadIdx.x] = INT_MAX;
-        row_last[threadIdx.x] = -1;
+    __shared__ TileSummary sm;
+    if (far_flag && far_flag[kFlagWords] == 0) return;
+    const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const TileCoord tc = strip_at(tile, tiles_x, tiles_y, batch);
+        const int b = tc.b;
+        if (far_flag && far_flag[b % kFlagWords] == 0) continue;          // wave-uniform
+        const int lx = 4 * (threadIdx.x % 16), ly = threadIdx.x / 16;
+        const int x = tc.tx * 64 + lx, y = tc.ty * 16 + ly;
+        const bool inb = x < W && y < H;
+        summary_init(sm);
+        const f32x4 own = ld_cached4(count + b * scb + (int64_t)min(y, H - 1) * sch + min(x, W - 4));
+        __syncthreads();
+        const bool hole = summary_add(sm, inb, own, lx, ly, x, y);
+        const int any_hole = __syncthreads_or(hole);       // (also orders the LDS atomics before the reads below)
+        summary_store(sm, any_hole, ws, tile, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
+        __syncthreads();                                   // before the next tile re-initialises the summary
     }
-    const f32x4 own = ld_cached4(count + b * scb + (int64_t)min(y, H - 1) * sch + min(x, W - 4));
-    __syncthreads();
-    bool hole = false;
-    int first = INT_MAX, last = -1;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (!inb) continue;
-        hole = hole || own[j] <= 0.0f;                     // what pass 3 fills (my_lib_kernel.cu:1757)
-        if (own[j] != 0.0f) {                              // what stops a walk (:1778-1797)
-            atomicMax(&col_last[lx + j], y);
-            first = min(first, x + j);
-            last = max(last, x + j);
-        }
-    }
-    if (last >= 0) {
-        atomicMin(&row_first[ly], first);
-        atomicMax(&row_last[ly], last);
-    }
-    const int any_hole = __syncthreads_or(hole);           // (also orders the LDS atomics before the reads below)
-    const int nty = tiles_y, ntx = tiles_x;
-    if (threadIdx.x < 64 && tx0 + (int)threadIdx.x < W)
-        ws.up[((int64_t)b * nty + tc.ty) * W + tx0 + threadIdx.x] = col_last[threadIdx.x];
-    if (threadIdx.x < 16 && ty0 + (int)threadIdx.x < H) {
-        const int64_t i = ((int64_t)b * H + ty0 + threadIdx.x) * ntx + tc.tx;
-        ws.right[i] = row_first[threadIdx.x] == INT_MAX ? -1 : row_first[threadIdx.x];
-        ws.left[i] = row_last[threadIdx.x];
-    }
-    if (threadIdx.x == 0) ws.hole[((int64_t)b * nty + tc.ty) * ntx + tc.tx] = any_hole ? 1 : 0;
 }
 
 // exclusive scans of the summaries, in place: one lane per image column (down the bands) / per image row (along
 // the tile columns, both ways).  A few hundred thousand lanes doing <= 45 / 2 x 60 steps on 11 MB.
 __global__ __launch_bounds__(256) void proj_fill_scan(int W, int H, int ntx, int nty, int batch, FillWs ws)
 {
+    // the values of a lane's chain are requested sixteen at a time (independent loads), then scanned in registers:
+    // a chain of dependent loads would cost ~0.5 us a step
+    auto scan = [](int *base, int64_t stride, int n, bool reverse) {
+        int carry = -1;
+        for (int i0 = 0; i0 < n; i0 += 16) {
+            int v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int i = min(i0 + k, n - 1);
+                v[k] = base[(int64_t)(reverse ? n - 1 - i : i) * stride];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (i0 + k < n) {
+                    const int i = i0 + k;
+                    base[(int64_t)(reverse ? n - 1 - i : i) * stride] = carry;
+                    if (v[k] >= 0) carry = v[k];
+                }
+            }
+        }
+    };
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t ncol = (int64_t)batch * W, nrow = (int64_t)batch * H;
     if (t < ncol) {
         const int b = (int)(t / W), x = (int)(t % W);
-        int carry = -1;
-        for (int ty = 0; ty < nty; ty++) {
-            int *p = ws.up + ((int64_t)b * nty + ty) * W + x;
-            const int here = *p;
-            *p = carry;
-            if (here >= 0) carry = here;
-        }
+        scan(ws.up + (int64_t)b * nty * W + x, W, nty, false);
     } else if (t < ncol + nrow) {
         const int64_t r = t - ncol;                        // = b * H + y
-        int carry = -1;
-        for (int tx = 0; tx < ntx; tx++) {
-            int *p = ws.left + r * ntx + tx;
-            const int here = *p;
-            *p = carry;
-            if (here >= 0) carry = here;
-        }
-        carry = -1;
-        for (int tx = ntx - 1; tx >= 0; tx--) {
-            int *p = ws.right + r * ntx + tx;
-            const int here = *p;
-            *p = carry;
-            if (here >= 0) carry = here;
-        }
+        scan(ws.left + r * ntx, 1, ntx, false);
+        scan(ws.right + r * ntx, 1, ntx, true);
     }
 }
 
 __global__ __launch_bounds__(256) void proj_fillhole_carry(
-    int W, int H, int tiles_x, int tiles_y, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch,
+    int W, int H, int tiles_x, int tiles_y, int batch, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch,
     const float *__restrict__ count, float *out, FillWs ws)
 {
     __shared__ __attribute__((aligned(16))) float cnt[16 * 64];
     __shared__ int n_holes;
     __shared__ unsigned short hole_list[1024];
-    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    // workgroup i serves segment i % kListSegs, entries i / kListSegs, + gridDim / kListSegs, ...
+    const int seg = blockIdx.x % kListSegs, n_seg = min(ws.n_list[seg], ws.cap), step = max((int)gridDim.x / kListSegs, 1);
+    for (int it = blockIdx.x / kListSegs; it < n_seg; it += step) {
+    const TileCoord tc = strip_at((unsigned)ws.list[(int64_t)seg * ws.cap + it], tiles_x, tiles_y, batch);
     const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
-    if (!ws.hole[((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx]) return;       // wave-uniform
     const float *cn = count + b * scb;
     const int lx = 4 * (threadIdx.x % 16), ly = threadIdx.x / 16;
     const int x = tx0 + lx, y = ty0 + ly;
@@ -688,6 +743,8 @@ __global__ __launch_bounds__(256) void proj_fillhole_carry(
                      fu * pl[(int64_t)ur * s1h + gx] + fd * *self) / (fl + fr + fu + fd);
         }
     }
+    __syncthreads();                                        // the LDS tile and list are reused by the next tile
+    }   // listed tiles
 }
 
 // general path, queued behind proj_owner: each kernel returns at once unless a far source was seen
@@ -1013,6 +1070,26 @@ static int *far_flag_for_current_device()
     return flags[dev] + (next[dev]++ % kSlots) * kSlotWords;
 }
 
+// hipMallocAsync serves the hole filler's workspace from the device's default memory pool; with the default
+// release threshold (0) the pool hands its memory back at every synchronisation and the next call pays for a
+// fresh allocation (measured: +200 us on some calls).  Once per device: let the pool keep what it has.
+static void keep_pool_memory()
+{
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[dev]) return;
+    done[dev] = true;
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+        uint64_t keep = UINT64_MAX;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    (void)hipGetLastError();
+}
+
 template <bool DEPTH>
 static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fillhole,
                            int s1b, int s1c, int s1h, int sdb, int sdh, int scb, int sch,
@@ -1033,26 +1110,55 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
         // (the owner kernel addresses the flow / depth planes with 32-bit offsets)
         int *flag = (g_proj_variant == 1 || g_proj_variant >= 2 || !plane_fits_u32(w, h, {s1h, sdh}))
                         ? nullptr : far_flag_for_current_device();                  // -1, -5, -8, -9: fast path
+        // workspace of the carry-based hole filler (see proj_fillhole_carry): stream-ordered, released below.
+        // Not to be had inside a stream capture or when the allocation fails -> the literal walker instead
+        // (also the measurement arms -8 / -9).
+        FillWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+        void *wsp = nullptr;
+        if (fillhole && g_proj_variant != -8 && g_proj_variant != -9) {
+            hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(stream, &capture);
+            const size_t n_up = (size_t)batch * nty * w, n_row = (size_t)batch * h * ntx, n_tile = (size_t)batch * nty * ntx;
+            const int cap = 2 * (int)((n_tile + kListSegs - 1) / kListSegs) + 2;       // (a tile can be listed twice)
+            const size_t bytes = (n_up + 2 * n_row + kListSegs + (size_t)kListSegs * cap) * sizeof(int);
+            keep_pool_memory();
+            if (capture == hipStreamCaptureStatusNone && hipMallocAsync(&wsp, bytes, stream) == hipSuccess) {
+                ws.up = static_cast<int *>(wsp);
+                ws.left = ws.up + n_up;
+                ws.right = ws.left + n_row;
+                ws.n_list = ws.right + n_row;
+                ws.list = ws.n_list + kListSegs;
+                ws.cap = cap;
+                if (hipMemsetAsync(ws.n_list, 0, kListSegs * sizeof(int), stream) != hipSuccess) return -1;
+            } else {
+                (void)hipGetLastError();
+                wsp = nullptr;
+            }
+        }
+        int status = 0;
         if (flag) {
-            // fast path: owner-computes (no atomics, fused averaging) + the general path behind a device flag
-            if (hipMemsetAsync(flag, 0, (kFlagWords + 1) * sizeof(int), stream) != hipSuccess) return -1;
-            if (g_proj_variant == -7)
-                hipLaunchKernelGGL((proj_owner<DEPTH, 24, true>), dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
-                                   (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, flag);
-            else if (g_proj_variant == -6)
-                hipLaunchKernelGGL((proj_owner<DEPTH, 16>), dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
-                                   (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, flag);
-            else
-                hipLaunchKernelGGL((proj_owner<DEPTH, 24>), dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
-                                   (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, flag);
-            if (launch_status() != 0) return -1;
-            if (g_proj_variant == -5 || g_proj_variant == -7) return 0;     // measurement arms: owner kernel alone
-            hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c, s1h,
-                               (int64_t)scb, sch, batch, count, out, flag);
-            MEMC_PROJ_SCATTER(0, flag);
-            hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
-                               s1h, (int64_t)scb, sch, batch, count, out, flag);
-            if (launch_status() != 0) return -1;
+            // fast path: owner-computes (no atomics, fused averaging, hole-filler summaries for free) + the general
+            // path behind a device flag
+            if (hipMemsetAsync(flag, 0, (kFlagWords + 1) * sizeof(int), stream) != hipSuccess) status = -1;
+#define MEMC_PROJ_OWNER(REACH, TRACE)                                                                              \
+    hipLaunchKernelGGL((proj_owner<DEPTH, REACH, TRACE>), dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b, \
+                       (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, flag, ws)
+            if (g_proj_variant == -7) MEMC_PROJ_OWNER(24, true);
+            else if (g_proj_variant == -6) MEMC_PROJ_OWNER(16, false);
+            else MEMC_PROJ_OWNER(24, false);
+#undef MEMC_PROJ_OWNER
+            if (launch_status() != 0) status = -1;
+            if (status == 0 && g_proj_variant != -5 && g_proj_variant != -7) {     // (-5 / -7: owner kernel alone)
+                hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
+                                   s1h, (int64_t)scb, sch, batch, count, out, flag);
+                MEMC_PROJ_SCATTER(0, flag);
+                hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
+                                   s1h, (int64_t)scb, sch, batch, count, out, flag);
+                if (ws.up)                      // summaries of the images the general path redid
+                    hipLaunchKernelGGL(proj_fill_summary, dim3(gs), dim3(256), 0, stream, w, h, ntx, nty, batch,
+                                       (int64_t)scb, sch, count, ws, flag);
+                if (launch_status() != 0) status = -1;
+            }
         } else {
             if (g_proj_variant < 2)             // (the ablation arms 2 / 3 time the scatter pass alone)
                 hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
@@ -1060,46 +1166,35 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
             if (g_proj_variant == 2) MEMC_PROJ_SCATTER(2, nullptr);
             else if (g_proj_variant == 3) MEMC_PROJ_SCATTER(3, nullptr);
             else MEMC_PROJ_SCATTER(0, nullptr);
-            if (g_proj_variant >= 2) return launch_status();   // ablation arms time the scatter pass alone
-            if (launch_status() != 0) return -1;
-            hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
-                               s1h, (int64_t)scb, sch, batch, count, out, nullptr);
-            if (launch_status() != 0) return -1;
-        }
-#undef MEMC_PROJ_SCATTER
-        if (fillhole) {
-            // carry-based filler (walks bounded by a tile) in a stream-ordered workspace; the literal walker when
-            // that is not to be had (stream capture, allocation failure) or asked for (measurement arms -8 / -9)
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(stream, &cap);
-            void *wsp = nullptr;
-            const size_t n_up = (size_t)batch * nty * w, n_row = (size_t)batch * h * ntx, n_tile = (size_t)batch * nty * ntx;
-            const size_t bytes = (n_up + 2 * n_row) * sizeof(int) + ((n_tile + 15) & ~(size_t)15);
-            const bool use_ws = g_proj_variant != -8 && g_proj_variant != -9 && cap == hipStreamCaptureStatusNone &&
-                                hipMallocAsync(&wsp, bytes, stream) == hipSuccess;
-            if (use_ws) {
-                FillWs ws;
-                ws.up = static_cast<int *>(wsp);
-                ws.left = ws.up + n_up;
-                ws.right = ws.left + n_row;
-                ws.hole = reinterpret_cast<unsigned char *>(ws.right + n_row);
-                hipLaunchKernelGGL(proj_fill_summary, dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)scb, sch,
-                                   count, ws);
-                const unsigned lanes = (unsigned)(((size_t)batch * (w + h) + 255) / 256);
-                hipLaunchKernelGGL(proj_fill_scan, dim3(lanes), dim3(256), 0, stream, w, h, ntx, nty, batch, ws);
-                hipLaunchKernelGGL(proj_fillhole_carry, dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
-                                   (int64_t)s1c, s1h, (int64_t)scb, sch, count, out, ws);
-                const int st = launch_status();
-                (void)hipFreeAsync(wsp, stream);
-                if (st != 0) return -1;
-            } else {
-                (void)hipGetLastError();
-                hipLaunchKernelGGL(proj_fillhole_v4, dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
-                                   (int64_t)s1c, s1h, (int64_t)scb, sch, count, out, g_proj_variant == -8 ? 1 : 0);
-                if (launch_status() != 0) return -1;
+            if (launch_status() != 0) status = -1;
+            if (status == 0 && g_proj_variant < 2) {         // (ablation arms time the scatter pass alone)
+                hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
+                                   s1h, (int64_t)scb, sch, batch, count, out, nullptr);
+                if (ws.up)
+                    hipLaunchKernelGGL(proj_fill_summary, dim3(gs), dim3(256), 0, stream, w, h, ntx, nty, batch,
+                                       (int64_t)scb, sch, count, ws, (const int *)nullptr);
+                if (launch_status() != 0) status = -1;
             }
         }
-        return 0;
+#undef MEMC_PROJ_SCATTER
+        const bool only_part = g_proj_variant == -5 || g_proj_variant == -7 || g_proj_variant >= 2;
+        if (status == 0 && fillhole && !only_part) {
+            if (ws.up) {
+                const unsigned lanes = (unsigned)(((size_t)batch * (w + h) + 255) / 256);
+                hipLaunchKernelGGL(proj_fill_scan, dim3(lanes), dim3(256), 0, stream, w, h, ntx, nty, batch, ws);
+                // one workgroup per tile of the image (rounded up to whole segments); those beyond their segment's
+                // fill count leave at once (~10 us for all of them)
+                hipLaunchKernelGGL(proj_fillhole_carry, dim3((nwg + kListSegs - 1) / kListSegs * kListSegs), dim3(256), 0,
+                                   stream, w, h, ntx, nty,
+                                   batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)scb, sch, count, out, ws);
+            } else {
+                hipLaunchKernelGGL(proj_fillhole_v4, dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
+                                   (int64_t)s1c, s1h, (int64_t)scb, sch, count, out, g_proj_variant == -8 ? 1 : 0);
+            }
+            if (launch_status() != 0) status = -1;
+        }
+        if (wsp) (void)hipFreeAsync(wsp, stream);
+        return status;
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
