@@ -518,3 +518,28 @@ def test_projection_forward_needs_no_zero_fill(oracle, case):
             close(N(out), dwant[0], "depth out variant %d" % variant)
     finally:
         my_lib._debug_set_variant("projection", -1)
+
+
+@pytest.mark.parametrize("shift", [(10.3, 0.0), (7.5, -5.2), (-12.0, 9.0), (0.0, 20.0)])
+def test_hole_filling_on_camera_pans(oracle, shift):
+    """A pan leaves an uncovered strip along one or two image borders: holes whose walks run the whole length of
+    the strip (the carry tables of proj_fillhole_carry), and holes with no neighbour at all in a direction.
+    Both hole fillers -- the carry-based one and the literal walker kept for stream captures -- against the oracle."""
+    import my_package._ext.my_lib as my_lib
+    rng = np.random.default_rng(41)
+    B, H, W = 2, 100, 196
+    flow = np.empty((B, 2, H, W), np.float32)
+    flow[:, 0], flow[:, 1] = shift
+    flow += rng.normal(0, 0.05, flow.shape).astype(np.float32)
+    want_out, want_cnt = oracle.flow_projection_forward(flow, 1)
+    assert (want_cnt == 0).mean() > 0.02                         # the strip is there
+    f = T(flow)
+    try:
+        for variant in (-1, -9, 1):                              # carry filler, literal walker, general path + carries
+            my_lib._debug_set_variant("projection", variant)
+            cnt, out = torch.full((B, 1, H, W), float("nan"), device=dev()), torch.full_like(f, float("nan"))
+            assert my_lib.FlowProjectionLayer_gpu_forward(f, cnt, out, 1) == 0
+            assert np.array_equal(N(cnt), want_cnt), variant
+            close(N(out), want_out, "pan %s variant %d" % (shift, variant))
+    finally:
+        my_lib._debug_set_variant("projection", -1)
