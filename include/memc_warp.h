@@ -19,10 +19,10 @@
  *   - fp32, NCHW, strides in ELEMENTS, w-stride must be 1;
  *   - every output / gradient buffer is borrowed: allocated AND zero-filled by the caller
  *     (my_package/functions/FilterInterpolationLayer.py:26-29,46-48; FlowProjectionLayer.py:27-29,54).
- *     (Of these, the library itself only RELIES on zeros in the scattered-into gradients -- FilterInterpolation /
- *     Interpolation gradinput1, Interpolation gradinput2, the projection backward's gradients on its scalar
- *     path: the forward outputs of every operator (projection count / output included) and the FilterInterpolation
- *     gradinput2 / gradinput3 are fully defined by the kernels, which is what lets the shipped Python layer skip
+ *     (Of these, the library itself only RELIES on zeros in the two scattered-into gradients -- FilterInterpolation
+ *     gradinput1 and Interpolation gradinput1: the forward outputs of every operator (projection count / output
+ *     included), FilterInterpolation gradinput2 / gradinput3, Interpolation gradinput2 and both projection
+ *     backward gradients are fully defined by the kernels, which is what lets the shipped Python layer skip
  *     those memsets.)
  *     With zero-filled buffers the results are the reference's.  With anything else they are unspecified,
  *     and in two places differ from the reference's `+=`: the FilterInterpolation backward STORES gradinput3

@@ -122,9 +122,9 @@ __global__ __launch_bounds__(256) void proj_fillhole(
 }
 
 // --------------------------------------------------------------------------------------------------
-// Backward (my_lib_kernel.cu:1866-1897 and :2296-2360): pure gather, no atomics.  gradinput buffers
-// are read-modify-written so that a caller-provided non-zero initial value accumulates as in the
-// reference (`+=`, four sequential terms per component).
+// Backward (my_lib_kernel.cu:1866-1897 and :2296-2360): pure gather, no atomics.  Scalar fallback of
+// proj_bwd_tiled: the reference's `+=` onto the caller's zero-filled buffer is a plain store here (each site
+// owns its elements; four sequential terms per component, in the reference's order).
 // --------------------------------------------------------------------------------------------------
 template <bool DEPTH>
 __global__ __launch_bounds__(256) void proj_bwd(
@@ -146,7 +146,14 @@ __global__ __launch_bounds__(256) void proj_bwd(
     const float fx = ld_stream(flow_p);
     const float fy = ld_stream(flow_p + s1c);
     const BlSite s = bl_locate<false>(x, y, W, H, fx, fy);
-    if (!s.valid) return;
+    // every site owns its gradient elements: they are STORED (invalid sites store the zero the reference leaves in
+    // the caller's zero-filled buffer), so the buffers need no memset beforehand -- same rule as proj_bwd_tiled
+    if (!s.valid) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) gin1[b * s1b + k * s1c + (int64_t)y * s1h + x] = 0.0f;
+        if (DEPTH) gin2[b * sdb + (int64_t)y * sdh + x] = 0.0f;
+        return;
+    }
     const float *cn = count + b * scb;
     const float c00 = cn[s.T * sch + s.L], c01 = cn[s.T * sch + s.R];
     const float c10 = cn[s.Bm * sch + s.L], c11 = cn[s.Bm * sch + s.R];
@@ -154,13 +161,12 @@ __global__ __launch_bounds__(256) void proj_bwd(
     float d = 1.0f;
     if (DEPTH) d = ld_stream(depth + b * sdb + (int64_t)y * sdh + x);
     float gd = 0.0f;
-    if (DEPTH) gd = gin2[b * sdb + (int64_t)y * sdh + x];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const float *go = gout + b * s1b + k * s1c;
         float *gp = gin1 + b * s1b + k * s1c + (int64_t)y * s1h + x;
         const float g00 = go[o00], g01 = go[o01], g10 = go[o10], g11 = go[o11];
-        float g = *gp;
+        float g = 0.0f;
         if (DEPTH) {
             g += -g00 * d / c00;  g += -g01 * d / c01;  g += -g10 * d / c10;  g += -g11 * d / c11;
             const float *fo = fwd_out + b * s1b + k * s1c;

@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256) void bl_bwd(
     const float fx = ld_stream(flow_b);
     const float fy = ld_stream(flow_b + s2c);
     const BlSite s = bl_locate<true>(x, y, W, H, fx, fy);
-    if (!s.valid) return;                                   // buffers keep the caller's zeros
+    float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
+    if (!s.valid) {                                         // the reference leaves the caller's zeros here
+        st_stream(g2, 0.0f);
+        st_stream(g2 + s2c, 0.0f);
+        return;
+    }
     const float x2 = (float)x + fx, y2 = (float)y + fy;
     const int oTL = s.T * s1h + s.L, oTR = s.T * s1h + s.R;
     const int oBL = s.Bm * s1h + s.L, oBR = s.Bm * s1h + s.R;
@@ -102,7 +107,6 @@ __global__ __launch_bounds__(256) void bl_bwd(
         tmp += (1 - gam_y) * (vBR - vTR);
         boty += g * tmp;
     }
-    float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
     st_stream(g2, botx);                                    // assignment, my_lib_kernel.cu:649,669
     st_stream(g2 + s2c, boty);
 }
@@ -264,12 +268,11 @@ __global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
 
     // ---- phase 1: flow gradient from the four corner values
     f32x4 gx4 = {0.f, 0.f, 0.f, 0.f}, gy4 = gx4;
-    unsigned wrote = 0, staged_mask = 0;
+    unsigned staged_mask = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (!st[j].valid) continue;
         const BlSite &s = st[j];
-        wrote |= 1u << j;
         const float x2 = (float)(x + j) + fx4[j], y2 = (float)y + fy4[j];
         const float gam_x = (float)s.Bm - y2, gam_y = (float)s.R - x2;   // clamped corners, my_lib_kernel.cu:634,652
         const bool staged = r.covers(s.L, s.R, s.T, s.Bm);
@@ -303,20 +306,12 @@ __global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
         gx4[j] = botx;
         gy4[j] = boty;
     }
-    // gradinput2 is ASSIGNED at valid sites and untouched elsewhere (my_lib_kernel.cu:649,669)
+    // gradinput2 is ASSIGNED at valid sites (my_lib_kernel.cu:649,669); the reference leaves the other sites at the
+    // caller's zeros, this kernel stores those zeros itself so the buffer needs no memset beforehand
     if (inb) {
         float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
-        if (wrote == 0xFu) {
-            st_stream4(g2, gx4);
-            st_stream4(g2 + s2c, gy4);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if ((wrote >> j) & 1) {
-                    g2[j] = gx4[j];
-                    g2[s2c + j] = gy4[j];
-                }
-        }
+        st_stream4(g2, gx4);
+        st_stream4(g2 + s2c, gy4);
     }
     __syncthreads();                           // the image has been read: the LDS becomes the accumulators
 

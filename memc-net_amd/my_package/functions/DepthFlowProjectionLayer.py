@@ -31,8 +31,8 @@ class _DepthFlowProjectionFunction(Function):
     def backward(ctx, gradoutput):
         input1, input2, count, output = ctx.saved_tensors
         gradoutput = f32c(gradoutput)
-        gradinput1 = torch.zeros_like(input1)
-        gradinput2 = torch.zeros_like(input2)
+        gradinput1 = torch.empty_like(input1)     # stored by the kernel, element by element (see FlowProjectionLayer)
+        gradinput2 = torch.empty_like(input2)
         err = my_lib.DepthFlowProjectionLayer_gpu_backward(
             input1, input2, count, output, gradoutput, gradinput1, gradinput2)
         check(err, "DepthFlowProjectionLayer_gpu_backward")

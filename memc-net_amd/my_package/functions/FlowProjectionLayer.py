@@ -33,7 +33,7 @@ class _FlowProjectionFunction(Function):
     def backward(ctx, gradoutput):
         input1, count = ctx.saved_tensors
         gradoutput = f32c(gradoutput)
-        gradinput1 = torch.zeros_like(input1)                                           # reference :54
+        gradinput1 = torch.empty_like(input1)     # reference zero-fills (:54); the kernel stores every element
         err = my_lib.FlowProjectionLayer_gpu_backward(input1, count, gradoutput, gradinput1)
         check(err, "FlowProjectionLayer_gpu_backward")
         return gradinput1, None

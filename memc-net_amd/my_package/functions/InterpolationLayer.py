@@ -31,7 +31,7 @@ def _make_bilinear_function(label, fwd_name, bwd_name):
             input1, input2 = ctx.saved_tensors
             gradoutput = f32c(gradoutput)
             gradinput1 = torch.zeros_like(input1)               # reference :40-41
-            gradinput2 = torch.zeros_like(input2)
+            gradinput2 = torch.empty_like(input2)               # assigned at every site (invalid: 0)
             check(bwd(input1, input2, gradoutput, gradinput1, gradinput2), bwd_name)
             return gradinput1, gradinput2
 

@@ -72,11 +72,11 @@ def reference_gpu_rows(rows):
     do0, dc0 = R.depth_flow_projection_forward(f, d, 0)
 
     def ours_fp_bwd():
-        g1 = torch.zeros_like(f)
+        g1 = torch.empty_like(f)                                                        # as the shipped layer does
         L.FlowProjectionLayer_gpu_backward(f, cnt0, gf, g1)
 
     def ours_dfp_bwd():
-        g1, g2 = torch.zeros_like(f), torch.zeros_like(d)
+        g1, g2 = torch.empty_like(f), torch.empty_like(d)
         L.DepthFlowProjectionLayer_gpu_backward(f, d, dc0, do0, gf, g1, g2)
 
     def ours_bl():
@@ -84,7 +84,7 @@ def reference_gpu_rows(rows):
         L.InterpolationLayer_gpu_forward(x, f, out)
 
     def ours_bl_bwd():
-        g1, g2 = torch.zeros_like(x), torch.zeros_like(f)
+        g1, g2 = torch.zeros_like(x), torch.empty_like(f)
         L.InterpolationLayer_gpu_backward(x, f, g, g1, g2)
 
     with torch.no_grad():

@@ -493,6 +493,40 @@ def test_backward_defines_flow_and_tap_gradients(oracle, case):
 
 
 @pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_backward_defines_bilinear_flow_and_projection_gradients(oracle, case):
+    """Interpolation(Ch) gradinput2 and both (Depth)FlowProjection backward gradients are handed over UNINITIALISED
+    by the Python layers: the kernels (tiled or scalar, whichever the shape selects) must store every element,
+    zeros at the sites the reference leaves at the caller's zero.  NaN-filled buffers through the C ABI."""
+    import my_package._ext.my_lib as my_lib
+    d = make(case)
+    x, f, g = T(d["x"]), T(d["flow"]), T(d["gout"])
+    pairs = [("InterpolationChLayer_gpu_backward", oracle.interpolation_ch_backward)]
+    if x.shape[1] == 3:
+        pairs.append(("InterpolationLayer_gpu_backward", oracle.interpolation_backward))
+    for name, want in pairs:
+        g1, g2 = torch.zeros_like(x), torch.full_like(f, float("nan"))
+        assert getattr(my_lib, name)(x, f, g, g1, g2) == 0
+        assert not torch.isnan(g2).any(), name
+        w1, w2 = want(d["x"], d["flow"], d["gout"])
+        close(N(g1), w1, name + " gradinput1", RTOL)
+        close(N(g2), w2, name + " gradinput2", RTOL)
+
+    dep, gf = T(d["depth"]), T(d["gflow"])
+    _, cnt = oracle.flow_projection_forward(d["flow"], 0)
+    g1 = torch.full_like(f, float("nan"))
+    assert my_lib.FlowProjectionLayer_gpu_backward(f, T(cnt), gf, g1) == 0
+    assert not torch.isnan(g1).any()
+    close(N(g1), oracle.flow_projection_backward(d["flow"], cnt, d["gflow"]), "projection gradinput1", RTOL)
+    out, cnt = oracle.depth_flow_projection_forward(d["flow"], d["depth"], 0)
+    g1, g2 = torch.full_like(f, float("nan")), torch.full_like(dep, float("nan"))
+    assert my_lib.DepthFlowProjectionLayer_gpu_backward(f, dep, T(cnt), T(out), gf, g1, g2) == 0
+    assert not torch.isnan(g1).any() and not torch.isnan(g2).any()
+    w1, w2 = oracle.depth_flow_projection_backward(d["flow"], d["depth"], cnt, out, d["gflow"])
+    close(N(g1), w1, "depth projection gradinput1", RTOL)
+    close(N(g2), w2, "depth projection gradinput2", RTOL)
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
 def test_projection_forward_needs_no_zero_fill(oracle, case):
     """(Depth)FlowProjection forward DEFINES count and output on every path (owner-computes fast path, the general
     path behind its far flag or on its own, the scalar kernels of odd widths): the Python layer passes
