@@ -290,6 +290,38 @@ def test_full_size_properties():
         assert abs(got - want) <= 1e-3 * max(1.0, abs(want))
 
 
+def test_tensors_beyond_2G_elements():
+    """Maximum sizes: 288 GB of HBM holds tensors with more than 2^31 elements (here 40 x 64 x 720 x 1280 = 2.36e9,
+    9.4 GB each), where any 32-bit element index would wrap.  Batch items are independent, so the last item of
+    the big call must equal the same item run alone (forward and flow/tap gradients: bit-exact gathers; image
+    gradient: atomics, tolerance)."""
+    import my_package._ext.my_lib as my_lib
+    free, _ = torch.cuda.mem_get_info()
+    if free < 70 * 2**30:
+        pytest.skip("needs 70 GB of free device memory")
+    B, C, H, W = 40, 64, 720, 1280
+    assert B * C * H * W > 2**31
+    t = synth.torch_inputs(dev(), B, C, H, W, flow_kind="smooth", seed=5, with_grad=True)
+    x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
+    last = lambda a: a[B - 1:].contiguous()
+    out = torch.empty_like(x)
+    assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+    out1 = torch.empty_like(last(x))
+    assert my_lib.FilterInterpolationLayer_gpu_forward(last(x), last(f), last(k), out1) == 0
+    assert torch.equal(out[B - 1:], out1)
+    assert my_lib.InterpolationChLayer_gpu_forward(x, f, out) == 0
+    assert my_lib.InterpolationChLayer_gpu_forward(last(x), last(f), out1) == 0
+    assert torch.equal(out[B - 1:], out1)
+    del out
+    g1, g2, g3 = torch.zeros_like(x), torch.empty_like(f), torch.empty_like(k)
+    assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+    h1, h2, h3 = torch.zeros_like(out1), torch.empty_like(last(f)), torch.empty_like(last(k))
+    assert my_lib.FilterInterpolationLayer_gpu_backward(last(x), last(f), last(k), last(g), h1, h2, h3) == 0
+    assert torch.equal(g2[B - 1:], h2) and torch.equal(g3[B - 1:], h3)
+    assert float((g1[B - 1:] - h1).abs().max()) <= ATOL
+    assert float(g1[B - 1:].abs().max()) > 0
+
+
 def test_stream_capture_and_replay(oracle):
     """The launchers allocate nothing and synchronise nothing, so a forward can be captured into a HIP graph and
     replayed (FlowProjection's one-time scratch allocation happens at its first call, made before capture)."""
