@@ -6,16 +6,6 @@
     returns [B, 3, H, W]  out(y, x) = bilinear(image, (x + dx, y + dy)); 0 where that point leaves the image
 
 Surface of the reference's module of this name (used by networks/MEMC_Net_VE.py:454-497)."""
-from my_package.functions.InterpolationLayer import InterpolationLayer
-from ._operator_module import OperatorModule
+from ._operator_module import operator_module
 
-
-class InterpolationModule(OperatorModule):
-    layer = InterpolationLayer
-
-    def __init__(self):
-        OperatorModule.__init__(self)
-        self._bind()
-
-    def forward(self, input1, input2):
-        return self.f(input1, input2)
+InterpolationModule = operator_module("InterpolationModule", ("input1", "input2"))
