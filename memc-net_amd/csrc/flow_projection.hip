@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void proj_bwd(
 // budget scatter their 12 adds straight to global memory.
 // ABL (measurement arms, results WRONG): 2 = no flush, 3 = no LDS adds.
 template <bool DEPTH, int ABL>
-__global__ __launch_bounds__(256) void proj_scatter_tiled(
-    int W, int H, int tiles_x, int tiles_y,
+__device__ __forceinline__ void proj_scatter_tile(
+    unsigned blk, unsigned nblk, char *smem, int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth,
     float *__restrict__ count, float *__restrict__ out, const int *__restrict__ far_flag)
@@ -211,12 +211,10 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
     constexpr int LX = 16;
     using G = TileGeom<LX>;
     using A = AccGeom<LX>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     float *acc = reinterpret_cast<float *>(smem);
     int *bb = reinterpret_cast<int *>(smem + 4 * A::kPlane * 4);
-    if (far_flag && far_flag[kFlagWords] == 0) return;   // queued behind proj_owner: nothing to redo at all
 
-    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const TileCoord tc = strip_walk(blk, nblk, tiles_x, tiles_y, nblk / (tiles_x * tiles_y));
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
     if (far_flag && far_flag[b % kFlagWords] == 0) return;   // this image was complete on the fast path
     const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
@@ -337,6 +335,25 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
                 if (v != 0.0f) atomic_add_f32(dst[pl] + (int64_t)gy * hs[pl] + gx, v);
             }
         }
+    }
+}
+
+// One workgroup per tile, or -- queued behind proj_owner, where it normally has nothing to do -- a short grid
+// whose workgroups stride over the tiles: leaving an idle grid of 2048 workgroups costs ~3 us, one of 28800 ~10.
+template <bool DEPTH, int ABL>
+__global__ __launch_bounds__(256) void proj_scatter_tiled(
+    int W, int H, int tiles_x, int tiles_y, unsigned ntiles,
+    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
+    const float *__restrict__ flow, const float *__restrict__ depth,
+    float *__restrict__ count, float *__restrict__ out, const int *__restrict__ far_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (far_flag && far_flag[kFlagWords] == 0) return;   // queued behind proj_owner: nothing to redo at all
+#pragma unroll 1
+    for (unsigned blk = blockIdx.x; blk < ntiles; blk += gridDim.x) {
+        proj_scatter_tile<DEPTH, ABL>(blk, ntiles, smem, W, H, tiles_x, tiles_y, s1b, s1c, s1h, sdb, sdh, scb, sch,
+                                      flow, depth, count, out, far_flag);
+        __syncthreads();                                 // the planes are rebuilt by the next tile
     }
 }
 
@@ -1110,9 +1127,9 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
         const unsigned nwg = (unsigned)ntx * nty * batch;
         const unsigned gs = 256 * 8;                      // grid-stride: 8 workgroups per CU
 #define MEMC_PROJ_SCATTER(ABL, FLAG)                                                                        \
-    hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3(nwg), dim3(256), 4 * A::kPlane * 4 + 64, stream, w, \
-                       h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow,   \
-                       depth, count, out, FLAG)
+    hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3((FLAG) != nullptr && nwg > gs ? gs : nwg), dim3(256), \
+                       4 * A::kPlane * 4 + 64, stream, w, h, ntx, nty, nwg, (int64_t)s1b, (int64_t)s1c, s1h,       \
+                       (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, FLAG)
         // (the owner kernel addresses the flow / depth planes with 32-bit offsets)
         int *flag = (g_proj_variant == 1 || g_proj_variant >= 2 || !plane_fits_u32(w, h, {s1h, sdh}))
                         ? nullptr : far_flag_for_current_device();                  // -1, -5, -8, -9: fast path
