@@ -206,6 +206,13 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
 #pragma unroll 1
         for (; c0 + 4 <= C; c0 += 4) {
             if (c0 > 0) __syncthreads();
+            // keep what only depends on the site inside the loop: hoisted, the per-plane addresses derived from it
+            // (staging rows, the rare global corner gathers) outgrow the register file and spill
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                asm volatile("" : "+v"(g.oTL[j]), "+v"(g.oTR[j]), "+v"(g.oBL[j]), "+v"(g.oBR[j]));
+                asm volatile("" : "+v"(st[j].L), "+v"(st[j].R), "+v"(st[j].T), "+v"(st[j].Bm));
+            }
             bl_fwd_chunk<4>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
         }
         if (c0 < C) {
