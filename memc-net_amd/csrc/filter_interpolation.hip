@@ -477,6 +477,11 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
             const int nch = C - c0;
             const float *plane0 = in_b + c0 * s1c;
             float *o = out_p + c0 * s1c;
+#pragma unroll
+            for (int k = 0; k < 16; k++)                   // as above: keep the tail's arithmetic in the tail
+                asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
             if (nch == 3)      fi_fwd_chunk<LX, 3>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
             else if (nch == 2) fi_fwd_chunk<LX, 2>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
             else               fi_fwd_chunk<LX, 1>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
