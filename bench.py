@@ -141,6 +141,9 @@ def main(argv=None):
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--flow", default="smooth", choices=["smooth", "iid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # plumbing test of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, gloo instead of
+    # RCCL, which refuses two ranks on one device): the line it prints is NOT a measurement
+    ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 
     import torch
@@ -151,12 +154,16 @@ def main(argv=None):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if args.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)      # nccl == RCCL on ROCm
+        if args.share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
 
     import my_package._ext.my_lib as my_lib                  # raises if libmemc_hip.so is missing
     from tools import synth
@@ -200,7 +207,8 @@ def main(argv=None):
             "metric": "Mpixels/s adaptive-warp fwd @720p batch32",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(worst / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not args.share_gpu else "synthetic; PLUMBING TEST (ranks share a GPU), not a measurement",
             "config": {"workload": workload, "batch_per_gpu": B, "global_batch": plan["global_batch"],
                        "prewarm_launches": args.prewarm,
                        "sharding": "independent frame pairs per rank, no data-path collective"},
