@@ -33,6 +33,7 @@ def main(argv=None):
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--json", default="")
+    ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)   # see bench.py
     ap.add_argument("--miopen-search", action="store_true",
                     help="torch.backends.cudnn.benchmark = True: let MIOpen time its convolution solvers per shape")
     ap.add_argument("--channels-last", action="store_true", help="NHWC activations / weights for the dense layers")
@@ -45,12 +46,16 @@ def main(argv=None):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("needs a GPU: the HIP operators have no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if a.share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if a.share_gpu:                                # plumbing test on a box with fewer GPUs than ranks
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     torch.backends.cudnn.benchmark = bool(a.miopen_search)
     import my_package._ext.my_lib as my_lib
@@ -110,7 +115,9 @@ def main(argv=None):
                 "config": {"workload": "MEMC_Net_star inference %dx%d (padded %dx%d), %d pairs/GPU" % (
                     a.width, a.height, a.width + pl + pr, a.height + pt + pb, a.pairs),
                     "global_pairs_per_step": world * a.pairs,
-                    "weights": "rank 0 -> all, %d RCCL broadcast message(s), %.1f MB, %.3f s" % (msgs, nbytes / 1e6, bcast_s)},
+                    "weights": "rank 0 -> all, %d %s broadcast message(s), %.1f MB, %.3f s"
+                               % (msgs, "gloo (PLUMBING TEST, ranks share a GPU)" if a.share_gpu else "RCCL",
+                                  nbytes / 1e6, bcast_s)},
                 "hot_path_ops_ms": {k: round(v, 3) for k, v in sorted(per_op.items())},
                 "hot_path_ops_calls": len(spans),
                 "hot_path_share_of_step": round(sum(per_op.values()) / pass_ms, 4), "instrumented_pass_ms": round(pass_ms, 2)}
