@@ -68,6 +68,14 @@ def main(argv=None):
     msgs, nbytes = networks.broadcast_module_state(net, src=0)
     torch.cuda.synchronize(dev)
     bcast_s = time.perf_counter() - t0
+    if world > 1:                                      # the replicas really are replicas: same checksum everywhere
+        import torch.distributed as dist
+        total = sum(float(v.double().abs().sum()) for v in net.state_dict().values())
+        lo, hi = torch.tensor([total], dtype=torch.float64, device=dev), torch.tensor([total], dtype=torch.float64, device=dev)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if float(lo) != float(hi):
+            raise SystemExit("weight broadcast left the ranks with different parameters")
 
     g = torch.Generator(device=dev).manual_seed(99 + rank)
     frames = torch.rand((2, a.pairs, 3, a.height, a.width), device=dev, generator=g)
@@ -107,7 +115,7 @@ def main(argv=None):
 
     if rank == 0:
         pairs = world * a.pairs * a.steps
-        line = {"metric": "MEMC_Net_star inference, interpolated 1280x720 frames/s", "value": round(pairs / worst, 3),
+        line = {"metric": "MEMC_Net_star inference, interpolated %dx%d frames/s" % (a.width, a.height), "value": round(pairs / worst, 3),
                 "unit": "frames/s", "mpixels_per_s": round(pairs * a.height * a.width / worst / 1e6, 2),
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(worst / a.steps * 1e3, 2),
                 "scaling": "weak", "dtype": "f32", "data": "synthetic, random weights",
