@@ -206,6 +206,7 @@ __device__ __forceinline__ void fi_fwd_chunk(
 // on their way to registers while the current chunk is gathered from LDS, so the round trip hides behind
 // ~1 us of FMA work per chunk (at C = 64 the operator is about as VALU-bound as it is HBM-bound).
 // --------------------------------------------------------------------------------------------------
+template <int SW>                              // 0: one tile column per XCD strip; 2 / 4: stripes SW tile columns wide
 __global__ __launch_bounds__(256, 2) void fi_fwd_tiled_c4n(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
@@ -218,7 +219,12 @@ __global__ __launch_bounds__(256, 2) void fi_fwd_tiled_c4n(
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
 
-    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    // With 64 channels the image is 88 % of the bytes read, and a tile stages its box dilated by the motion: what
+    // the neighbouring tiles re-read must come out of THIS XCD's L2.  Stripes keep horizontal neighbours on one
+    // XCD and in flight together (the grid then covers ceil(tiles_x / SW) * SW virtual columns).
+    const TileCoord tc = SW ? stripe_walk<(SW ? SW : 1)>(blockIdx.x, gridDim.x, tiles_x, tiles_y)
+                            : strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    if (SW && tc.tx >= tiles_x) return;
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
     const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
     const bool inb = x < W && y < H;
@@ -1487,9 +1493,16 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
         } else if (channel % 4 == 0 && channel >= 8 && variant != 4 && variant != 6) {
             using G = TileGeom<16>;
             const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-            hipLaunchKernelGGL(fi_fwd_tiled_c4n, dim3((unsigned)ntx * nty * batch), dim3(256), tile_lds_bytes<16>(),
-                               stream, w, h, channel, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,
-                               (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
+#define MEMC_FI_C4N(SW)                                                                                        \
+            hipLaunchKernelGGL(fi_fwd_tiled_c4n<SW>, dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) *  \
+                                                                  (SW ? SW : 1)) * nty * batch),                \
+                               dim3(256), tile_lds_bytes<16>(), stream, w, h, channel, ntx, nty, (int64_t)s1b,    \
+                               (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c,    \
+                               s3h, input1, input2, input3, output)
+            if (variant == 30) MEMC_FI_C4N(2);
+            else if (variant == 31) MEMC_FI_C4N(4);
+            else MEMC_FI_C4N(0);
+#undef MEMC_FI_C4N
         } else if (variant == 4) {
             if (channel == 3) MEMC_FI_TILED(16, 3, 3); else MEMC_FI_TILED(16, 0, 3);
         } else {                                           // default: 64x16 tiles, strip walk
