@@ -951,7 +951,7 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth, const float *__restrict__ count,
     const float *__restrict__ fwd_out, const float *__restrict__ gout,
-    float *__restrict__ gin1, float *__restrict__ gin2)
+    float *__restrict__ gin1, float *__restrict__ gin2, int sw)
 {
     constexpr int LX = 16;
     using G = TileGeom<LX>;
@@ -959,7 +959,8 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
 
-    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const TileCoord tc = tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, sw);
+    if (tc.tx >= tiles_x) return;
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
     const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
     const bool inb = x < W && y < H;
@@ -1248,11 +1249,12 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
     if (vec && g_proj_variant != 0) {
         using G = TileGeom<16>;
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-        const unsigned nwg = (unsigned)ntx * nty * batch;
+        const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : 0;
+        const unsigned nwg = walk_grid(ntx, nty, batch, sw);
         const int lds = tile_lds_bytes<16>();
         hipLaunchKernelGGL(proj_bwd_tiled<DEPTH>, dim3(nwg), dim3(256), lds, stream, w, h, ntx, nty, (int64_t)s1b,
                            (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, fwd_out,
-                           gout, gin1, gin2);
+                           gout, gin1, gin2, sw);
         return launch_status();
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;

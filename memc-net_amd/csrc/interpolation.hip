@@ -155,7 +155,7 @@ template <int CT>
 __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
-    const float *__restrict__ in1, const float *__restrict__ flow, float *__restrict__ out)
+    const float *__restrict__ in1, const float *__restrict__ flow, float *__restrict__ out, int sw)
 {
     constexpr int LX = 16;
     using G = TileGeom<LX>;
@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
 
-    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const TileCoord tc = tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, sw);
+    if (tc.tx >= tiles_x) return;
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
     const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
     const bool inb = x < W && y < H;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
-    float *__restrict__ gin1, float *__restrict__ gin2)
+    float *__restrict__ gin1, float *__restrict__ gin2, int sw)
 {
     constexpr int LX = 16;
     using G = TileGeom<LX>;
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
     double *acc = reinterpret_cast<double *>(smem);
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
 
-    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const TileCoord tc = tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, sw);
+    if (tc.tx >= tiles_x) return;
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
     const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
     const bool inb = x < W && y < H;
@@ -359,15 +361,16 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
     if (vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, output})) {
         using G = TileGeom<16>;
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-        const unsigned nwg_t = (unsigned)ntx * nty * batch;
+        const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : 0;
+        const unsigned nwg_t = walk_grid(ntx, nty, batch, sw);
         if (channel == 3)
             hipLaunchKernelGGL(bl_fwd_tiled<3>, dim3(nwg_t), dim3(256), tile_lds_bytes<16>(), stream, w, h, channel,
                                ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1,
-                               input2, output);
+                               input2, output, sw);
         else
             hipLaunchKernelGGL(bl_fwd_tiled<0>, dim3(nwg_t), dim3(256), tile_lds_bytes<16>(), stream, w, h, channel,
                                ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1,
-                               input2, output);
+                               input2, output, sw);
         return launch_status();
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
@@ -393,8 +396,10 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
                       "the accumulator plane aliases the staged image");
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const int lds = tile_lds_bytes<16>();
-        hipLaunchKernelGGL(bl_bwd_tiled_c3, dim3((unsigned)ntx * nty * batch), dim3(256), lds, stream, w, h, ntx, nty, (int64_t)s1b, (int64_t)s1c,
-                           s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, gradoutput, gradinput1, gradinput2);
+        const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : 0;
+        hipLaunchKernelGGL(bl_bwd_tiled_c3, dim3(walk_grid(ntx, nty, batch, sw)), dim3(256), lds, stream, w, h, ntx, nty,
+                           (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, gradoutput,
+                           gradinput1, gradinput2, sw);
         return launch_status();
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
@@ -413,6 +418,9 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
 }  // namespace memc
 
 using namespace memc;
+
+int memc::g_tile_walk_sw = -1;
+extern "C" void memc_debug_set_walk(int stripe_width) { memc::g_tile_walk_sw = stripe_width; }
 
 extern "C" int InterpolationLayer_gpu_forward_kernel(
     memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,

@@ -112,6 +112,43 @@ __device__ __forceinline__ TileCoord stripe_walk(unsigned bid, unsigned nwg, int
     return c;
 }
 
+// Walk chosen at run time: sw == 0 -> strip_walk over a grid of tiles_x * tiles_y * batch workgroups; sw > 0 ->
+// stripes sw tile columns wide over a grid of walk_grid(...) workgroups, tx >= tiles_x means "no such tile".
+__device__ __forceinline__ TileCoord tile_walk(unsigned bid, unsigned nwg, int tiles_x, int tiles_y, int sw)
+{
+    if (sw == 0) return strip_walk(bid, nwg, tiles_x, tiles_y, nwg / (tiles_x * tiles_y));
+    const int stripes_x = (tiles_x + sw - 1) / sw;
+    const unsigned p = xcd_chunked_id(bid, nwg);
+    const unsigned per = (unsigned)sw * tiles_y;
+    const unsigned S = nwg / per;                          // stripes in the launch
+    const unsigned Q = S / kXcds, R = S % kXcds;
+    const unsigned big = (Q + 1) * per;
+    unsigned k, rem;
+    if (p < R * big) {
+        k = p / big;
+        rem = p % big;
+    } else {
+        const unsigned pp = p - R * big, small = Q * per;
+        k = R + pp / small;
+        rem = pp % small;
+    }
+    const unsigned s = k + kXcds * (rem / per);
+    const unsigned in_stripe = rem % per;
+    TileCoord c;
+    c.b = s / stripes_x;
+    c.tx = (s % stripes_x) * sw + in_stripe % sw;
+    c.ty = in_stripe / sw;
+    return c;
+}
+
+inline unsigned walk_grid(int tiles_x, int tiles_y, int batch, int sw)
+{
+    const int cols = sw > 0 ? (tiles_x + sw - 1) / sw * sw : tiles_x;
+    return (unsigned)cols * tiles_y * batch;
+}
+
+extern int g_tile_walk_sw;                                 // measurement knob (memc_debug_set_walk), default per launcher
+
 // Streaming accesses: every filter-tap / flow / output element is touched exactly once per launch,
 // so keep it from displacing the (re-used) source-image lines in L1/L2.
 __device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }

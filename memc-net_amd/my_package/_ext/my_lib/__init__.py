@@ -134,4 +134,5 @@ _lib.memc_debug_set_projection_variant.restype = None
 def _debug_set_variant(op, variant):
     {"fi_fwd": _lib.memc_debug_set_fi_fwd_variant,
      "fi_bwd": _lib.memc_debug_set_fi_bwd_variant,
-     "projection": _lib.memc_debug_set_projection_variant}[op](int(variant))
+     "projection": _lib.memc_debug_set_projection_variant,
+     "walk": _lib.memc_debug_set_walk}[op](int(variant))
