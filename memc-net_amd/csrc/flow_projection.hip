@@ -1249,7 +1249,7 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
     if (vec && g_proj_variant != 0) {
         using G = TileGeom<16>;
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-        const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : 0;
+        const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         const unsigned nwg = walk_grid(ntx, nty, batch, sw);
         const int lds = tile_lds_bytes<16>();
         hipLaunchKernelGGL(proj_bwd_tiled<DEPTH>, dim3(nwg), dim3(256), lds, stream, w, h, ntx, nty, (int64_t)s1b,

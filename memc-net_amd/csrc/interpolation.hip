@@ -361,7 +361,7 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
     if (vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, output})) {
         using G = TileGeom<16>;
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-        const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : 0;
+        const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         const unsigned nwg_t = walk_grid(ntx, nty, batch, sw);
         if (channel == 3)
             hipLaunchKernelGGL(bl_fwd_tiled<3>, dim3(nwg_t), dim3(256), tile_lds_bytes<16>(), stream, w, h, channel,
@@ -396,7 +396,7 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
                       "the accumulator plane aliases the staged image");
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const int lds = tile_lds_bytes<16>();
-        const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : 0;
+        const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         hipLaunchKernelGGL(bl_bwd_tiled_c3, dim3(walk_grid(ntx, nty, batch, sw)), dim3(256), lds, stream, w, h, ntx, nty,
                            (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, gradoutput,
                            gradinput1, gradinput2, sw);

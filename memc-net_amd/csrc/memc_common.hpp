@@ -147,7 +147,12 @@ inline unsigned walk_grid(int tiles_x, int tiles_y, int batch, int sw)
     return (unsigned)cols * tiles_y * batch;
 }
 
-extern int g_tile_walk_sw;                                 // measurement knob (memc_debug_set_walk), default per launcher
+extern int g_tile_walk_sw;                                 // measurement knob (memc_debug_set_walk); < 0: the default below
+// Default: one tile column per XCD strip (0).  Stripes n tile columns wide keep horizontal neighbours on one XCD:
+// measured on the bilinear warp / projection backward (rocprofv3 FETCH_SIZE, tools/probes/pmc_walk.py) they read 22 %
+// less (865 -> 677 MB) but run within +-2 % of the strips (those kernels are latency-, not traffic-bound), so the
+// strips stay.
+constexpr int kDefaultStripe = 0;
 
 // Streaming accesses: every filter-tap / flow / output element is touched exactly once per launch,
 // so keep it from displacing the (re-used) source-image lines in L1/L2.
