@@ -364,7 +364,7 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         const unsigned nwg_t = walk_grid(ntx, nty, batch, sw);
         if (channel == 3)
-            hipLaunchKernelGGL(bl_fwd_tiled<3>, dim3(nwg_t), dim3(256), tile_lds_bytes<16>(), stream, w, h, channel,
+            hipLaunchKernelGGL(bl_fwd_tiled<3>, dim3(nwg_t), dim3(256), tile_lds_bytes<16>() + g_extra_lds, stream, w, h, channel,
                                ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1,
                                input2, output, sw);
         else
@@ -420,6 +420,8 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
 using namespace memc;
 
 int memc::g_tile_walk_sw = -1;
+int memc::g_extra_lds = 0;
+extern "C" void memc_debug_set_extra_lds(int bytes) { memc::g_extra_lds = bytes > 0 ? bytes : 0; }
 extern "C" void memc_debug_set_walk(int stripe_width) { memc::g_tile_walk_sw = stripe_width; }
 
 extern "C" int InterpolationLayer_gpu_forward_kernel(

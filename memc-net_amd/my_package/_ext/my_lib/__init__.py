@@ -135,4 +135,5 @@ def _debug_set_variant(op, variant):
     {"fi_fwd": _lib.memc_debug_set_fi_fwd_variant,
      "fi_bwd": _lib.memc_debug_set_fi_bwd_variant,
      "projection": _lib.memc_debug_set_projection_variant,
-     "walk": _lib.memc_debug_set_walk}[op](int(variant))
+     "walk": _lib.memc_debug_set_walk,
+     "extra_lds": _lib.memc_debug_set_extra_lds}[op](int(variant))
