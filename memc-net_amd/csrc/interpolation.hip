@@ -151,14 +151,14 @@ __device__ __forceinline__ void bl_fwd_chunk(const Region &r, const BlSite4 &g, 
         st_stream4(out_p + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
 }
 
-template <int CT>
+template <int CT, int CAP>
 __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
     const float *__restrict__ in1, const float *__restrict__ flow, float *__restrict__ out, int sw)
 {
     constexpr int LX = 16;
-    using G = TileGeom<LX>;
+    using G = TileGeom<LX, CAP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
             rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
         }
     }
-    const Region r = tile_region<LX, true>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    const Region r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
     BlSite4 g;
     g.valid = g.staged = 0;
 #pragma unroll
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
 // Backward, tiled, RGB: image gradient splatted into LDS accumulators and flushed with coalesced atomics
 // (memc_tile.hpp "LDS-privatised scatter"); the flow gradient needs the four corner values, gathered from a
 // staged LDS image of the same box.
+template <int CAP>
 __global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
     float *__restrict__ gin1, float *__restrict__ gin2, int sw)
 {
     constexpr int LX = 16;
-    using G = TileGeom<LX>;
+    using G = TileGeom<LX, CAP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // phase 1 uses the LDS as the staged image (48 KiB of pixel quads), phase 2 re-uses the same bytes as ONE
     // transposed fp64 accumulator plane (AccT, 32 KiB) that the colour channels take in turn: three workgroups
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
             rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
         }
     }
-    const Region r = tile_region<LX>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    const Region r = tile_region<LX, false, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
     const float *in_b = in1 + b * s1b;
     float *gin1_b = gin1 + b * s1b;
     tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
@@ -363,14 +364,20 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         const unsigned nwg_t = walk_grid(ntx, nty, batch, sw);
-        if (channel == 3)
-            hipLaunchKernelGGL(bl_fwd_tiled<3>, dim3(nwg_t), dim3(256), tile_lds_bytes<16>() + g_extra_lds, stream, w, h, channel,
-                               ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1,
-                               input2, output, sw);
-        else
-            hipLaunchKernelGGL(bl_fwd_tiled<0>, dim3(nwg_t), dim3(256), tile_lds_bytes<16>(), stream, w, h, channel,
-                               ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1,
-                               input2, output, sw);
+#define MEMC_BL_FWD(CT, CAP)                                                                                    \
+            hipLaunchKernelGGL((bl_fwd_tiled<CT, CAP>), dim3(nwg_t), dim3(256), (tile_lds_bytes<16, CAP>() + g_extra_lds), \
+                               stream, w, h, channel, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,          \
+                               (int64_t)s2c, s2h, input1, input2, output, sw)
+        if (channel == 3) {
+            // 39 KiB instead of 48: 4 workgroups per CU.  The kernel is bound by the latency of a tile's serial chain
+            // (1 / 2 / 3 per CU: 483 / 280 / 215 us), its 2x2 footprint rarely needs the rows given up: 218 -> 190 us
+            if (g_cap_sel == 0) MEMC_BL_FWD(3, 3072);
+            else if (g_cap_sel == 2) MEMC_BL_FWD(3, 1984);     // 5 per CU: 198-202 us
+            else MEMC_BL_FWD(3, 2496);
+        } else {
+            MEMC_BL_FWD(0, 3072);
+        }
+#undef MEMC_BL_FWD
         return launch_status();
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
@@ -395,11 +402,17 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
         static_assert(AccT::kPlane * 8 <= G::kCapPx * 16 && G::kPitch <= AccT::kMaxW && G::kRows <= AccT::kRows,
                       "the accumulator plane aliases the staged image");
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-        const int lds = tile_lds_bytes<16>();
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
-        hipLaunchKernelGGL(bl_bwd_tiled_c3, dim3(walk_grid(ntx, nty, batch, sw)), dim3(256), lds, stream, w, h, ntx, nty,
-                           (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, gradoutput,
-                           gradinput1, gradinput2, sw);
+        static_assert(AccT::kPlane * 8 <= 2496 * 16, "the smaller budget still holds the accumulator plane");
+#define MEMC_BL_BWD(CAP)                                                                                        \
+        hipLaunchKernelGGL(bl_bwd_tiled_c3<CAP>, dim3(walk_grid(ntx, nty, batch, sw)), dim3(256),                  \
+                           (tile_lds_bytes<16, CAP>()), stream, w, h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h,  \
+                           (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, gradoutput, gradinput1, gradinput2, sw)
+        // the smaller budget LOSES here (522 -> 601 us): the fixed-pitch accumulator plane gets 26 rows instead of 32
+        // and the sites beyond them scatter with global atomics
+        if (g_cap_sel == 1) MEMC_BL_BWD(2496);
+        else MEMC_BL_BWD(3072);
+#undef MEMC_BL_BWD
         return launch_status();
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
@@ -421,6 +434,8 @@ using namespace memc;
 
 int memc::g_tile_walk_sw = -1;
 int memc::g_extra_lds = 0;
+int memc::g_cap_sel = -1;
+extern "C" void memc_debug_set_bl_cap(int which) { memc::g_cap_sel = which; }
 extern "C" void memc_debug_set_extra_lds(int bytes) { memc::g_extra_lds = bytes > 0 ? bytes : 0; }
 extern "C" void memc_debug_set_walk(int stripe_width) { memc::g_tile_walk_sw = stripe_width; }
 

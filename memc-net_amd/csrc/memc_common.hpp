@@ -153,6 +153,7 @@ extern int g_tile_walk_sw;                                 // measurement knob (
 // less (865 -> 677 MB) but run within +-2 % of the strips (those kernels are latency-, not traffic-bound), so the
 // strips stay.
 constexpr int kDefaultStripe = 0;
+extern int g_cap_sel;                                      // measurement knob: LDS staging budget of the 2x2-footprint kernels
 extern int g_extra_lds;                                    // occupancy experiment: unused dynamic LDS added to bl_fwd_tiled<3>
 
 // Streaming accesses: every filter-tap / flow / output element is touched exactly once per launch,

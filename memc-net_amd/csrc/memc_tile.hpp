@@ -107,21 +107,23 @@ inline bool vec4_ok(int w, std::initializer_list<long> strides, std::initializer
 }
 
 // Tile geometry: 256 threads, LX lanes per tile row, 4 sites per lane.
-template <int LX>
+// CAP: the LDS budget in pixel quads.  3072 px * 16 B = 48 KiB -> 3 workgroups per CU (the 4x4-window kernels, whose
+// boxes need it); the 2x2-footprint kernels stage smaller boxes and trade budget for workgroups per CU.
+template <int LX, int CAP = 3072>
 struct TileGeom {
     static constexpr int kThreads = 256;
     static constexpr int kTW = 4 * LX;                 // tile width  (sites)
     static constexpr int kTH = kThreads / LX;          // tile height (sites)
     static constexpr int kPitch = kTW + 32;            // LDS row pitch in pixels; multiple of 16 (swizzle span)
-    static constexpr int kCapPx = 3072;                // LDS budget: 3072 px * 16 B = 48 KiB -> 3 workgroups / CU
+    static constexpr int kCapPx = CAP;
     static constexpr int kRows = kCapPx / kPitch;      // staged rows that fit
     static_assert(kPitch % 16 == 0, "swizzle needs a pitch that is a multiple of 16 pixels");
     static_assert(kPitch / 4 <= 32, "staging uses 32 lanes per region row");
 };
 
 // LDS carve: [0, kCapPx*16) pixel quads, then 16 ints of per-wave bounding boxes.
-template <int LX>
-constexpr int tile_lds_bytes() { return TileGeom<LX>::kCapPx * 16 + 64; }
+template <int LX, int CAP = 3072>
+constexpr int tile_lds_bytes() { return TileGeom<LX, CAP>::kCapPx * 16 + 64; }
 
 // min over the 64 lanes of a wave, returned in every lane (wave-uniform)
 __device__ __forceinline__ int wave_min_i32(int v)
@@ -152,11 +154,11 @@ struct Region {
 // (cmin > cmax).  One __syncthreads.
 // DYN: the pixel-quad image uses the narrowest pitch (multiple of 16) that holds the box, which buys rows:
 // 96 -> 32 rows, 80 -> 38, 64 -> 48.  Kernels that also keep fixed-shape accumulator planes pass DYN = false.
-template <int LX, bool DYN = false>
+template <int LX, bool DYN = false, int CAP = 3072>
 __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int rmax, int tile_x0, int tile_y0,
                                               int *bb /* 16 ints in LDS */)
 {
-    using G = TileGeom<LX>;
+    using G = TileGeom<LX, CAP>;
     // wave-level reduction on the VALU/SALU only (DPP row shifts, then the four row leaders through readlane);
     // ds_bpermute-based shuffles would put ~700 clocks of LDS round trips on the tile's critical chain
     cmin = wave_min_i32(cmin);

@@ -136,4 +136,5 @@ def _debug_set_variant(op, variant):
      "fi_bwd": _lib.memc_debug_set_fi_bwd_variant,
      "projection": _lib.memc_debug_set_projection_variant,
      "walk": _lib.memc_debug_set_walk,
-     "extra_lds": _lib.memc_debug_set_extra_lds}[op](int(variant))
+     "extra_lds": _lib.memc_debug_set_extra_lds,
+     "bl_cap": _lib.memc_debug_set_bl_cap}[op](int(variant))
