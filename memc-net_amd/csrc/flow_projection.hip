@@ -1257,6 +1257,7 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
                            depth, count, fwd_out, gout, gin1, gin2, sw)
         // 39 KiB of staged cells instead of 48 -> 4 workgroups per CU: 205 -> 180 us (depth 271 -> 256), same results
         if (g_cap_sel == 0) MEMC_PROJ_BWD(3072);
+        else if (g_cap_sel == 2) MEMC_PROJ_BWD(1984);          // 5 per CU
         else MEMC_PROJ_BWD(2496);
 #undef MEMC_PROJ_BWD
         return launch_status();
