@@ -290,6 +290,46 @@ def test_full_size_properties():
         assert abs(got - want) <= 1e-3 * max(1.0, abs(want))
 
 
+@pytest.mark.parametrize("case", [CASES[i] for i in (0, 5, 6, 8, 12, 16)], ids=[IDS[i] for i in (0, 5, 6, 8, 12, 16)])
+def test_tile_walks_and_staging_budgets(oracle, case):
+    """The 2x2-footprint kernels take their tile walk (strips / stripes of n tile columns per XCD) and their LDS
+    staging budget (48 / 39 / 31 KiB) from measurement knobs; every combination must give the oracle's results
+    (a smaller budget only moves sites from the staged to the global-gather path)."""
+    import my_package._ext.my_lib as my_lib
+    d = make(case)
+    if d["x"].shape[1] != 3:
+        pytest.skip("RGB kernels")
+    x, f, g, dep, gf = T(d["x"]), T(d["flow"]), T(d["gout"]), T(d["depth"]), T(d["gflow"])
+    want_fwd = oracle.interpolation_forward(d["x"], d["flow"])
+    want_g1, want_g2 = oracle.interpolation_backward(d["x"], d["flow"], d["gout"])
+    _, cnt = oracle.flow_projection_forward(d["flow"], 0)
+    want_p = oracle.flow_projection_backward(d["flow"], cnt, d["gflow"])
+    dout, dcnt = oracle.depth_flow_projection_forward(d["flow"], d["depth"], 0)
+    want_q1, want_q2 = oracle.depth_flow_projection_backward(d["flow"], d["depth"], dcnt, dout, d["gflow"])
+    try:
+        for walk, cap in ((0, 0), (2, 1), (4, 2), (3, -1), (-1, 1)):
+            my_lib._debug_set_variant("walk", walk)
+            my_lib._debug_set_variant("bl_cap", cap)
+            tag = "walk %d budget %d" % (walk, cap)
+            o = torch.full_like(x, float("nan"))
+            assert my_lib.InterpolationLayer_gpu_forward(x, f, o) == 0
+            close(N(o), want_fwd, "interpolation forward, " + tag)
+            g1, g2 = torch.zeros_like(x), torch.full_like(f, float("nan"))
+            assert my_lib.InterpolationLayer_gpu_backward(x, f, g, g1, g2) == 0
+            close(N(g1), want_g1, "interpolation gradinput1, " + tag, RTOL)
+            close(N(g2), want_g2, "interpolation gradinput2, " + tag, RTOL)
+            p1 = torch.full_like(f, float("nan"))
+            assert my_lib.FlowProjectionLayer_gpu_backward(f, T(cnt), gf, p1) == 0
+            close(N(p1), want_p, "projection backward, " + tag, RTOL)
+            q1, q2 = torch.full_like(f, float("nan")), torch.full_like(dep, float("nan"))
+            assert my_lib.DepthFlowProjectionLayer_gpu_backward(f, dep, T(dcnt), T(dout), gf, q1, q2) == 0
+            close(N(q1), want_q1, "depth projection gradinput1, " + tag, RTOL)
+            close(N(q2), want_q2, "depth projection gradinput2, " + tag, RTOL)
+    finally:
+        my_lib._debug_set_variant("walk", -1)
+        my_lib._debug_set_variant("bl_cap", -1)
+
+
 def test_tensors_beyond_2G_elements():
     """Maximum sizes: 288 GB of HBM holds tensors with more than 2^31 elements (here 40 x 64 x 720 x 1280 = 2.36e9,
     9.4 GB each), where any 32-bit element index would wrap.  Batch items are independent, so the last item of
