@@ -31,15 +31,15 @@
  *     assigned, as in the reference;
  *   - `output`, `gradoutput` and `gradinput1` are indexed with input1's b/c/h strides
  *     (my_lib_kernel.cu:1184,1276-1283), `gradinput2`/`gradinput3` with input2's/input3's;
- *   - work is enqueued asynchronously on `stream`; no host synchronisation and no state carried from one call
- *     to the next.  One exception to "never allocates": the first (Depth)FlowProjection FORWARD call on a
- *     device allocates 40 KiB of device scratch (per-image "far source" flags of its fast path) and keeps it
- *     for the life of the process; every call clears its slice on its own stream.  Make that first call
- *     outside a stream capture (inside one the library silently uses its general path instead).  A second one:
- *     a (Depth)FlowProjection forward call WITH hole filling takes a workspace of about 0.4 bytes per pixel from
- *     the device's default memory pool (hipMallocAsync, released in stream order by hipFreeAsync; the pool's
- *     release threshold is raised once so that it keeps the memory).  Inside a stream capture, or if the
- *     allocation fails, the hole filler falls back to a variant that needs none;
+ *   - work is enqueued asynchronously on `stream`; no host synchronisation, no state carried from one call to
+ *     the next, nothing shared between concurrent calls (any number of streams / host threads), nothing read from
+ *     the environment.  One exception to "never allocates": a (Depth)FlowProjection FORWARD call takes a
+ *     stream-ordered scratch allocation for the duration of the call (1.3 KiB of per-image "far source" flags for
+ *     its fast path; with hole filling also the filler's carry tables, about 0.4 bytes per pixel), released in
+ *     stream order before the call returns (hipMallocFromPoolAsync / hipFreeAsync).  It comes from a PRIVATE memory
+ *     pool of the stream's device, created on the first such call and kept for the life of the process; the
+ *     device's default pool and its attributes are not touched.  Inside a stream capture, or if the allocation
+ *     fails, the call uses its general path and a hole filler that need no scratch (slower, same results);
  *   - return 0 on success, -1 on a failed shape/stride check or a launch error (my_lib_cuda.c:611-646,
  *     my_lib_kernel.cu:1559-1566).
  *
@@ -53,6 +53,10 @@
 
 #ifdef __cplusplus
 extern "C" {
+#endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
 #endif
 
 typedef void *memc_stream_t;            /* hipStream_t */
@@ -236,6 +240,9 @@ int FilterInterpolationBlend_gpu_forward_kernel(
     const float *input0, const float *input2, const float *flow0, const float *flow1,
     const float *filter0, const float *filter1, const float *occlusion0, const float *occlusion1, float *output);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

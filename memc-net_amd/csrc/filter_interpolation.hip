@@ -18,8 +18,6 @@
 #include "memc_internal.h"
 #include "memc_tile.hpp"
 
-#include <stdlib.h>
-
 namespace memc {
 
 // --------------------------------------------------------------------------------------------------
@@ -139,7 +137,6 @@ __device__ __forceinline__ void fi_gather_store(
     const Region &r, const FiSite4 &g, const f32x4 (&tp)[16], bool inb, int x, int y, int W, int H,
     const float *__restrict__ plane0, float *__restrict__ out_p, int64_t s1c, int s1h, const f32x4 *tile)
 {
-    using G = TileGeom<LX>;
     if (!inb) return;
     f32x4 res[4];                                          // res[j][c]: site j, channel c
 #pragma unroll
@@ -748,6 +745,7 @@ __global__ __launch_bounds__(256) void fi_fwd_generic(
     }
 }
 
+#ifdef MEMC_MEASURE
 // --------------------------------------------------------------------------------------------------
 // Measurement arm only (bench_ops.py): a kernel with the REFERENCE's structure -- block (32,16), one
 // thread per site, taps re-read from global for every channel, no streaming hints, blockIdx-ordered
@@ -784,6 +782,8 @@ __global__ __launch_bounds__(512) void fi_fwd_refshape(
         for (int c = 0; c < C; c++) out_p[c * s1c] = p[c * s1c];
     }
 }
+
+#endif  // MEMC_MEASURE
 
 // --------------------------------------------------------------------------------------------------
 // Backward, fs == 4, direct.  Per valid site (my_lib_kernel.cu:1248-1515):
@@ -1400,10 +1400,13 @@ __global__ __launch_bounds__(256) void fi_bwd_generic(
 
 using namespace memc;
 
-// Variant selection for A/B measurement (memc_internal.h); -1 = automatic.
-static int g_fi_fwd_variant = -1;
+// Variant selection for A/B measurement (memc_internal.h); -1 = automatic.  Measurement build only: in the product
+// build both are compile-time constants (-1), every `variant == n` branch below folds away and the ablation kernels
+// are never instantiated.  Nothing is read from the environment in either build.
+#ifdef MEMC_MEASURE
+MEMC_KNOB_STATIC(g_fi_fwd_variant, -1);
+MEMC_KNOB_STATIC(g_fi_bwd_variant, -1);
 extern "C" void memc_debug_set_fi_fwd_variant(int v) { g_fi_fwd_variant = v; }
-static int g_fi_bwd_variant = -1;
 extern "C" void memc_debug_set_fi_bwd_variant(int v) { g_fi_bwd_variant = v; }
 // device buffer of gridDim.x * 16 uint64 for the timestamp arm (fi_bwd variant 9); tools/trace_kernel.py
 extern "C" int memc_debug_set_trace_buffer(void *p)
@@ -1411,16 +1414,7 @@ extern "C" int memc_debug_set_trace_buffer(void *p)
     unsigned long long *q = (unsigned long long *)p;
     return hipMemcpyToSymbol(HIP_SYMBOL(memc::g_trace_buf), &q, sizeof(q)) == hipSuccess ? 0 : -1;
 }
-// MEMC_FI_FWD_VARIANT=<n> in the environment forces a kernel variant (measurement / test matrix only).
-static int fi_fwd_variant()
-{
-    static const int from_env = [] {
-        const char *e = getenv("MEMC_FI_FWD_VARIANT");
-        return e ? atoi(e) : -1;
-    }();
-    return g_fi_fwd_variant >= 0 ? g_fi_fwd_variant : from_env;
-}
-
+#endif
 extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
     memc_stream_t stream_, const int nElement, const int w, const int h, const int channel, const int batch,
     const int filter_size,
@@ -1432,19 +1426,8 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
     (void)nElement; (void)s1w; (void)s2w; (void)s3w;
     hipStream_t stream = (hipStream_t)stream_;
     if (w <= 0 || h <= 0 || channel <= 0 || batch <= 0) return 0;
-    const int variant = fi_fwd_variant();
-
-    if (variant == 0) {  // reference-structure measurement arm
-        dim3 block(32, 16, 1), grid((w + 31) / 32, (h + 15) / 16, batch);
-        hipLaunchKernelGGL(fi_fwd_refshape, grid, block, 0, stream, w, h, channel, filter_size,
-                           (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
-                           (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
-        return launch_status();
-    }
-    // production path: LDS-tiled, 16 B per lane (needs 4-element-aligned geometry; variants 1-3 force the
-    // scalar direct-gather kernels for A/B measurement)
+    // production path: LDS-tiled, 16 B per lane (needs 4-element-aligned geometry)
     const bool vec = vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h}, {input1, input2, input3, output});
-    if (filter_size == 4 && vec && (variant < 0 || variant >= 4)) {
 #define MEMC_FI_TILED(LX, CT, MINW)   MEMC_FI_TILED_A(LX, CT, MINW, 0)
 #define MEMC_FI_TILED_A(LX, CT, MINW, ABL)                                                                      \
     do {                                                                                                   \
@@ -1455,12 +1438,58 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, \
                            s3h, input1, input2, input3, output);                                           \
     } while (0)
+#define MEMC_FI_C4N(SW)                                                                                        \
+    do {                                                                                                   \
+        using G = TileGeom<16>;                                                                            \
+        const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                        \
+        hipLaunchKernelGGL(fi_fwd_tiled_c4n<SW>, dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) *  \
+                                                              (SW ? SW : 1)) * nty * batch),                \
+                           dim3(256), tile_lds_bytes<16>(), stream, w, h, channel, ntx, nty, (int64_t)s1b,    \
+                           (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c,    \
+                           s3h, input1, input2, input3, output);                                           \
+    } while (0)
+#define MEMC_FI_FWD_LAUNCH(CT, ROWS)                                                                       \
+    do {                                                                                                   \
+        const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + (ROWS) - 1) / (ROWS);                  \
+        const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;                                          \
+        hipLaunchKernelGGL((fi_fwd_direct_fs4<CT, ROWS>), dim3(nwg), dim3(64 * (ROWS)), 0, stream, w, h,   \
+                           channel, tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,       \
+                           (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3,     \
+                           output);                                                                        \
+    } while (0)
+
+#ifdef MEMC_MEASURE
+    // ---- measurement build only: A/B and ablation arms (tools/bench_ops.py); several return WRONG results ----
+    const int variant = g_fi_fwd_variant;
+    if (variant == 0) {  // reference-structure measurement arm
+        dim3 block(32, 16, 1), grid((w + 31) / 32, (h + 15) / 16, batch);
+        hipLaunchKernelGGL(fi_fwd_refshape, grid, block, 0, stream, w, h, channel, filter_size,
+                           (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                           (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
+        return launch_status();
+    }
+    if (filter_size == 4 && variant >= 1 && variant <= 3) {       // force the scalar direct-gather kernels
+        if (channel == 3) {
+            if (variant == 2) MEMC_FI_FWD_LAUNCH(3, 8);
+            else if (variant == 3) MEMC_FI_FWD_LAUNCH(3, 2);
+            else MEMC_FI_FWD_LAUNCH(3, 4);
+        } else {
+            if (variant == 2) MEMC_FI_FWD_LAUNCH(0, 8);
+            else if (variant == 3) MEMC_FI_FWD_LAUNCH(0, 2);
+            else MEMC_FI_FWD_LAUNCH(0, 4);
+        }
+        return launch_status();
+    }
+    if (filter_size == 4 && vec && variant >= 4) {
+        bool handled = true;
         if (variant == 5) {
             if (channel == 3) MEMC_FI_TILED(8, 3, 3); else MEMC_FI_TILED(8, 0, 3);
         } else if (variant == 6) {
             if (channel == 3) MEMC_FI_TILED(16, 3, 2); else MEMC_FI_TILED(16, 0, 2);
         } else if (variant == 7) {
             if (channel == 3) MEMC_FI_TILED(8, 3, 2); else MEMC_FI_TILED(8, 0, 2);
+        } else if (variant == 4) {
+            if (channel == 3) MEMC_FI_TILED(16, 3, 3); else MEMC_FI_TILED(16, 0, 3);
         } else if (variant == 8 && channel == 3) {
             MEMC_FI_TILED_A(16, 3, 2, 1);
         } else if (variant == 9 && channel == 3) {
@@ -1481,6 +1510,7 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             if (variant == 15) MEMC_FI_STRIPE(5, 2);
             else if (variant == 16) MEMC_FI_STRIPE(6, 2);
             else MEMC_FI_STRIPE(4, 2);                     // 17: row-major chunk per XCD at 2 waves/SIMD
+#undef MEMC_FI_STRIPE
         } else if (variant == 18 && channel == 3) {
             MEMC_FI_TILED_A(16, 3, 2, 7);                  // flow prefetch 32 / 64 / 96 positions ahead (18/19/20)
         } else if (variant == 19 && channel == 3) {
@@ -1489,58 +1519,38 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             MEMC_FI_TILED_A(16, 3, 2, 10);
         } else if (variant == 21 && channel == 3) {
             MEMC_FI_TILED_A(16, 3, 2, 11);                 // split tap stream around the staging loads
-#undef MEMC_FI_STRIPE
-        } else if (channel % 4 == 0 && channel >= 8 && variant != 4 && variant != 6) {
-            using G = TileGeom<16>;
-            const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-#define MEMC_FI_C4N(SW)                                                                                        \
-            hipLaunchKernelGGL(fi_fwd_tiled_c4n<SW>, dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) *  \
-                                                                  (SW ? SW : 1)) * nty * batch),                \
-                               dim3(256), tile_lds_bytes<16>(), stream, w, h, channel, ntx, nty, (int64_t)s1b,    \
-                               (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c,    \
-                               s3h, input1, input2, input3, output)
-            if (variant == 30) MEMC_FI_C4N(2);
-            else if (variant == 31) MEMC_FI_C4N(4);
-            else MEMC_FI_C4N(0);
-#undef MEMC_FI_C4N
-        } else if (variant == 4) {
-            if (channel == 3) MEMC_FI_TILED(16, 3, 3); else MEMC_FI_TILED(16, 0, 3);
-        } else {                                           // default: 64x16 tiles, strip walk
-            if (channel == 3) MEMC_FI_TILED(16, 3, 2); else MEMC_FI_TILED(16, 0, 2);
+        } else if (variant == 30 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N(2);
+        } else if (variant == 31 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N(4);
+        } else {
+            handled = false;
         }
-#undef MEMC_FI_TILED
-#undef MEMC_FI_TILED_A
+        if (handled) return launch_status();
+    }
+#endif  // MEMC_MEASURE
+
+    if (filter_size == 4 && vec) {
+        if (channel % 4 == 0 && channel >= 8) MEMC_FI_C4N(0);          // e.g. the 64-channel context warp
+        else if (channel == 3) MEMC_FI_TILED(16, 3, 2);                // default: 64x16 tiles, strip walk
+        else MEMC_FI_TILED(16, 0, 2);
         return launch_status();
     }
-    const int tiles_x = (w + kWave - 1) / kWave;
     if (filter_size != 4) {
-        const int tiles_y = (h + 3) / 4;
+        const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
         const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
         hipLaunchKernelGGL(fi_fwd_generic, dim3(nwg), dim3(256), 0, stream, w, h, channel, filter_size,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
         return launch_status();
     }
-#define MEMC_FI_FWD_LAUNCH(CT, ROWS)                                                                       \
-    do {                                                                                                   \
-        const int tiles_y = (h + (ROWS) - 1) / (ROWS);                                                     \
-        const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;                                          \
-        hipLaunchKernelGGL((fi_fwd_direct_fs4<CT, ROWS>), dim3(nwg), dim3(64 * (ROWS)), 0, stream, w, h,   \
-                           channel, tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,       \
-                           (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3,     \
-                           output);                                                                        \
-    } while (0)
-    const int rows = (variant == 2) ? 8 : (variant == 3 ? 2 : 4);
-    if (channel == 3) {
-        if (rows == 8) MEMC_FI_FWD_LAUNCH(3, 8);
-        else if (rows == 2) MEMC_FI_FWD_LAUNCH(3, 2);
-        else MEMC_FI_FWD_LAUNCH(3, 4);
-    } else {
-        if (rows == 8) MEMC_FI_FWD_LAUNCH(0, 8);
-        else if (rows == 2) MEMC_FI_FWD_LAUNCH(0, 2);
-        else MEMC_FI_FWD_LAUNCH(0, 4);
-    }
+    // odd widths / unaligned views: scalar direct-gather kernels
+    if (channel == 3) MEMC_FI_FWD_LAUNCH(3, 4);
+    else MEMC_FI_FWD_LAUNCH(0, 4);
 #undef MEMC_FI_FWD_LAUNCH
+#undef MEMC_FI_C4N
+#undef MEMC_FI_TILED
+#undef MEMC_FI_TILED_A
     return launch_status();
 }
 
@@ -1587,6 +1597,7 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
             hipLaunchKernelGGL(fi_bwd_tiled_c3_persistent<PF>, dim3(grid), dim3(256), lds, stream,                 \
                                MEMC_FI_BWD_ARGS);                                                                  \
         } while (0)
+#ifdef MEMC_MEASURE
         switch (g_fi_bwd_variant) {
         case 1: MEMC_FI_BWD(1); break;
         case 2: MEMC_FI_BWD(2); break;
@@ -1602,6 +1613,9 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
         case 11: MEMC_FI_BWD_P(false); break;
         default: MEMC_FI_BWD(0);
         }
+#else
+        MEMC_FI_BWD(0);
+#endif
 #undef MEMC_FI_BWD
 #undef MEMC_FI_BWD_P
 #undef MEMC_FI_BWD_ARGS

@@ -359,40 +359,56 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
 
 // ==================================================================================================
 // OWNER-COMPUTES forward (the fast path).  The splat is a scatter only because the reference walks SOURCE
-// sites; flow is cheap to re-read (8 B per site), so here a workgroup owns a 64x16 tile of OUTPUT cells and
+// sites; flow is cheap to re-read (8 B per site), so here a workgroup owns a 64 x TH tile of OUTPUT cells and
 // scans every source that can reach it:
 //   * sources in the tile dilated by kReach (+ alignment) are read as dwordx4 (the halo comes out of L2);
-//   * a source whose point (T, L) falls into the tile's point window [ty0-1, ty0+15] x [tx0-1, tx0+63] is
+//   * a source whose point (T, L) falls into the tile's point window [ty0-1, ty0+TH-1] x [tx0-1, tx0+63] is
 //     splatted into fp64 LDS planes (ds_add_f64: fast on this chip, and more accurate than fp32 atomics);
 //   * then every lane owns four cells: 2x2 box sum of the points (border duplicates as weights 2, see
 //     proj_scatter_tiled), normalisation by the count, one dwordx4 STORE per plane.
 // No global atomics, no separate averaging pass, no dependence on the caller's zero fill; HBM traffic is the
-// algorithmic 20 B per site (24 with depth).
+// algorithmic 20 B per site (24 with depth) plus the scan's halo.
 //
 // Reach: a source with |fx| >= kReach or |fy| >= kReach is invisible to the owners of its targets.  Such "far"
 // sources are skipped consistently by every owner, and the workgroup that is HOME to one raises a device flag.
 // The launcher then queues the general path (zero, scatter with atomics, average), whose kernels return at
 // once when the flag is clear: correctness never depends on the motion being small, only speed does.
+//
+// Round 2 (proj_owner2).  The round-1 kernel (kept as a measurement arm, proj_owner) scanned 7.6x the sources it
+// owned and ran the whole per-source body -- locate, window test, three fp64 LDS atomics -- under exec masks with
+// ~1 lane in 8 active: VALU-bound (74 % busy) with 151 LDS-atomic wave-instructions per tile at 22 lanes each.
+//   * The scan is now a TEST: x2 = x + fx, y2 = y + fy and two compares per axis against wave-uniform bounds (the
+//     upper one on the float's bit pattern, which folds "inside the image" and "inside the window" into one
+//     integer compare for the non-negative values that passed the lower one).  Quads whose rows cannot reach the
+//     tile leave after the four y tests (a scalar branch on a ballot).
+//   * Hits are COMPACTED: each wave appends its hits (cell, vx, vy, vc: 16 B) to a private 128-entry LDS ring --
+//     rank by v_mbcnt over the ballot, no atomics, no workgroup barrier -- and whenever 64 are waiting all 64 lanes
+//     splat one each: dense fp64 atomics (1 wave-instruction per 64 lane-operations instead of per ~22).
+//   * The tile is 64 x TH with TH a template parameter (256 / 512 / 1024 threads): a taller tile scans fewer
+//     sources per owned cell (7.6x / 4.7x / 3.3x at reach 24) for more LDS (36 / 71 / 139 KiB).
+//   * Tiles are walked in stripes `sw` tile columns wide per XCD (tile_walk), so that the horizontal halo of the
+//     scan is an L2 hit on the same XCD instead of a second HBM read (strips: 1.41x the algorithmic traffic).
 // ==================================================================================================
-constexpr int kPtW = 68, kPtH = 17;           // point window 65 x 17, pitch 68
+constexpr int kPtW = 68;                      // pitch of the point planes: 65 columns used, rows 16 B aligned
 
-// kReach = supported |flow| on the fast path (pixels)
 // ---- carry-based hole filling (pass 3), shared pieces; the scheme is described at proj_fillhole_carry ----------
 struct FillWs {
     int *up, *left, *right;       // left starts out as "last non-zero column in the tile", right as "first"
     int *n_list, *list;           // tiles that contain a hole, in kListSegs segments of `cap` entries: fill counts,
-    int cap;                      // then tile positions (strip order).  Segmented so that 30 000 workgroups do not
-};                                // all bump ONE counter (same-address atomics serialise: +150 us when every tile
-constexpr int kListSegs = 256;    // has a hole).
+    int cap;                      // then tile ids ((b * tiles_y + ty) * tiles_x + tx).  Segmented so that 30 000
+};                                // workgroups do not all bump ONE counter (same-address atomics serialise: +150 us
+constexpr int kListSegs = 256;    // when every tile has a hole).
 
+template <int TH>
 struct TileSummary {              // LDS
-    int col_last[64], row_first[16], row_last[16];
+    int col_last[64], row_first[TH], row_last[TH];
 };
 
-__device__ __forceinline__ void summary_init(TileSummary &t)
+template <int TH>
+__device__ __forceinline__ void summary_init(TileSummary<TH> &t)
 {
     if (threadIdx.x < 64) t.col_last[threadIdx.x] = -1;
-    if (threadIdx.x < 16) {
+    if (threadIdx.x < TH) {
         t.row_first[threadIdx.x] = INT_MAX;
         t.row_last[threadIdx.x] = -1;
     }
@@ -400,7 +416,8 @@ __device__ __forceinline__ void summary_init(TileSummary &t)
 
 // the lane's four counts at (x .. x+3, y), local coordinates (lx .. lx+3, ly); returns "one of them is a hole".
 // A barrier must separate summary_init from this, and this from summary_store.
-__device__ __forceinline__ bool summary_add(TileSummary &t, bool inb, const f32x4 &c4, int lx, int ly, int x, int y)
+template <int TH>
+__device__ __forceinline__ bool summary_add(TileSummary<TH> &t, bool inb, const f32x4 &c4, int lx, int ly, int x, int y)
 {
     bool hole = false;
     int first = INT_MAX, last = -1;
@@ -421,25 +438,408 @@ __device__ __forceinline__ bool summary_add(TileSummary &t, bool inb, const f32x
     return hole;
 }
 
-__device__ __forceinline__ void summary_store(const TileSummary &t, int any_hole, const FillWs &ws, unsigned tile, int b,
-                                              int tx, int ty, int W, int H, int ntx, int nty)
+template <int TH>
+__device__ __forceinline__ void summary_store(const TileSummary<TH> &t, int any_hole, const FillWs &ws, int b, int tx,
+                                              int ty, int W, int H, int ntx, int nty)
 {
-    const int tx0 = tx * 64, ty0 = ty * 16;
+    const int tx0 = tx * 64, ty0 = ty * TH;
     if (threadIdx.x < 64 && tx0 + (int)threadIdx.x < W)
         ws.up[((int64_t)b * nty + ty) * W + tx0 + threadIdx.x] = t.col_last[threadIdx.x];
-    if (threadIdx.x < 16 && ty0 + (int)threadIdx.x < H) {
+    if (threadIdx.x < TH && ty0 + (int)threadIdx.x < H) {
         const int64_t i = ((int64_t)b * H + ty0 + threadIdx.x) * ntx + tx;
         ws.right[i] = t.row_first[threadIdx.x] == INT_MAX ? -1 : t.row_first[threadIdx.x];
         ws.left[i] = t.row_last[threadIdx.x];
     }
-    // (a tile may be listed twice -- by proj_owner and again after the general path redid its image: the filler
-    // re-reads the counts and filling is idempotent)
+    // (a tile may be listed twice -- by the owner kernel and again after the general path redid its image: the
+    // filler re-reads the counts and filling is idempotent)
     if (threadIdx.x == 0 && any_hole) {
+        const unsigned tile = ((unsigned)b * nty + ty) * ntx + tx;
         const int seg = tile % kListSegs, slot = atomicAdd(ws.n_list + seg, 1);
         if (slot < ws.cap) ws.list[(int64_t)seg * ws.cap + slot] = (int)tile;      // (cap holds every tile twice)
     }
 }
 
+template <bool DEPTH, int TH, int kReach>
+__global__ __launch_bounds__(16 * TH) void proj_owner2(
+    int W, int H, int tiles_x, int tiles_y,
+    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
+    const float *__restrict__ flow, const float *__restrict__ depth,
+    float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, FillWs ws, int sw)
+{
+    constexpr int NT = 16 * TH, NW = NT / kWave;      // one lane per four owned cells
+    constexpr int kPtH = TH + 1, kPlane = kPtH * kPtW;
+    constexpr int kScanPadX = kReach + 4;         // dilated tile: columns, kept 4-aligned
+    constexpr int kScanW = 64 + 2 * kScanPadX;    // source columns
+    constexpr int kScanH = TH + 2 * kReach + 1;   // source rows: [ty0 - kReach - 1, ty0 + TH + kReach)
+    constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + NT - 1) / NT;
+    constexpr int kRing = 128;                    // entries per wave; at most 63 + 64 wait at any time
+    static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
+    __shared__ __attribute__((aligned(16))) double P[3 * kPlane];
+    __shared__ __attribute__((aligned(16))) f32x4 ring[NW * kRing];
+    __shared__ TileSummary<TH> sm;                // for the hole filler, when one follows (ws.up != nullptr)
+
+    const TileCoord tc = tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, sw);
+    if (tc.tx >= tiles_x) return;                 // virtual column of the last stripe
+    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * TH;
+    const int tid = threadIdx.x;
+    summary_init(sm);
+    {
+        f32x4 *pz = reinterpret_cast<f32x4 *>(P);
+        for (int i = tid; i < 3 * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // scan: kCols4 float4 columns x kScanH rows of slots, kIts per lane; all loads first.  Slot -> (row, column) by
+    // one division and increments, addresses as wave-uniform base + 32-bit lane offset.
+    // Slot `it` of the NT lanes covers scan rows [NT it / kCols4, (NT it + NT - 1) / kCols4]; the tile is rows
+    // [kReach + 1, kReach + 1 + TH): the slot is "far" when all of its rows are at least kNearRows away from the
+    // tile -- such rows almost never pass the row test, so only their fy is requested up front (fx / depth follow
+    // inside the branch if they do): the scan moves several times the tile's own bytes through the CU's 64 B/clk
+    // L1 path, which is a bound of its own.
+    constexpr int kNearRows = 8;
+    auto far_it = [](int it) {
+        const int first = NT * it / kCols4, last = (NT * it + NT - 1) / kCols4;
+        return last <= kReach + 1 - kNearRows || first >= kReach + 1 + TH + kNearRows;
+    };
+    const float *flow_b = flow + b * s1b;
+    const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
+    f32x4 fx[kIts], fy[kIts], dd[kIts];
+    int sx[kIts], sy[kIts];
+    bool live[kIts];
+    int row = tid / kCols4, c4 = tid % kCols4;
+#pragma unroll
+    for (int it = 0; it < kIts; it++) {
+        sx[it] = tx0 - kScanPadX + 4 * c4;
+        sy[it] = ty0 - kReach - 1 + row;
+        live[it] = row < kScanH && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
+        // dead slots read the plane's first pixels (unconditional loads)
+        const unsigned off = live[it] ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
+        fy[it] = ld_cached4_u(flow_b + s1c, off);
+        if (!far_it(it)) {
+            fx[it] = ld_cached4_u(flow_b, off);
+            if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+        }
+        row += NT / kCols4;                    // the next slot of this lane is NT further on
+        c4 += NT % kCols4;
+        if (c4 >= kCols4) {
+            c4 -= kCols4;
+            row++;
+        }
+    }
+    __syncthreads();                           // P is zero
+
+    // wave-uniform window bounds.  A source is a hit when its point (T, L) = ((int)y2, (int)x2) lies in the window
+    // and the site is valid (x2, y2 inside the image, my_lib_kernel.cu:1670): x2 >= max(tx0 - 1, 0) and
+    // x2 < tx0 + 64 and x2 <= W - 1.  For x2 >= 0 the float order is the order of the bit patterns, so the last two
+    // are ONE integer compare against min(bits(tx0 + 64), bits(W - 1) + 1).
+    const float xlo = (float)max(tx0 - 1, 0), ylo = (float)max(ty0 - 1, 0);
+    const int xhi_bits = min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1);
+    const int yhi_bits = min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1);
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    f32x4 *const my_ring = ring + wave * kRing;
+    unsigned head = 0, tail = 0;               // wave-uniform ring positions
+    bool far = false;
+
+    // all 64 lanes splat one waiting entry each
+    auto flush64 = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the entries are other lanes' LDS writes
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const f32x4 e = my_ring[(head + lane) & (kRing - 1)];
+        double *q = P + __float_as_int(e[0]);
+        lds_add_f64(q, (double)e[1]);
+        lds_add_f64(q + kPlane, (double)e[2]);
+        lds_add_f64(q + 2 * kPlane, (double)e[3]);
+        head += kWave;
+    };
+
+#pragma unroll
+    for (int it = 0; it < kIts; it++) {
+        const bool lv = live[it];
+        const float syf = (float)sy[it], sxf = (float)sx[it];
+        // the quad lies inside the tile itself (tx0, the pad and sx are multiples of 4: all four sites or none)
+        const bool homeq = lv && (unsigned)(sy[it] - ty0) < (unsigned)TH && (unsigned)(sx[it] - tx0) < 64u;
+        float y2[4];
+        bool wy[4], rowany = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            y2[j] = syf + fy[it][j];
+            wy[j] = lv && y2[j] >= ylo && __float_as_int(y2[j]) < yhi_bits;
+            rowany = rowany || wy[j];
+        }
+        // rows farther from the tile than the local motion: the whole wave leaves after the four y tests
+        if (__builtin_amdgcn_ballot_w64(rowany || homeq) == 0) continue;
+        f32x4 fxq = fx[it], ddq = dd[it];
+        if (far_it(it)) {                      // rare: requested only now (and consumed inside this branch)
+            const unsigned off = lv ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
+            fxq = ld_cached4_u(flow_b, off);
+            if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float fxv = fxq[j], fyv = fy[it][j];
+            const float x2 = (sxf + (float)j) + fxv;           // (float)x + fx, as the reference rounds it
+            const bool nearj = fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach;
+            if (homeq && !nearj) {             // a far source whose home is this tile: the image takes the general path
+                const bool valid = x2 >= 0.0f && y2[j] >= 0.0f && x2 <= (float)(W - 1) && y2[j] <= (float)(H - 1);
+                far = far || valid;
+            }
+            const bool hit = wy[j] && nearj && x2 >= xlo && __float_as_int(x2) < xhi_bits;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            if (m == 0) continue;              // wave-uniform
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (hit) {
+                const int py = (int)y2[j] - (ty0 - 1), px = (int)x2 - (tx0 - 1);
+                float vx = -fxv, vy = -fyv, vc = 1.0f;
+                if (DEPTH) {                   // my_lib_kernel.cu:2102-2114
+                    vx = -ddq[j] * fxv;
+                    vy = -ddq[j] * fyv;
+                    vc = ddq[j] * 1.0f;
+                }
+                my_ring[(tail + rank) & (kRing - 1)] = f32x4{__int_as_float(py * kPtW + px), vx, vy, vc};
+            }
+            tail += (unsigned)__builtin_popcountll(m);
+            if (tail - head >= (unsigned)kWave) flush64();
+        }
+    }
+    {                                          // what is still waiting (< 64 entries)
+        const unsigned n = tail - head;
+        if (n != 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if ((unsigned)lane < n) {
+                const f32x4 e = my_ring[(head + lane) & (kRing - 1)];
+                double *q = P + __float_as_int(e[0]);
+                lds_add_f64(q, (double)e[1]);
+                lds_add_f64(q + kPlane, (double)e[2]);
+                lds_add_f64(q + 2 * kPlane, (double)e[3]);
+            }
+        }
+    }
+    if (far) {                                 // this image needs the general path
+        far_flag[b % kFlagWords] = 1;
+        far_flag[kFlagWords] = 1;
+    }
+    __syncthreads();                           // every wave's points are in P
+
+    // every lane owns four cells of a row
+    const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
+    const bool inb = cx < W && cy < H;            // (no early exit: the summary below has a barrier)
+    const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
+    f32x4 ox, oy, oc;
+    // The lane's four cells need the point sums of columns c-1 .. c+3 of two rows, per plane: read them once as
+    // 2 x (two 16-byte pairs + one double) instead of 16 single doubles -- lanes are four cells apart, which for
+    // 8-byte reads is a 4-way bank conflict.
+    double top[3][5], bot[3][5];               // [plane][column c-1 .. c+3], rows cy-1 and cy
+    {
+        const int col0 = cx - tx0;             // P column of cell cx-1 (a multiple of 4: 16-byte aligned pairs)
+        const double *r0 = P + (cy - ty0) * kPtW + col0, *r1 = r0 + kPtW;
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const double *a = r0 + pl * kPlane, *c = r1 + pl * kPlane;
+            const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
+            const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
+            top[pl][0] = a01[0]; top[pl][1] = a01[1]; top[pl][2] = a23[0]; top[pl][3] = a23[1]; top[pl][4] = a[4];
+            bot[pl][0] = c01[0]; bot[pl][1] = c01[1]; bot[pl][2] = c23[0]; bot[pl][3] = c23[1]; bot[pl][4] = c[4];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
+        float v[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            // the four contributions are rounded to fp32 one by one and added in a fixed order (the
+            // reference's order is arbitrary: fp32 atomics)
+            float t = 0.0f;
+            t += wy0 * wx0 * (float)bot[pl][j + 1];
+            t += wy0 * (float)bot[pl][j];
+            t += wx0 * (float)top[pl][j + 1];
+            t += (float)top[pl][j];
+            v[pl] = t;
+        }
+        if (v[2] > 0.0f) {                     // my_lib_kernel.cu:1730-1735; one reciprocal for both components
+            const float inv = 1.0f / v[2];     // (<= 1 ulp from the two divisions)
+            v[0] = v[0] * inv;
+            v[1] = v[1] * inv;
+        }
+        ox[j] = v[0];  oy[j] = v[1];  oc[j] = v[2];
+    }
+    if (inb) {
+        float *o = out + b * s1b + (int64_t)cy * s1h + cx;
+        *reinterpret_cast<f32x4 *>(o) = ox;    // plain stores: pass 3 (hole fill) re-reads them
+        *reinterpret_cast<f32x4 *>(o + s1c) = oy;
+        *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
+    }
+    if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
+        const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
+        const int any_hole = __syncthreads_or(hole);
+        summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// Pass 3 with carries: the hole filler whose walks never leave a tile.
+// The reference walks from every hole to the nearest cell with a non-zero count to its left, to its right and above
+// (my_lib_kernel.cu:1776-1800).  Walked literally, a camera pan -- an uncovered strip along one image border --
+// makes every hole of a vertical strip climb the whole strip (measured: projection + fill 765 .. 1320 us against
+// 244 .. 266 us without, 720p batch 32).  Here a walk covers its own 64 x TH tile only; what lies beyond comes from
+// three small carry tables built by two tiny scans over per-tile summaries:
+//   up   [b][ty][x]   nearest row above band ty  whose cell in column x has a non-zero count   (-1: none)
+//   left [b][y ][tx]  nearest column left of tile column tx with a non-zero count in row y      (-1: none)
+//   right[b][y ][tx]  likewise to the right
+// plus the list of the tiles that contain a hole (the filler is launched over that list only).
+// Same cells, same flags, same arithmetic as the walks -- identical results.  The tables (0.4 B per pixel) live in
+// a stream-ordered allocation made and released by the launcher.
+// --------------------------------------------------------------------------------------------------
+// Summaries from the count plane, for the paths on which the owner kernel did not write them: the general path on
+// its own (far_flag == nullptr: every tile) or behind the far flag (only the images it redid; returns at once when
+// no image was flagged).  Grid-stride over tiles.
+template <int TH>
+__global__ __launch_bounds__(256) void proj_fill_summary(
+    int W, int H, int tiles_x, int tiles_y, int batch, int64_t scb, int sch, const float *__restrict__ count,
+    FillWs ws, const int *__restrict__ far_flag)
+{
+    __shared__ TileSummary<TH> sm;
+    if (far_flag && far_flag[kFlagWords] == 0) return;
+    const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((unsigned)tiles_x * tiles_y);
+        if (far_flag && far_flag[b % kFlagWords] == 0) continue;          // wave-uniform
+        summary_init(sm);
+        __syncthreads();
+        bool hole = false;
+#pragma unroll
+        for (int r = 0; r < TH / 16; r++) {
+            const int lx = 4 * (threadIdx.x % 16), ly = threadIdx.x / 16 + 16 * r;
+            const int x = tx * 64 + lx, y = ty * TH + ly;
+            const bool inb = x < W && y < H;
+            const f32x4 own = ld_cached4(count + b * scb + (int64_t)min(y, H - 1) * sch + min(x, W - 4));
+            hole = summary_add(sm, inb, own, lx, ly, x, y) || hole;
+        }
+        const int any_hole = __syncthreads_or(hole);       // (also orders the LDS atomics before the reads below)
+        summary_store(sm, any_hole, ws, b, tx, ty, W, H, tiles_x, tiles_y);
+        __syncthreads();                                   // before the next tile re-initialises the summary
+    }
+}
+
+// exclusive scans of the summaries, in place: one lane per image column (down the bands) / per image row (along
+// the tile columns, both ways).  A few hundred thousand lanes doing <= 45 / 2 x 60 steps on 11 MB.
+__global__ __launch_bounds__(256) void proj_fill_scan(int W, int H, int ntx, int nty, int batch, FillWs ws)
+{
+    // the values of a lane's chain are requested sixteen at a time (independent loads), then scanned in registers:
+    // a chain of dependent loads would cost ~0.5 us a step
+    auto scan = [](int *base, int64_t stride, int n, bool reverse) {
+        int carry = -1;
+        for (int i0 = 0; i0 < n; i0 += 16) {
+            int v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int i = min(i0 + k, n - 1);
+                v[k] = base[(int64_t)(reverse ? n - 1 - i : i) * stride];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (i0 + k < n) {
+                    const int i = i0 + k;
+                    base[(int64_t)(reverse ? n - 1 - i : i) * stride] = carry;
+                    if (v[k] >= 0) carry = v[k];
+                }
+            }
+        }
+    };
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t ncol = (int64_t)batch * W, nrow = (int64_t)batch * H;
+    if (t < ncol) {
+        const int b = (int)(t / W), x = (int)(t % W);
+        scan(ws.up + (int64_t)b * nty * W + x, W, nty, false);
+    } else if (t < ncol + nrow) {
+        const int64_t r = t - ncol;                        // = b * H + y
+        scan(ws.left + r * ntx, 1, ntx, false);
+        scan(ws.right + r * ntx, 1, ntx, true);
+    }
+}
+
+template <int TH>
+__global__ __launch_bounds__(256) void proj_fillhole_carry(
+    int W, int H, int tiles_x, int tiles_y, int batch, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch,
+    const float *__restrict__ count, float *out, FillWs ws)
+{
+    __shared__ __attribute__((aligned(16))) float cnt[TH * 64];
+    __shared__ int n_holes;
+    __shared__ unsigned short hole_list[TH * 64];
+    // workgroup i serves segment i % kListSegs, entries i / kListSegs, + gridDim / kListSegs, ...
+    const int seg = blockIdx.x % kListSegs, n_seg = min(ws.n_list[seg], ws.cap), step = max((int)gridDim.x / kListSegs, 1);
+    for (int it = blockIdx.x / kListSegs; it < n_seg; it += step) {
+    const unsigned tile = (unsigned)ws.list[(int64_t)seg * ws.cap + it];
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((unsigned)tiles_x * tiles_y);
+    const int tx0 = tx * 64, ty0 = ty * TH;
+    const float *cn = count + b * scb;
+    if (threadIdx.x == 0) n_holes = 0;
+    f32x4 own[TH / 16];
+#pragma unroll
+    for (int r = 0; r < TH / 16; r++) {
+        const int lx = 4 * (threadIdx.x % 16), ly = threadIdx.x / 16 + 16 * r;
+        const int x = tx0 + lx, y = ty0 + ly;
+        const bool inb = x < W && y < H;
+        own[r] = ld_cached4(cn + (int64_t)min(y, H - 1) * sch + min(x, W - 4));
+        // cells past the image edge are staged as "non-zero": the walks below test the edge themselves
+        *reinterpret_cast<f32x4 *>(cnt + ly * 64 + lx) = inb ? own[r] : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TH / 16; r++) {
+        const int lx = 4 * (threadIdx.x % 16), ly = threadIdx.x / 16 + 16 * r;
+        if (tx0 + lx < W && ty0 + ly < H) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (own[r][j] <= 0.0f) hole_list[atomicAdd(&n_holes, 1)] = (unsigned short)((ly << 6) | (lx + j));
+        }
+    }
+    __syncthreads();
+    const int n = n_holes;
+    float *o = out + b * s1b;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int cell = hole_list[i], hx = cell & 63, hy = cell >> 6;
+        const int gx = tx0 + hx, gy = ty0 + hy;
+        // inside the tile: LDS; beyond it: the carry tables (position only -- the count there is read back)
+        int lo = -1, ro = -1, uo = -1;
+        for (int c = hx - 1; c >= 0 && lo < 0; c--)
+            if (cnt[hy * 64 + c] != 0.0f) lo = tx0 + c;
+        if (lo < 0) lo = ws.left[((int64_t)b * H + gy) * tiles_x + tx];
+        for (int c = hx + 1; c < 64 && tx0 + c < W && ro < 0; c++)
+            if (cnt[hy * 64 + c] != 0.0f) ro = tx0 + c;
+        if (ro < 0) ro = ws.right[((int64_t)b * H + gy) * tiles_x + tx];
+        for (int r = hy - 1; r >= 0 && uo < 0; r--)
+            if (cnt[r * 64 + hx] != 0.0f) uo = ty0 + r;
+        if (uo < 0) uo = ws.up[((int64_t)b * tiles_y + ty) * W + gx];
+        // the counts the walks stopped at (0 when they ran into the image border)
+        const float lt = lo >= 0 ? cn[(int64_t)gy * sch + lo] : 0.0f;
+        const float rt = ro >= 0 ? cn[(int64_t)gy * sch + ro] : 0.0f;
+        const float ut = uo >= 0 ? cn[(int64_t)uo * sch + gx] : 0.0f;
+        const float dt = 0.0f;                              // dead downward search (my_lib_kernel.cu:1799)
+        if (lt + rt + ut + dt <= 0.0f) continue;
+        const float fl = lt > 0.0f ? 1.0f : 0.0f, fr = rt > 0.0f ? 1.0f : 0.0f;
+        const float fu = ut > 0.0f ? 1.0f : 0.0f, fd = 0.0f;
+        // a walk that found nothing ends at the border cell (column 0 / W-1, row 0): its flag is 0, but the
+        // reference still multiplies that cell's value by it -- keep the operand finite and identical
+        const int lc = lo >= 0 ? lo : 0, rc = ro >= 0 ? ro : W - 1, ur = uo >= 0 ? uo : 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            float *pl = o + k * s1c;
+            float *self = pl + (int64_t)gy * s1h + gx;
+            *self = (fl * pl[(int64_t)gy * s1h + lc] + fr * pl[(int64_t)gy * s1h + rc] +
+                     fu * pl[(int64_t)ur * s1h + gx] + fd * *self) / (fl + fr + fu + fd);
+        }
+    }
+    __syncthreads();                                        // the LDS tile and list are reused by the next tile
+    }   // listed tiles
+}
+
+#ifdef MEMC_MEASURE
+// ---- round-1 owner kernel, kept as the A/B arm of proj_owner2 (variants -10 / -7 / -6) ----
 // Per-workgroup phase timestamps (shader clock) for tools/trace_kernel.py; written by the TRACE instance only.
 __device__ unsigned long long *g_trace_buf_proj = nullptr;
 template <bool ON>
@@ -458,11 +858,12 @@ __global__ __launch_bounds__(256) void proj_owner(
     constexpr int kScanPadX = kReach + 4;         // dilated tile: columns, kept 4-aligned
     constexpr int kScanW = 64 + 2 * kScanPadX;    // source columns
     constexpr int kScanH = 16 + 2 * kReach + 1;   // source rows: [ty0 - kReach - 1, ty0 + 16 + kReach)
+    constexpr int kPtH = 17;                      // point window 65 x 17
     __shared__ __attribute__((aligned(16))) double P[3 * kPtH * kPtW];
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
     const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
     trace_mark_proj<TRACE>(0);
-    __shared__ TileSummary sm;                   // for the hole filler, when one follows (ws.up != nullptr)
+    __shared__ TileSummary<16> sm;                   // for the hole filler, when one follows (ws.up != nullptr)
     summary_init(sm);
     {
         static_assert((3 * kPtH * kPtW) % 2 == 0, "P is zeroed 16 bytes at a time");
@@ -622,153 +1023,10 @@ __global__ __launch_bounds__(256) void proj_owner(
     if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
         const bool hole = summary_add(sm, inb, oc, 4 * (threadIdx.x % 16), threadIdx.x / 16, cx, cy);
         const int any_hole = __syncthreads_or(hole);
-        summary_store(sm, any_hole, ws, xcd_chunked_id(blockIdx.x, gridDim.x), b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
+        summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
     }
 }
-
-// --------------------------------------------------------------------------------------------------
-// Pass 3 with carries: the hole filler whose walks never leave a tile.
-// The reference walks from every hole to the nearest cell with a non-zero count to its left, to its right and above
-// (my_lib_kernel.cu:1776-1800).  Walked literally, a camera pan -- an uncovered strip along one image border --
-// makes every hole of a vertical strip climb the whole strip (measured: projection + fill 765 .. 1320 us against
-// 244 .. 266 us without, 720p batch 32).  Here a walk covers its own 64x16 tile only; what lies beyond comes from
-// three small carry tables built by two tiny scans over per-tile summaries:
-//   up   [b][ty][x]   nearest row above band ty  whose cell in column x has a non-zero count   (-1: none)
-//   left [b][y ][tx]  nearest column left of tile column tx with a non-zero count in row y      (-1: none)
-//   right[b][y ][tx]  likewise to the right
-// plus the list of the tiles that contain a hole (the filler is launched over that list only).
-// Same cells, same flags, same arithmetic as the walks -- identical results.  The tables (0.4 B per pixel) live in
-// a stream-ordered allocation made and released by the launcher (hipMallocAsync / hipFreeAsync).
-// --------------------------------------------------------------------------------------------------
-// Summaries from the count plane, for the paths on which proj_owner did not write them: the general path on its
-// own (far_flag == nullptr: every tile) or behind the far flag (only the images it redid; returns at once when
-// no image was flagged).  Grid-stride over tiles.
-__global__ __launch_bounds__(256) void proj_fill_summary(
-    int W, int H, int tiles_x, int tiles_y, int batch, int64_t scb, int sch, const float *__restrict__ count,
-    FillWs ws, const int *__restrict__ far_flag)
-{
-    __shared__ TileSummary sm;
-    if (far_flag && far_flag[kFlagWords] == 0) return;
-    const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const TileCoord tc = strip_at(tile, tiles_x, tiles_y, batch);
-        const int b = tc.b;
-        if (far_flag && far_flag[b % kFlagWords] == 0) continue;          // wave-uniform
-        const int lx = 4 * (threadIdx.x % 16), ly = threadIdx.x / 16;
-        const int x = tc.tx * 64 + lx, y = tc.ty * 16 + ly;
-        const bool inb = x < W && y < H;
-        summary_init(sm);
-        const f32x4 own = ld_cached4(count + b * scb + (int64_t)min(y, H - 1) * sch + min(x, W - 4));
-        __syncthreads();
-        const bool hole = summary_add(sm, inb, own, lx, ly, x, y);
-        const int any_hole = __syncthreads_or(hole);       // (also orders the LDS atomics before the reads below)
-        summary_store(sm, any_hole, ws, tile, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
-        __syncthreads();                                   // before the next tile re-initialises the summary
-    }
-}
-
-// exclusive scans of the summaries, in place: one lane per image column (down the bands) / per image row (along
-// the tile columns, both ways).  A few hundred thousand lanes doing <= 45 / 2 x 60 steps on 11 MB.
-__global__ __launch_bounds__(256) void proj_fill_scan(int W, int H, int ntx, int nty, int batch, FillWs ws)
-{
-    // the values of a lane's chain are requested sixteen at a time (independent loads), then scanned in registers:
-    // a chain of dependent loads would cost ~0.5 us a step
-    auto scan = [](int *base, int64_t stride, int n, bool reverse) {
-        int carry = -1;
-        for (int i0 = 0; i0 < n; i0 += 16) {
-            int v[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int i = min(i0 + k, n - 1);
-                v[k] = base[(int64_t)(reverse ? n - 1 - i : i) * stride];
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if (i0 + k < n) {
-                    const int i = i0 + k;
-                    base[(int64_t)(reverse ? n - 1 - i : i) * stride] = carry;
-                    if (v[k] >= 0) carry = v[k];
-                }
-            }
-        }
-    };
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t ncol = (int64_t)batch * W, nrow = (int64_t)batch * H;
-    if (t < ncol) {
-        const int b = (int)(t / W), x = (int)(t % W);
-        scan(ws.up + (int64_t)b * nty * W + x, W, nty, false);
-    } else if (t < ncol + nrow) {
-        const int64_t r = t - ncol;                        // = b * H + y
-        scan(ws.left + r * ntx, 1, ntx, false);
-        scan(ws.right + r * ntx, 1, ntx, true);
-    }
-}
-
-__global__ __launch_bounds__(256) void proj_fillhole_carry(
-    int W, int H, int tiles_x, int tiles_y, int batch, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch,
-    const float *__restrict__ count, float *out, FillWs ws)
-{
-    __shared__ __attribute__((aligned(16))) float cnt[16 * 64];
-    __shared__ int n_holes;
-    __shared__ unsigned short hole_list[1024];
-    // workgroup i serves segment i % kListSegs, entries i / kListSegs, + gridDim / kListSegs, ...
-    const int seg = blockIdx.x % kListSegs, n_seg = min(ws.n_list[seg], ws.cap), step = max((int)gridDim.x / kListSegs, 1);
-    for (int it = blockIdx.x / kListSegs; it < n_seg; it += step) {
-    const TileCoord tc = strip_at((unsigned)ws.list[(int64_t)seg * ws.cap + it], tiles_x, tiles_y, batch);
-    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
-    const float *cn = count + b * scb;
-    const int lx = 4 * (threadIdx.x % 16), ly = threadIdx.x / 16;
-    const int x = tx0 + lx, y = ty0 + ly;
-    const bool inb = x < W && y < H;
-    const f32x4 own = ld_cached4(cn + (int64_t)min(y, H - 1) * sch + min(x, W - 4));
-    // cells past the image edge are staged as "non-zero": the walks below test the edge themselves
-    *reinterpret_cast<f32x4 *>(cnt + ly * 64 + lx) = inb ? own : f32x4{1.f, 1.f, 1.f, 1.f};
-    if (threadIdx.x == 0) n_holes = 0;
-    __syncthreads();
-    if (inb) {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (own[j] <= 0.0f) hole_list[atomicAdd(&n_holes, 1)] = (unsigned short)((ly << 6) | (lx + j));
-    }
-    __syncthreads();
-    const int n = n_holes;
-    float *o = out + b * s1b;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int cell = hole_list[i], hx = cell & 63, hy = cell >> 6;
-        const int gx = tx0 + hx, gy = ty0 + hy;
-        // inside the tile: LDS; beyond it: the carry tables (position only -- the count there is read back)
-        int lo = -1, ro = -1, uo = -1;
-        for (int c = hx - 1; c >= 0 && lo < 0; c--)
-            if (cnt[hy * 64 + c] != 0.0f) lo = tx0 + c;
-        if (lo < 0) lo = ws.left[((int64_t)b * H + gy) * tiles_x + tc.tx];
-        for (int c = hx + 1; c < 64 && tx0 + c < W && ro < 0; c++)
-            if (cnt[hy * 64 + c] != 0.0f) ro = tx0 + c;
-        if (ro < 0) ro = ws.right[((int64_t)b * H + gy) * tiles_x + tc.tx];
-        for (int r = hy - 1; r >= 0 && uo < 0; r--)
-            if (cnt[r * 64 + hx] != 0.0f) uo = ty0 + r;
-        if (uo < 0) uo = ws.up[((int64_t)b * tiles_y + tc.ty) * W + gx];
-        // the counts the walks stopped at (0 when they ran into the image border)
-        const float lt = lo >= 0 ? cn[(int64_t)gy * sch + lo] : 0.0f;
-        const float rt = ro >= 0 ? cn[(int64_t)gy * sch + ro] : 0.0f;
-        const float ut = uo >= 0 ? cn[(int64_t)uo * sch + gx] : 0.0f;
-        const float dt = 0.0f;                              // dead downward search (my_lib_kernel.cu:1799)
-        if (lt + rt + ut + dt <= 0.0f) continue;
-        const float fl = lt > 0.0f ? 1.0f : 0.0f, fr = rt > 0.0f ? 1.0f : 0.0f;
-        const float fu = ut > 0.0f ? 1.0f : 0.0f, fd = 0.0f;
-        // a walk that found nothing ends at the border cell (column 0 / W-1, row 0): its flag is 0, but the
-        // reference still multiplies that cell's value by it -- keep the operand finite and identical
-        const int lc = lo >= 0 ? lo : 0, rc = ro >= 0 ? ro : W - 1, ur = uo >= 0 ? uo : 0;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            float *pl = o + k * s1c;
-            float *self = pl + (int64_t)gy * s1h + gx;
-            *self = (fl * pl[(int64_t)gy * s1h + lc] + fr * pl[(int64_t)gy * s1h + rc] +
-                     fu * pl[(int64_t)ur * s1h + gx] + fd * *self) / (fl + fr + fu + fd);
-        }
-    }
-    __syncthreads();                                        // the LDS tile and list are reused by the next tile
-    }   // listed tiles
-}
+#endif  // MEMC_MEASURE
 
 // general path, queued behind proj_owner: each kernel returns at once unless a far source was seen
 __global__ __launch_bounds__(256) void proj_redo_zero(int W, int H, int64_t s1b, int64_t s1c, int s1h, int64_t scb,
@@ -1068,50 +1326,200 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
     if (DEPTH) *reinterpret_cast<f32x4 *>(g2p) = acc_d;
 }
 
-static int g_proj_variant = -1;
+MEMC_KNOB_STATIC(g_proj_variant, -1);          // measurement build only (memc_common.hpp)
 
-// The fast path needs a few device words (per-image far flags) that outlive a kernel: 40 KiB per device,
-// allocated on first use and kept for the life of the process (the only state in the library; it carries no
-// information from one call to the next -- every call clears it on its own stream first).  Returns nullptr if
-// the allocation is impossible (e.g. inside a stream capture): the caller then uses the general path.
-static int *far_flag_for_current_device()
+// Owner kernel geometry of the product build (measured): tile height and stripe width of the walk.
+constexpr int kOwnerTH = 32, kOwnerSW = 4;
+
+// The forward pass needs a few device words that outlive a kernel (per-image "far source" flags of the fast path)
+// and, with hole filling, the filler's carry tables: ONE stream-ordered allocation per call, released in stream
+// order before the call returns (hipFreeAsync) -- nothing is shared between calls, streams or threads.  It comes
+// from a private memory pool per device (created on first use, kept for the life of the process, release threshold
+// "never": with the default threshold a pool hands its memory back at every synchronisation and the next call pays
+// for a fresh allocation, measured +200 us); the device's default pool and its attributes are left alone.
+static hipMemPool_t pool_for_device(int dev)
 {
     static std::mutex mu;
-    static int *flags[64] = {nullptr};
-    static unsigned next[64] = {0};
-    constexpr unsigned kSlots = 32, kSlotWords = 320;   // calls rotate over 32 flag blocks (concurrent streams)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    static hipMemPool_t pools[64] = {};
+    static bool tried[64] = {};
+    if (dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    if (!flags[dev]) {
-        void *p = nullptr;
-        if (hipMalloc(&p, kSlots * kSlotWords * sizeof(int)) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
+    if (!tried[dev]) {
+        tried[dev] = true;
+        hipMemPoolProps props = {};
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        hipMemPool_t pool = nullptr;
+        if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
+            uint64_t keep = UINT64_MAX;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            pools[dev] = pool;
         }
-        flags[dev] = static_cast<int *>(p);
+        (void)hipGetLastError();
     }
-    return flags[dev] + (next[dev]++ % kSlots) * kSlotWords;
+    return pools[dev];
 }
 
-// hipMallocAsync serves the hole filler's workspace from the device's default memory pool; with the default
-// release threshold (0) the pool hands its memory back at every synchronisation and the next call pays for a
-// fresh allocation (measured: +200 us on some calls).  Once per device: let the pool keep what it has.
-static void keep_pool_memory()
-{
-    static std::mutex mu;
-    static bool done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
-    std::lock_guard<std::mutex> lock(mu);
-    if (done[dev]) return;
-    done[dev] = true;
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-        uint64_t keep = UINT64_MAX;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+// stream-ordered scratch of one call; freed (in stream order) when it goes out of scope, on every exit path
+struct CallScratch {
+    void *p = nullptr;
+    hipStream_t stream = nullptr;
+    bool alloc(size_t bytes, hipStream_t s)
+    {
+        stream = s;
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &capture);
+        if (capture != hipStreamCaptureStatusNone) return false;      // no allocation inside a stream capture
+        int dev = -1;
+        if (hipStreamGetDevice(s, &dev) != hipSuccess) {              // the STREAM's device, not the current one
+            (void)hipGetLastError();
+            if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        }
+        hipMemPool_t pool = pool_for_device(dev);
+        hipError_t e = pool ? hipMallocFromPoolAsync(&p, bytes, pool, s) : hipMallocAsync(&p, bytes, s);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+        }
+        return p != nullptr;
     }
-    (void)hipGetLastError();
+    ~CallScratch()
+    {
+        if (p) (void)hipFreeAsync(p, stream);
+    }
+};
+
+struct ProjArgs {
+    hipStream_t stream;
+    int w, h, batch, fillhole;
+    int s1b, s1c, s1h, sdb, sdh, scb, sch;
+    const float *flow, *depth;
+    float *count, *out;
+};
+
+// vectorised forward: owner-computes fast path + the general path behind its far flag (+ hole filling), with the
+// tile height TH of the owner kernel and the filler.  variant: measurement build only (-1 otherwise).
+template <bool DEPTH, int TH>
+static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
+{
+    using A = AccGeom<16>;
+    const hipStream_t stream = a.stream;
+    const int w = a.w, h = a.h, batch = a.batch;
+    const int ntx = (w + 63) / 64, nty = (h + TH - 1) / TH;
+    const unsigned ntiles = (unsigned)ntx * nty * batch;
+    const int snty = (h + 15) / 16;                          // the general path scatters from 64x16 SOURCE tiles
+    const unsigned sntiles = (unsigned)ntx * snty * batch;
+    const unsigned gs = 256 * 8;                             // grid-stride: 8 workgroups per CU
+    const int64_t s1b = a.s1b, s1c = a.s1c, sdb = a.sdb, scb = a.scb;
+    const int s1h = a.s1h, sdh = a.sdh, sch = a.sch;
+
+    // (the owner kernel addresses the flow / depth planes with 32-bit offsets)
+    const bool want_fast = variant != 1 && variant < 2 && plane_fits_u32(w, h, {s1h, sdh});
+    const bool want_carry = a.fillhole && variant != -8 && variant != -9;
+    // scratch layout (ints): [0, 320) far flags (image b -> word b % 256, word 256 = "any"), [320, 576) list fill
+    // counts, then -- with hole filling -- the three carry tables and the hole-tile list
+    constexpr size_t kHead = 320 + kListSegs;
+    const size_t n_up = (size_t)batch * nty * w, n_row = (size_t)batch * h * ntx;
+    const int cap = 2 * (int)((ntiles + kListSegs - 1) / kListSegs) + 2;          // (a tile can be listed twice)
+    const size_t ints = kHead + (want_carry ? n_up + 2 * n_row + (size_t)kListSegs * cap : 0);
+    CallScratch scratch;
+    int *flag = nullptr;
+    FillWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if ((want_fast || want_carry) && scratch.alloc(ints * sizeof(int), stream)) {
+        int *base = static_cast<int *>(scratch.p);
+        if (hipMemsetAsync(base, 0, kHead * sizeof(int), stream) != hipSuccess) return -1;
+        if (want_fast) flag = base;
+        if (want_carry) {
+            ws.n_list = base + 320;
+            ws.up = base + kHead;
+            ws.left = ws.up + n_up;
+            ws.right = ws.left + n_row;
+            ws.list = ws.right + n_row;
+            ws.cap = cap;
+        }
+    }
+    // Without scratch (inside a stream capture, or the allocation failed): the general path on its own and the
+    // literal hole walker -- slower, same results.
+
+#define MEMC_PROJ_SCATTER(ABL, FLAG)                                                                        \
+    hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3((FLAG) != nullptr && sntiles > gs ? gs : sntiles), \
+                       dim3(256), 4 * A::kPlane * 4 + 64, stream, w, h, ntx, snty, sntiles, s1b, s1c, s1h, sdb, sdh,  \
+                       scb, sch, a.flow, a.depth, a.count, a.out, FLAG)
+    bool only_part = false;                                  // measurement arms that time one piece
+    if (flag) {
+        // fast path: owner-computes (no atomics, fused averaging, hole-filler summaries for free) + the general
+        // path behind a device flag
+        bool launched = false;
+#ifdef MEMC_MEASURE
+        if (variant == -10 || variant == -7 || variant == -6) {       // round-1 owner kernel (64x16, strips)
+            const unsigned nwg = ntiles;
+#define MEMC_PROJ_OWNER(REACH, TRACE)                                                                              \
+            hipLaunchKernelGGL((proj_owner<DEPTH, REACH, TRACE>), dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, s1b, \
+                               s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag, ws)
+            if (TH == 16) {
+                if (variant == -7) MEMC_PROJ_OWNER(24, true);
+                else if (variant == -6) MEMC_PROJ_OWNER(16, false);
+                else MEMC_PROJ_OWNER(24, false);
+                launched = true;
+            }
+#undef MEMC_PROJ_OWNER
+        }
+        only_part = variant == -5 || variant == -7;
+#endif
+        if (!launched)
+            hipLaunchKernelGGL((proj_owner2<DEPTH, TH, 24>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(16 * TH), 0,
+                               stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
+                               a.out, flag, ws, sw);
+        if (launch_status() != 0) return -1;
+        if (!only_part) {
+            hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
+                               a.count, a.out, flag);
+            MEMC_PROJ_SCATTER(0, flag);
+            hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
+                               a.count, a.out, flag);
+            if (ws.up)                          // summaries of the images the general path redid
+                hipLaunchKernelGGL(proj_fill_summary<TH>, dim3(gs), dim3(256), 0, stream, w, h, ntx, nty, batch, scb,
+                                   sch, a.count, ws, flag);
+            if (launch_status() != 0) return -1;
+        }
+    } else {
+        // the general path on its own: it DEFINES count and output (zero, scatter, average), it does not rely on
+        // the caller's zero fill
+#ifdef MEMC_MEASURE
+        only_part = variant >= 2;               // (the ablation arms 2 / 3 time the scatter pass alone)
+        if (variant == 2) MEMC_PROJ_SCATTER(2, (const int *)nullptr);
+        else if (variant == 3) MEMC_PROJ_SCATTER(3, (const int *)nullptr);
+#endif
+        if (!only_part) {
+            hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
+                               a.count, a.out, (const int *)nullptr);
+            MEMC_PROJ_SCATTER(0, (const int *)nullptr);
+            hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
+                               a.count, a.out, (const int *)nullptr);
+            if (ws.up)
+                hipLaunchKernelGGL(proj_fill_summary<TH>, dim3(gs), dim3(256), 0, stream, w, h, ntx, nty, batch, scb,
+                                   sch, a.count, ws, (const int *)nullptr);
+        }
+        if (launch_status() != 0) return -1;
+    }
+#undef MEMC_PROJ_SCATTER
+    if (a.fillhole && !only_part) {
+        if (ws.up) {
+            const unsigned lanes = (unsigned)(((size_t)batch * (w + h) + 255) / 256);
+            hipLaunchKernelGGL(proj_fill_scan, dim3(lanes), dim3(256), 0, stream, w, h, ntx, nty, batch, ws);
+            // one workgroup per tile of the image (rounded up to whole segments); those beyond their segment's
+            // fill count leave at once
+            hipLaunchKernelGGL(proj_fillhole_carry<TH>, dim3((ntiles + kListSegs - 1) / kListSegs * kListSegs),
+                               dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c, s1h, scb, sch, a.count, a.out, ws);
+        } else {
+            hipLaunchKernelGGL(proj_fillhole_v4, dim3(sntiles), dim3(256), 0, stream, w, h, ntx, snty, s1b, s1c, s1h,
+                               scb, sch, a.count, a.out, variant == -8 ? 1 : 0);
+        }
+        if (launch_status() != 0) return -1;
+    }
+    return 0;
 }
 
 template <bool DEPTH>
@@ -1122,103 +1530,24 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
     const bool vec = vec4_ok(w, {s1b, s1c, s1h, sdb, sdh, scb, sch}, {flow, depth, count, out});
     if (vec && g_proj_variant != 0) {
-        using G = TileGeom<16>;
-        using A = AccGeom<16>;
-        const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-        const unsigned nwg = (unsigned)ntx * nty * batch;
-        const unsigned gs = 256 * 8;                      // grid-stride: 8 workgroups per CU
-#define MEMC_PROJ_SCATTER(ABL, FLAG)                                                                        \
-    hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3((FLAG) != nullptr && nwg > gs ? gs : nwg), dim3(256), \
-                       4 * A::kPlane * 4 + 64, stream, w, h, ntx, nty, nwg, (int64_t)s1b, (int64_t)s1c, s1h,       \
-                       (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, FLAG)
-        // (the owner kernel addresses the flow / depth planes with 32-bit offsets)
-        int *flag = (g_proj_variant == 1 || g_proj_variant >= 2 || !plane_fits_u32(w, h, {s1h, sdh}))
-                        ? nullptr : far_flag_for_current_device();                  // -1, -5, -8, -9: fast path
-        // workspace of the carry-based hole filler (see proj_fillhole_carry): stream-ordered, released below.
-        // Not to be had inside a stream capture or when the allocation fails -> the literal walker instead
-        // (also the measurement arms -8 / -9).
-        FillWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-        void *wsp = nullptr;
-        if (fillhole && g_proj_variant != -8 && g_proj_variant != -9) {
-            hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(stream, &capture);
-            const size_t n_up = (size_t)batch * nty * w, n_row = (size_t)batch * h * ntx, n_tile = (size_t)batch * nty * ntx;
-            const int cap = 2 * (int)((n_tile + kListSegs - 1) / kListSegs) + 2;       // (a tile can be listed twice)
-            const size_t bytes = (n_up + 2 * n_row + kListSegs + (size_t)kListSegs * cap) * sizeof(int);
-            keep_pool_memory();
-            if (capture == hipStreamCaptureStatusNone && hipMallocAsync(&wsp, bytes, stream) == hipSuccess) {
-                ws.up = static_cast<int *>(wsp);
-                ws.left = ws.up + n_up;
-                ws.right = ws.left + n_row;
-                ws.n_list = ws.right + n_row;
-                ws.list = ws.n_list + kListSegs;
-                ws.cap = cap;
-                if (hipMemsetAsync(ws.n_list, 0, kListSegs * sizeof(int), stream) != hipSuccess) return -1;
-            } else {
-                (void)hipGetLastError();
-                wsp = nullptr;
-            }
+        const ProjArgs a = {stream, w, h, batch, fillhole, s1b, s1c, s1h, sdb, sdh, scb, sch, flow, depth, count, out};
+#ifdef MEMC_MEASURE
+        // 100 + 10 * log2(TH / 16) + stripe width: owner geometry under test; -10 / -7 / -6: the round-1 owner
+        int v = g_proj_variant, th = kOwnerTH, sw = kOwnerSW;
+        if (v >= 100 && v < 130) {
+            th = 16 << ((v - 100) / 10);
+            sw = (v - 100) % 10;
+            v = -1;
+        } else if (v == -10 || v == -7 || v == -6) {
+            th = 16;
+            sw = 0;
         }
-        int status = 0;
-        if (flag) {
-            // fast path: owner-computes (no atomics, fused averaging, hole-filler summaries for free) + the general
-            // path behind a device flag
-            if (hipMemsetAsync(flag, 0, (kFlagWords + 1) * sizeof(int), stream) != hipSuccess) status = -1;
-#define MEMC_PROJ_OWNER(REACH, TRACE)                                                                              \
-    hipLaunchKernelGGL((proj_owner<DEPTH, REACH, TRACE>), dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b, \
-                       (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count, out, flag, ws)
-            if (g_proj_variant == -7) MEMC_PROJ_OWNER(24, true);
-            else if (g_proj_variant == -6) MEMC_PROJ_OWNER(16, false);
-            else MEMC_PROJ_OWNER(24, false);
-#undef MEMC_PROJ_OWNER
-            if (launch_status() != 0) status = -1;
-            if (status == 0 && g_proj_variant != -5 && g_proj_variant != -7) {     // (-5 / -7: owner kernel alone)
-                hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
-                                   s1h, (int64_t)scb, sch, batch, count, out, flag);
-                MEMC_PROJ_SCATTER(0, flag);
-                hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
-                                   s1h, (int64_t)scb, sch, batch, count, out, flag);
-                if (ws.up)                      // summaries of the images the general path redid
-                    hipLaunchKernelGGL(proj_fill_summary, dim3(gs), dim3(256), 0, stream, w, h, ntx, nty, batch,
-                                       (int64_t)scb, sch, count, ws, flag);
-                if (launch_status() != 0) status = -1;
-            }
-        } else {
-            if (g_proj_variant < 2)             // (the ablation arms 2 / 3 time the scatter pass alone)
-                hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
-                                   s1h, (int64_t)scb, sch, batch, count, out, (const int *)nullptr);
-            if (g_proj_variant == 2) MEMC_PROJ_SCATTER(2, nullptr);
-            else if (g_proj_variant == 3) MEMC_PROJ_SCATTER(3, nullptr);
-            else MEMC_PROJ_SCATTER(0, nullptr);
-            if (launch_status() != 0) status = -1;
-            if (status == 0 && g_proj_variant < 2) {         // (ablation arms time the scatter pass alone)
-                hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, (int64_t)s1b, (int64_t)s1c,
-                                   s1h, (int64_t)scb, sch, batch, count, out, nullptr);
-                if (ws.up)
-                    hipLaunchKernelGGL(proj_fill_summary, dim3(gs), dim3(256), 0, stream, w, h, ntx, nty, batch,
-                                       (int64_t)scb, sch, count, ws, (const int *)nullptr);
-                if (launch_status() != 0) status = -1;
-            }
-        }
-#undef MEMC_PROJ_SCATTER
-        const bool only_part = g_proj_variant == -5 || g_proj_variant == -7 || g_proj_variant >= 2;
-        if (status == 0 && fillhole && !only_part) {
-            if (ws.up) {
-                const unsigned lanes = (unsigned)(((size_t)batch * (w + h) + 255) / 256);
-                hipLaunchKernelGGL(proj_fill_scan, dim3(lanes), dim3(256), 0, stream, w, h, ntx, nty, batch, ws);
-                // one workgroup per tile of the image (rounded up to whole segments); those beyond their segment's
-                // fill count leave at once (~10 us for all of them)
-                hipLaunchKernelGGL(proj_fillhole_carry, dim3((nwg + kListSegs - 1) / kListSegs * kListSegs), dim3(256), 0,
-                                   stream, w, h, ntx, nty,
-                                   batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)scb, sch, count, out, ws);
-            } else {
-                hipLaunchKernelGGL(proj_fillhole_v4, dim3(nwg), dim3(256), 0, stream, w, h, ntx, nty, (int64_t)s1b,
-                                   (int64_t)s1c, s1h, (int64_t)scb, sch, count, out, g_proj_variant == -8 ? 1 : 0);
-            }
-            if (launch_status() != 0) status = -1;
-        }
-        if (wsp) (void)hipFreeAsync(wsp, stream);
-        return status;
+        if (th == 16) return run_proj_fwd<DEPTH, 16>(a, sw, v);
+        if (th == 64) return run_proj_fwd<DEPTH, 64>(a, sw, v);
+        return run_proj_fwd<DEPTH, 32>(a, sw, v);
+#else
+        return run_proj_fwd<DEPTH, kOwnerTH>(a, kOwnerSW, -1);
+#endif
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
@@ -1256,9 +1585,12 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
                            h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow,   \
                            depth, count, fwd_out, gout, gin1, gin2, sw)
         // 39 KiB of staged cells instead of 48 -> 4 workgroups per CU: 205 -> 180 us (depth 271 -> 256), same results
+#ifdef MEMC_MEASURE
         if (g_cap_sel == 0) MEMC_PROJ_BWD(3072);
         else if (g_cap_sel == 2) MEMC_PROJ_BWD(1984);          // 5 per CU
-        else MEMC_PROJ_BWD(2496);
+        else
+#endif
+        MEMC_PROJ_BWD(2496);
 #undef MEMC_PROJ_BWD
         return launch_status();
     }
@@ -1274,12 +1606,14 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
 
 using namespace memc;
 
+#ifdef MEMC_MEASURE
 extern "C" void memc_debug_set_projection_variant(int v) { g_proj_variant = v; }
 extern "C" int memc_debug_set_trace_buffer_proj(void *p)
 {
     unsigned long long *q = (unsigned long long *)p;
     return hipMemcpyToSymbol(HIP_SYMBOL(memc::g_trace_buf_proj), &q, sizeof(q)) == hipSuccess ? 0 : -1;
 }
+#endif
 
 extern "C" int FlowProjection_gpu_forward_kernel(
     memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,

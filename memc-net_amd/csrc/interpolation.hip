@@ -371,9 +371,12 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
         if (channel == 3) {
             // 39 KiB instead of 48: 4 workgroups per CU.  The kernel is bound by the latency of a tile's serial chain
             // (1 / 2 / 3 per CU: 483 / 280 / 215 us), its 2x2 footprint rarely needs the rows given up: 218 -> 190 us
+#ifdef MEMC_MEASURE
             if (g_cap_sel == 0) MEMC_BL_FWD(3, 3072);
             else if (g_cap_sel == 2) MEMC_BL_FWD(3, 1984);     // 5 per CU: 198-202 us
-            else MEMC_BL_FWD(3, 2496);
+            else
+#endif
+            MEMC_BL_FWD(3, 2496);
         } else {
             MEMC_BL_FWD(0, 3072);
         }
@@ -410,8 +413,11 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
                            (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, gradoutput, gradinput1, gradinput2, sw)
         // the smaller budget LOSES here (522 -> 601 us): the fixed-pitch accumulator plane gets 26 rows instead of 32
         // and the sites beyond them scatter with global atomics
+#ifdef MEMC_MEASURE
         if (g_cap_sel == 1) MEMC_BL_BWD(2496);
-        else MEMC_BL_BWD(3072);
+        else
+#endif
+        MEMC_BL_BWD(3072);
 #undef MEMC_BL_BWD
         return launch_status();
     }
@@ -432,12 +438,14 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
 
 using namespace memc;
 
+#ifdef MEMC_MEASURE
 int memc::g_tile_walk_sw = -1;
 int memc::g_extra_lds = 0;
 int memc::g_cap_sel = -1;
 extern "C" void memc_debug_set_bl_cap(int which) { memc::g_cap_sel = which; }
 extern "C" void memc_debug_set_extra_lds(int bytes) { memc::g_extra_lds = bytes > 0 ? bytes : 0; }
 extern "C" void memc_debug_set_walk(int stripe_width) { memc::g_tile_walk_sw = stripe_width; }
+#endif
 
 extern "C" int InterpolationLayer_gpu_forward_kernel(
     memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,

@@ -90,7 +90,11 @@ int bilinear_backward(bool require_c3, memc_stream_t stream, const memc_tensor4 
 
 extern "C" {
 
-const char *memc_hip_version(void) { return "memc_hip 0.1 gfx950"; }
+#ifdef MEMC_MEASURE
+const char *memc_hip_version(void) { return "memc_hip 0.2 gfx950 MEASUREMENT BUILD (ablation arms present)"; }
+#else
+const char *memc_hip_version(void) { return "memc_hip 0.2 gfx950"; }
+#endif
 
 int InterpolationLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
                                    const memc_tensor4 *input2, const memc_tensor4 *output)

@@ -147,14 +147,29 @@ inline unsigned walk_grid(int tiles_x, int tiles_y, int batch, int sw)
     return (unsigned)cols * tiles_y * batch;
 }
 
-extern int g_tile_walk_sw;                                 // measurement knob (memc_debug_set_walk); < 0: the default below
+// Measurement knobs.  They exist only in the MEASUREMENT build (-DMEMC_MEASURE -> lib/libmemc_hip_measure.so, used by
+// tools/ and by the tests that force a particular kernel).  In the product build (libmemc_hip.so) every knob is a
+// compile-time constant at its default: the ablation arms -- some of which return wrong results by construction --
+// are not even instantiated, no memc_debug_* symbol is exported and nothing is read from the environment.
+#ifdef MEMC_MEASURE
+#define MEMC_KNOB_STATIC(name, dflt) static int name = dflt
+extern int g_tile_walk_sw;                                 // memc_debug_set_walk; < 0: the default below
+#else
+#define MEMC_KNOB_STATIC(name, dflt) static constexpr int name = dflt
+constexpr int g_tile_walk_sw = -1;
+#endif
 // Default: one tile column per XCD strip (0).  Stripes n tile columns wide keep horizontal neighbours on one XCD:
 // measured on the bilinear warp / projection backward (rocprofv3 FETCH_SIZE, tools/probes/pmc_walk.py) they read 22 %
 // less (865 -> 677 MB) but run within +-2 % of the strips (those kernels are latency-, not traffic-bound), so the
 // strips stay.
 constexpr int kDefaultStripe = 0;
-extern int g_cap_sel;                                      // measurement knob: LDS staging budget of the 2x2-footprint kernels
+#ifdef MEMC_MEASURE
+extern int g_cap_sel;                                      // LDS staging budget of the 2x2-footprint kernels
 extern int g_extra_lds;                                    // occupancy experiment: unused dynamic LDS added to bl_fwd_tiled<3>
+#else
+constexpr int g_cap_sel = -1;
+constexpr int g_extra_lds = 0;
+#endif
 
 // Streaming accesses: every filter-tap / flow / output element is touched exactly once per launch,
 // so keep it from displacing the (re-used) source-image lines in L1/L2.

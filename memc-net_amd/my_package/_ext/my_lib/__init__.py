@@ -59,8 +59,8 @@ def _describe(t, name):
     return d
 
 
-def _bind(symbol, n_tensors, trailing_int=False):
-    cfunc = getattr(_lib, symbol)
+def _bind(symbol, n_tensors, trailing_int=False, lib=None):
+    cfunc = getattr(lib if lib is not None else _lib, symbol)
     cfunc.restype = ctypes.c_int
     cfunc.argtypes = ([ctypes.c_void_p] + [ctypes.POINTER(_Tensor4)] * n_tensors
                       + ([ctypes.c_int] if trailing_int else []))
@@ -122,19 +122,3 @@ for _name in list(_SYMBOLS):
     _cpu = _name.replace("_gpu_", "_cpu_")
     globals()[_cpu] = _cpu_unavailable(_cpu)
     __all__.append(_cpu)
-
-
-# measurement hooks (csrc/memc_internal.h); used by tools/bench_ops.py only
-_lib.memc_debug_set_fi_fwd_variant.argtypes = [ctypes.c_int]
-_lib.memc_debug_set_fi_fwd_variant.restype = None
-_lib.memc_debug_set_projection_variant.argtypes = [ctypes.c_int]
-_lib.memc_debug_set_projection_variant.restype = None
-
-
-def _debug_set_variant(op, variant):
-    {"fi_fwd": _lib.memc_debug_set_fi_fwd_variant,
-     "fi_bwd": _lib.memc_debug_set_fi_bwd_variant,
-     "projection": _lib.memc_debug_set_projection_variant,
-     "walk": _lib.memc_debug_set_walk,
-     "extra_lds": _lib.memc_debug_set_extra_lds,
-     "bl_cap": _lib.memc_debug_set_bl_cap}[op](int(variant))

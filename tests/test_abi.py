@@ -103,3 +103,66 @@ def test_empty_batch_is_a_no_op(lib):
     f.restype = ctypes.c_int
     e = lambda c: desc((0, c, 8, 8), data=0)     # noqa: E731
     assert f(None, P(e(3)), P(e(2)), P(e(16)), P(e(3))) == 0
+
+
+def _exported(path):
+    """Dynamic symbols a shared library DEFINES (nm -D --defined-only), as {name: type letter}."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, text=True, check=True).stdout
+    syms = {}
+    for line in out.splitlines():
+        parts = line.split()
+        if len(parts) == 3:
+            syms[parts[2]] = parts[1]
+    return syms
+
+
+def _is_hip_plumbing(name):
+    # host-side handles of the __global__ kernels (C++-mangled, namespace memc) and hipcc's fat-binary bookkeeping
+    return name.startswith("_ZN4memc") or name.startswith("__hip_")
+
+
+def test_product_library_exports_exactly_the_header(hip_lib_path):
+    """The shipped library is built -fvisibility=hidden: its C surface is include/memc_warp.h, nothing more -- in
+    particular no memc_debug_* measurement hook (those live in libmemc_hip_measure.so only)."""
+    syms = _exported(hip_lib_path)
+    c_surface = sorted(n for n in syms if not _is_hip_plumbing(n))
+    assert c_surface == sorted(declared_symbols()), set(c_surface) ^ set(declared_symbols())
+    assert not [n for n in syms if "debug" in n]
+
+
+def test_product_library_has_no_measurement_arms(hip_lib_path):
+    """No ablation / A-B kernel (several return wrong results by construction), no environment lookup."""
+    syms = _exported(hip_lib_path)
+    blob = open(hip_lib_path, "rb").read()
+    for marker in (b"MEMC_FI_FWD_VARIANT", b"getenv"):
+        assert marker not in blob, marker
+    kernels = [n for n in syms if n.startswith("_ZN4memc")]
+    assert kernels, "kernel handles expected"
+    for k in kernels:
+        for arm in ("fi_fwd_refshape", "persistent", "10proj_ownerI"):
+            assert arm not in k, k
+    # the tiled FI forward exists in exactly its production instantiations (ABL == 0 is the last template argument)
+    fwd = [k for k in kernels if "16fi_fwd_tiled_fs4" in k]
+    assert fwd and all(k.split("EEEv")[0].endswith("Li0") for k in fwd), fwd
+    bwd = [k for k in kernels if "15fi_bwd_tiled_c3" in k]
+    assert bwd == [k for k in bwd if "ILi0ELi2EEE" in k], bwd
+
+
+def test_measurement_library_is_separate_and_says_so(hip_lib_path):
+    import os
+    path = os.path.join(os.path.dirname(hip_lib_path), "libmemc_hip_measure.so")
+    if not os.path.exists(path):
+        pytest.skip("measurement build not present")
+    syms = _exported(path)
+    assert "memc_debug_set_projection_variant" in syms and "memc_debug_set_fi_fwd_variant" in syms
+    m = ctypes.CDLL(path)
+    m.memc_hip_version.restype = ctypes.c_char_p
+    assert b"MEASUREMENT" in m.memc_hip_version()
+    # nothing under the product package refers to it
+    root = os.path.join(ROOT, "memc-net_amd")
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "measure" not in text.lower(), os.path.join(dirpath, f)

@@ -295,7 +295,8 @@ def test_tile_walks_and_staging_budgets(oracle, case):
     """The 2x2-footprint kernels take their tile walk (strips / stripes of n tile columns per XCD) and their LDS
     staging budget (48 / 39 / 31 KiB) from measurement knobs; every combination must give the oracle's results
     (a smaller budget only moves sites from the staged to the global-gather path)."""
-    import my_package._ext.my_lib as my_lib
+    from tools import measure as M          # forced paths exist in the measurement build only
+    my_lib = M.bound()                      # (the same sources, -DMEMC_MEASURE; my_package stays on the product library)
     d = make(case)
     if d["x"].shape[1] != 3:
         pytest.skip("RGB kernels")
@@ -308,8 +309,8 @@ def test_tile_walks_and_staging_budgets(oracle, case):
     want_q1, want_q2 = oracle.depth_flow_projection_backward(d["flow"], d["depth"], dcnt, dout, d["gflow"])
     try:
         for walk, cap in ((0, 0), (2, 1), (4, 2), (3, -1), (-1, 1)):
-            my_lib._debug_set_variant("walk", walk)
-            my_lib._debug_set_variant("bl_cap", cap)
+            M.set_variant("walk", walk)
+            M.set_variant("bl_cap", cap)
             tag = "walk %d budget %d" % (walk, cap)
             o = torch.full_like(x, float("nan"))
             assert my_lib.InterpolationLayer_gpu_forward(x, f, o) == 0
@@ -326,8 +327,8 @@ def test_tile_walks_and_staging_budgets(oracle, case):
             close(N(q1), want_q1, "depth projection gradinput1, " + tag, RTOL)
             close(N(q2), want_q2, "depth projection gradinput2, " + tag, RTOL)
     finally:
-        my_lib._debug_set_variant("walk", -1)
-        my_lib._debug_set_variant("bl_cap", -1)
+        M.set_variant("walk", -1)
+        M.set_variant("bl_cap", -1)
 
 
 def test_tensors_beyond_2G_elements():
@@ -603,14 +604,17 @@ def test_projection_forward_needs_no_zero_fill(oracle, case):
     """(Depth)FlowProjection forward DEFINES count and output on every path (owner-computes fast path, the general
     path behind its far flag or on its own, the scalar kernels of odd widths): the Python layer passes
     uninitialised buffers.  NaN-filled buffers through the C ABI, every path forced in turn."""
-    import my_package._ext.my_lib as my_lib
+    from tools import measure as M          # forced paths exist in the measurement build only
+    my_lib = M.bound()                      # (the same sources, -DMEMC_MEASURE; my_package stays on the product library)
     d = make(case)
     f, dep = T(d["flow"]), T(d["depth"])
     want = {fh: oracle.flow_projection_forward(d["flow"], fh) for fh in (0, 1)}
     dwant = oracle.depth_flow_projection_forward(d["flow"], d["depth"], 1)
     try:
-        for variant in (-1, 1, 0):                       # automatic (fast path where it applies), general, scalar
-            my_lib._debug_set_variant("projection", variant)
+        # automatic (fast path where it applies), general, scalar; then the owner kernel's geometries (tile height
+        # 16 / 32 / 64 x walk in strips / stripes 2 / 4 tile columns wide) and the round-1 owner kernel
+        for variant in (-1, 1, 0, 100, 104, 110, 112, 120, 124, -10):
+            M.set_variant("projection", variant)
             for fh in (0, 1):
                 cnt = torch.full((f.shape[0], 1, f.shape[2], f.shape[3]), float("nan"), device=dev())
                 out = torch.full_like(f, float("nan"))
@@ -623,7 +627,7 @@ def test_projection_forward_needs_no_zero_fill(oracle, case):
             close(N(cnt), dwant[1], "depth count variant %d" % variant, RTOL)
             close(N(out), dwant[0], "depth out variant %d" % variant)
     finally:
-        my_lib._debug_set_variant("projection", -1)
+        M.set_variant("projection", -1)
 
 
 @pytest.mark.parametrize("shift", [(10.3, 0.0), (7.5, -5.2), (-12.0, 9.0), (0.0, 20.0)])
@@ -631,7 +635,8 @@ def test_hole_filling_on_camera_pans(oracle, shift):
     """A pan leaves an uncovered strip along one or two image borders: holes whose walks run the whole length of
     the strip (the carry tables of proj_fillhole_carry), and holes with no neighbour at all in a direction.
     Both hole fillers -- the carry-based one and the literal walker kept for stream captures -- against the oracle."""
-    import my_package._ext.my_lib as my_lib
+    from tools import measure as M          # forced paths exist in the measurement build only
+    my_lib = M.bound()                      # (the same sources, -DMEMC_MEASURE; my_package stays on the product library)
     rng = np.random.default_rng(41)
     B, H, W = 2, 100, 196
     flow = np.empty((B, 2, H, W), np.float32)
@@ -641,11 +646,12 @@ def test_hole_filling_on_camera_pans(oracle, shift):
     assert (want_cnt == 0).mean() > 0.02                         # the strip is there
     f = T(flow)
     try:
-        for variant in (-1, -9, 1):                              # carry filler, literal walker, general path + carries
-            my_lib._debug_set_variant("projection", variant)
+        # carry filler, literal walker, general path + carries; carry filler over 16 / 32 / 64-row bands
+        for variant in (-1, -9, 1, 100, 114, 124, -10):
+            M.set_variant("projection", variant)
             cnt, out = torch.full((B, 1, H, W), float("nan"), device=dev()), torch.full_like(f, float("nan"))
             assert my_lib.FlowProjectionLayer_gpu_forward(f, cnt, out, 1) == 0
             assert np.array_equal(N(cnt), want_cnt), variant
             close(N(out), want_out, "pan %s variant %d" % (shift, variant))
     finally:
-        my_lib._debug_set_variant("projection", -1)
+        M.set_variant("projection", -1)

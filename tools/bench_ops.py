@@ -22,6 +22,8 @@ for _p in (ROOT, os.path.join(ROOT, "memc-net_amd")):
 import torch  # noqa: E402
 
 import my_package._ext.my_lib as L  # noqa: E402
+from tools import measure as M  # noqa: E402
+M.use()                             # the measurement build: ablation / A-B arms live only there
 from tools import synth  # noqa: E402
 
 PEAK = 8.0e12
@@ -71,7 +73,7 @@ def bench_fi_fwd(rows, dev, B, C, H, W, flow_kind, variants, tag, rounds=4):
     x, f, k = t["x"], t["flow"], t["filt"]
     out = torch.zeros_like(x)
     fn = lambda: L.FilterInterpolationLayer_gpu_forward(x, f, k, out)   # noqa: E731
-    L._debug_set_variant("fi_fwd", variants[0])
+    M.set_variant("fi_fwd", variants[0])
     for _ in range(max(20, int(0.08 / max(1e-5, time_launches(fn, warmup=1, iters=3)[0])))):   # ~80 ms pre-warm
         fn()
     samples = {v: [] for v in variants}
@@ -79,7 +81,7 @@ def bench_fi_fwd(rows, dev, B, C, H, W, flow_kind, variants, tag, rounds=4):
     ref = None
     for _ in range(rounds if len(variants) > 1 else 1):
         for v in variants:
-            L._debug_set_variant("fi_fwd", v)
+            M.set_variant("fi_fwd", v)
             for _ in range(2):
                 fn()
             torch.cuda.synchronize()
@@ -99,7 +101,7 @@ def bench_fi_fwd(rows, dev, B, C, H, W, flow_kind, variants, tag, rounds=4):
                                                                        " (bursts of 20)" if B * H * W < 4e6 else ""),
                B * H * W, 4 * (2 * C + 2 + 16), statistics.median(samples[v]), min(samples[v]),
                {"variant": v, "matches_first_variant": same[v]})
-    L._debug_set_variant("fi_fwd", -1)
+    M.set_variant("fi_fwd", -1)
 
 
 def bench_fi_blend(rows, dev, B, H, W, flow_kind):
@@ -130,12 +132,12 @@ def bench_fi_bwd(rows, dev, B, C, H, W, flow_kind, tag, variants=()):
         g1.zero_(); g2.zero_(); g3.zero_()
     burst = 20 if B * H * W < 4e6 else 1
     for v in variants:
-        L._debug_set_variant("fi_bwd", v)
+        M.set_variant("fi_bwd", v)
         med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre,
                                 burst=burst)
         report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s ABLATION variant=%d" % (tag, C, B, H, W, flow_kind, v),
                B * H * W, 4 * (3 * C + 2 * (2 + 16)), med, mn)
-    L._debug_set_variant("fi_bwd", -1)
+    M.set_variant("fi_bwd", -1)
     med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre, burst=burst)
     report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s%s" % (tag, C, B, H, W, flow_kind, " (bursts of 20)" if burst > 1 else ""),
            B * H * W, 4 * (3 * C + 2 * (2 + 16)), med, mn)
@@ -153,16 +155,16 @@ def bench_projection(rows, dev, B, H, W, flow_kind, tag, proj_variants=()):
     def pre():
         cnt.zero_(); out.zero_()
     for pv in proj_variants:
-        L._debug_set_variant("projection", pv)
+        M.set_variant("projection", pv)
         med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0), pre)
         report(rows, "flow_projection_fwd %s %dx%dx%d flow=%s ABLATION variant=%d" % (tag, B, H, W, flow_kind, pv),
                B * H * W, 20, med, mn)
     if proj_variants:
-        L._debug_set_variant("projection", -8)
+        M.set_variant("projection", -8)
         med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 1), pre)
         report(rows, "flow_projection_fwd %s %dx%dx%d flow=%s fillhole=1 ABLATION holes detected, none filled" % (
             tag, B, H, W, flow_kind), B * H * W, 20, med, mn)
-    L._debug_set_variant("projection", -1)
+    M.set_variant("projection", -1)
     for fh in (0, 1):
         med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, fh), pre)
         report(rows, "flow_projection_fwd %s %dx%dx%d flow=%s fillhole=%d" % (tag, B, H, W, flow_kind, fh),

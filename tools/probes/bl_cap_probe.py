@@ -3,6 +3,8 @@ import sys, os, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "memc-net_amd"))
 import my_package._ext.my_lib as L
+from tools import measure as M  # noqa: E402
+M.use()                             # the measurement build: ablation / A-B arms live only there
 from tools import synth
 dev = torch.device("cuda:0")
 for kind in ("smooth", "iid", "video"):
@@ -10,7 +12,7 @@ for kind in ("smooth", "iid", "video"):
     x, f = t["x"], t["flow"]
     outs = []
     for cap in (0, 1, 2, 0, 1, 2):
-        L._debug_set_variant("bl_cap", cap)
+        M.set_variant("bl_cap", cap)
         o = torch.full_like(x, float("nan"))
         fn = lambda: L.InterpolationLayer_gpu_forward(x, f, o)
         for _ in range(60): fn()
@@ -22,4 +24,4 @@ for kind in ("smooth", "iid", "video"):
         print("flow=%-6s budget %s: %.1f us   equal to 48 KiB result: %s" % (
             kind, ("48 KiB (3/CU)", "39 KiB (4/CU)", "31 KiB (5/CU)")[cap], e0.elapsed_time(e1) * 1e3 / 50,
             torch.equal(o, outs[0])))
-L._debug_set_variant("bl_cap", -1)
+M.set_variant("bl_cap", -1)

@@ -4,6 +4,8 @@ import sys, os, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "memc-net_amd"))
 import my_package._ext.my_lib as L
+from tools import measure as M  # noqa: E402
+M.use()                             # the measurement build: ablation / A-B arms live only there
 from tools import synth
 dev = torch.device("cuda:0")
 for kind in ("smooth", "video"):
@@ -14,7 +16,7 @@ for kind in ("smooth", "video"):
     L.DepthFlowProjectionLayer_gpu_forward(f, d, cnt, pout, 0)
     res = {}
     for cap in (0, 1, 2, 1, 2):
-        L._debug_set_variant("bl_cap", cap)
+        M.set_variant("bl_cap", cap)
         o, g1, g2 = torch.empty_like(x), torch.zeros_like(x), torch.empty_like(f)
         p1, q1, q2 = torch.empty_like(f), torch.empty_like(f), torch.empty_like(d)
         ops = {"interp_fwd": lambda: L.InterpolationLayer_gpu_forward(x, f, o),
@@ -35,4 +37,4 @@ for kind in ("smooth", "video"):
             res[cap] = [a.clone() for a in cur]
         diffs = ["%.1e" % float((a - b).abs().max()) for a, b in zip(cur, res[0])]
         print("flow=%-6s budget %s  %s   max diff vs 48 KiB %s" % (kind, ("48K", "39K", "31K")[cap], "  ".join(line), diffs))
-L._debug_set_variant("bl_cap", -1)
+M.set_variant("bl_cap", -1)

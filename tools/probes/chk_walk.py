@@ -4,6 +4,8 @@ import sys, os, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "memc-net_amd"))
 import my_package._ext.my_lib as L
+from tools import measure as M  # noqa: E402
+M.use()                             # the measurement build: ablation / A-B arms live only there
 from tools import synth
 dev = torch.device("cuda:0")
 
@@ -24,12 +26,12 @@ for (B, H, W) in ((2, 720, 1280), (3, 50, 200), (1, 33, 456), (5, 16, 64)):
     t["gflow"] = torch.rand_like(t["flow"])
     cnt, pout = torch.empty_like(t["depth"]), torch.empty_like(t["flow"])
     L.DepthFlowProjectionLayer_gpu_forward(t["flow"], t["depth"], cnt, pout, 0)
-    L._debug_set_variant("walk", 0); ref = run(t, cnt, pout)
+    M.set_variant("walk", 0); ref = run(t, cnt, pout)
     for sw in (2, 4, 5):
-        L._debug_set_variant("walk", sw); got = run(t, cnt, pout)
+        M.set_variant("walk", sw); got = run(t, cnt, pout)
         errs = [float((a - b).abs().max()) for a, b in zip(ref, got)]
         print((B, H, W), "sw", sw, "max diffs", ["%.1e" % e for e in errs], "nan", any(bool(torch.isnan(a).any()) for a in got))
-L._debug_set_variant("walk", -1)
+M.set_variant("walk", -1)
 
 t = synth.torch_inputs(dev, 32, 3, 720, 1280, flow_kind="smooth", with_grad=True, with_depth=True)
 t["gflow"] = torch.rand_like(t["flow"])
@@ -44,7 +46,7 @@ ops = {"interp_fwd": lambda: L.InterpolationLayer_gpu_forward(x, f, o),
        "dproj_bwd": lambda: L.DepthFlowProjectionLayer_gpu_backward(f, d, cnt, pout, gf, p1, q2)}
 for rep in range(2):
     for sw in (0, 2, 4, 0, 2, 4):
-        L._debug_set_variant("walk", sw)
+        M.set_variant("walk", sw)
         line = []
         for name, fn in ops.items():
             for _ in range(40): fn()
@@ -55,4 +57,4 @@ for rep in range(2):
             line.append("%s %.1f" % (name, e0.elapsed_time(e1) * 1e3 / 40))
         print("sw=%d  " % sw + "  ".join(line))
     break
-L._debug_set_variant("walk", -1)
+M.set_variant("walk", -1)

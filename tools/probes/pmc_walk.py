@@ -14,6 +14,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "memc-net_amd"))
 import my_package._ext.my_lib as L
+from tools import measure as M  # noqa: E402
+M.use()                             # the measurement build: ablation / A-B arms live only there
 from tools import synth
 dev = torch.device("cuda:0")
 t = synth.torch_inputs(dev, 32, 3, 720, 1280, flow_kind="smooth", with_grad=True, with_depth=True)
@@ -23,7 +25,7 @@ cnt, pout = torch.empty_like(d), torch.empty_like(f)
 L.DepthFlowProjectionLayer_gpu_forward(f, d, cnt, pout, 0)
 o, g1, g2, p1 = torch.empty_like(x), torch.zeros_like(x), torch.empty_like(f), torch.empty_like(f)
 for sw in (0, 3):
-    L._debug_set_variant("walk", sw)
+    M.set_variant("walk", sw)
     for _ in range(10):
         L.InterpolationLayer_gpu_forward(x, f, o)
         L.InterpolationLayer_gpu_backward(x, f, g, g1, g2)

@@ -7,6 +7,8 @@ for p in (ROOT, os.path.join(ROOT, "memc-net_amd")):
     sys.path.insert(0, p)
 import torch
 import my_package._ext.my_lib as L
+from tools import measure as M  # noqa: E402
+M.use()                             # the measurement build: ablation / A-B arms live only there
 
 dev = torch.device("cuda:0")
 bad = 0
@@ -18,7 +20,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     d = torch.rand(B, 1, H, W, device=dev, generator=g) + 0.1
     res = {}
     for v in (0, -1, 1):
-        L._debug_set_variant("projection", v)
+        M.set_variant("projection", v)
         for fh in (0, 1):
             c = f.new_zeros(B, 1, H, W); o = torch.zeros_like(f)
             assert L.FlowProjectionLayer_gpu_forward(f, c, o, fh) == 0
@@ -38,5 +40,5 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
             if not torch.equal(a[0], b[0]):
                 idx = (a[0] != b[0]).nonzero()
                 print("   count diffs:", idx.shape[0], idx[:5].tolist(), a[0][a[0] != b[0]][:5].tolist(), b[0][a[0] != b[0]][:5].tolist())
-L._debug_set_variant("projection", -1)
+M.set_variant("projection", -1)
 print("stress done, mismatches:", bad)

@@ -16,6 +16,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "memc-net_amd"))
 import my_package._ext.my_lib as L      # noqa: E402
+from tools import measure as M  # noqa: E402
+M.use()                             # the measurement build: ablation / A-B arms live only there
 from tools import synth                 # noqa: E402
 
 KERNELS = {
@@ -46,16 +48,16 @@ def main():
         fn = lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0)                   # noqa: E731
     ntiles = ((W + 63) // 64) * ((H + 15) // 16) * B
     buf = torch.zeros(ntiles * 16, dtype=torch.int64, device=dev)
-    setter = getattr(L._lib, K["setter"])
+    setter = getattr(M.lib(), K["setter"])
     setter.argtypes = [ctypes.c_void_p]
     assert setter(ctypes.c_void_p(buf.data_ptr())) == 0
     for _ in range(30):
         fn()
-    L._debug_set_variant(K["op"], K["variant"])
+    M.set_variant(K["op"], K["variant"])
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); fn(); b.record(); b.synchronize()
-    L._debug_set_variant(K["op"], -1)
+    M.set_variant(K["op"], -1)
     ts = buf.cpu().numpy().reshape(ntiles, 16).astype(np.int64)
     us = a.elapsed_time(b) * 1e3
     tot = (ts[:, K["last"]] - ts[:, 0]).astype(np.float64)
