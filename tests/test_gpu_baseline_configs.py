@@ -1,0 +1,148 @@
+"""BASELINE.json's configurations at their STATED sizes: the HIP path against the reference's own GPU kernels
+(oracle/_ref, see oracle/ref_gpu.py) on identical device-generated inputs, within the north star's 1e-4.
+
+    config 2   fused adaptive warp fwd + bwd, 448x256, batch 8            (all three gradients)
+    config 3   FlowProjection + DepthFlowProjection, 1280x720, batch 32   (fillhole 0 / 1, count bit for bit)
+    config 5   adaptive warp fwd, 3840x2160, batch 8                      (the 16-plane filter tensor is 4.25 GB:
+               offsets cross 2^31 BYTES; the reference's all-int ELEMENT indexing still fits at C = 3)
+
+Comparisons stay on the device (a 4K batch is 0.8 - 4.2 GB per tensor).  The last test calls the kernel-launcher
+level of the C ABI (`*_gpu_*_kernel`, int strides: include/memc_warp.h) directly instead of the layer entry points.
+"""
+import ctypes
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import ref_gpu as R            # noqa: E402
+from tools import synth                    # noqa: E402
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not R.available(), reason="oracle/_ref/libmemc_ref_gpu.so not built")]
+ATOL, RTOL = 1e-4, 1e-5                    # as tests/test_gpu_parity.py
+
+
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test run without a GPU: the HIP path cannot be exercised (no fallback exists)")
+    return torch.device("cuda:0")
+
+
+def close(got, want, what):
+    assert got.shape == want.shape, what
+    err = (got.double() - want.double()).abs()
+    bound = ATOL + RTOL * want.double().abs()
+    worst = float((err - bound).max())
+    assert worst <= 0, "%s: max abs err %.3g (|want| up to %.3g)" % (what, float(err.max()), float(want.abs().max()))
+
+
+@pytest.mark.parametrize("kind", ["smooth", "iid"])
+def test_config2_adaptive_warp_fwd_bwd_448x256_batch8(kind):
+    import my_package._ext.my_lib as L
+    B, C, H, W = 8, 3, 256, 448
+    t = synth.torch_inputs(dev(), B, C, H, W, flow_kind=kind, seed=21, with_grad=True)
+    x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
+    out = torch.full_like(x, float("nan"))
+    assert L.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+    close(out, R.filter_interpolation_forward(x, f, k), "config 2 forward (%s)" % kind)
+    g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
+    assert L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+    w1, w2, w3 = R.filter_interpolation_backward(x, f, k, g)
+    close(g1, w1, "config 2 gradinput1 (%s)" % kind)
+    close(g2, w2, "config 2 gradinput2 (%s)" % kind)
+    close(g3, w3, "config 2 gradinput3 (%s)" % kind)
+    # and through the drop-in module, autograd end to end
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    xr, fr, kr = (v.clone().requires_grad_(True) for v in (x, f, k))
+    FilterInterpolationModule()(xr, fr, kr).backward(g)
+    close(xr.grad, w1, "module gradinput1"); close(fr.grad, w2, "module gradinput2"); close(kr.grad, w3, "module gradinput3")
+
+
+@pytest.mark.parametrize("kind", ["smooth", "iid"])
+def test_config3_projection_scatter_1280x720_batch32(kind):
+    import my_package._ext.my_lib as L
+    B, H, W = 32, 720, 1280
+    t = synth.torch_inputs(dev(), B, 3, H, W, flow_kind=kind, seed=33, with_depth=True)
+    f, dep = t["flow"], t["depth"]
+    del t
+    for fh in (0, 1):
+        cnt, out = torch.full_like(dep, float("nan")), torch.full_like(f, float("nan"))
+        assert L.FlowProjectionLayer_gpu_forward(f, cnt, out, fh) == 0
+        wo, wc = R.flow_projection_forward(f, fh)
+        assert torch.equal(cnt, wc), "config 3 count, fillhole %d (%s)" % (fh, kind)       # integers: bit for bit
+        close(out, wo, "config 3 FlowProjection, fillhole %d (%s)" % (fh, kind))
+        if fh == 1:
+            assert int((wc == 0).sum()) > 0                                                  # there were holes to fill
+        cnt, out = torch.full_like(dep, float("nan")), torch.full_like(f, float("nan"))
+        assert L.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, out, fh) == 0
+        wo, wc = R.depth_flow_projection_forward(f, dep, fh)
+        close(cnt, wc, "config 3 depth count, fillhole %d (%s)" % (fh, kind))
+        close(out, wo, "config 3 DepthFlowProjection, fillhole %d (%s)" % (fh, kind))
+    # backward at the same size (the scatter's adjoint: a gather)
+    gf = torch.rand_like(f)
+    cnt, out = torch.zeros_like(dep), torch.zeros_like(f)
+    assert L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0) == 0
+    g1 = torch.full_like(f, float("nan"))
+    assert L.FlowProjectionLayer_gpu_backward(f, cnt, gf, g1) == 0
+    close(g1, R.flow_projection_backward(f, cnt, gf), "config 3 FlowProjection backward (%s)" % kind)
+
+
+def test_config5_adaptive_warp_4k_batch8():
+    import my_package._ext.my_lib as L
+    B, C, H, W = 8, 3, 2160, 3840
+    t = synth.torch_inputs(dev(), B, C, H, W, flow_kind="smooth", seed=55)
+    x, f, k = t["x"], t["flow"], t["filt"]
+    del t
+    assert k.numel() * 4 > 2 ** 31 and k.numel() < 2 ** 31            # bytes cross 2^31, the reference's int index fits
+    out = torch.full_like(x, float("nan"))
+    assert L.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+    want = R.filter_interpolation_forward(x, f, k)
+    close(out, want, "config 5 forward, 8x3x2160x3840")
+    # the last image alone (highest offsets) must equal the same image run as a batch of one
+    o1 = torch.full_like(x[7:8], float("nan"))
+    assert L.FilterInterpolationLayer_gpu_forward(x[7:8].contiguous(), f[7:8].contiguous(), k[7:8].contiguous(), o1) == 0
+    assert torch.equal(o1, out[7:8])
+
+
+def test_launcher_level_abi_with_int_strides():
+    """`<Op>_gpu_{forward,backward}_kernel` (my_lib_kernel.h:67-220: stream, nElement, w, h, channel, batch, [fs |
+    fillhole], four int strides per tensor, pointers) called DIRECTLY on the product library -- the reference-side
+    glue my_lib_cuda.c would bind exactly these -- against the reference's launchers of the same names."""
+    import my_package._ext.my_lib as L
+    product = ctypes.CDLL(L.LIB_PATH)              # a private handle (RTLD_LOCAL): same symbol names as the reference's
+    B, C, H, W = 2, 3, 72, 128
+    t = synth.torch_inputs(dev(), B, C, H, W, flow_kind="smooth", seed=9, with_grad=True, with_depth=True)
+    x, f, k, g, dep = t["x"], t["flow"], t["filt"], t["gout"], t["depth"]
+    gf = torch.rand_like(f)
+
+    def run(lib):
+        saved, R._lib = R._lib, lib                # oracle/ref_gpu.py's wrappers pass the reference's own argument lists
+        try:
+            res = {}
+            res["fi_fwd"] = R.filter_interpolation_forward(x, f, k)
+            res["fi_g1"], res["fi_g2"], res["fi_g3"] = R.filter_interpolation_backward(x, f, k, g)
+            res["bl_fwd"] = R.interpolation_forward(x, f)
+            res["bl_g1"], res["bl_g2"] = R.interpolation_backward(x, f, g)
+            res["blch_fwd"] = R.interpolation_forward(x, f, ch=True)
+            res["blch_g1"], res["blch_g2"] = R.interpolation_backward(x, f, g, ch=True)
+            for fh in (0, 1):
+                res["fp_out%d" % fh], res["fp_cnt%d" % fh] = R.flow_projection_forward(f, fh)
+                res["dfp_out%d" % fh], res["dfp_cnt%d" % fh] = R.depth_flow_projection_forward(f, dep, fh)
+            res["fp_g1"] = R.flow_projection_backward(f, res["fp_cnt0"], gf)
+            res["dfp_g1"], res["dfp_g2"] = R.depth_flow_projection_backward(f, dep, res["dfp_cnt0"], res["dfp_out0"], gf)
+            torch.cuda.synchronize()
+            return res
+        finally:
+            R._lib = saved
+
+    want = run(R._load())
+    got = run(product)
+    assert sorted(got) == sorted(want)
+    for name in sorted(want):
+        if name.startswith("fp_cnt"):
+            assert torch.equal(got[name], want[name]), name
+        else:
+            close(got[name], want[name], "launcher-level " + name)

@@ -22,8 +22,28 @@ for _p in (ROOT, os.path.join(ROOT, "memc-net_amd")):
 import torch  # noqa: E402
 
 import my_package._ext.my_lib as L  # noqa: E402
-from tools import measure as M  # noqa: E402
-M.use()                             # the measurement build: ablation / A-B arms live only there
+from tools import measure  # noqa: E402
+
+
+class _Knobs(object):
+    """Variant selection.  The sweep runs on the PRODUCT library unless A/B or ablation variants are asked for
+    (--variants / --proj-variants / --bwd-variants): those exist in the measurement build only (tools/measure.py),
+    which then serves every row of the run."""
+    active = False
+
+    def enable(self):
+        if not self.active:
+            measure.use()
+            self.active = True
+
+    def set_variant(self, op, v):
+        if self.active:
+            measure.set_variant(op, v)
+        elif int(v) != -1:
+            raise RuntimeError("variant %s=%d needs the measurement build (call M.enable() first)" % (op, v))
+
+
+M = _Knobs()
 from tools import synth  # noqa: E402
 
 PEAK = 8.0e12
@@ -156,9 +176,13 @@ def bench_projection(rows, dev, B, H, W, flow_kind, tag, proj_variants=()):
         cnt.zero_(); out.zero_()
     for pv in proj_variants:
         M.set_variant("projection", pv)
-        med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0), pre)
-        report(rows, "flow_projection_fwd %s %dx%dx%d flow=%s ABLATION variant=%d" % (tag, B, H, W, flow_kind, pv),
-               B * H * W, 20, med, mn)
+        for fh in (0, 1):
+            med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, fh), pre)
+            report(rows, "flow_projection_fwd %s %dx%dx%d flow=%s fillhole=%d A/B variant=%d" % (
+                tag, B, H, W, flow_kind, fh, pv), B * H * W, 20, med, mn)
+        med, mn = time_launches(lambda: L.DepthFlowProjectionLayer_gpu_forward(f, d, cnt, out, 1), pre)
+        report(rows, "depth_flow_projection_fwd %s %dx%dx%d flow=%s fillhole=1 A/B variant=%d" % (
+            tag, B, H, W, flow_kind, pv), B * H * W, 24, med, mn)
     if proj_variants:
         M.set_variant("projection", -8)
         med, mn = time_launches(lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 1), pre)
@@ -215,7 +239,7 @@ def main():
     ap.add_argument("--ctx-only", action="store_true", help="fi_fwd: only the C=64 context-warp row")
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "bench_ops.json"))
-    ap.add_argument("--variants", default="-1,1,0")
+    ap.add_argument("--variants", default="-1", help="fi_fwd A/B arms, e.g. -1,1,0 (measurement build)")
     ap.add_argument("--proj-variants", default="")
     ap.add_argument("--bwd-variants", default="", help="fi_bwd ablation arms (timing only, wrong results)")
     args = ap.parse_args()
@@ -223,10 +247,12 @@ def main():
     only = set(filter(None, args.only.split(",")))
     variants = [int(v) for v in args.variants.split(",")]
     rows = []
+    if args.variants != "-1" or args.proj_variants or args.bwd_variants:
+        M.enable()
 
     def want(k):
         return not only or k in only
-    print(L.version(), torch.cuda.get_device_name(0), flush=True)
+    print(measure.version() if M.active else L.version(), torch.cuda.get_device_name(0), flush=True)
     if want("copy"):
         bench_copy(rows, dev)
     if want("fi_fwd") and args.ctx_only:
@@ -253,13 +279,14 @@ def main():
         bench_projection(rows, dev, 32, 720, 1280, "smooth", "c3",
                          [int(v) for v in args.proj_variants.split(",") if v])
         if not args.quick:
-            bench_projection(rows, dev, 32, 720, 1280, "iid", "c3")
+            pv2 = [int(v) for v in args.proj_variants.split(",") if v]
+            bench_projection(rows, dev, 32, 720, 1280, "iid", "c3", pv2)
             bench_projection(rows, dev, 32, 720, 1280, "video", "c3")
     if want("interp"):
         bench_interp(rows, dev, 32, 3, 720, 1280, "smooth", "720p")
     # baselines (the CPU oracle, the reference's own kernels on this GPU) live under tests/: tests/bench_baselines.py
     os.makedirs(os.path.dirname(args.json), exist_ok=True)
-    json.dump({"device": torch.cuda.get_device_name(0), "lib": L.version(), "rows": rows}, open(args.json, "w"),
+    json.dump({"device": torch.cuda.get_device_name(0), "lib": measure.version() if M.active else L.version(), "rows": rows}, open(args.json, "w"),
               indent=1)
     print("wrote", args.json)
 

@@ -11,6 +11,8 @@ from tools import measure as M  # noqa: E402
 M.use()                             # the measurement build: ablation / A-B arms live only there
 
 dev = torch.device("cuda:0")
+# automatic, general path, owner geometries (tile height 16 / 32 / 64, strips / stripes), the round-1 owner kernel
+OTHERS = (-1, 1, 100, 104, 110, 114, 120, 122, -10)
 bad = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     g = torch.Generator(device=dev); g.manual_seed(it)
@@ -19,7 +21,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     f = torch.randn(B, 2, H, W, device=dev, generator=g) * sig
     d = torch.rand(B, 1, H, W, device=dev, generator=g) + 0.1
     res = {}
-    for v in (0, -1, 1):
+    for v in (0,) + OTHERS:
         M.set_variant("projection", v)
         for fh in (0, 1):
             c = f.new_zeros(B, 1, H, W); o = torch.zeros_like(f)
@@ -28,7 +30,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
             assert L.DepthFlowProjectionLayer_gpu_forward(f, d, c2, o2, fh) == 0
             res[(v, fh)] = (c, o, c2, o2)
     torch.cuda.synchronize()
-    for fh, other in ((0, -1), (1, -1), (0, 1), (1, 1)):
+    for fh, other in [(fh, o) for o in OTHERS for fh in (0, 1)]:
         a, b = res[(0, fh)], res[(other, fh)]
         ok = torch.equal(a[0], b[0]) and (a[1] - b[1]).abs().max().item() <= 1e-4 and \
             (a[2] - b[2]).abs().max().item() <= 1e-4 and (a[3] - b[3]).abs().max().item() <= 2e-4
