@@ -391,6 +391,14 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
 // ==================================================================================================
 constexpr int kPtW = 68;                      // pitch of the point planes: 65 columns used, rows 16 B aligned
 
+// Per-workgroup phase timestamps (shader clock) for tools/trace_kernel.py; written by the TRACE instance only.
+__device__ unsigned long long *g_trace_buf_proj = nullptr;
+template <bool ON>
+__device__ __forceinline__ void trace_mark_proj(int slot)
+{
+    if (ON && threadIdx.x == 0) g_trace_buf_proj[(size_t)blockIdx.x * 16 + slot] = __builtin_readcyclecounter();
+}
+
 // ---- carry-based hole filling (pass 3), shared pieces; the scheme is described at proj_fillhole_carry ----------
 struct FillWs {
     int *up, *left, *right;       // left starts out as "last non-zero column in the tile", right as "first"
@@ -459,7 +467,9 @@ __device__ __forceinline__ void summary_store(const TileSummary<TH> &t, int any_
     }
 }
 
-template <bool DEPTH, int TH, int kReach>
+// ABL / TRACE: measurement build only (timing arms, results WRONG for ABL != 0): 1 no scan, 2 no fp64 adds,
+// 3 no read-out, 4 no halo loads (own tile only), 5 no loads and no scan; TRACE: per-workgroup phase timestamps.
+template <bool DEPTH, int TH, int kReach, int ABL = 0, bool TRACE = false>
 __global__ __launch_bounds__(16 * TH) void proj_owner2(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
@@ -482,6 +492,7 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
     if (tc.tx >= tiles_x) return;                 // virtual column of the last stripe
     const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * TH;
     const int tid = threadIdx.x;
+    trace_mark_proj<TRACE>(0);
     summary_init(sm);
     {
         f32x4 *pz = reinterpret_cast<f32x4 *>(P);
@@ -511,12 +522,18 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
         sx[it] = tx0 - kScanPadX + 4 * c4;
         sy[it] = ty0 - kReach - 1 + row;
         live[it] = row < kScanH && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
+        if (ABL == 4)                          // (timing arm: the tile's own sources only)
+            live[it] = live[it] && (unsigned)(sy[it] - ty0) < (unsigned)TH && (unsigned)(sx[it] - tx0) < 64u;
         // dead slots read the plane's first pixels (unconditional loads)
         const unsigned off = live[it] ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
-        fy[it] = ld_cached4_u(flow_b + s1c, off);
-        if (!far_it(it)) {
-            fx[it] = ld_cached4_u(flow_b, off);
-            if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+        if (ABL == 5) {
+            fx[it] = fy[it] = dd[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            fy[it] = ld_cached4_u(flow_b + s1c, off);
+            if (!far_it(it)) {
+                fx[it] = ld_cached4_u(flow_b, off);
+                if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+            }
         }
         row += NT / kCols4;                    // the next slot of this lane is NT further on
         c4 += NT % kCols4;
@@ -526,6 +543,9 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
         }
     }
     __syncthreads();                           // P is zero
+    trace_mark_proj<TRACE>(1);                 // loads issued, P zeroed
+    if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    trace_mark_proj<TRACE>(2);                 // loads arrived
 
     // wave-uniform window bounds.  A source is a hit when its point (T, L) = ((int)y2, (int)x2) lies in the window
     // and the site is valid (x2, y2 inside the image, my_lib_kernel.cu:1670): x2 >= max(tx0 - 1, 0) and
@@ -547,14 +567,22 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const f32x4 e = my_ring[(head + lane) & (kRing - 1)];
         double *q = P + __float_as_int(e[0]);
-        lds_add_f64(q, (double)e[1]);
-        lds_add_f64(q + kPlane, (double)e[2]);
-        lds_add_f64(q + 2 * kPlane, (double)e[3]);
+        if (ABL == 2) {
+            asm volatile("" ::"v"(q), "v"(e[1]), "v"(e[2]), "v"(e[3]));
+        } else {
+            lds_add_f64(q, (double)e[1]);
+            lds_add_f64(q + kPlane, (double)e[2]);
+            lds_add_f64(q + 2 * kPlane, (double)e[3]);
+        }
         head += kWave;
     };
 
 #pragma unroll
     for (int it = 0; it < kIts; it++) {
+        if (ABL == 1 || ABL == 5) {            // (timing arm: no scan; the loads stay)
+            asm volatile("" ::"v"(fx[it]), "v"(fy[it]), "v"(dd[it]));
+            continue;
+        }
         const bool lv = live[it];
         const float syf = (float)sy[it], sxf = (float)sx[it];
         // the quad lies inside the tile itself (tx0, the pad and sx are multiples of 4: all four sites or none)
@@ -621,7 +649,9 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
         far_flag[b % kFlagWords] = 1;
         far_flag[kFlagWords] = 1;
     }
+    trace_mark_proj<TRACE>(3);                 // scan + splat done (wave 0)
     __syncthreads();                           // every wave's points are in P
+    trace_mark_proj<TRACE>(4);                 // all waves done
 
     // every lane owns four cells of a row
     const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
@@ -632,7 +662,12 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
     // 2 x (two 16-byte pairs + one double) instead of 16 single doubles -- lanes are four cells apart, which for
     // 8-byte reads is a 4-way bank conflict.
     double top[3][5], bot[3][5];               // [plane][column c-1 .. c+3], rows cy-1 and cy
-    {
+    if (ABL == 3) {
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+            for (int i = 0; i < 5; i++) top[pl][i] = bot[pl][i] = 0.0;
+    } else {
         const int col0 = cx - tx0;             // P column of cell cx-1 (a multiple of 4: 16-byte aligned pairs)
         const double *r0 = P + (cy - ty0) * kPtW + col0, *r1 = r0 + kPtW;
         typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -673,6 +708,7 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
         *reinterpret_cast<f32x4 *>(o + s1c) = oy;
         *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
     }
+    trace_mark_proj<TRACE>(5);                 // outputs stored (issued)
     if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
         const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
         const int any_hole = __syncthreads_or(hole);
@@ -840,13 +876,6 @@ __global__ __launch_bounds__(256) void proj_fillhole_carry(
 
 #ifdef MEMC_MEASURE
 // ---- round-1 owner kernel, kept as the A/B arm of proj_owner2 (variants -10 / -7 / -6) ----
-// Per-workgroup phase timestamps (shader clock) for tools/trace_kernel.py; written by the TRACE instance only.
-__device__ unsigned long long *g_trace_buf_proj = nullptr;
-template <bool ON>
-__device__ __forceinline__ void trace_mark_proj(int slot)
-{
-    if (ON && threadIdx.x == 0) g_trace_buf_proj[(size_t)blockIdx.x * 16 + slot] = __builtin_readcyclecounter();
-}
 
 template <bool DEPTH, int kReach, bool TRACE = false>
 __global__ __launch_bounds__(256) void proj_owner(
@@ -1468,10 +1497,25 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
         }
         only_part = variant == -5 || variant == -7;
 #endif
-        if (!launched)
-            hipLaunchKernelGGL((proj_owner2<DEPTH, TH, 24>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(16 * TH), 0,
-                               stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
-                               a.out, flag, ws, sw);
+#define MEMC_PROJ_OWNER2(ABL, TRACE)                                                                              \
+            hipLaunchKernelGGL((proj_owner2<DEPTH, TH, 24, ABL, TRACE>), dim3(walk_grid(ntx, nty, batch, sw)),          \
+                               dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,       \
+                               a.depth, a.count, a.out, flag, ws, sw)
+#ifdef MEMC_MEASURE
+        if (!launched && variant <= -20) {     // -21 .. -25: timing arms of proj_owner2 (wrong results); -29: timestamps
+            only_part = true;
+            launched = true;
+            if (variant == -21) MEMC_PROJ_OWNER2(1, false);
+            else if (variant == -22) MEMC_PROJ_OWNER2(2, false);
+            else if (variant == -23) MEMC_PROJ_OWNER2(3, false);
+            else if (variant == -24) MEMC_PROJ_OWNER2(4, false);
+            else if (variant == -25) MEMC_PROJ_OWNER2(5, false);
+            else if (variant == -29) MEMC_PROJ_OWNER2(0, true);
+            else launched = false;
+        }
+#endif
+        if (!launched) MEMC_PROJ_OWNER2(0, false);
+#undef MEMC_PROJ_OWNER2
         if (launch_status() != 0) return -1;
         if (!only_part) {
             hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
@@ -1541,6 +1585,10 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
         } else if (v == -10 || v == -7 || v == -6) {
             th = 16;
             sw = 0;
+        } else if (v >= 200 && v < 300) {      // 200 + 10 * arm + log2(TH / 16): timing arms / timestamps of proj_owner2
+            th = 16 << (v % 10);
+            sw = 0;
+            v = -(20 + (v - 200) / 10);
         }
         if (th == 16) return run_proj_fwd<DEPTH, 16>(a, sw, v);
         if (th == 64) return run_proj_fwd<DEPTH, 64>(a, sw, v);

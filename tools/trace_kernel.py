@@ -26,11 +26,17 @@ KERNELS = {
                           (4, "phase 1 (taps/flow grads)"), (5, "zero plane"), (6, "adds c0"), (7, "flush c0"),
                           (8, "adds c1"), (9, "flush c1"), (10, "adds c2"), (11, "flush c2"),
                           (12, "later bands / tail")]),
-    "proj": dict(setter="memc_debug_set_trace_buffer_proj", op="projection", variant=-7, last=5,
+    "proj": dict(setter="memc_debug_set_trace_buffer_proj", op="projection", variant=-7, last=5, th=16,
                  marks=[(1, "issue scan loads + zero P + barrier"), (2, "wait for the loads"),
                         (3, "scan: locate + fp64 splat (wave 0)"), (4, "barrier (slowest wave)"),
                         (5, "box sum + normalise + store")]),
 }
+_PROJ2_MARKS = [(1, "issue scan loads + zero P + barrier"), (2, "wait for the loads"),
+                (3, "scan: window test + compaction + dense fp64 splat (wave 0)"), (4, "barrier (slowest wave)"),
+                (5, "box sum + normalise + store")]
+for _code, _th in ((0, 16), (1, 32), (2, 64)):      # proj_owner2 (round 2), tile height 16 / 32 / 64
+    KERNELS["proj2_%d" % _th] = dict(setter="memc_debug_set_trace_buffer_proj", op="projection", variant=290 + _code,
+                                     last=5, th=_th, marks=_PROJ2_MARKS)
 
 
 def main():
@@ -46,7 +52,8 @@ def main():
     else:
         cnt, out = f.new_zeros((B, 1, H, W)), torch.zeros_like(f)
         fn = lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0)                   # noqa: E731
-    ntiles = ((W + 63) // 64) * ((H + 15) // 16) * B
+    th = K.get("th", 16)
+    ntiles = ((W + 63) // 64) * ((H + th - 1) // th) * B
     buf = torch.zeros(ntiles * 16, dtype=torch.int64, device=dev)
     setter = getattr(M.lib(), K["setter"])
     setter.argtypes = [ctypes.c_void_p]
