@@ -9,9 +9,13 @@ the operator over one batch (one kernel launch through the C ABI, on torch's cur
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: frame pairs are independent, so each rank owns its own batch-32 shard (weak scaling) and there is
-no collective on the data path; RCCL is used only to broadcast the run configuration from rank 0 before the
-timed region and to take the max of the per-rank times after it.
+Multi-GPU: frame pairs are independent, so the batch is sharded over the ranks and there is no collective on the
+data path; RCCL is used only to broadcast the run configuration from rank 0 before the timed region and to take the
+max of the per-rank times after it.  Default = STRONG scaling, as BASELINE.json / SURVEY.md section 8(e) state it:
+the global batch stays 32 frame pairs and rank r owns the contiguous shard of 32 / N of them (32 / 16 / 8 / 4 per GPU
+at N = 1 / 2 / 4 / 8); `--scaling weak` gives every rank its own batch of 32 instead (global batch 32 N).  A shard of
+4 frames is a 67 us launch: below ~8 M sites per launch the K timed steps are replayed from ONE captured HIP graph
+(`--launch graph`, automatic), so that the host's per-launch cost (~4 us through ctypes) is not what is measured.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement" for the field definitions).
 """
@@ -40,12 +44,22 @@ def dist_env():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def shard_plan(rank, world, batch_per_gpu, base_seed):
-    """Weak scaling over independent frame pairs: every rank owns `batch_per_gpu` items of a global batch of
-    world * batch_per_gpu; item g of the global batch lives on rank g // batch_per_gpu.  No halo, no exchange."""
-    first = rank * batch_per_gpu
-    return {"rank": rank, "world": world, "first_item": first, "items": batch_per_gpu,
-            "global_batch": world * batch_per_gpu, "seed": base_seed + rank}
+def shard_plan(rank, world, batch, base_seed, scaling="weak"):
+    """Independent frame pairs, contiguous shards, no halo, no exchange.
+    weak:   every rank owns `batch` items of a global batch of world * batch (item g lives on rank g // batch).
+    strong: the global batch IS `batch`; rank r owns items [first, first + items) with the remainder spread over
+            the first ranks (32 over 8 ranks: 4 each; 32 over 3 ranks: 11, 11, 10)."""
+    if scaling == "weak":
+        first, items, total = rank * batch, batch, world * batch
+    elif scaling == "strong":
+        q, r = divmod(batch, world)
+        items = q + (1 if rank < r else 0)
+        first = rank * q + min(rank, r)
+        total = batch
+    else:
+        raise ValueError(scaling)
+    return {"rank": rank, "world": world, "first_item": first, "items": items, "global_batch": total,
+            "seed": base_seed + rank, "scaling": scaling}
 
 
 def broadcast_config(cfg, world, device):
@@ -115,16 +129,48 @@ def cpu_baseline(x, flow, filt, target_seconds=12.0):
                       "%.1f s, OpenMP over batch x rows" % (nb, nb, xs.shape[1], xs.shape[2], xs.shape[3], reps, spent)}
 
 
+def kernel_source_hash():
+    """sha256 over the HIP sources of the dominant kernel: the PMC traffic record is only quoted for the very code
+    it was measured on (tools/pmc_traffic.py stores the same hash)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("filter_interpolation.hip", "memc_tile.hpp", "memc_common.hpp"):
+        with open(os.path.join(ROOT, "memc-net_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(workload_key):
-    """HBM bytes per launch from the committed PMC profile of this same command (profiles/traffic.json,
-    written by tools/pmc_traffic.py); None when no profile matches."""
+    """HBM bytes per launch from the committed PMC profile of this same command (profiles/traffic.json, written by
+    tools/pmc_traffic.py in separate FETCH_SIZE / WRITE_SIZE passes); None when there is no record for this
+    workload or the kernel sources changed since it was taken (stale counters are not quoted)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         data = json.load(open(path))
         rec = data.get(workload_key)
-        return None if rec is None else rec.get("hbm_bytes_per_launch")
+        if rec is None or rec.get("kernel_source_hash") != kernel_source_hash():
+            return None
+        return rec.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
+
+
+def copy_calibration(device, nbytes, iters=20):
+    """What THIS box's HBM gives a plain streaming copy of the same byte volume (read n/2, write n/2), by HIP
+    events: the guide quotes 6.29 TB/s for a float4 copy, the boxes of this pool deliver 5.1 - 5.4.  Reported next
+    to the 8 TB/s spec peak as `roofline.achievable_peak` so that `frac` can be read against both."""
+    import torch
+    n = nbytes // 8
+    a = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    b = torch.empty_like(a)
+    for _ in range(5):
+        b.copy_(a)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s0, s1 in ev:
+        s0.record(); b.copy_(a); s1.record()
+    torch.cuda.synchronize(device)
+    ts = sorted(s0.elapsed_time(s1) for s0, s1 in ev)
+    return 8.0 * n / (ts[len(ts) // 2] * 1e-3)
 
 
 def main(argv=None):
@@ -135,7 +181,11 @@ def main(argv=None):
     ap.add_argument("--prewarm", type=int, default=200,
                     help="untimed launches before the warm-up steps: the device needs ~100 launches (60 ms) to "
                          "reach its steady clocks (tools/timeline.py); never part of the timed region")
-    ap.add_argument("--batch", type=int, default=32, help="frames per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="frame pairs: the GLOBAL batch (strong) / per GPU (weak)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
+                    help="graph: the K timed steps are one captured HIP graph replay (auto: below 8 M sites per launch)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the i.i.d.-flow row and the copy calibration")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--channels", type=int, default=3)
@@ -171,8 +221,11 @@ def main(argv=None):
     cfg = broadcast_config({"batch": args.batch, "height": args.height, "width": args.width,
                             "channels": args.channels, "seed": 1234, "steps": args.steps,
                             "warmup": args.warmup}, world, device)
-    B, C, H, W, fs = cfg["batch"], cfg["channels"], cfg["height"], cfg["width"], 4
-    plan = shard_plan(rank, world, B, cfg["seed"])
+    C, H, W, fs = cfg["channels"], cfg["height"], cfg["width"], 4
+    plan = shard_plan(rank, world, cfg["batch"], cfg["seed"], args.scaling)
+    B = plan["items"]                           # this rank's shard
+    if B == 0:
+        raise SystemExit("rank %d has no frame pair (global batch %d over %d ranks)" % (rank, cfg["batch"], world))
     t = synth.torch_inputs(device, B, C, H, W, fs=fs, flow_kind=args.flow, seed=plan["seed"])
     x, flow, filt = t["x"], t["flow"], t["filt"]
     out = torch.zeros_like(x)                 # caller-allocated, caller-zeroed (reference contract)
@@ -190,34 +243,91 @@ def main(argv=None):
         if err != 0:
             raise RuntimeError("FilterInterpolationLayer_gpu_forward returned %d" % err)
 
+    sites_per_launch = B * H * W
+    use_graph = args.launch == "graph" or (args.launch == "auto" and sites_per_launch < 8_000_000)
     for _ in range(args.prewarm):
         step(None)
-    worst, _local = timed_steps(step, steps, warmup, world, device)
-    sites_per_launch = B * H * W
-    kernel_ms = [a.elapsed_time(b) for a, b in zip(starts, stops)]
-    avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+    if use_graph:
+        # the K timed steps as ONE graph of K kernel nodes on a side stream; HIP events bracket the replay on that
+        # stream (an event inside a captured graph cannot be timed), so the per-launch duration below includes the
+        # ~1.5 us boundary between two dependent kernels
+        side = torch.cuda.Stream(device)
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(device)
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(steps):
+                step(None)
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(warmup):
+            step(None)
+        with torch.cuda.stream(side):
+            graph.replay()                      # one untimed replay (first replay uploads the graph)
+        barrier_sync(world, device)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(side):
+            g0.record()
+            graph.replay()
+            g1.record()
+        barrier_sync(world, device)
+        local = time.perf_counter() - t0
+        worst = local
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([local], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            worst = float(tt.item())
+        avg_kernel_s = g0.elapsed_time(g1) / steps / 1e3
+    else:
+        worst, _local = timed_steps(step, steps, warmup, world, device)
+        kernel_ms = [a.elapsed_time(b) for a, b in zip(starts, stops)]
+        avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
     alg_bytes = BYTES_PER_SITE["fi_fwd"](C, fs) * sites_per_launch
     achieved = alg_bytes / avg_kernel_s                                 # B/s, this rank's dominant kernel
-    value = world * sites_per_launch * steps / worst / 1e6
+    total_sites = plan["global_batch"] * H * W                          # all ranks' sites per step
+    value = total_sites * steps / worst / 1e6
+
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # the stress flow SURVEY.md section 8(d) asks for (i.i.d. N(0, 3^2) per pixel: defeats any tiling), same
+        # launches / events, outside the timed region; and what a plain copy gets on this box
+        t2 = synth.torch_inputs(device, B, C, H, W, fs=fs, flow_kind="iid", seed=plan["seed"] + 1)
+        e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(60)]
+        for _ in range(20):
+            my_lib.FilterInterpolationLayer_gpu_forward(t2["x"], t2["flow"], t2["filt"], out)
+        for a0, a1 in e:
+            a0.record()
+            my_lib.FilterInterpolationLayer_gpu_forward(t2["x"], t2["flow"], t2["filt"], out)
+            a1.record()
+        torch.cuda.synchronize(device)
+        iid_s = sum(a0.elapsed_time(a1) for a0, a1 in e) / len(e) / 1e3
+        del t2
+        secondary = {"iid_flow": {"avg_launch_us": round(iid_s * 1e6, 2), "mpixels_s": round(sites_per_launch / iid_s / 1e6, 1),
+                                  "frac": round(alg_bytes / iid_s / HBM_PEAK_BPS, 4)},
+                     "copy_Bps": copy_calibration(device, alg_bytes)}
 
     if rank == 0:
-        workload = "FilterInterpolation fwd fs=4 C=%d batch=%d %dx%d fp32 flow=%s" % (C, B, W, H, args.flow)
-        traffic = load_traffic(workload)
+        workload = "FilterInterpolation fwd fs=4 C=%d batch=%d %dx%d fp32 flow=%s" % (C, cfg["batch"], W, H, args.flow)
+        traffic = load_traffic(workload) if B == cfg["batch"] else None        # (per-launch counters of the full batch)
         line = {
             "metric": "Mpixels/s adaptive-warp fwd @720p batch32",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(worst / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(worst / steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not args.share_gpu else "synthetic; PLUMBING TEST (ranks share a GPU), not a measurement",
             "config": {"workload": workload, "batch_per_gpu": B, "global_batch": plan["global_batch"],
-                       "prewarm_launches": args.prewarm,
-                       "sharding": "independent frame pairs per rank, no data-path collective"},
+                       "prewarm_launches": args.prewarm, "launch": "hip_graph" if use_graph else "eager",
+                       "sharding": "independent frame pairs, contiguous shards per rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BPS, 4),
                          "traffic": traffic,
                          "kernel": "fi_fwd", "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(avg_kernel_s * 1e6, 2)},
         }
+        if secondary:
+            # achievable_peak: a plain copy of the same byte volume on THIS box, same run (spec peak stays `peak`)
+            line["roofline"]["achievable_peak"] = round(secondary["copy_Bps"] / 1e9, 1)
+            line["roofline"]["frac_of_achievable"] = round(achieved / secondary["copy_Bps"], 4)
+            line["secondary"] = {"iid_flow": secondary["iid_flow"]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(x, flow, filt)
         print(json.dumps(line), flush=True)

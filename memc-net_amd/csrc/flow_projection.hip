@@ -717,6 +717,246 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
 }
 
 // --------------------------------------------------------------------------------------------------
+// proj_owner3: proj_owner2 as a PERSISTENT, software-pipelined kernel.
+// Measured on proj_owner2 (tools/bench_ops.py arms 200..251, tools/trace_kernel.py proj2_32): without any scan work
+// the kernel still takes 178 us where its stores alone take 82 -- the scan's loads are issued at the start of a
+// workgroup's life and nothing is in flight while it tests, splats and reads out (39 % of a workgroup's life is
+// "issue the loads, wait for them"): with 2 - 4 workgroups per CU the bytes in flight average ~30 KB per CU, a
+// quarter of what the latency needs.  Here WGCU workgroups per CU walk the tiles of their XCD's chunk of the stripe
+// order (tile positions p, p + grid, ...; grid % 8 == 0) and the NEXT tile's flow is requested before the current
+// tile is scanned, into a second register set (the loop is unrolled by two so that the sets swap by name).
+// --------------------------------------------------------------------------------------------------
+template <bool DEPTH, int TH, int kReach, int WGCU>
+__global__ __launch_bounds__(16 * TH, (16 * TH / 256) * WGCU) void proj_owner3(
+    int W, int H, int tiles_x, int tiles_y, unsigned npos,
+    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
+    const float *__restrict__ flow, const float *__restrict__ depth,
+    float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, FillWs ws, int sw)
+{
+    constexpr int NT = 16 * TH, NW = NT / kWave;
+    constexpr int kPtH = TH + 1, kPlane = kPtH * kPtW;
+    constexpr int kScanPadX = kReach + 4, kScanW = 64 + 2 * kScanPadX, kScanH = TH + 2 * kReach + 1;
+    constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + NT - 1) / NT;
+    constexpr int kRing = 128;
+    constexpr int kNearRows = 8;
+    static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
+    __shared__ __attribute__((aligned(16))) double P[3 * kPlane];
+    __shared__ __attribute__((aligned(16))) f32x4 ring[NW * kRing];
+    __shared__ TileSummary<TH> sm;
+
+    // What is prefetched one tile ahead is the fy plane of the scan region only: the row test needs nothing else,
+    // and two full register sets (fy + fx [+ depth], twice) do not fit the 128 VGPRs that 16 waves per CU leave a
+    // lane -- the allocator then spills freshly loaded values, which waits for them on the spot.  fx (and depth) of
+    // the rows near the tile are requested at the start of the tile's own turn, ahead of the P zeroing, the next
+    // tile's fy requests and the barrier.
+    struct Regs {
+        f32x4 fy[kIts];
+    };
+    auto far_it = [](int it) {                 // see proj_owner2
+        const int first = NT * it / kCols4, last = (NT * it + NT - 1) / kCols4;
+        return last <= kReach + 1 - kNearRows || first >= kReach + 1 + TH + kNearRows;
+    };
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    f32x4 *const my_ring = ring + wave * kRing;
+    // (threadIdx through an opaque asm, once per tile and phase: everything derived from it -- slot rows, columns,
+    // byte offsets -- would otherwise be hoisted out of the tile loop and kept, i.e. spilled, kernel-wide)
+
+    // position of the next real tile of this workgroup's walk (stripes have virtual columns past the image)
+    auto real_from = [&](unsigned p) {
+        while (p < npos && tile_walk(p, npos, tiles_x, tiles_y, sw).tx >= tiles_x) p += gridDim.x;
+        return p;
+    };
+    // slot `it` of this lane in the scan region of the tile at (tx0, ty0)
+    auto slot = [&](int tid, int it, int tx0, int ty0, int &sx, int &sy, bool &live) {
+        const int s = it * NT + tid, row = s / kCols4, c4 = s - row * kCols4;
+        sx = tx0 - kScanPadX + 4 * c4;
+        sy = ty0 - kReach - 1 + row;
+        live = row < kScanH && sx >= 0 && sx < W && sy >= 0 && sy < H;            // W % 4 == 0
+    };
+    auto request = [&](unsigned p, Regs &r) {
+        const TileCoord tc = tile_walk(p, npos, tiles_x, tiles_y, sw);
+        const float *flow_b = flow + tc.b * s1b;
+        const int tid = tid_now();
+#pragma unroll
+        for (int it = 0; it < kIts; it++) {
+            int sx, sy;
+            bool live;
+            slot(tid, it, tc.tx * 64, tc.ty * TH, sx, sy, live);
+            const unsigned off = live ? 4u * (unsigned)(sy * s1h + sx) : 0u;      // dead slots read pixel 0
+            r.fy[it] = ld_cached4_u(flow_b + s1c, off);
+        }
+    };
+
+    // one tile: `cur` holds its flow (requested one tile earlier); the flow of the tile at `pn` goes into `nxt`
+    auto process = [&](unsigned p, Regs &cur, unsigned pn, Regs &nxt) {
+        const TileCoord tc = tile_walk(p, npos, tiles_x, tiles_y, sw);
+        const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * TH;
+        const float *flow_b = flow + b * s1b;
+        const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
+        const int tid = tid_now();
+        const int lane = tid & (kWave - 1);
+        f32x4 cfx[kIts], cdd[kIts];            // this tile's fx / depth, rows near the tile
+#pragma unroll
+        for (int it = 0; it < kIts; it++) {
+            if (far_it(it)) continue;
+            int sx, sy;
+            bool lv;
+            slot(tid, it, tx0, ty0, sx, sy, lv);
+            cfx[it] = ld_cached4_u(flow_b, lv ? 4u * (unsigned)(sy * s1h + sx) : 0u);
+            if (DEPTH) cdd[it] = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy * sdh + sx) : 0u);
+        }
+        summary_init(sm);
+        {
+            f32x4 *pz = reinterpret_cast<f32x4 *>(P);
+            for (int i = tid; i < 3 * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        request(pn, nxt);                      // in flight while this tile is scanned, splatted and read out
+        __syncthreads();                       // P is zero
+
+        const float xlo = (float)max(tx0 - 1, 0), ylo = (float)max(ty0 - 1, 0);
+        const int xhi_bits = min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1);
+        const int yhi_bits = min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1);
+        unsigned head = 0, tail = 0;
+        bool far = false;
+        auto splat = [&](unsigned n) {         // the first n (<= 64) waiting entries, one per lane
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if ((unsigned)lane < n) {
+                const f32x4 e = my_ring[(head + lane) & (kRing - 1)];
+                double *q = P + __float_as_int(e[0]);
+                lds_add_f64(q, (double)e[1]);
+                lds_add_f64(q + kPlane, (double)e[2]);
+                lds_add_f64(q + 2 * kPlane, (double)e[3]);
+            }
+            head += n;
+        };
+#pragma unroll
+        for (int it = 0; it < kIts; it++) {
+            int sx, sy;
+            bool lv;
+            slot(tid, it, tx0, ty0, sx, sy, lv);
+            const float syf = (float)sy, sxf = (float)sx;
+            const bool homeq = lv && (unsigned)(sy - ty0) < (unsigned)TH && (unsigned)(sx - tx0) < 64u;
+            float y2[4];
+            bool wy[4], rowany = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                y2[j] = syf + cur.fy[it][j];
+                wy[j] = lv && y2[j] >= ylo && __float_as_int(y2[j]) < yhi_bits;
+                rowany = rowany || wy[j];
+            }
+            if (__builtin_amdgcn_ballot_w64(rowany || homeq) == 0) continue;
+            f32x4 fxq = cfx[it], ddq = cdd[it];
+            if (far_it(it)) {
+                const unsigned off = lv ? 4u * (unsigned)(sy * s1h + sx) : 0u;
+                fxq = ld_cached4_u(flow_b, off);
+                if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy * sdh + sx) : 0u);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float fxv = fxq[j], fyv = cur.fy[it][j];
+                const float x2 = (sxf + (float)j) + fxv;
+                const bool nearj = fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach;
+                if (homeq && !nearj) {
+                    const bool valid = x2 >= 0.0f && y2[j] >= 0.0f && x2 <= (float)(W - 1) && y2[j] <= (float)(H - 1);
+                    far = far || valid;
+                }
+                const bool hit = wy[j] && nearj && x2 >= xlo && __float_as_int(x2) < xhi_bits;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                if (m == 0) continue;
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (hit) {
+                    const int py = (int)y2[j] - (ty0 - 1), px = (int)x2 - (tx0 - 1);
+                    float vx = -fxv, vy = -fyv, vc = 1.0f;
+                    if (DEPTH) {
+                        vx = -ddq[j] * fxv;
+                        vy = -ddq[j] * fyv;
+                        vc = ddq[j] * 1.0f;
+                    }
+                    my_ring[(tail + rank) & (kRing - 1)] = f32x4{__int_as_float(py * kPtW + px), vx, vy, vc};
+                }
+                tail += (unsigned)__builtin_popcountll(m);
+                if (tail - head >= (unsigned)kWave) splat(kWave);
+            }
+        }
+        if (tail != head) splat(tail - head);
+        if (far) {
+            far_flag[b % kFlagWords] = 1;
+            far_flag[kFlagWords] = 1;
+        }
+        __syncthreads();                       // every wave's points are in P
+
+        const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
+        const bool inb = cx < W && cy < H;
+        const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
+        // one plane at a time (the next tile's flow occupies a register set of its own: reading all three planes'
+        // thirty doubles at once would not fit beside it)
+        f32x4 val[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            typedef double f64x2 __attribute__((ext_vector_type(2)));
+            const double *a = P + pl * kPlane + (cy - ty0) * kPtW + (cx - tx0), *c = a + kPtW;
+            const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
+            const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
+            const double top[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
+            const double bot[5] = {c01[0], c01[1], c23[0], c23[1], c[4]};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
+                float t = 0.0f;                // same order as proj_owner2
+                t += wy0 * wx0 * (float)bot[j + 1];
+                t += wy0 * (float)bot[j];
+                t += wx0 * (float)top[j + 1];
+                t += (float)top[j];
+                val[pl][j] = t;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 ox, oy, oc;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v0 = val[0][j], v1 = val[1][j];
+            const float v2 = val[2][j];
+            if (v2 > 0.0f) {
+                const float inv = 1.0f / v2;
+                v0 = v0 * inv;
+                v1 = v1 * inv;
+            }
+            ox[j] = v0;  oy[j] = v1;  oc[j] = v2;
+        }
+        if (inb) {
+            float *o = out + b * s1b + (int64_t)cy * s1h + cx;
+            *reinterpret_cast<f32x4 *>(o) = ox;
+            *reinterpret_cast<f32x4 *>(o + s1c) = oy;
+            *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
+        }
+        if (ws.up) {
+            const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
+            const int any_hole = __syncthreads_or(hole);
+            summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
+        }
+        __syncthreads();                       // P, the summary and the rings are rebuilt by the next tile
+    };
+
+    unsigned p = real_from(blockIdx.x);
+    if (p >= npos) return;
+    Regs ra, rb;
+    request(p, ra);
+#pragma unroll 1
+    for (;;) {
+        unsigned pn = real_from(p + gridDim.x);
+        process(p, ra, pn < npos ? pn : p, rb);             // (past the end: re-request this tile -- unconditional loads)
+        if (pn >= npos) break;
+        p = pn;
+        pn = real_from(p + gridDim.x);
+        process(p, rb, pn < npos ? pn : p, ra);
+        if (pn >= npos) break;
+        p = pn;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // Pass 3 with carries: the hole filler whose walks never leave a tile.
 // The reference walks from every hole to the nearest cell with a non-zero count to its left, to its right and above
 // (my_lib_kernel.cu:1776-1800).  Walked literally, a camera pan -- an uncovered strip along one image border --
@@ -1514,7 +1754,26 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             else launched = false;
         }
 #endif
-        if (!launched) MEMC_PROJ_OWNER2(0, false);
+#define MEMC_PROJ_OWNER3(WGCU)                                                                                    \
+        do {                                                                                                     \
+            const unsigned npos = walk_grid(ntx, nty, batch, sw);                                                \
+            const unsigned pg = persistent_grid(WGCU);                                                           \
+            hipLaunchKernelGGL((proj_owner3<DEPTH, TH, 24, WGCU>), dim3(npos < pg ? (npos + 7) / 8 * 8 : pg),     \
+                               dim3(16 * TH), 0, stream, w, h, ntx, nty, npos, s1b, s1c, s1h, sdb, sdh, scb, sch,    \
+                               a.flow, a.depth, a.count, a.out, flag, ws, sw);                                   \
+        } while (0)
+#ifdef MEMC_MEASURE
+        if (!launched && variant == -30) {     // proj_owner2 (one tile per workgroup) instead of the persistent kernel
+            MEMC_PROJ_OWNER2(0, false);
+            launched = true;
+        }
+#endif
+        if (!launched) {
+            if constexpr (TH == 16) MEMC_PROJ_OWNER3(3);
+            else if constexpr (TH == 32) MEMC_PROJ_OWNER3(2);
+            else MEMC_PROJ_OWNER3(1);
+        }
+#undef MEMC_PROJ_OWNER3
 #undef MEMC_PROJ_OWNER2
         if (launch_status() != 0) return -1;
         if (!only_part) {
@@ -1578,10 +1837,14 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
 #ifdef MEMC_MEASURE
         // 100 + 10 * log2(TH / 16) + stripe width: owner geometry under test; -10 / -7 / -6: the round-1 owner
         int v = g_proj_variant, th = kOwnerTH, sw = kOwnerSW;
-        if (v >= 100 && v < 130) {
+        if (v >= 100 && v < 130) {             // persistent owner kernel (proj_owner3)
             th = 16 << ((v - 100) / 10);
             sw = (v - 100) % 10;
             v = -1;
+        } else if (v >= 130 && v < 160) {      // one tile per workgroup (proj_owner2), same geometry code + 30
+            th = 16 << ((v - 130) / 10);
+            sw = (v - 130) % 10;
+            v = -30;
         } else if (v == -10 || v == -7 || v == -6) {
             th = 16;
             sw = 0;

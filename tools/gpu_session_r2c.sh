@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round 2, session C: persistent pipelined owner kernel (proj_owner3): correctness + sweep
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/r02c
+mkdir -p "$OUT"
+cd "$REPO"
+echo "== projection tests"; timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_reference.py tests/test_gpu_baseline_configs.py -m gpu -x -q -k "projection or hole or stream or capture or config3 or reference_kernels or launcher" 2>&1 | tail -8 | tee "$OUT/pytest_proj.log"
+echo "== stress"; timeout 600 python tools/stress_projection.py 45 2>&1 | tail -8 | tee "$OUT/stress.log"
+echo "== sweep"
+timeout 900 python tools/bench_ops.py --only proj --quick --proj-variants=-10,100,104,110,112,114,120,124,130,140,144,150 --json "$OUT/bench_proj.json" 2>&1 | tee "$OUT/bench_proj.log" | grep -v "^$"
+ls "$OUT"
