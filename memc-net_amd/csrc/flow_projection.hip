@@ -389,7 +389,9 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
 //   * Tiles are walked in stripes `sw` tile columns wide per XCD (tile_walk), so that the horizontal halo of the
 //     scan is an L2 hit on the same XCD instead of a second HBM read (strips: 1.41x the algorithmic traffic).
 // ==================================================================================================
-constexpr int kPtW = 68;                      // pitch of the point planes: 65 columns used, rows 16 B aligned
+#ifdef MEMC_MEASURE
+constexpr int kPtW = 68;                      // point-plane pitch of the measurement-build kernels (65 columns used)
+#endif
 
 // Per-workgroup phase timestamps (shader clock) for tools/trace_kernel.py; written by the TRACE instance only.
 __device__ unsigned long long *g_trace_buf_proj = nullptr;
@@ -454,7 +456,8 @@ __device__ __forceinline__ void summary_store(const TileSummary<TH> &t, int any_
     if (threadIdx.x < 64 && tx0 + (int)threadIdx.x < W)
         ws.up[((int64_t)b * nty + ty) * W + tx0 + threadIdx.x] = t.col_last[threadIdx.x];
     if (threadIdx.x < TH && ty0 + (int)threadIdx.x < H) {
-        const int64_t i = ((int64_t)b * H + ty0 + threadIdx.x) * ntx + tx;
+        // [b][tx][y]: a tile's rows are one contiguous run (row-major [b][y][tx] made these TH scattered 4-byte stores)
+        const int64_t i = ((int64_t)b * ntx + tx) * H + ty0 + threadIdx.x;
         ws.right[i] = t.row_first[threadIdx.x] == INT_MAX ? -1 : t.row_first[threadIdx.x];
         ws.left[i] = t.row_last[threadIdx.x];
     }
@@ -467,6 +470,8 @@ __device__ __forceinline__ void summary_store(const TileSummary<TH> &t, int any_
     }
 }
 
+#ifdef MEMC_MEASURE
+// ---- measurement build only: proj_owner2 (LDS compaction rings, three planes) and proj_owner3 (persistent) ----
 // ABL / TRACE: measurement build only (timing arms, results WRONG for ABL != 0): 1 no scan, 2 no fp64 adds,
 // 3 no read-out, 4 no halo loads (own tile only), 5 no loads and no scan; TRACE: per-workgroup phase timestamps.
 template <bool DEPTH, int TH, int kReach, int ABL = 0, bool TRACE = false>
@@ -484,7 +489,8 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
     constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + NT - 1) / NT;
     constexpr int kRing = 128;                    // entries per wave; at most 63 + 64 wait at any time
     static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
-    __shared__ __attribute__((aligned(16))) double P[3 * kPlane];
+    constexpr int kPlanes = ABL == 6 ? 2 : 3;     // (timing arm 6: two planes -> 52 KiB at TH = 32, three workgroups per CU)
+    __shared__ __attribute__((aligned(16))) double P[kPlanes * kPlane];
     __shared__ __attribute__((aligned(16))) f32x4 ring[NW * kRing];
     __shared__ TileSummary<TH> sm;                // for the hole filler, when one follows (ws.up != nullptr)
 
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
     summary_init(sm);
     {
         f32x4 *pz = reinterpret_cast<f32x4 *>(P);
-        for (int i = tid; i < 3 * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid; i < kPlanes * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // scan: kCols4 float4 columns x kScanH rows of slots, kIts per lane; all loads first.  Slot -> (row, column) by
@@ -572,7 +578,7 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
         } else {
             lds_add_f64(q, (double)e[1]);
             lds_add_f64(q + kPlane, (double)e[2]);
-            lds_add_f64(q + 2 * kPlane, (double)e[3]);
+            if (kPlanes == 3) lds_add_f64(q + 2 * kPlane, (double)e[3]);
         }
         head += kWave;
     };
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
                 double *q = P + __float_as_int(e[0]);
                 lds_add_f64(q, (double)e[1]);
                 lds_add_f64(q + kPlane, (double)e[2]);
-                lds_add_f64(q + 2 * kPlane, (double)e[3]);
+                if (kPlanes == 3) lds_add_f64(q + 2 * kPlane, (double)e[3]);
             }
         }
     }
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(16 * TH) void proj_owner2(
         typedef double f64x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int pl = 0; pl < 3; pl++) {
-            const double *a = r0 + pl * kPlane, *c = r1 + pl * kPlane;
+            const double *a = r0 + (pl % kPlanes) * kPlane, *c = r1 + (pl % kPlanes) * kPlane;
             const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
             const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
             top[pl][0] = a01[0]; top[pl][1] = a01[1]; top[pl][2] = a23[0]; top[pl][3] = a23[1]; top[pl][4] = a[4];
@@ -956,6 +962,516 @@ __global__ __launch_bounds__(16 * TH, (16 * TH / 256) * WGCU) void proj_owner3(
     }
 }
 
+#endif  // MEMC_MEASURE
+
+// --------------------------------------------------------------------------------------------------
+// The production owner kernels.  What proj_owner2's timing arms showed (tools/bench_ops.py variants 200..261,
+// DESIGN.md): the kernel is bound by how many workgroups a CU holds -- the scan's loads are issued at the start of a
+// workgroup's life and nothing is in flight while it tests, splats and reads out, so the bytes in flight per CU are
+// (workgroups per CU) x 64 KB.  With 71 KiB of LDS (three fp64 planes + the compaction rings) two 64x32 tiles fit a
+// CU: 240 us; the same kernel with two planes (53 KiB, three per CU): 183 us.  A persistent, software-pipelined form
+// (proj_owner3, next tile's fy prefetched) LOST (285 us): on gfx9 a wave's loads and stores share one in-order
+// counter, so the first wait of a tile also waits for the previous tile's stores.  Hence:
+//   * no LDS rings: a wave compacts its hits in REGISTERS.  ds_permute_b32 (the LDS crossbar, no LDS memory) pushes
+//     the hits of one ballot to consecutive lanes of a cyclic 64-entry batch kept in three (four) VGPRs; whenever
+//     the batch is full all 64 lanes splat it.  -16 KiB per workgroup.
+//   * FlowProjection (count = number of sources, an integer) keeps TWO planes: A = count * 2^20 + sum(vx), B =
+//     sum(vy).  At most (2 kReach + 1)^2 = 2401 sources can reach one point and |vx| < kReach, so |sum(vx)| < 2^19
+//     splits off exactly (count = rint(A / 2^20)); a double holding count * 2^20 <= 2^32 still resolves 2^-20 px,
+//     2^-32 px for the counts that actually occur -- finer than the fp32 atomics of the reference.  The depth
+//     operator (count = sum of depths, not an integer) keeps three planes.
+//   * point-plane pitch 66 (65 columns used): the depth operator's three planes then leave room for three
+//     workgroups per CU (52.8 KiB), FlowProjection's two for four (35.3 KiB).
+//
+// Far sources (|f| >= kReach), round 2: proj_owner4 also records, per tile, the largest |fx| and |fy| of its own FAR
+// sources (in the cold branch that raises the flag: the hot loop pays nothing).  The images whose flag was raised are then redone by proj_owner_far -- the same owner-computes tile, but
+// scanning whole SOURCE TILES, and only those whose recorded motion bound lets them reach the window: exact for any
+// flow, no atomics, no zeroing or averaging pass, cost proportional to the actual motion.  One normally idle launch
+// instead of the general path's three or four (each idle launch costs ~5 us + a 1.5 us boundary).
+// --------------------------------------------------------------------------------------------------
+constexpr int kPtW4 = 66;
+constexpr double kCountUnit = 1048576.0;          // 2^20
+
+// One owned 64 x TH tile: its point planes, window bounds and the wave's register batch of waiting hits.
+template <bool DEPTH, int TH>
+struct OwnerTile {
+    static constexpr int NP = DEPTH ? 3 : 2;      // planes: (count, vx, vy) or (count * 2^20 + vx, vy)
+    static constexpr int kPlane = (TH + 1) * kPtW4;
+    static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
+    double *P;
+    int tx0, ty0;
+    float xlo, ylo;
+    int xhi_bits, yhi_bits;
+    unsigned lane, fill;                          // fill: valid entries of the batch (wave-uniform); entry i in lane i
+    int p_cell;
+    float p_vx, p_vy, p_vc;
+
+    // Window bounds.  A source is a hit when its point (T, L) = ((int)y2, (int)x2) lies in the window
+    // [ty0 - 1, ty0 + TH - 1] x [tx0 - 1, tx0 + 63] and the site is valid (x2, y2 inside the image,
+    // my_lib_kernel.cu:1670): x2 >= max(tx0 - 1, 0) and x2 < tx0 + 64 and x2 <= W - 1.  For x2 >= 0 the float order
+    // is the order of the bit patterns, so the last two are ONE integer compare against
+    // min(bits(tx0 + 64), bits(W - 1) + 1).
+    __device__ __forceinline__ void begin(double *P_, int tx0_, int ty0_, int W, int H, unsigned lane_)
+    {
+        P = P_;  tx0 = tx0_;  ty0 = ty0_;  lane = lane_;  fill = 0;
+        p_cell = 0;  p_vx = p_vy = p_vc = 0.0f;
+        xlo = (float)max(tx0 - 1, 0);
+        ylo = (float)max(ty0 - 1, 0);
+        xhi_bits = min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1);
+        yhi_bits = min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1);
+    }
+    template <int NT>
+    __device__ __forceinline__ void zero(int tid) const
+    {
+        f32x4 *pz = reinterpret_cast<f32x4 *>(P);
+        for (int i = tid; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void splat(int cell, float vx, float vy, float vc) const
+    {
+        double *q = P + cell;
+        if (DEPTH) {
+            lds_add_f64(q, (double)vc);
+            lds_add_f64(q + kPlane, (double)vx);
+            lds_add_f64(q + 2 * kPlane, (double)vy);
+        } else {
+            lds_add_f64(q, (double)vx + kCountUnit);           // one source: count += 1, sum(vx) += vx
+            lds_add_f64(q + kPlane, (double)vy);
+        }
+    }
+    // the four y tests of a quad of sources in row sy
+    __device__ __forceinline__ bool rows(bool lv, float syf, const f32x4 &fy4, float (&y2)[4], bool (&wy)[4]) const
+    {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            y2[j] = syf + fy4[j];
+            wy[j] = lv && y2[j] >= ylo && __float_as_int(y2[j]) < yhi_bits;
+            any = any || wy[j];
+        }
+        return any;
+    }
+    // One source per lane (`pre`: passed the y test and whatever else the caller demands): x test, then the hits of
+    // the wave are pushed to the consecutive lanes fill, fill + 1, ... (cyclically) of the batch -- lanes without
+    // a hit aim at the LAST slot of the cycle, which a hit only takes when all 64 lanes hit (no such lane then).
+    // Wave-uniform control flow: call from converged code only.
+    __device__ __forceinline__ void source(bool pre, float x2, float y2, float fxv, float fyv, float d)
+    {
+        const bool hit = pre && x2 >= xlo && __float_as_int(x2) < xhi_bits;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (m == 0) return;                    // wave-uniform
+        const unsigned n = (unsigned)__builtin_popcountll(m);
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const int dst = (int)((fill + (hit ? rank : 63u)) & 63u) << 2;
+        const int py = (int)y2 - (ty0 - 1), px = (int)x2 - (tx0 - 1);                       // (garbage without a hit)
+        float vx = -fxv, vy = -fyv, vc = 1.0f;
+        if (DEPTH) {                           // my_lib_kernel.cu:2102-2114
+            vx = -d * fxv;
+            vy = -d * fyv;
+            vc = d * 1.0f;
+        }
+        const int r_cell = __builtin_amdgcn_ds_permute(dst, py * kPtW4 + px);
+        const float r_vx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vx)));
+        const float r_vy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vy)));
+        float r_vc = 1.0f;
+        if (DEPTH) r_vc = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vc)));
+        if (fill + n < (unsigned)kWave) {      // (wave-uniform) not full yet: lanes [fill, fill + n) take theirs
+            const bool recv = ((lane - fill) & 63u) < n;
+            p_cell = recv ? r_cell : p_cell;
+            p_vx = recv ? r_vx : p_vx;
+            p_vy = recv ? r_vy : p_vy;
+            if (DEPTH) p_vc = recv ? r_vc : p_vc;
+            fill += n;
+        } else {                               // full: lanes [fill, 64) hold new entries, lanes [0, fill) waiting ones
+            const bool fresh = lane >= fill;
+            splat(fresh ? r_cell : p_cell, fresh ? r_vx : p_vx, fresh ? r_vy : p_vy, fresh ? r_vc : p_vc);
+            fill = fill + n - (unsigned)kWave; // the entries that wrapped around: lanes [0, fill)
+            p_cell = r_cell;  p_vx = r_vx;  p_vy = r_vy;  p_vc = r_vc;
+        }
+    }
+    __device__ __forceinline__ void finish() const
+    {
+        if (lane < fill) splat(p_cell, p_vx, p_vy, p_vc);      // what is still waiting
+    }
+    // After a barrier: the lane's four cells (cx .. cx + 3, cy) -- 2x2 box sums of the points of columns c-1 .. c+3,
+    // rows cy-1 and cy (border duplicates as weights 2, see proj_scatter_tiled), normalised by the count.
+    __device__ __forceinline__ void readout(int cx, int cy, int W, int H, f32x4 &ox, f32x4 &oy, f32x4 &oc) const
+    {
+        const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
+        float top[3][5], bot[3][5];            // [count, vx, vy][column], each point sum rounded to fp32 once
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const double *r0 = P + (cy - ty0) * kPtW4 + (cx - tx0);   // column offset a multiple of 4: 16-byte pairs
+#pragma unroll
+        for (int pl = 0; pl < NP; pl++) {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const double *a = r0 + pl * kPlane + rr * kPtW4;
+                const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
+                const double v[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
+                float (&dst_c)[5] = rr ? bot[0] : top[0];
+                float (&dst_x)[5] = rr ? bot[1] : top[1];
+                float (&dst_y)[5] = rr ? bot[2] : top[2];
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    if (DEPTH) {
+                        (pl == 0 ? dst_c : (pl == 1 ? dst_x : dst_y))[i] = (float)v[i];
+                    } else if (pl == 0) {      // A = count * 2^20 + sum(vx): split exactly
+                        const double cnt = __builtin_rint(v[i] * (1.0 / kCountUnit));
+                        dst_c[i] = (float)cnt;
+                        dst_x[i] = (float)__builtin_fma(cnt, -kCountUnit, v[i]);
+                    } else {
+                        dst_y[i] = (float)v[i];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
+            float v[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                // the four contributions are added in a fixed order (the reference's order is arbitrary: fp32 atomics)
+                float t = 0.0f;
+                t += wy0 * wx0 * bot[pl][j + 1];
+                t += wy0 * bot[pl][j];
+                t += wx0 * top[pl][j + 1];
+                t += top[pl][j];
+                v[pl] = t;
+            }
+            if (v[0] > 0.0f) {                 // my_lib_kernel.cu:1730-1735; one reciprocal for both components
+                const float inv = 1.0f / v[0]; // (<= 1 ulp from the two divisions)
+                v[1] = v[1] * inv;
+                v[2] = v[2] * inv;
+            }
+            oc[j] = v[0];  ox[j] = v[1];  oy[j] = v[2];
+        }
+    }
+};
+
+// stores, and the hole filler's per-tile summaries (the counts are in registers: they are free)
+template <int TH>
+__device__ __forceinline__ void owner_store(TileSummary<TH> &sm, const FillWs &ws, int tid, int b, int tx, int ty, int W,
+                                            int H, int tiles_x, int tiles_y, int64_t s1b, int64_t s1c, int s1h,
+                                            int64_t scb, int sch, float *count, float *out, const f32x4 &ox,
+                                            const f32x4 &oy, const f32x4 &oc)
+{
+    const int cx = tx * 64 + 4 * (tid % 16), cy = ty * TH + tid / 16;
+    const bool inb = cx < W && cy < H;            // (no early exit: the summary below has a barrier)
+    if (inb) {
+        float *o = out + b * s1b + (int64_t)cy * s1h + cx;
+        *reinterpret_cast<f32x4 *>(o) = ox;    // plain stores: pass 3 (hole fill) re-reads them
+        *reinterpret_cast<f32x4 *>(o + s1c) = oy;
+        *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
+    }
+    if (ws.up) {
+        const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
+        const int any_hole = __syncthreads_or(hole);
+        summary_store(sm, any_hole, ws, b, tx, ty, W, H, tiles_x, tiles_y);
+    }
+}
+
+// (Written out rather than built from OwnerTile's methods: at 64 VGPRs -- eight waves per SIMD, which is what lets
+// four workgroups share a CU -- the allocator is at its limit, and the method form of the very same code spilled five
+// registers and ran 25 % slower.)
+// BOUNDS = false (measurement build only): no motion bounds; flagged images are then redone by the general path.
+template <bool DEPTH, int TH, int kReach, int MINW, bool BOUNDS = true>
+__global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
+    int W, int H, int tiles_x, int tiles_y,
+    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
+    const float *__restrict__ flow, const float *__restrict__ depth,
+    float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, int *__restrict__ bounds,
+    FillWs ws, int sw)
+{
+    constexpr int NT = 16 * TH;                   // one lane per four owned cells
+    constexpr int NP = DEPTH ? 3 : 2;             // planes: (count, vx, vy) or (count * 2^20 + vx, vy)
+    constexpr int kPtH = TH + 1, kPlane = kPtH * kPtW4;
+    constexpr int kScanPadX = kReach + 4;         // dilated tile: columns, kept 4-aligned
+    constexpr int kScanW = 64 + 2 * kScanPadX;    // source columns
+    constexpr int kScanH = TH + 2 * kReach + 1;   // source rows: [ty0 - kReach - 1, ty0 + TH + kReach)
+    constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + NT - 1) / NT;
+    static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
+    static_assert((2 * kReach + 1) * (2 * kReach + 1) < 4096 && kReach <= 128, "count * 2^20 + sum(vx) must split exactly");
+    __shared__ __attribute__((aligned(16))) double P[NP * kPlane];
+    __shared__ TileSummary<TH> sm;                // for the hole filler, when one follows (ws.up != nullptr)
+    __shared__ int tile_max[2];                   // bit patterns of max |fx|, max |fy| over the tile's own FAR sources (0: none)
+
+    const TileCoord tc = tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, sw);
+    if (tc.tx >= tiles_x) return;                 // virtual column of the last stripe
+    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * TH;
+    const int tid = threadIdx.x;
+    summary_init(sm);
+    if (BOUNDS && tid < 2) tile_max[tid] = 0;
+    {
+        f32x4 *pz = reinterpret_cast<f32x4 *>(P);
+        for (int i = tid; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // scan loads: see proj_owner2 (slots, far rows, unconditional addresses)
+    constexpr int kNearRows = 8;
+    auto far_it = [](int it) {
+        const int first = NT * it / kCols4, last = (NT * it + NT - 1) / kCols4;
+        return last <= kReach + 1 - kNearRows || first >= kReach + 1 + TH + kNearRows;
+    };
+    const float *flow_b = flow + b * s1b;
+    const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
+    f32x4 fx[kIts], fy[kIts], dd[kIts];
+    int sx[kIts], sy[kIts];
+    bool live[kIts];
+    int row = tid / kCols4, c4 = tid % kCols4;
+#pragma unroll
+    for (int it = 0; it < kIts; it++) {
+        sx[it] = tx0 - kScanPadX + 4 * c4;
+        sy[it] = ty0 - kReach - 1 + row;
+        live[it] = row < kScanH && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
+        const unsigned off = live[it] ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;         // dead slots read pixel 0
+        fy[it] = ld_cached4_u(flow_b + s1c, off);
+        if (!far_it(it)) {
+            fx[it] = ld_cached4_u(flow_b, off);
+            if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+        }
+        row += NT / kCols4;
+        c4 += NT % kCols4;
+        if (c4 >= kCols4) {
+            c4 -= kCols4;
+            row++;
+        }
+    }
+    __syncthreads();                           // P is zero
+
+    // wave-uniform window bounds (see proj_owner2: the upper bounds are compared as bit patterns)
+    const float xlo = (float)max(tx0 - 1, 0), ylo = (float)max(ty0 - 1, 0);
+    const int xhi_bits = min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1);
+    const int yhi_bits = min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1);
+    const unsigned lane = tid & (kWave - 1);
+    // the wave's batch of waiting hits: entry i sits in lane i; `fill` of them are valid (wave-uniform)
+    int p_cell = 0;
+    float p_vx = 0.0f, p_vy = 0.0f, p_vc = 0.0f;
+    unsigned fill = 0;
+    bool far = false;
+
+    auto splat = [&](int cell, float vx, float vy, float vc) {
+        double *q = P + cell;
+        if (DEPTH) {
+            lds_add_f64(q, (double)vc);
+            lds_add_f64(q + kPlane, (double)vx);
+            lds_add_f64(q + 2 * kPlane, (double)vy);
+        } else {
+            lds_add_f64(q, (double)vx + kCountUnit);           // one source: count += 1, sum(vx) += vx
+            lds_add_f64(q + kPlane, (double)vy);
+        }
+    };
+
+#pragma unroll
+    for (int it = 0; it < kIts; it++) {
+        const bool lv = live[it];
+        const float syf = (float)sy[it], sxf = (float)sx[it];
+        // the quad lies inside the tile itself (tx0, the pad and sx are multiples of 4: all four sites or none)
+        const bool homeq = lv && (unsigned)(sy[it] - ty0) < (unsigned)TH && (unsigned)(sx[it] - tx0) < 64u;
+        float y2[4];
+        bool wy[4], rowany = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            y2[j] = syf + fy[it][j];
+            wy[j] = lv && y2[j] >= ylo && __float_as_int(y2[j]) < yhi_bits;
+            rowany = rowany || wy[j];
+        }
+        // rows farther from the tile than the local motion: the whole wave leaves after the four y tests
+        if (__builtin_amdgcn_ballot_w64(rowany || homeq) == 0) continue;
+        f32x4 fxq = fx[it], ddq = dd[it];
+        if (far_it(it)) {                      // rare: requested only now (and consumed inside this branch)
+            const unsigned off = lv ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
+            fxq = ld_cached4_u(flow_b, off);
+            if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float fxv = fxq[j], fyv = fy[it][j];
+            const float x2 = (sxf + (float)j) + fxv;           // (float)x + fx, as the reference rounds it
+            const bool nearj = fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach;
+            if (homeq && !nearj) {             // a far source whose home is this tile: the image is redone
+                const bool valid = x2 >= 0.0f && y2[j] >= 0.0f && x2 <= (float)(W - 1) && y2[j] <= (float)(H - 1);
+                far = far || valid;
+                if (BOUNDS && valid) {         // (cold) the tile's bound on its far sources' motion, for proj_owner_far:
+                    atomicMax(&tile_max[0], __float_as_int(fabsf(fxv)));      // non-negative floats order like their bits
+                    atomicMax(&tile_max[1], __float_as_int(fabsf(fyv)));
+                }
+            }
+            const bool hit = wy[j] && nearj && x2 >= xlo && __float_as_int(x2) < xhi_bits;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+            if (m == 0) continue;              // wave-uniform
+            const unsigned n = (unsigned)__builtin_popcountll(m);
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            // Push the hits to the consecutive lanes fill, fill + 1, ... (cyclically) of the batch.  Lanes without a
+            // hit aim at the LAST slot of the cycle, which a hit only takes when all 64 lanes hit (no such lane then).
+            const int dst = (int)((fill + (hit ? rank : 63u)) & 63u) << 2;
+            const int py = (int)y2[j] - (ty0 - 1), px = (int)x2 - (tx0 - 1);                 // (garbage without a hit)
+            float vx = -fxv, vy = -fyv, vc = 1.0f;
+            if (DEPTH) {                       // my_lib_kernel.cu:2102-2114
+                vx = -ddq[j] * fxv;
+                vy = -ddq[j] * fyv;
+                vc = ddq[j] * 1.0f;
+            }
+            const int r_cell = __builtin_amdgcn_ds_permute(dst, py * kPtW4 + px);
+            const float r_vx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vx)));
+            const float r_vy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vy)));
+            float r_vc = 1.0f;
+            if (DEPTH) r_vc = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vc)));
+            if (fill + n < (unsigned)kWave) {  // (wave-uniform) the batch is not full yet: lanes [fill, fill + n) take theirs
+                const bool recv = ((lane - fill) & 63u) < n;
+                p_cell = recv ? r_cell : p_cell;
+                p_vx = recv ? r_vx : p_vx;
+                p_vy = recv ? r_vy : p_vy;
+                if (DEPTH) p_vc = recv ? r_vc : p_vc;
+                fill += n;
+            } else {                           // full: lanes [fill, 64) hold new entries, lanes [0, fill) waiting ones
+                const bool fresh = lane >= fill;
+                splat(fresh ? r_cell : p_cell, fresh ? r_vx : p_vx, fresh ? r_vy : p_vy, fresh ? r_vc : p_vc);
+                fill = fill + n - (unsigned)kWave;            // the entries that wrapped around: lanes [0, fill)
+                p_cell = r_cell;  p_vx = r_vx;  p_vy = r_vy;  p_vc = r_vc;
+            }
+        }
+    }
+    if (lane < fill) splat(p_cell, p_vx, p_vy, p_vc);          // what is still waiting
+    if (far) {                                 // this image needs the general path
+        far_flag[b % kFlagWords] = 1;
+        far_flag[kFlagWords] = 1;
+    }
+    __syncthreads();                           // every wave's points are in P (and the tile's motion bound in tile_max)
+    if (BOUNDS && tid < 2) bounds[2 * (((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx) + tid] = tile_max[tid];
+
+    // every lane owns four cells of a row: 2x2 box sums of the points of columns c-1 .. c+3, rows cy-1 and cy
+    const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
+    const bool inb = cx < W && cy < H;            // (no early exit: the summary below has a barrier)
+    const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
+    float top[3][5], bot[3][5];                // [count, vx, vy][column], each point sum rounded to fp32 once
+    {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const double *r0 = P + (cy - ty0) * kPtW4 + (cx - tx0);   // column offset a multiple of 4: 16-byte pairs
+#pragma unroll
+        for (int pl = 0; pl < NP; pl++) {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const double *a = r0 + pl * kPlane + rr * kPtW4;
+                const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
+                const double v[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
+#pragma unroll
+                for (int i = 0; i < 5; i++) {
+                    float (&dst_c)[5] = rr ? bot[0] : top[0];
+                    float (&dst_x)[5] = rr ? bot[1] : top[1];
+                    float (&dst_y)[5] = rr ? bot[2] : top[2];
+                    if (DEPTH) {
+                        (pl == 0 ? dst_c : (pl == 1 ? dst_x : dst_y))[i] = (float)v[i];
+                    } else if (pl == 0) {      // A = count * 2^20 + sum(vx): split exactly
+                        const double cnt = __builtin_rint(v[i] * (1.0 / kCountUnit));
+                        dst_c[i] = (float)cnt;
+                        dst_x[i] = (float)__builtin_fma(cnt, -kCountUnit, v[i]);
+                    } else {
+                        dst_y[i] = (float)v[i];
+                    }
+                }
+            }
+        }
+    }
+    f32x4 ox, oy, oc;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
+        float v[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            // the four contributions are added in a fixed order (the reference's order is arbitrary: fp32 atomics)
+            float t = 0.0f;
+            t += wy0 * wx0 * bot[pl][j + 1];
+            t += wy0 * bot[pl][j];
+            t += wx0 * top[pl][j + 1];
+            t += top[pl][j];
+            v[pl] = t;
+        }
+        if (v[0] > 0.0f) {                     // my_lib_kernel.cu:1730-1735; one reciprocal for both components
+            const float inv = 1.0f / v[0];     // (<= 1 ulp from the two divisions)
+            v[1] = v[1] * inv;
+            v[2] = v[2] * inv;
+        }
+        oc[j] = v[0];  ox[j] = v[1];  oy[j] = v[2];
+    }
+    if (inb) {
+        float *o = out + b * s1b + (int64_t)cy * s1h + cx;
+        *reinterpret_cast<f32x4 *>(o) = ox;    // plain stores: pass 3 (hole fill) re-reads them
+        *reinterpret_cast<f32x4 *>(o + s1c) = oy;
+        *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
+    }
+    if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
+        const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
+        const int any_hole = __syncthreads_or(hole);
+        summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
+    }
+}
+
+// The images flagged by proj_owner4, redone exactly: every tile of such an image scans whole source tiles -- those
+// whose motion bound (kReach, or what proj_owner4 recorded in bounds[] for the tile's far sources: max |fx|, max |fy|)
+// lets one of their sources land in the window -- with no limit on |flow|.  Queued behind proj_owner4 as a short grid that strides over the tiles; returns
+// at once when no flag was raised.
+template <bool DEPTH, int TH, int kReach>
+__global__ __launch_bounds__(16 * TH) void proj_owner_far(
+    int W, int H, int tiles_x, int tiles_y, int batch,
+    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
+    const float *__restrict__ flow, const float *__restrict__ depth,
+    float *__restrict__ count, float *__restrict__ out, const int *__restrict__ far_flag,
+    const int *__restrict__ bounds, FillWs ws)
+{
+    using OT = OwnerTile<DEPTH, TH>;
+    constexpr int NT = 16 * TH;
+    __shared__ __attribute__((aligned(16))) double P[OT::NP * OT::kPlane];
+    __shared__ TileSummary<TH> sm;
+    if (far_flag[kFlagWords] == 0) return;
+    const unsigned per_image = (unsigned)tiles_x * tiles_y, ntiles = per_image * batch;
+#pragma unroll 1
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / per_image, tx = (tile % per_image) % tiles_x, ty = (tile % per_image) / tiles_x;
+        if (far_flag[b % kFlagWords] == 0) continue;             // wave-uniform: this image was complete
+        const int tid = tid_now();
+        const int tx0 = tx * 64, ty0 = ty * TH;
+        OT t;
+        t.begin(P, tx0, ty0, W, H, tid & (kWave - 1));
+        summary_init(sm);
+        t.template zero<NT>(tid);
+        __syncthreads();
+        const float *flow_b = flow + b * s1b;
+        const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
+        const int *bnd = bounds + 2 * (int64_t)b * per_image;
+#pragma unroll 1
+        for (unsigned s = 0; s < per_image; s++) {
+            const int stx = s % tiles_x, sty = s / tiles_x;
+            // (recorded: the tile's far sources; its other sources move by less than kReach)
+            const float mx = fmaxf(__int_as_float(bnd[2 * s]), (float)kReach), my = fmaxf(__int_as_float(bnd[2 * s + 1]), (float)kReach);
+            // can a source of tile s, moved by at most (mx, my) (+1: the rounding of x + fx), land in the window?
+            const float sx0 = (float)(stx * 64), sy0 = (float)(sty * TH);
+            const bool cand = sx0 + 64.0f + mx >= (float)(tx0 - 1) && sx0 - mx - 1.0f < (float)(tx0 + 64) &&
+                              sy0 + (float)TH + my >= (float)(ty0 - 1) && sy0 - my - 1.0f < (float)(ty0 + TH);
+            if (!cand) continue;               // wave-uniform (scalar data)
+            const int sx = stx * 64 + 4 * (tid % 16), sy = sty * TH + tid / 16;   // one quad of sources per lane
+            const bool lv = sx < W && sy < H;
+            const unsigned off = lv ? 4u * (unsigned)(sy * s1h + sx) : 0u;
+            const f32x4 fxq = ld_cached4_u(flow_b, off), fyq = ld_cached4_u(flow_b + s1c, off);
+            f32x4 ddq = {1.f, 1.f, 1.f, 1.f};
+            if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy * sdh + sx) : 0u);
+            float y2[4];
+            bool wy[4];
+            const bool rowany = t.rows(lv, (float)sy, fyq, y2, wy);
+            if (__builtin_amdgcn_ballot_w64(rowany) == 0) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                t.source(wy[j], ((float)sx + (float)j) + fxq[j], y2[j], fxq[j], fyq[j], ddq[j]);
+        }
+        t.finish();
+        __syncthreads();                       // every wave's points are in P
+        f32x4 ox, oy, oc;
+        t.readout(tx0 + 4 * (tid % 16), ty0 + tid / 16, W, H, ox, oy, oc);
+        owner_store(sm, ws, tid, b, tx, ty, W, H, tiles_x, tiles_y, s1b, s1c, s1h, scb, sch, count, out, ox, oy, oc);
+        __syncthreads();                       // P and the summary are rebuilt by the next tile
+    }
+}
+
 // --------------------------------------------------------------------------------------------------
 // Pass 3 with carries: the hole filler whose walks never leave a tile.
 // The reference walks from every hole to the nearest cell with a non-zero count to its left, to its right and above
@@ -963,9 +1479,11 @@ __global__ __launch_bounds__(16 * TH, (16 * TH / 256) * WGCU) void proj_owner3(
 // makes every hole of a vertical strip climb the whole strip (measured: projection + fill 765 .. 1320 us against
 // 244 .. 266 us without, 720p batch 32).  Here a walk covers its own 64 x TH tile only; what lies beyond comes from
 // three small carry tables built by two tiny scans over per-tile summaries:
-//   up   [b][ty][x]   nearest row above band ty  whose cell in column x has a non-zero count   (-1: none)
-//   left [b][y ][tx]  nearest column left of tile column tx with a non-zero count in row y      (-1: none)
-//   right[b][y ][tx]  likewise to the right
+//   up   [b][ty][x]   last row of band ty whose cell in column x has a non-zero count            (-1: none)
+//   left [b][tx][y]   last column of tile column tx with a non-zero count in row y               (-1: none)
+//   right[b][tx][y]   first such column
+// (round 1 turned these into "nearest beyond the tile" tables with a scan kernel; now the filler walks the
+// neighbouring tiles' entries itself, nearest first -- one launch and 13 us less, usually one step)
 // plus the list of the tiles that contain a hole (the filler is launched over that list only).
 // Same cells, same flags, same arithmetic as the walks -- identical results.  The tables (0.4 B per pixel) live in
 // a stream-ordered allocation made and released by the launcher.
@@ -998,43 +1516,6 @@ __global__ __launch_bounds__(256) void proj_fill_summary(
         const int any_hole = __syncthreads_or(hole);       // (also orders the LDS atomics before the reads below)
         summary_store(sm, any_hole, ws, b, tx, ty, W, H, tiles_x, tiles_y);
         __syncthreads();                                   // before the next tile re-initialises the summary
-    }
-}
-
-// exclusive scans of the summaries, in place: one lane per image column (down the bands) / per image row (along
-// the tile columns, both ways).  A few hundred thousand lanes doing <= 45 / 2 x 60 steps on 11 MB.
-__global__ __launch_bounds__(256) void proj_fill_scan(int W, int H, int ntx, int nty, int batch, FillWs ws)
-{
-    // the values of a lane's chain are requested sixteen at a time (independent loads), then scanned in registers:
-    // a chain of dependent loads would cost ~0.5 us a step
-    auto scan = [](int *base, int64_t stride, int n, bool reverse) {
-        int carry = -1;
-        for (int i0 = 0; i0 < n; i0 += 16) {
-            int v[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int i = min(i0 + k, n - 1);
-                v[k] = base[(int64_t)(reverse ? n - 1 - i : i) * stride];
-            }
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if (i0 + k < n) {
-                    const int i = i0 + k;
-                    base[(int64_t)(reverse ? n - 1 - i : i) * stride] = carry;
-                    if (v[k] >= 0) carry = v[k];
-                }
-            }
-        }
-    };
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t ncol = (int64_t)batch * W, nrow = (int64_t)batch * H;
-    if (t < ncol) {
-        const int b = (int)(t / W), x = (int)(t % W);
-        scan(ws.up + (int64_t)b * nty * W + x, W, nty, false);
-    } else if (t < ncol + nrow) {
-        const int64_t r = t - ncol;                        // = b * H + y
-        scan(ws.left + r * ntx, 1, ntx, false);
-        scan(ws.right + r * ntx, 1, ntx, true);
     }
 }
 
@@ -1084,13 +1565,14 @@ __global__ __launch_bounds__(256) void proj_fillhole_carry(
         int lo = -1, ro = -1, uo = -1;
         for (int c = hx - 1; c >= 0 && lo < 0; c--)
             if (cnt[hy * 64 + c] != 0.0f) lo = tx0 + c;
-        if (lo < 0) lo = ws.left[((int64_t)b * H + gy) * tiles_x + tx];
+        // (tile summaries of this row, nearest first: the last non-zero column of each tile to the left)
+        for (int t = tx - 1; t >= 0 && lo < 0; t--) lo = ws.left[((int64_t)b * tiles_x + t) * H + gy];
         for (int c = hx + 1; c < 64 && tx0 + c < W && ro < 0; c++)
             if (cnt[hy * 64 + c] != 0.0f) ro = tx0 + c;
-        if (ro < 0) ro = ws.right[((int64_t)b * H + gy) * tiles_x + tx];
+        for (int t = tx + 1; t < tiles_x && ro < 0; t++) ro = ws.right[((int64_t)b * tiles_x + t) * H + gy];
         for (int r = hy - 1; r >= 0 && uo < 0; r--)
             if (cnt[r * 64 + hx] != 0.0f) uo = ty0 + r;
-        if (uo < 0) uo = ws.up[((int64_t)b * tiles_y + ty) * W + gx];
+        for (int t = ty - 1; t >= 0 && uo < 0; t--) uo = ws.up[((int64_t)b * tiles_y + t) * W + gx];
         // the counts the walks stopped at (0 when they ran into the image border)
         const float lt = lo >= 0 ? cn[(int64_t)gy * sch + lo] : 0.0f;
         const float rt = ro >= 0 ? cn[(int64_t)gy * sch + ro] : 0.0f;
@@ -1681,6 +2163,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     const int snty = (h + 15) / 16;                          // the general path scatters from 64x16 SOURCE tiles
     const unsigned sntiles = (unsigned)ntx * snty * batch;
     const unsigned gs = 256 * 8;                             // grid-stride: 8 workgroups per CU
+    const unsigned gq = 256 * 2;                             // ... of the kernels queued behind the far flag (normally idle)
     const int64_t s1b = a.s1b, s1c = a.s1c, sdb = a.sdb, scb = a.scb;
     const int s1h = a.s1h, sdh = a.sdh, sch = a.sch;
 
@@ -1688,21 +2171,26 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     const bool want_fast = variant != 1 && variant < 2 && plane_fits_u32(w, h, {s1h, sdh});
     const bool want_carry = a.fillhole && variant != -8 && variant != -9;
     // scratch layout (ints): [0, 320) far flags (image b -> word b % 256, word 256 = "any"), [320, 576) list fill
-    // counts, then -- with hole filling -- the three carry tables and the hole-tile list
+    // counts, the tiles' motion bounds (2 per tile), then -- with hole filling -- the three tables of per-tile
+    // summaries and the hole-tile list
     constexpr size_t kHead = 320 + kListSegs;
+    const size_t n_bnd = want_fast ? 2 * (size_t)ntiles : 0;
     const size_t n_up = (size_t)batch * nty * w, n_row = (size_t)batch * h * ntx;
     const int cap = 2 * (int)((ntiles + kListSegs - 1) / kListSegs) + 2;          // (a tile can be listed twice)
-    const size_t ints = kHead + (want_carry ? n_up + 2 * n_row + (size_t)kListSegs * cap : 0);
+    const size_t ints = kHead + n_bnd + (want_carry ? n_up + 2 * n_row + (size_t)kListSegs * cap : 0);
     CallScratch scratch;
-    int *flag = nullptr;
+    int *flag = nullptr, *bounds = nullptr;
     FillWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if ((want_fast || want_carry) && scratch.alloc(ints * sizeof(int), stream)) {
         int *base = static_cast<int *>(scratch.p);
         if (hipMemsetAsync(base, 0, kHead * sizeof(int), stream) != hipSuccess) return -1;
-        if (want_fast) flag = base;
+        if (want_fast) {
+            flag = base;
+            bounds = base + kHead;
+        }
         if (want_carry) {
             ws.n_list = base + 320;
-            ws.up = base + kHead;
+            ws.up = base + kHead + n_bnd;
             ws.left = ws.up + n_up;
             ws.right = ws.left + n_row;
             ws.list = ws.right + n_row;
@@ -1713,14 +2201,15 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     // literal hole walker -- slower, same results.
 
 #define MEMC_PROJ_SCATTER(ABL, FLAG)                                                                        \
-    hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3((FLAG) != nullptr && sntiles > gs ? gs : sntiles), \
+    hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3((FLAG) != nullptr && sntiles > gq ? gq : sntiles), \
                        dim3(256), 4 * A::kPlane * 4 + 64, stream, w, h, ntx, snty, sntiles, s1b, s1c, s1h, sdb, sdh,  \
                        scb, sch, a.flow, a.depth, a.count, a.out, FLAG)
     bool only_part = false;                                  // measurement arms that time one piece
     if (flag) {
-        // fast path: owner-computes (no atomics, fused averaging, hole-filler summaries for free) + the general
-        // path behind a device flag
-        bool launched = false;
+        // fast path: owner-computes (no atomics, fused averaging, hole-filler summaries for free); images with a
+        // far source are redone by proj_owner_far behind a device flag (round-1 / ring kernels of the measurement
+        // build: by the general path behind the same flag)
+        bool launched = false, own4 = false;
 #ifdef MEMC_MEASURE
         if (variant == -10 || variant == -7 || variant == -6) {       // round-1 owner kernel (64x16, strips)
             const unsigned nwg = ntiles;
@@ -1737,12 +2226,12 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
         }
         only_part = variant == -5 || variant == -7;
 #endif
+#ifdef MEMC_MEASURE
 #define MEMC_PROJ_OWNER2(ABL, TRACE)                                                                              \
             hipLaunchKernelGGL((proj_owner2<DEPTH, TH, 24, ABL, TRACE>), dim3(walk_grid(ntx, nty, batch, sw)),          \
                                dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,       \
                                a.depth, a.count, a.out, flag, ws, sw)
-#ifdef MEMC_MEASURE
-        if (!launched && variant <= -20) {     // -21 .. -25: timing arms of proj_owner2 (wrong results); -29: timestamps
+        if (!launched && variant <= -20 && variant > -30) {   // -21 .. -26: timing arms of proj_owner2 (wrong results); -29: timestamps
             only_part = true;
             launched = true;
             if (variant == -21) MEMC_PROJ_OWNER2(1, false);
@@ -1750,40 +2239,57 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             else if (variant == -23) MEMC_PROJ_OWNER2(3, false);
             else if (variant == -24) MEMC_PROJ_OWNER2(4, false);
             else if (variant == -25) MEMC_PROJ_OWNER2(5, false);
+            else if (variant == -26) MEMC_PROJ_OWNER2(6, false);
             else if (variant == -29) MEMC_PROJ_OWNER2(0, true);
-            else launched = false;
+            else launched = false;                         // -20: the production kernel alone
         }
-#endif
-#define MEMC_PROJ_OWNER3(WGCU)                                                                                    \
-        do {                                                                                                     \
-            const unsigned npos = walk_grid(ntx, nty, batch, sw);                                                \
-            const unsigned pg = persistent_grid(WGCU);                                                           \
-            hipLaunchKernelGGL((proj_owner3<DEPTH, TH, 24, WGCU>), dim3(npos < pg ? (npos + 7) / 8 * 8 : pg),     \
-                               dim3(16 * TH), 0, stream, w, h, ntx, nty, npos, s1b, s1c, s1h, sdb, sdh, scb, sch,    \
-                               a.flow, a.depth, a.count, a.out, flag, ws, sw);                                   \
-        } while (0)
-#ifdef MEMC_MEASURE
-        if (!launched && variant == -30) {     // proj_owner2 (one tile per workgroup) instead of the persistent kernel
+        if (!launched && variant == -30) {     // proj_owner2: LDS rings, three planes
             MEMC_PROJ_OWNER2(0, false);
             launched = true;
         }
+        if (!launched && variant == -31) {     // proj_owner3: persistent, next tile's fy prefetched
+            if constexpr (TH == 32) {
+                const unsigned npos = walk_grid(ntx, nty, batch, sw), pg = persistent_grid(2);
+                hipLaunchKernelGGL((proj_owner3<DEPTH, 32, 24, 2>), dim3(npos < pg ? (npos + 7) / 8 * 8 : pg), dim3(512), 0,
+                                   stream, w, h, ntx, nty, npos, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth,
+                                   a.count, a.out, flag, ws, sw);
+                launched = true;
+            }
+        }
+#undef MEMC_PROJ_OWNER2
 #endif
         if (!launched) {
-            if constexpr (TH == 16) MEMC_PROJ_OWNER3(3);
-            else if constexpr (TH == 32) MEMC_PROJ_OWNER3(2);
-            else MEMC_PROJ_OWNER3(1);
+            // waves per SIMD the register allocator must leave room for = what the LDS admits: FlowProjection 4
+            // workgroups per CU at TH = 32 (2 planes, 35 KiB), the depth operator 3 (53 KiB)
+            constexpr int kWgCu = TH == 16 ? (DEPTH ? 4 : 6) : (TH == 32 ? (DEPTH ? 3 : 4) : 1);
+            constexpr int kMinW = (kWgCu * (16 * TH / 64) + 3) / 4 > 8 ? 8 : (kWgCu * (16 * TH / 64) + 3) / 4;
+#ifdef MEMC_MEASURE
+            if (variant == -32)                // A/B: without the motion bounds; flagged images take the general path
+                hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW, false>), dim3(walk_grid(ntx, nty, batch, sw)),
+                                   dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,
+                                   a.depth, a.count, a.out, flag, bounds, ws, sw);
+            else
+#endif
+            hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(16 * TH), 0,
+                               stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
+                               a.out, flag, bounds, ws, sw);
+            own4 = variant != -32;
         }
-#undef MEMC_PROJ_OWNER3
-#undef MEMC_PROJ_OWNER2
         if (launch_status() != 0) return -1;
-        if (!only_part) {
-            hipLaunchKernelGGL(proj_redo_zero, dim3(gs), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
+        if (own4 && !only_part) {
+            const unsigned pg = persistent_grid(1);
+            hipLaunchKernelGGL((proj_owner_far<DEPTH, TH, 24>), dim3(ntiles < pg ? ntiles : pg), dim3(16 * TH), 0, stream, w, h,
+                               ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,
+                               bounds, ws);
+            if (launch_status() != 0) return -1;
+        } else if (!only_part) {
+            hipLaunchKernelGGL(proj_redo_zero, dim3(gq), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
                                a.count, a.out, flag);
             MEMC_PROJ_SCATTER(0, flag);
-            hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
+            hipLaunchKernelGGL(proj_average_v4, dim3(gq), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
                                a.count, a.out, flag);
             if (ws.up)                          // summaries of the images the general path redid
-                hipLaunchKernelGGL(proj_fill_summary<TH>, dim3(gs), dim3(256), 0, stream, w, h, ntx, nty, batch, scb,
+                hipLaunchKernelGGL(proj_fill_summary<TH>, dim3(gq), dim3(256), 0, stream, w, h, ntx, nty, batch, scb,
                                    sch, a.count, ws, flag);
             if (launch_status() != 0) return -1;
         }
@@ -1810,12 +2316,12 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
 #undef MEMC_PROJ_SCATTER
     if (a.fillhole && !only_part) {
         if (ws.up) {
-            const unsigned lanes = (unsigned)(((size_t)batch * (w + h) + 255) / 256);
-            hipLaunchKernelGGL(proj_fill_scan, dim3(lanes), dim3(256), 0, stream, w, h, ntx, nty, batch, ws);
-            // one workgroup per tile of the image (rounded up to whole segments); those beyond their segment's
-            // fill count leave at once
-            hipLaunchKernelGGL(proj_fillhole_carry<TH>, dim3((ntiles + kListSegs - 1) / kListSegs * kListSegs),
-                               dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c, s1h, scb, sch, a.count, a.out, ws);
+            // workgroup i serves list segment i % 256, entries i / 256, + grid / 256, ...: at most 16 workgroups per
+            // segment (most tiles have no hole: 13 % on the benchmark's smooth flow; a workgroup beyond its segment's
+            // fill count leaves at once)
+            const unsigned per_seg = (ntiles + kListSegs - 1) / kListSegs;
+            hipLaunchKernelGGL(proj_fillhole_carry<TH>, dim3(kListSegs * (per_seg < 16 ? per_seg : 16)), dim3(256), 0,
+                               stream, w, h, ntx, nty, batch, s1b, s1c, s1h, scb, sch, a.count, a.out, ws);
         } else {
             hipLaunchKernelGGL(proj_fillhole_v4, dim3(sntiles), dim3(256), 0, stream, w, h, ntx, snty, s1b, s1c, s1h,
                                scb, sch, a.count, a.out, variant == -8 ? 1 : 0);
@@ -1837,14 +2343,22 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
 #ifdef MEMC_MEASURE
         // 100 + 10 * log2(TH / 16) + stripe width: owner geometry under test; -10 / -7 / -6: the round-1 owner
         int v = g_proj_variant, th = kOwnerTH, sw = kOwnerSW;
-        if (v >= 100 && v < 130) {             // persistent owner kernel (proj_owner3)
+        if (v >= 100 && v < 130) {             // the production kernel (proj_owner4) in another geometry
             th = 16 << ((v - 100) / 10);
             sw = (v - 100) % 10;
             v = -1;
-        } else if (v >= 130 && v < 160) {      // one tile per workgroup (proj_owner2), same geometry code + 30
+        } else if (v >= 130 && v < 160) {      // proj_owner2 (LDS rings, three planes), same geometry code + 30
             th = 16 << ((v - 130) / 10);
             sw = (v - 130) % 10;
             v = -30;
+        } else if (v >= 170 && v < 180) {      // proj_owner4 without motion bounds + general path behind the flag
+            th = 32;
+            sw = v - 170;
+            v = -32;
+        } else if (v >= 160 && v < 170) {      // proj_owner3 (persistent, TH = 32), stripe width v - 160
+            th = 32;
+            sw = v - 160;
+            v = -31;
         } else if (v == -10 || v == -7 || v == -6) {
             th = 16;
             sw = 0;

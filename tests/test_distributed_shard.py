@@ -76,6 +76,62 @@ def test_single_rank_plan():
     assert bench.BYTES_PER_SITE["fi_fwd"](3, 4) == 96 and bench.BYTES_PER_SITE["fi_fwd"](64, 4) == 584
 
 
+def test_strong_scaling_plan():
+    """the global batch stays 32 frame pairs, rank r owns a contiguous 32 / N of them."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (1, 2, 4, 8, 3, 5):
+        plans = [bench.shard_plan(r, world, 32, 1234, "strong") for r in range(world)]
+        assert all(p["global_batch"] == 32 and p["scaling"] == "strong" for p in plans)
+        assert sum(p["items"] for p in plans) == 32
+        assert plans[0]["first_item"] == 0
+        for a, b in zip(plans, plans[1:]):
+            assert b["first_item"] == a["first_item"] + a["items"]            # contiguous, disjoint, complete
+        assert max(p["items"] for p in plans) - min(p["items"] for p in plans) <= 1
+        assert len({p["seed"] for p in plans}) == world
+    assert [bench.shard_plan(r, 8, 32, 0, "strong")["items"] for r in range(8)] == [4] * 8
+    assert [bench.shard_plan(r, 3, 32, 0, "strong")["items"] for r in range(3)] == [11, 11, 10]
+    # weak: every rank its own batch
+    assert [bench.shard_plan(r, 4, 32, 0, "weak")["first_item"] for r in range(4)] == [0, 32, 64, 96]
+
+
+def _strong_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    cfg = bench.broadcast_config({"batch": 32 if rank == 0 else 5, "seed": 1234 + rank}, world, dev)
+    plan = bench.shard_plan(rank, world, cfg["batch"], cfg["seed"], "strong")
+    # every rank processes ITS items; together they cover the global batch exactly once
+    mine = torch.zeros(cfg["batch"], dtype=torch.int64)
+    mine[plan["first_item"]:plan["first_item"] + plan["items"]] += 1
+    dist.all_reduce(mine)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, plan, mine.tolist()))
+
+
+def test_strong_scaling_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, plan0, cover0), (_, plan1, cover1) = res
+    assert (plan0["first_item"], plan0["items"]) == (0, 16) and (plan1["first_item"], plan1["items"]) == (16, 16)
+    assert plan0["global_batch"] == plan1["global_batch"] == 32
+    assert cover0 == cover1 == [1] * 32
+
+
 def _bcast_worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(ROOT, "memc-net_amd"))
     import importlib.util

@@ -168,6 +168,8 @@ def bench_projection(rows, dev, B, H, W, flow_kind, tag, proj_variants=()):
     f, d = t["flow"], t["depth"]
     cnt = f.new_zeros((B, 1, H, W))
     out = torch.zeros_like(f)
+    for _ in range(150):                        # the device needs ~100 launches (60 ms) to reach its steady clocks
+        L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0)
     gout = torch.rand_like(f)
     gin = torch.zeros_like(f)
     gd = torch.zeros_like(d)

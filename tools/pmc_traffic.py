@@ -24,6 +24,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402
 
 
 def run_pmc(counter, outdir, name, cmd):
@@ -50,7 +52,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc"))
     ap.add_argument("--kernel", default="fi_fwd_tiled")
-    ap.add_argument("--bench-args", default="--steps 6 --warmup 2 --no-cpu-baseline")
+    ap.add_argument("--bench-args", default="--steps 6 --warmup 2 --no-cpu-baseline --no-secondary --launch eager")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     py = sys.executable
@@ -82,6 +84,8 @@ def main():
                         "k_fetch": k_fetch, "k_write": k_write},
         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg,
         "profiled_launch_us": res["FETCH_SIZE"]["kernel"][5] / 1e3,
+        # bench.py quotes this record only while the kernel sources are the ones it was measured on
+        "kernel_source_hash": kernel_source_hash(),
     }
     out = {workload: rec}
     json.dump(out, open(os.path.join(a.out, "traffic.json"), "w"), indent=1)
