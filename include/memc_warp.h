@@ -240,6 +240,37 @@ int FilterInterpolationBlend_gpu_forward_kernel(
     const float *input0, const float *input2, const float *flow0, const float *flow1,
     const float *filter0, const float *filter1, const float *occlusion0, const float *occlusion1, float *output);
 
+/* ------------------------------------------------------------------------------------------------------
+ * EXTENSION -- no reference counterpart.  networks/MEMC_Net_star.py:273-285 warps a frame
+ * and its 64-channel context features with the SAME flow and the same 16 filter planes (FilterInterpolate, then
+ * FilterInterpolate_ctx).  One pass per direction: flow + taps are streamed once for both,
+ *
+ *     context_out = FilterInterpolation(context, flow, filter)
+ *     image_out   = FilterInterpolation(image, flow, filter)                                   (prev == NULL)
+ *     image_out   = occlusion_prev * prev + occlusion_this * FilterInterpolation(image, ...)   (otherwise)
+ *
+ * the second form being MEMC_Net_star.py:277's blend with `prev` = the other direction's image_out.  image, prev,
+ * image_out: [B, 3, H, W], one layout; context, context_out: [B, C, H, W], C a multiple of 4, one layout; the two
+ * occlusions [B, 1, H, W], one layout; prev / occlusion_prev / occlusion_this all NULL or all given.  Forward only,
+ * filter_size 4, 16-byte aligned geometry: anything else returns -1 and the caller uses the entry points above.
+ * Outputs need not be zero-filled.
+ * ------------------------------------------------------------------------------------------------------ */
+int FilterInterpolationCtxLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *image,
+                                            const memc_tensor4 *context, const memc_tensor4 *flow,
+                                            const memc_tensor4 *filter, const memc_tensor4 *prev,
+                                            const memc_tensor4 *occlusion_prev, const memc_tensor4 *occlusion_this,
+                                            const memc_tensor4 *image_out, const memc_tensor4 *context_out);
+
+int FilterInterpolationCtx_gpu_forward_kernel(
+    memc_stream_t stream, const int w, const int h, const int channel, const int batch, const int filter_size,
+    const int image_b_stride, const int image_c_stride, const int image_h_stride,
+    const int context_b_stride, const int context_c_stride, const int context_h_stride,
+    const int flow_b_stride, const int flow_c_stride, const int flow_h_stride,
+    const int filter_b_stride, const int filter_c_stride, const int filter_h_stride,
+    const int occlusion_b_stride, const int occlusion_h_stride,
+    const float *image, const float *context, const float *flow, const float *filter,
+    const float *prev, const float *occlusion_prev, const float *occlusion_this, float *image_out, float *context_out);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

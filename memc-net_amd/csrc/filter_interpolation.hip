@@ -639,6 +639,189 @@ __global__ __launch_bounds__(256, 2) void fi_fwd_blend_c3(
 }
 
 // --------------------------------------------------------------------------------------------------
+// EXTENSION (no reference counterpart): the IMAGE warp and the 64-channel CONTEXT warp of one
+// direction in one pass.  networks/MEMC_Net_star.py:273-285 warps the frame and its context features with the SAME
+// flow and the same 16 filter planes (FilterInterpolate, then FilterInterpolate_ctx): as two launches the 72 B per
+// site of flow + taps are streamed twice.  Here the image is simply one more chunk in front of fi_fwd_tiled_c4n's
+// chunk loop (3 channels + a duplicate plane in the pixel quad), and with BLEND the image chunk's epilogue is the
+// occlusion-weighted blend of MEMC_Net_star.py:277,
+//     image_out = occ_prev * prev + occ_this * FI(image, flow, filter)
+// where `prev` is the other direction's warp (written by the BLEND == false launch before): per frame pair
+// 2 * (584 + 24) + 20 = 1236 B per site instead of 188 + 2 * 584 = 1356.
+// Same arithmetic as fi_fwd_blend_c3 (two products, one sum) and as fi_fwd_tiled_c4n: identical results.
+// --------------------------------------------------------------------------------------------------
+template <bool BLEND>
+__global__ __launch_bounds__(256, 2) void fi_fwd_ctx_img(
+    int W, int H, int C, int tiles_x, int tiles_y,
+    int64_t sib, int64_t sic, int sih,               // image, prev, image_out  [B, 3, H, W]
+    int64_t s1b, int64_t s1c, int s1h,               // context, context_out    [B, C, H, W], C % 4 == 0
+    int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h, int64_t sob, int soh,
+    const float *__restrict__ img, const float *__restrict__ in1, const float *__restrict__ flow,
+    const float *__restrict__ filt, const float *__restrict__ prev, const float *__restrict__ occ_prev,
+    const float *__restrict__ occ_this, float *__restrict__ img_out, float *__restrict__ out)
+{
+    constexpr int LX = 16;
+    using G = TileGeom<LX>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
+    const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
+    const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
+    const bool inb = x < W && y < H;
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
+    const float *tap_p = filt + b * s3b + (int64_t)ys * s3h + xs;
+    const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s2c);
+    f32x4 tp[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) tp[k] = ld_stream4(tap_p + k * s3c);
+
+    FiSite4 g;
+    g.valid = 0;
+    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
+        g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
+        if (inb && s.valid) {
+            g.valid |= 1u << j;
+            cmin = min(cmin, max(s.ix - 1, 0));  cmax = max(cmax, min(s.ix + 2, W - 1));
+            rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
+        }
+    }
+    const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
+    const Bands bands = make_bands<LX>(box);
+    const float *img_b = img + b * sib;
+    const float *in_b = in1 + b * s1b;
+    float *iout_p = img_out + b * sib + (int64_t)y * sih + x;
+    float *out_p = out + b * s1b + (int64_t)y * s1h + x;
+    // blend of ONE element (rare paths): two products, one sum, as the reference's torch expression (and
+    // fi_fwd_blend_c3).  Addresses are rebuilt at the use: six more live pointer registers do not fit this kernel.
+    auto blend1 = [&](float w, int c, int j) {
+        if (!BLEND) return w;
+        const int64_t oi = b * sib + c * sic + (int64_t)y * sih + x + j, oo = b * sob + (int64_t)y * soh + x + j;
+        const float p0 = occ_prev[oo] * prev[oi], p2 = occ_this[oo] * w;
+        return p0 + p2;
+    };
+    unsigned done = 0;
+    const int nchunks = C / 4 + 1;                 // chunk 0: the image (RGB + a duplicate plane); then the context
+#pragma unroll 1
+    for (int bi = 0; bi < bands.n; bi++) {
+        const Region r = band_region(box, bands, bi);
+        const unsigned sel = inb ? fi_covered(r, g, W, H) & ~done : 0u;
+        // later bands only run when somebody still needs them; the vote is also the barrier that frees the LDS
+        if (bi > 0 && !__syncthreads_or(sel != 0)) continue;
+        done |= sel;
+        // band 0 also writes the out-of-range sites (they copy the input pixel)
+        const unsigned wr = sel | (bi == 0 && inb ? ~g.valid & 0xFu : 0u);
+        const StageSlot sl = stage_slots(r);
+        StageRegs<4> sr;
+        {
+            const float *const planes[4] = {img_b, img_b + sic, img_b + 2 * sic, img_b + 2 * sic};
+            const int hs[4] = {sih, sih, sih, sih};
+            tile_stage_load_planes<4>(r, sl, planes, hs, sr);
+        }
+#pragma unroll 1
+        for (int vc = 0; vc < nchunks; vc++) {
+            tile_stage_store<4>(r, sl, sr, tile);
+            __syncthreads();
+            // next chunk's rows: in flight while this chunk is gathered (the last iteration re-reads its own
+            // chunk -- harmless, keeps the loads unconditional)
+            const int cn = vc + 1 < nchunks ? vc * 4 : (vc - 1) * 4;      // context channel of the next chunk
+            tile_stage_load<4>(r, sl, in_b + cn * s1c, s1c, s1h, sr);
+            // keep the loop-invariant tap splats / LDS addresses inside the loop (see fi_fwd_tiled_fs4)
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
+            f32x4 res[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) res[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            fi_gather<LX, 4>(r, g, tp, sel, W, H, tile, res);
+            if (vc == 0) {                         // ---- the image chunk: three channels, optional blend ----
+                if (wr & ~g.valid) {               // out-of-range sites copy the input pixel
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const f32x4 own = ld_cached4(img_b + c * sic + (int64_t)y * sih + x);
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (!((g.valid >> j) & 1)) res[j][c] = own[j];
+                    }
+                }
+                if (wr == 0xFu) {
+                    // (wave-uniform bases + one 32-bit lane offset per layout, see ld_stream4_u)
+                    const unsigned oi = 4u * (unsigned)(y * sih + x), oo = 4u * (unsigned)(y * soh + x);
+                    f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = oa;
+                    if (BLEND) {
+                        oa = ld_stream4_u(occ_prev + b * sob, oo);
+                        ob = ld_stream4_u(occ_this + b * sob, oo);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        f32x4 v = {res[0][c], res[1][c], res[2][c], res[3][c]};
+                        if (BLEND) {
+                            const f32x4 pv = ld_stream4_u(prev + b * sib + c * sic, oi);
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const float p0 = oa[j] * pv[j], p2 = ob[j] * v[j];
+                                v[j] = p0 + p2;
+                            }
+                        }
+                        st_stream4(iout_p + c * sic, v);
+                    }
+                } else if (wr) {                   // a lane whose sites are split over bands
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if ((wr >> j) & 1) {
+#pragma unroll
+                            for (int c = 0; c < 3; c++) iout_p[c * sic + j] = blend1(res[j][c], c, j);
+                        }
+                }
+            } else {                               // ---- a context chunk: exactly fi_fwd_tiled_c4n ----
+                const int c0 = (vc - 1) * 4;
+                const float *plane0 = in_b + c0 * s1c;
+                float *o = out_p + c0 * s1c;
+                if (wr & ~g.valid) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const f32x4 own = ld_cached4(plane0 + c * s1c + (int64_t)y * s1h + x);
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (!((g.valid >> j) & 1)) res[j][c] = own[j];
+                    }
+                }
+                if (wr == 0xFu) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) st_stream4(o + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
+                } else if (wr) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if ((wr >> j) & 1) {
+#pragma unroll
+                            for (int c = 0; c < 4; c++) o[c * s1c + j] = res[j][c];
+                        }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    unsigned slow = inb ? g.valid & ~done : 0u;            // not coverable within kMaxBands bands
+    while (slow) {
+        const int j = __ffs(slow) - 1;
+        slow &= slow - 1;
+        fi_site_scalar(x + j, y, W, H, C, 4, in_b, s1c, s1h, flow_p + j, s2c, tap_p + j, s3c, out_p + j);
+        fi_site_scalar(x + j, y, W, H, 3, 4, img_b, sic, sih, flow_p + j, s2c, tap_p + j, s3c, iout_p + j);
+        if (BLEND) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) iout_p[c * sic + j] = blend1(iout_p[c * sic + j], c, j);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // Forward, fs == 4, direct gather from global memory through L1/L2.
 //   ROWS waves per workgroup, one image row each: tile = 64 x ROWS sites.
 //   CT > 0: channel count known at compile time (fully unrolled); CT == 0: run-time channel loop.
@@ -1657,5 +1840,40 @@ extern "C" int FilterInterpolationBlend_gpu_forward_kernel(
                        h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,
                        (int64_t)s3c, s3h, (int64_t)sob, soh, input0, input2, flow0, flow1, filter0, filter1,
                        occlusion0, occlusion1, output);
+    return launch_status();
+}
+
+// EXTENSION (no reference counterpart): image + context warp of one direction in one pass, see fi_fwd_ctx_img.
+// image / prev / image_out share (sib, sic, sih) and have 3 channels; context / context_out share (s1b, s1c, s1h) and
+// have `channel` (a multiple of 4, >= 4) channels; prev / occlusion_prev / occlusion_this are all NULL (plain warp of the
+// image) or all given (image_out = occlusion_prev * prev + occlusion_this * warp).  fs == 4 only, 16-byte aligned
+// geometry; returns -1 otherwise (the caller then uses the separate entry points).
+extern "C" int FilterInterpolationCtx_gpu_forward_kernel(
+    memc_stream_t stream_, const int w, const int h, const int channel, const int batch, const int filter_size,
+    const int sib, const int sic, const int sih, const int s1b, const int s1c, const int s1h,
+    const int s2b, const int s2c, const int s2h, const int s3b, const int s3c, const int s3h,
+    const int sob, const int soh,
+    const float *image, const float *context, const float *flow, const float *filter,
+    const float *prev, const float *occlusion_prev, const float *occlusion_this, float *image_out, float *context_out)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (w <= 0 || h <= 0 || batch <= 0) return 0;
+    if (filter_size != 4 || channel < 4 || channel % 4 != 0) return -1;
+    const bool blend = prev != nullptr;
+    if (blend != (occlusion_prev != nullptr) || blend != (occlusion_this != nullptr)) return -1;
+    if (!vec4_ok(w, {sib, sic, sih, s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h, blend ? sob : 0, blend ? soh : 0},
+                 {image, context, flow, filter, prev, occlusion_prev, occlusion_this, image_out, context_out}))
+        return -1;
+    if (!plane_fits_u32(w, h, {sih, blend ? soh : 0})) return -1;
+    using G = TileGeom<16>;
+    const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+#define MEMC_FI_CTX(BLEND)                                                                                       \
+    hipLaunchKernelGGL(fi_fwd_ctx_img<BLEND>, dim3((unsigned)ntx * nty * batch), dim3(256), tile_lds_bytes<16>(), stream, \
+                       w, h, channel, ntx, nty, (int64_t)sib, (int64_t)sic, sih, (int64_t)s1b, (int64_t)s1c, s1h,       \
+                       (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, (int64_t)sob, soh, image,      \
+                       context, flow, filter, prev, occlusion_prev, occlusion_this, image_out, context_out)
+    if (blend) MEMC_FI_CTX(true);
+    else MEMC_FI_CTX(false);
+#undef MEMC_FI_CTX
     return launch_status();
 }

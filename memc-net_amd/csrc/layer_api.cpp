@@ -187,6 +187,40 @@ int FilterInterpolationBlendLayer_gpu_forward(memc_stream_t stream, const memc_t
         flow0->data, flow1->data, filter0->data, filter1->data, occlusion0->data, occlusion1->data, output->data);
 }
 
+// EXTENSION (memc_warp.h): image + context warp of one direction in one pass, optional blend epilogue.
+int FilterInterpolationCtxLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *image,
+                                            const memc_tensor4 *context, const memc_tensor4 *flow,
+                                            const memc_tensor4 *filter, const memc_tensor4 *prev,
+                                            const memc_tensor4 *occlusion_prev, const memc_tensor4 *occlusion_this,
+                                            const memc_tensor4 *image_out, const memc_tensor4 *context_out)
+{
+    const memc_tensor4 *need[] = {image, context, flow, filter, image_out, context_out};
+    for (const memc_tensor4 *t : need)
+        if (!ok(t)) return kErr;
+    const bool blend = prev != nullptr;
+    if (blend != (occlusion_prev != nullptr) || blend != (occlusion_this != nullptr)) return kErr;
+    if (blend && (!ok(prev) || !ok(occlusion_prev) || !ok(occlusion_this))) return kErr;
+    if (image->size[1] != 3 || !flow_matches(image, flow) || !flow_matches(context, flow)) return kErr;
+    if (!same_layout(image, image_out) || !same_layout(context, context_out)) return kErr;
+    if (filter->size[0] != image->size[0] || filter->size[2] != image->size[2] || filter->size[3] != image->size[3])
+        return kErr;
+    if (blend) {
+        if (!same_layout(image, prev) || !same_layout(occlusion_prev, occlusion_this)) return kErr;
+        if (occlusion_prev->size[0] != image->size[0] || occlusion_prev->size[1] != 1 ||
+            occlusion_prev->size[2] != image->size[2] || occlusion_prev->size[3] != image->size[3])
+            return kErr;
+    }
+    const int filter_size = (int)sqrt((float)filter->size[1]);
+    return FilterInterpolationCtx_gpu_forward_kernel(
+        stream, (int)image->size[3], (int)image->size[2], (int)context->size[1], (int)image->size[0], filter_size,
+        (int)image->stride[0], (int)image->stride[1], (int)image->stride[2], (int)context->stride[0],
+        (int)context->stride[1], (int)context->stride[2], (int)flow->stride[0], (int)flow->stride[1],
+        (int)flow->stride[2], (int)filter->stride[0], (int)filter->stride[1], (int)filter->stride[2],
+        blend ? (int)occlusion_prev->stride[0] : 0, blend ? (int)occlusion_prev->stride[2] : 0, image->data,
+        context->data, flow->data, filter->data, blend ? prev->data : nullptr, blend ? occlusion_prev->data : nullptr,
+        blend ? occlusion_this->data : nullptr, image_out->data, context_out->data);
+}
+
 // count tensor [N,1,H,W] matching the flow tensor; my_lib_cuda.c:813-817
 static bool count_matches(const memc_tensor4 *flow, const memc_tensor4 *count)
 {

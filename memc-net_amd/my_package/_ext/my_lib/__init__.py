@@ -59,7 +59,8 @@ def _describe(t, name):
     return d
 
 
-def _bind(symbol, n_tensors, trailing_int=False, lib=None):
+def _bind(symbol, n_tensors, trailing_int=False, lib=None, optional=()):
+    """optional: positions of tensor arguments that may be None (passed to C as NULL; extension entry points only)."""
     cfunc = getattr(lib if lib is not None else _lib, symbol)
     cfunc.restype = ctypes.c_int
     cfunc.argtypes = ([ctypes.c_void_p] + [ctypes.POINTER(_Tensor4)] * n_tensors
@@ -70,15 +71,16 @@ def _bind(symbol, n_tensors, trailing_int=False, lib=None):
             raise TypeError("%s takes %d arguments (%d given)"
                             % (symbol, n_tensors + (1 if trailing_int else 0), len(args)))
         tensors = args[:n_tensors]
-        descs = [_describe(t, "%s arg %d" % (symbol, i)) for i, t in enumerate(tensors)]
+        descs = [None if (t is None and i in optional) else _describe(t, "%s arg %d" % (symbol, i))
+                 for i, t in enumerate(tensors)]
         dev = tensors[0].device
         for t in tensors[1:]:
-            if t.device != dev:
+            if t is not None and t.device != dev:
                 raise TypeError("%s: all tensors must live on the same device" % symbol)
         extra = [int(args[-1])] if trailing_int else []
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            return int(cfunc(stream, *[ctypes.byref(d) for d in descs], *extra))
+            return int(cfunc(stream, *[None if d is None else ctypes.byref(d) for d in descs], *extra))
 
     call.__name__ = symbol
     call.__doc__ = "ctypes binding of %s (include/memc_warp.h)" % symbol
@@ -98,14 +100,18 @@ _SYMBOLS = {
     "DepthFlowProjectionLayer_gpu_forward": (4, True),
     "DepthFlowProjectionLayer_gpu_backward": (7, False),
 }
-# extension without a reference counterpart (include/memc_warp.h, "EXTENSION"): fused dual warp + blend
+# extensions without a reference counterpart (include/memc_warp.h, "EXTENSION"): fused dual warp + blend; image +
+# context warp of one direction in one pass (image, context, flow, filter, prev | None, occlusion_prev | None,
+# occlusion_this | None, image_out, context_out)
 _EXTENSIONS = {
     "FilterInterpolationBlendLayer_gpu_forward": (9, False),
+    "FilterInterpolationCtxLayer_gpu_forward": (9, False),
 }
+_OPTIONAL = {"FilterInterpolationCtxLayer_gpu_forward": (4, 5, 6)}
 
 __all__ = ["version", "LIB_PATH"]
 for _name, (_n, _flag) in list(_SYMBOLS.items()) + list(_EXTENSIONS.items()):
-    globals()[_name] = _bind(_name, _n, _flag)
+    globals()[_name] = _bind(_name, _n, _flag, optional=_OPTIONAL.get(_name, ()))
     __all__.append(_name)
 
 

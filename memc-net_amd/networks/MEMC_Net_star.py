@@ -36,5 +36,8 @@ class MEMC_Net_star(MEMCNetBase):
         ctx2 = warp(self.ctxNet(frame2), flows[1], filters[1]).detach()
         return ctx0, ctx2
 
+    def _context_features(self, frame0, frame2):
+        return self.ctxNet(frame0), self.ctxNet(frame2)
+
     def _rectify(self, x):
         return self.rectifyNet(x)

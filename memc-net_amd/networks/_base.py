@@ -4,6 +4,8 @@ U-Nets (interpolation filters, occlusion masks), the adaptive warp + blend, and 
 Reference: networks/MEMC_Net.py:77-170, networks/MEMC_Net_star.py:78-176 (the two forward() bodies differ only
 in the context-feature branch and in the rectifier).
 """
+import warnings
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -14,6 +16,10 @@ try:        # extension of this repository's my_package; absent from the referen
     from my_package.modules.FilterInterpolationBlendModule import FilterInterpolationBlendModule
 except ImportError:
     FilterInterpolationBlendModule = None
+try:        # likewise: frames + context features warped with one stream of flow / taps per direction
+    from my_package.modules.FilterInterpolationCtxBlendModule import FilterInterpolationCtxBlendModule
+except ImportError:
+    FilterInterpolationCtxBlendModule = None
 
 from ._blocks import FlowEstimator, run_unet, unet_head, unet_trunk
 
@@ -27,6 +33,10 @@ class MEMCNetBase(nn.Module):
         self.training = training
         self.align_corners = align_corners
         self.fused_blend = True             # one kernel for both warps + the blend where my_package offers it
+        # frames + context features in one launch per direction (section 8f-3): measured SLOWER than the fused blend
+        # plus two context warps (2705 vs 2485 us at 8x720x1280, 64 context channels: the context kernel sits at 239
+        # of 256 VGPRs and the extra image chunk makes the compiler's chunk loop ~15 % slower), so off by default
+        self.fused_context = False
         fs2 = filter_size * filter_size
         self.initScaleNets_filter = unet_trunk(2 * channel, align_corners, batch_norm)
         self.initScaleNets_filter1 = unet_head(fs2)
@@ -34,6 +44,20 @@ class MEMCNetBase(nn.Module):
         self.initScaleNets_occlusion = unet_trunk(2 * channel, align_corners, batch_norm)
         self.initScaleNets_occlusion1 = unet_head(1)
         self.initScaleNets_occlusion2 = unet_head(1)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """The published MEMC-Net checkpoints were trained under PyTorch 0.2, whose bilinear `nn.Upsample` sampled
+        with what is now `align_corners=True`; the reference's unmodified code under a current PyTorch -- and this
+        class by default -- samples with `align_corners=False`, which shifts the x4 flow upsampling and the U-Net
+        upsamplings by up to 1.5 pixels and visibly degrades the interpolated frames.  Loading weights into a model
+        built with the default therefore warns (once per model); pass `align_corners=True` for published weights."""
+        if not self.align_corners and not getattr(self, "_warned_align_corners", False):
+            self._warned_align_corners = True
+            warnings.warn("%s was built with align_corners=False (what the reference's code does under current "
+                          "PyTorch).  Checkpoints published with MEMC-Net were trained with PyTorch 0.2 "
+                          "(align_corners=True semantics): construct the model with align_corners=True to reproduce "
+                          "their results." % type(self).__name__, stacklevel=2)
+        return super().load_state_dict(state_dict, *args, **kwargs)
 
     def _init_convs(self, init_fn):
         """The reference initialises every Conv2d that exists at this point of its constructor and lets modules
@@ -67,6 +91,10 @@ class MEMCNetBase(nn.Module):
         """extra rectifier inputs (none in MEMC_Net; warped context features in MEMC_Net_star)"""
         return ()
 
+    def _context_features(self, frame0, frame2):
+        """unwarped context features of the two frames, or None when the model has none (MEMC_Net)"""
+        return None
+
     # ---- forward ----------------------------------------------------------------------------------------
     def forward(self, input):
         if self.training:
@@ -85,13 +113,21 @@ class MEMCNetBase(nn.Module):
                                                        self.initScaleNets_occlusion2, both)]
 
         warp = FilterInterpolationModule()
-        if self.fused_blend and FilterInterpolationBlendModule is not None:
-            blended = FilterInterpolationBlendModule()(frame0, frame2, flows[0], flows[1], filters[0], filters[1],
-                                                       occlusions[0], occlusions[1])
+        feats = self._context_features(frame0, frame2) if self.fused_context else None
+        if feats is not None and FilterInterpolationCtxBlendModule is not None:
+            # frames and context features ride the same flow + taps: one launch per direction, blend included
+            blended, ctx0, ctx2 = FilterInterpolationCtxBlendModule()(
+                frame0, frame2, feats[0], feats[1], flows[0], flows[1], filters[0], filters[1], occlusions[0],
+                occlusions[1])
+            extra = (ctx0, ctx2)
         else:
-            blended = (occlusions[0] * warp(frame0, flows[0], filters[0])
-                       + occlusions[1] * warp(frame2, flows[1], filters[1]))
-        extra = self._context(frame0, frame2, flows, filters, warp)
+            if self.fused_blend and FilterInterpolationBlendModule is not None:
+                blended = FilterInterpolationBlendModule()(frame0, frame2, flows[0], flows[1], filters[0], filters[1],
+                                                           occlusions[0], occlusions[1])
+            else:
+                blended = (occlusions[0] * warp(frame0, flows[0], filters[0])
+                           + occlusions[1] * warp(frame2, flows[1], filters[1]))
+            extra = self._context(frame0, frame2, flows, filters, warp)
 
         rect_in = torch.cat((blended, flows[0], flows[1], filters[0], filters[1], occlusions[0], occlusions[1])
                             + tuple(extra), dim=1)

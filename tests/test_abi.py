@@ -15,7 +15,7 @@ def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"^\s*(?:const\s+char\s*\*\s*|int\s+)(\w+)\s*\(", text, flags=re.M)
-    assert len(names) == 23, names      # 10 layer entry points + 10 kernel launchers + memc_hip_version + the 2 of the blend extension
+    assert len(names) == 25, names      # 10 layer entry points + 10 kernel launchers + memc_hip_version + 2 x 2 of the two extensions
     return names
 
 

@@ -83,3 +83,18 @@ def test_inference_720p_runs_and_is_deterministic_in_shape(net):
     torch.cuda.synchronize()
     assert frames_out[1].shape == (1, 3, 768, 1280) and torch.isfinite(frames_out[1]).all()
     assert flows[0].shape == (1, 2, 768, 1280) and filters[1].shape == (1, 16, 768, 1280)
+
+
+def test_fused_context_path_gives_the_same_network(net):
+    """section 8f-3: with `fused_context` the frames and their context features ride one launch per direction
+    (FilterInterpolationCtxBlendModule); the network's outputs must not move (MEMC_Net has no context branch: no-op)."""
+    x = _netutil.frames(11, 1, net.size, net.size).cuda()
+    with torch.no_grad():
+        base = net(x)[0]
+        net.fused_context = True
+        try:
+            fused = net(x)[0]
+        finally:
+            net.fused_context = False
+    for a, b in zip(base, fused):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))

@@ -656,3 +656,80 @@ def test_hole_filling_on_camera_pans(oracle, shift):
             close(N(out), want_out, "pan %s variant %d" % (shift, variant))
     finally:
         M.set_variant("projection", -1)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# EXTENSION: frames AND context features warped with one stream of flow + taps per direction, blend included
+# (MEMC_Net_star.py:273-285).  Expected values = the oracle composition; the fused results
+# must also agree with the separate HIP operators they replace to a few ulps (same arithmetic, other kernels).
+# ------------------------------------------------------------------------------------------------------------
+CTX_CASES = [
+    # (B, Cctx, H, W, flow kind, sigma, seed)
+    (2, 8, 40, 64, "smooth", 4.0, 41), (1, 64, 24, 128, "smooth", 4.0, 42), (1, 12, 100, 132, "iid", 3.0, 43),
+    (1, 8, 64, 256, "iid", 20.0, 44),           # box far beyond the LDS budget: bands + per-site fallback
+    (1, 8, 96, 256, "smooth", 25.0, 45),        # bands, lanes split over bands
+    (1, 6, 24, 48, "smooth", 4.0, 46),          # context channels not a multiple of 4: composed path
+    (1, 8, 19, 23, "iid", 2.0, 47),             # width not a multiple of 4: composed path
+]
+
+
+@pytest.mark.parametrize("case", CTX_CASES, ids=["%dx%dx%dx%d-%s" % c[:5] for c in CTX_CASES])
+def test_filter_interpolation_ctx_blend(oracle, case):
+    from my_package.modules.FilterInterpolationCtxBlendModule import FilterInterpolationCtxBlendModule
+    from my_package.modules.FilterInterpolationBlendModule import FilterInterpolationBlendModule
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    B, Cc, H, W, kind, sigma, seed = case
+    img_case = (B, 3, H, W, kind, sigma, seed)
+    a, b2 = make(img_case), make(img_case[:6] + (seed + 100,))
+    rng = np.random.default_rng(seed + 7)
+    host = dict(x0=a["x"], x2=b2["x"], c0=rng.random((B, Cc, H, W), dtype=np.float32),
+                c2=rng.random((B, Cc, H, W), dtype=np.float32), f0=a["flow"], f1=b2["flow"], k0=a["filt"],
+                k1=b2["filt"], o0=rng.random((B, 1, H, W), dtype=np.float32), o1=rng.random((B, 1, H, W), dtype=np.float32))
+    names = ("x0", "x2", "c0", "c2", "f0", "f1", "k0", "k1", "o0", "o1")
+    t = {n: T(host[n], n not in ("c0", "c2")) for n in names}
+    blended, c0w, c2w = FilterInterpolationCtxBlendModule()(*[t[n] for n in names])
+    assert not c0w.requires_grad and not c2w.requires_grad           # detached, as MEMC_Net_star.py:284-285
+    blended.backward(T(a["gout"]))
+    w0 = oracle.filter_interpolation_forward(host["x0"], host["f0"], host["k0"])
+    w2 = oracle.filter_interpolation_forward(host["x2"], host["f1"], host["k1"])
+    close(N(blended), host["o0"] * w0 + host["o1"] * w2, "blended frame")
+    close(N(c0w), oracle.filter_interpolation_forward(host["c0"], host["f0"], host["k0"]), "context 0")
+    close(N(c2w), oracle.filter_interpolation_forward(host["c2"], host["f1"], host["k1"]), "context 2")
+    gout = a["gout"]
+    for x, f, k, o, w in (("x0", "f0", "k0", "o0", w0), ("x2", "f1", "k1", "o1", w2)):
+        g1, g2, g3 = oracle.filter_interpolation_backward(host[x], host[f], host[k], (gout * host[o]).astype(np.float32))
+        close(N(t[x].grad), g1, "grad " + x, RTOL)
+        close(N(t[f].grad), g2, "grad " + f, RTOL)
+        close(N(t[k].grad), g3, "grad " + k, RTOL)
+        close(N(t[o].grad), (gout * w).sum(axis=1, keepdims=True), "grad " + o, RTOL)
+    # bit-identical to the operators it replaces
+    with torch.no_grad():
+        d = {n: t[n].detach() for n in names}
+        ref_b = FilterInterpolationBlendModule()(d["x0"], d["x2"], d["f0"], d["f1"], d["k0"], d["k1"], d["o0"], d["o1"])
+        warp = FilterInterpolationModule()
+        # (the same expressions compiled into different kernels: fused multiply-adds may contract differently)
+        assert float((blended.detach() - ref_b).abs().max()) <= 2e-6
+        assert float((c0w - warp(d["c0"], d["f0"], d["k0"])).abs().max()) <= 2e-6
+        assert float((c2w - warp(d["c2"], d["f1"], d["k1"])).abs().max()) <= 2e-6
+
+
+def test_filter_interpolation_ctx_c_abi_checks():
+    """the C entry point: outputs need no zero fill; prev / occlusions all given or all NULL; rejects what the kernel
+    does not cover (the Python layer then composes the result)"""
+    import my_package._ext.my_lib as my_lib
+    B, H, W = 1, 32, 64
+    z = lambda c: torch.rand(B, c, H, W, device=dev())          # noqa: E731
+    img, ctxf, flow, filt = z(3), z(8), z(2) * 4 - 2, z(16) / 16
+    io, co = torch.full((B, 3, H, W), float("nan"), device=dev()), torch.full((B, 8, H, W), float("nan"), device=dev())
+    assert my_lib.FilterInterpolationCtxLayer_gpu_forward(img, ctxf, flow, filt, None, None, None, io, co) == 0
+    assert float((io - _fi(my_lib, img, flow, filt)).abs().max()) <= 2e-6
+    assert float((co - _fi(my_lib, ctxf, flow, filt)).abs().max()) <= 2e-6
+    prev, oa, ob = z(3), z(1), z(1)
+    io2 = torch.full_like(io, float("nan"))
+    assert my_lib.FilterInterpolationCtxLayer_gpu_forward(img, ctxf, flow, filt, prev, oa, ob, io2, co) == 0
+    assert float((io2 - (oa * prev + ob * io)).abs().max()) <= 1e-6
+    assert my_lib.FilterInterpolationCtxLayer_gpu_forward(img, ctxf, flow, filt, prev, None, ob, io2, co) == -1
+    assert my_lib.FilterInterpolationCtxLayer_gpu_forward(img, z(6), flow, filt, None, None, None, io,
+                                                          torch.zeros(B, 6, H, W, device=dev())) == -1
+    assert my_lib.FilterInterpolationCtxLayer_gpu_forward(z(4), ctxf, flow, filt, None, None, None,
+                                                          torch.zeros(B, 4, H, W, device=dev()), co) == -1

@@ -126,3 +126,26 @@ def test_blend_extension_surface_and_no_cpu_path():
         with pytest.raises(RuntimeError, match="no CPU path"):
             FilterInterpolationBlendModule()(z(1, c, 8, w), z(1, c, 8, w), z(1, 2, 8, w), z(1, 2, 8, w),
                                              z(1, 16, 8, w), z(1, 16, 8, w), z(1, 1, 8, w), z(1, 1, 8, w))
+
+
+def test_ctx_blend_extension_surface_and_no_cpu_path():
+    """Frames + context features in one pass per direction (extension): module / layer names, argument order, the
+    fused-kernel predicate (ADVICE: alignment and occlusion shape are part of it), and no CPU path on either branch."""
+    from my_package.modules.FilterInterpolationCtxBlendModule import FilterInterpolationCtxBlendModule
+    from my_package.functions.FilterInterpolationCtxBlendLayer import FilterInterpolationCtxBlendLayer
+    from my_package.functions.FilterInterpolationBlendLayer import fused_supported
+    import my_package._ext.my_lib as my_lib
+    assert list(inspect.signature(FilterInterpolationCtxBlendModule.forward).parameters) == [
+        "self", "input0", "input2", "ctx0", "ctx2", "flow0", "flow1", "filter0", "filter1", "occlusion0", "occlusion1"]
+    assert callable(FilterInterpolationCtxBlendLayer()) and callable(my_lib.FilterInterpolationCtxLayer_gpu_forward)
+    z = torch.zeros
+    # a [B, 3, H, W] occlusion is legal in the reference's broadcast expression but not in the fused kernel
+    assert fused_supported(z(1, 3, 8, 8), z(1, 16, 8, 8), z(1, 3, 8, 8), z(1, 2, 8, 8), z(1, 2, 8, 8), z(1, 16, 8, 8),
+                           z(1, 1, 8, 8), z(1, 1, 8, 8))
+    assert not fused_supported(z(1, 3, 8, 8), z(1, 16, 8, 8), z(1, 3, 8, 8), z(1, 2, 8, 8), z(1, 2, 8, 8),
+                               z(1, 16, 8, 8), z(1, 3, 8, 8), z(1, 3, 8, 8))
+    for cc, w in ((8, 8), (6, 8), (8, 6)):
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            FilterInterpolationCtxBlendModule()(z(1, 3, 8, w), z(1, 3, 8, w), z(1, cc, 8, w), z(1, cc, 8, w),
+                                                z(1, 2, 8, w), z(1, 2, 8, w), z(1, 16, 8, w), z(1, 16, 8, w),
+                                                z(1, 1, 8, w), z(1, 1, 8, w))

@@ -143,6 +143,46 @@ def bench_fi_blend(rows, dev, B, H, W, flow_kind):
     report(rows, "fi_blend composed (2 fwd + torch blend) %dx%dx%d" % (B, H, W), B * H * W, 188, med, mn)
 
 
+def bench_fi_ctx(rows, dev, B, C, H, W, flow_kind):
+    """the warp stage of MEMC_Net_star for one frame pair (blended frame + both warped context tensors): one launch
+    per direction with shared flow / tap reads (section 8f-3) against the fused blend + two context warps"""
+    a = synth.torch_inputs(dev, B, 3, H, W, flow_kind=flow_kind, seed=11)
+    b = synth.torch_inputs(dev, B, 3, H, W, flow_kind=flow_kind, seed=12)
+    c0, c2 = torch.rand(B, C, H, W, device=dev), torch.rand(B, C, H, W, device=dev)
+    o0, o1 = torch.rand(B, 1, H, W, device=dev), torch.rand(B, 1, H, W, device=dev)
+    w0, out = torch.empty_like(a["x"]), torch.empty_like(a["x"])
+    c0w, c2w = torch.empty_like(c0), torch.empty_like(c2)
+    sites = B * H * W
+
+    def fused():
+        L.FilterInterpolationCtxLayer_gpu_forward(a["x"], c0, a["flow"], a["filt"], None, None, None, w0, c0w)
+        L.FilterInterpolationCtxLayer_gpu_forward(b["x"], c2, b["flow"], b["filt"], w0, o0, o1, out, c2w)
+    for _ in range(40):
+        fused()
+    med, mn = time_launches(fused)
+    alg = 188 + 2 * 8 * C                   # compulsory bytes per site of the whole stage (each tensor once)
+    report(rows, "warp stage C=3+%d fused per direction (2 launches) %dx%dx%d flow=%s" % (C, B, H, W, flow_kind),
+           sites, alg, med, mn)
+
+    med, mn = time_launches(lambda: L.FilterInterpolationCtxLayer_gpu_forward(
+        a["x"], c0, a["flow"], a["filt"], None, None, None, w0, c0w))
+    report(rows, "  image + context warp, one direction, no blend %dx%dx%d" % (B, H, W), sites, 4 * (2 * C + 6 + 18), med, mn)
+    med, mn = time_launches(lambda: L.FilterInterpolationCtxLayer_gpu_forward(
+        b["x"], c2, b["flow"], b["filt"], w0, o0, o1, out, c2w))
+    report(rows, "  image + context warp, one direction, blend epilogue %dx%dx%d" % (B, H, W), sites,
+           4 * (2 * C + 6 + 18 + 5), med, mn)
+    med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_forward(c0, a["flow"], a["filt"], c0w))
+    report(rows, "  context warp alone (fi_fwd_tiled_c4n) %dx%dx%d" % (B, H, W), sites, 4 * (2 * C + 18), med, mn)
+
+    def separate():
+        L.FilterInterpolationBlendLayer_gpu_forward(a["x"], b["x"], a["flow"], b["flow"], a["filt"], b["filt"], o0, o1, out)
+        L.FilterInterpolationLayer_gpu_forward(c0, a["flow"], a["filt"], c0w)
+        L.FilterInterpolationLayer_gpu_forward(c2, b["flow"], b["filt"], c2w)
+    med, mn = time_launches(separate)
+    report(rows, "warp stage C=3+%d blend + 2 context warps (3 launches) %dx%dx%d flow=%s" % (C, B, H, W, flow_kind),
+           sites, alg, med, mn)
+
+
 def bench_fi_bwd(rows, dev, B, C, H, W, flow_kind, tag, variants=()):
     t = synth.torch_inputs(dev, B, C, H, W, flow_kind=flow_kind, with_grad=True)
     x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
@@ -270,6 +310,8 @@ def main():
             bench_fi_fwd(rows, dev, 8, 3, 2160, 3840, "smooth", variants[:1], "c5_4k")
     if want("fi_blend"):
         bench_fi_blend(rows, dev, 32, 720, 1280, "smooth")
+    if want("fi_ctx"):
+        bench_fi_ctx(rows, dev, 8, 64, 720, 1280, "smooth")
     if want("fi_bwd"):
         bench_fi_bwd(rows, dev, 8, 3, 256, 448, "smooth", "c2", [int(v) for v in args.bwd_variants.split(",") if v])
         if not args.quick:

@@ -62,7 +62,7 @@ def bound():
     if _bound is None:
         b = _Bound()
         for name, (n, flag) in list(L._SYMBOLS.items()) + list(L._EXTENSIONS.items()):
-            setattr(b, name, L._bind(name, n, flag, lib=lib()))
+            setattr(b, name, L._bind(name, n, flag, lib=lib(), optional=L._OPTIONAL.get(name, ())))
         _bound = b
     return _bound
 
