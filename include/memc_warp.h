@@ -271,6 +271,22 @@ int FilterInterpolationCtx_gpu_forward_kernel(
     const float *image, const float *context, const float *flow, const float *filter,
     const float *prev, const float *occlusion_prev, const float *occlusion_this, float *image_out, float *context_out);
 
+/* ------------------------------------------------------------------------------------------------------
+ * EXTENSION -- no reference counterpart.  The prologue of FlowProjection in the networks,
+ * networks/MEMC_Net_star.py:172-176: output = bilinear_x4((mul * input) / div), i.e.
+ * F.interpolate(div_flow * flow / 2.0, scale_factor=4, mode="bilinear", align_corners=...) as one kernel (torch's
+ * sampling rule, ATen area_pixel_compute_source_index).  input [B, C, h, w], output [B, C, 4h, 4w] (16-byte aligned
+ * rows); forward only (the Python layer differentiates it with ATen's upsample_bilinear2d_backward).
+ * ------------------------------------------------------------------------------------------------------ */
+int FlowUpsample4Layer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input, const memc_tensor4 *output,
+                                   float mul, float div, int align_corners);
+
+int FlowUpsample4_gpu_forward_kernel(
+    memc_stream_t stream, const int w, const int h, const int channel, const int batch,
+    const int input_b_stride, const int input_c_stride, const int input_h_stride,
+    const int output_b_stride, const int output_c_stride, const int output_h_stride,
+    const float mul, const float div, const int align_corners, const float *input, float *output);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

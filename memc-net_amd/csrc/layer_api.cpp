@@ -221,6 +221,20 @@ int FilterInterpolationCtxLayer_gpu_forward(memc_stream_t stream, const memc_ten
         blend ? occlusion_this->data : nullptr, image_out->data, context_out->data);
 }
 
+// EXTENSION (memc_warp.h): scale + x4 bilinear upsampling of the quarter-resolution flow in one kernel.
+int FlowUpsample4Layer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input, const memc_tensor4 *output,
+                                   float mul, float div, int align_corners)
+{
+    if (!ok(input) || !ok(output)) return kErr;
+    if (output->size[0] != input->size[0] || output->size[1] != input->size[1] ||
+        output->size[2] != 4 * input->size[2] || output->size[3] != 4 * input->size[3])
+        return kErr;
+    return FlowUpsample4_gpu_forward_kernel(
+        stream, (int)input->size[3], (int)input->size[2], (int)input->size[1], (int)input->size[0],
+        (int)input->stride[0], (int)input->stride[1], (int)input->stride[2], (int)output->stride[0],
+        (int)output->stride[1], (int)output->stride[2], mul, div, align_corners, input->data, output->data);
+}
+
 // count tensor [N,1,H,W] matching the flow tensor; my_lib_cuda.c:813-817
 static bool count_matches(const memc_tensor4 *flow, const memc_tensor4 *count)
 {

@@ -115,6 +115,29 @@ for _name, (_n, _flag) in list(_SYMBOLS.items()) + list(_EXTENSIONS.items()):
     __all__.append(_name)
 
 
+def _bind_upsample():
+    """FlowUpsample4Layer_gpu_forward(input, output, mul, div, align_corners) -- extension (include/memc_warp.h)"""
+    cfunc = _lib.FlowUpsample4Layer_gpu_forward
+    cfunc.restype = ctypes.c_int
+    cfunc.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Tensor4), ctypes.POINTER(_Tensor4), ctypes.c_float,
+                      ctypes.c_float, ctypes.c_int]
+
+    def call(input, output, mul, div, align_corners):
+        a, b = _describe(input, "FlowUpsample4Layer_gpu_forward arg 0"), _describe(output, "FlowUpsample4Layer_gpu_forward arg 1")
+        if input.device != output.device:
+            raise TypeError("FlowUpsample4Layer_gpu_forward: all tensors must live on the same device")
+        with torch.cuda.device(input.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(input.device).cuda_stream)
+            return int(cfunc(stream, ctypes.byref(a), ctypes.byref(b), float(mul), float(div), int(bool(align_corners))))
+
+    call.__name__ = "FlowUpsample4Layer_gpu_forward"
+    return call
+
+
+FlowUpsample4Layer_gpu_forward = _bind_upsample()
+__all__.append("FlowUpsample4Layer_gpu_forward")
+
+
 def _cpu_unavailable(symbol):
     def call(*args):
         raise RuntimeError(

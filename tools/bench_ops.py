@@ -265,6 +265,19 @@ def bench_interp(rows, dev, B, C, H, W, flow_kind, tag):
            4 * (3 * C + 4), med, mn)
 
 
+def bench_prologue(rows, dev, B, h, w):
+    """FlowProjection's prologue in the networks: (20 * flow) / 2, x4 bilinear upsampling (MEMC_Net_star.py:172-176)"""
+    import torch.nn.functional as F
+    flow = torch.randn(B, 2, h, w, device=dev)
+    out = torch.empty(B, 2, 4 * h, 4 * w, device=dev)
+    sites = B * 16 * h * w
+    med, mn = time_launches(lambda: L.FlowUpsample4Layer_gpu_forward(flow, out, 20.0, 2.0, False), warmup=40)
+    report(rows, "flow prologue fused (x20 / 2, x4 bilinear) -> %dx2x%dx%d" % (B, 4 * h, 4 * w), sites, 8.5, med, mn)
+    med, mn = time_launches(lambda: F.interpolate(20 * flow / 2.0, scale_factor=4, mode="bilinear", align_corners=False),
+                            warmup=40)
+    report(rows, "flow prologue torch (mul, div, interpolate) -> %dx2x%dx%d" % (B, 4 * h, 4 * w), sites, 8.5, med, mn)
+
+
 def bench_copy(rows, dev):
     """calibration: a plain device copy of the same byte volume as the headline launch"""
     n = 2831155200 // 8
@@ -310,6 +323,8 @@ def main():
             bench_fi_fwd(rows, dev, 8, 3, 2160, 3840, "smooth", variants[:1], "c5_4k")
     if want("fi_blend"):
         bench_fi_blend(rows, dev, 32, 720, 1280, "smooth")
+    if want("prologue"):
+        bench_prologue(rows, dev, 32, 180, 320)
     if want("fi_ctx"):
         bench_fi_ctx(rows, dev, 8, 64, 720, 1280, "smooth")
     if want("fi_bwd"):
