@@ -403,11 +403,11 @@ __device__ __forceinline__ void trace_mark_proj(int slot)
 
 // ---- carry-based hole filling (pass 3), shared pieces; the scheme is described at proj_fillhole_carry ----------
 struct FillWs {
-    int *up, *left, *right;       // left starts out as "last non-zero column in the tile", right as "first"
-    int *n_list, *list;           // tiles that contain a hole, in kListSegs segments of `cap` entries: fill counts,
-    int cap;                      // then tile ids ((b * tiles_y + ty) * tiles_x + tx).  Segmented so that 30 000
-};                                // workgroups do not all bump ONE counter (same-address atomics serialise: +150 us
-constexpr int kListSegs = 256;    // when every tile has a hole).
+    int *up, *left, *right;       // per-tile summaries: last non-zero row per column, last / first non-zero column per row
+    int *hole;                    // hole[tile] != 0: the tile (id (b * tiles_y + ty) * tiles_x + tx) contains a hole.
+};                                // Every tile writes its own entry with a plain store -- round 1 appended such tiles
+                                  // to a list with a RETURNING global atomic, i.e. a workgroup that was otherwise done
+                                  // sat on its CU for another memory round trip (~10 us of the kernel)
 
 template <int TH>
 struct TileSummary {              // LDS
@@ -461,13 +461,7 @@ __device__ __forceinline__ void summary_store(const TileSummary<TH> &t, int any_
         ws.right[i] = t.row_first[threadIdx.x] == INT_MAX ? -1 : t.row_first[threadIdx.x];
         ws.left[i] = t.row_last[threadIdx.x];
     }
-    // (a tile may be listed twice -- by the owner kernel and again after the general path redid its image: the
-    // filler re-reads the counts and filling is idempotent)
-    if (threadIdx.x == 0 && any_hole) {
-        const unsigned tile = ((unsigned)b * nty + ty) * ntx + tx;
-        const int seg = tile % kListSegs, slot = atomicAdd(ws.n_list + seg, 1);
-        if (slot < ws.cap) ws.list[(int64_t)seg * ws.cap + slot] = (int)tile;      // (cap holds every tile twice)
-    }
+    if (threadIdx.x == 0) ws.hole[((int64_t)b * nty + ty) * ntx + tx] = any_hole;
 }
 
 #ifdef MEMC_MEASURE
@@ -1174,7 +1168,7 @@ __device__ __forceinline__ void owner_store(TileSummary<TH> &sm, const FillWs &w
 // four workgroups share a CU -- the allocator is at its limit, and the method form of the very same code spilled five
 // registers and ran 25 % slower.)
 // BOUNDS = false (measurement build only): no motion bounds; flagged images are then redone by the general path.
-template <bool DEPTH, int TH, int kReach, int MINW, bool BOUNDS = true>
+template <bool DEPTH, int TH, int kReach, int MINW, bool BOUNDS = true, int NEARROWS = 8>
 __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
@@ -1207,7 +1201,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
     }
 
     // scan loads: see proj_owner2 (slots, far rows, unconditional addresses)
-    constexpr int kNearRows = 8;
+    constexpr int kNearRows = NEARROWS;
     auto far_it = [](int it) {
         const int first = NT * it / kCols4, last = (NT * it + NT - 1) / kCols4;
         return last <= kReach + 1 - kNearRows || first >= kReach + 1 + TH + kNearRows;
@@ -1395,10 +1389,16 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
         oc[j] = v[0];  ox[j] = v[1];  oy[j] = v[2];
     }
     if (inb) {
-        float *o = out + b * s1b + (int64_t)cy * s1h + cx;
-        *reinterpret_cast<f32x4 *>(o) = ox;    // plain stores: pass 3 (hole fill) re-reads them
-        *reinterpret_cast<f32x4 *>(o + s1c) = oy;
-        *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
+        float *o = out + b * s1b + (int64_t)cy * s1h + cx, *cn = count + b * scb + (int64_t)cy * sch + cx;
+        if (ws.up) {                           // plain stores: pass 3 (hole fill) re-reads them
+            *reinterpret_cast<f32x4 *>(o) = ox;
+            *reinterpret_cast<f32x4 *>(o + s1c) = oy;
+            *reinterpret_cast<f32x4 *>(cn) = oc;
+        } else {                               // single-use streams otherwise
+            st_stream4(o, ox);
+            st_stream4(o + s1c, oy);
+            st_stream4(cn, oc);
+        }
     }
     if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
         const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
@@ -1527,10 +1527,13 @@ __global__ __launch_bounds__(256) void proj_fillhole_carry(
     __shared__ __attribute__((aligned(16))) float cnt[TH * 64];
     __shared__ int n_holes;
     __shared__ unsigned short hole_list[TH * 64];
-    // workgroup i serves segment i % kListSegs, entries i / kListSegs, + gridDim / kListSegs, ...
-    const int seg = blockIdx.x % kListSegs, n_seg = min(ws.n_list[seg], ws.cap), step = max((int)gridDim.x / kListSegs, 1);
-    for (int it = blockIdx.x / kListSegs; it < n_seg; it += step) {
-    const unsigned tile = (unsigned)ws.list[(int64_t)seg * ws.cap + it];
+    // workgroup i looks after the tiles i, i + grid, ...: their flags are fetched by one load (lane k: tile i + k grid),
+    // then the flagged ones are taken in turn
+    const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
+    const unsigned mine = blockIdx.x + (threadIdx.x & 63u) * gridDim.x;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(mine < ntiles && ws.hole[mine < ntiles ? mine : 0] != 0);
+    for (; todo; todo &= todo - 1) {
+    const unsigned tile = blockIdx.x + (unsigned)__builtin_ctzll(todo) * gridDim.x;
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((unsigned)tiles_x * tiles_y);
     const int tx0 = tx * 64, ty0 = ty * TH;
     const float *cn = count + b * scb;
@@ -2170,17 +2173,15 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     // (the owner kernel addresses the flow / depth planes with 32-bit offsets)
     const bool want_fast = variant != 1 && variant < 2 && plane_fits_u32(w, h, {s1h, sdh});
     const bool want_carry = a.fillhole && variant != -8 && variant != -9;
-    // scratch layout (ints): [0, 320) far flags (image b -> word b % 256, word 256 = "any"), [320, 576) list fill
-    // counts, the tiles' motion bounds (2 per tile), then -- with hole filling -- the three tables of per-tile
-    // summaries and the hole-tile list
-    constexpr size_t kHead = 320 + kListSegs;
+    // scratch layout (ints): [0, 320) far flags (image b -> word b % 256, word 256 = "any"), the tiles' motion bounds
+    // (2 per tile), then -- with hole filling -- the three tables of per-tile summaries and the per-tile hole flags
+    constexpr size_t kHead = 320;
     const size_t n_bnd = want_fast ? 2 * (size_t)ntiles : 0;
     const size_t n_up = (size_t)batch * nty * w, n_row = (size_t)batch * h * ntx;
-    const int cap = 2 * (int)((ntiles + kListSegs - 1) / kListSegs) + 2;          // (a tile can be listed twice)
-    const size_t ints = kHead + n_bnd + (want_carry ? n_up + 2 * n_row + (size_t)kListSegs * cap : 0);
+    const size_t ints = kHead + n_bnd + (want_carry ? n_up + 2 * n_row + (size_t)ntiles : 0);
     CallScratch scratch;
     int *flag = nullptr, *bounds = nullptr;
-    FillWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    FillWs ws = {nullptr, nullptr, nullptr, nullptr};
     if ((want_fast || want_carry) && scratch.alloc(ints * sizeof(int), stream)) {
         int *base = static_cast<int *>(scratch.p);
         if (hipMemsetAsync(base, 0, kHead * sizeof(int), stream) != hipSuccess) return -1;
@@ -2189,12 +2190,10 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             bounds = base + kHead;
         }
         if (want_carry) {
-            ws.n_list = base + 320;
             ws.up = base + kHead + n_bnd;
             ws.left = ws.up + n_up;
             ws.right = ws.left + n_row;
-            ws.list = ws.right + n_row;
-            ws.cap = cap;
+            ws.hole = ws.right + n_row;
         }
     }
     // Without scratch (inside a stream capture, or the allocation failed): the general path on its own and the
@@ -2264,7 +2263,17 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             constexpr int kWgCu = TH == 16 ? (DEPTH ? 4 : 6) : (TH == 32 ? (DEPTH ? 3 : 4) : 1);
             constexpr int kMinW = (kWgCu * (16 * TH / 64) + 3) / 4 > 8 ? 8 : (kWgCu * (16 * TH / 64) + 3) / 4;
 #ifdef MEMC_MEASURE
-            if (variant == -32)                // A/B: without the motion bounds; flagged images take the general path
+            if (variant <= -40 && variant >= -43) {    // A/B: rows whose fx / depth loads are deferred (kNearRows 0 / 4 / 12 / 16)
+#define MEMC_PROJ_NR(NR)                                                                                        \
+                hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW, true, NR>), dim3(walk_grid(ntx, nty, batch, sw)),  \
+                                   dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,    \
+                                   a.depth, a.count, a.out, flag, bounds, ws, sw)
+                if (variant == -40) MEMC_PROJ_NR(0);
+                else if (variant == -41) MEMC_PROJ_NR(4);
+                else if (variant == -42) MEMC_PROJ_NR(12);
+                else MEMC_PROJ_NR(16);
+#undef MEMC_PROJ_NR
+            } else if (variant == -32)         // A/B: without the motion bounds; flagged images take the general path
                 hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW, false>), dim3(walk_grid(ntx, nty, batch, sw)),
                                    dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,
                                    a.depth, a.count, a.out, flag, bounds, ws, sw);
@@ -2316,12 +2325,11 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
 #undef MEMC_PROJ_SCATTER
     if (a.fillhole && !only_part) {
         if (ws.up) {
-            // workgroup i serves list segment i % 256, entries i / 256, + grid / 256, ...: at most 16 workgroups per
-            // segment (most tiles have no hole: 13 % on the benchmark's smooth flow; a workgroup beyond its segment's
-            // fill count leaves at once)
-            const unsigned per_seg = (ntiles + kListSegs - 1) / kListSegs;
-            hipLaunchKernelGGL(proj_fillhole_carry<TH>, dim3(kListSegs * (per_seg < 16 ? per_seg : 16)), dim3(256), 0,
-                               stream, w, h, ntx, nty, batch, s1b, s1c, s1h, scb, sch, a.count, a.out, ws);
+            // workgroup i looks after the tiles i, i + grid, ... (at most 64 of them: one flag per lane of a wave); most
+            // tiles have no hole (13 % on the benchmark's smooth flow) and cost their workgroup one flag load
+            const unsigned fg = ntiles < 4096u ? ntiles : (ntiles + 63u) / 64u > 4096u ? (ntiles + 63u) / 64u : 4096u;
+            hipLaunchKernelGGL(proj_fillhole_carry<TH>, dim3(fg), dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c, s1h,
+                               scb, sch, a.count, a.out, ws);
         } else {
             hipLaunchKernelGGL(proj_fillhole_v4, dim3(sntiles), dim3(256), 0, stream, w, h, ntx, snty, s1b, s1c, s1h,
                                scb, sch, a.count, a.out, variant == -8 ? 1 : 0);
@@ -2351,6 +2359,10 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
             th = 16 << ((v - 130) / 10);
             sw = (v - 130) % 10;
             v = -30;
+        } else if (v >= 180 && v < 184) {      // proj_owner4 with kNearRows = 0 / 4 / 12 / 16
+            th = 32;
+            sw = 4;
+            v = -40 - (v - 180);
         } else if (v >= 170 && v < 180) {      // proj_owner4 without motion bounds + general path behind the flag
             th = 32;
             sw = v - 170;
