@@ -32,8 +32,9 @@
  *   - `output`, `gradoutput` and `gradinput1` are indexed with input1's b/c/h strides
  *     (my_lib_kernel.cu:1184,1276-1283), `gradinput2`/`gradinput3` with input2's/input3's;
  *   - work is enqueued asynchronously on `stream`; no host synchronisation, no state carried from one call to
- *     the next, nothing shared between concurrent calls (any number of streams / host threads), nothing read from
- *     the environment.  One exception to "never allocates": a (Depth)FlowProjection FORWARD call takes a
+ *     the next (one process-wide call COUNTER excepted: it only makes every call's "far source" flag value unique),
+ *     nothing shared between concurrent calls (any number of streams / host threads), nothing read from the
+ *     environment.  One exception to "never allocates": a (Depth)FlowProjection FORWARD call takes a
  *     stream-ordered scratch allocation for the duration of the call (1.3 KiB of per-image "far source" flags for
  *     its fast path; with hole filling also the filler's carry tables, about 0.4 bytes per pixel), released in
  *     stream order before the call returns (hipMallocFromPoolAsync / hipFreeAsync).  It comes from a PRIVATE memory

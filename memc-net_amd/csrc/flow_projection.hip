@@ -12,6 +12,7 @@
 #include "memc_internal.h"
 #include "memc_tile.hpp"
 
+#include <atomic>
 #include <mutex>
 
 namespace memc {
@@ -426,6 +427,21 @@ __device__ __forceinline__ void summary_init(TileSummary<TH> &t)
 
 // the lane's four counts at (x .. x+3, y), local coordinates (lx .. lx+3, ly); returns "one of them is a hole".
 // A barrier must separate summary_init from this, and this from summary_store.
+// min over each group of 16 consecutive lanes (one DPP row), valid in the group's LAST lane
+__device__ __forceinline__ int row16_min_i32(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));      // row_shr:1,2,4,8
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    return v;
+}
+
+// The lane's four counts at (x .. x+3, y), local coordinates (lx .. lx+3, ly); returns "one of them is a hole".
+// Lane layout: the 16 lanes of a tile row are 16 CONSECUTIVE lanes (lx = 4 * (lane % 16)) -- a row's first / last
+// non-zero column is then a DPP reduction and one plain LDS store by the row's last lane (sixteen lanes bumping
+// one LDS word with atomics serialise); the columns' last non-zero rows span waves and stay LDS atomics.
+// Converged code only.  A barrier must separate summary_init from this, and this from summary_store.
 template <int TH>
 __device__ __forceinline__ bool summary_add(TileSummary<TH> &t, bool inb, const f32x4 &c4, int lx, int ly, int x, int y)
 {
@@ -441,9 +457,11 @@ __device__ __forceinline__ bool summary_add(TileSummary<TH> &t, bool inb, const 
             last = max(last, x + j);
         }
     }
-    if (last >= 0) {
-        atomicMin(&t.row_first[ly], first);
-        atomicMax(&t.row_last[ly], last);
+    first = row16_min_i32(first);
+    last = -row16_min_i32(-last);
+    if ((threadIdx.x & 15) == 15) {                        // one writer per row
+        t.row_first[ly] = first;
+        t.row_last[ly] = last;
     }
     return hole;
 }
@@ -1168,13 +1186,14 @@ __device__ __forceinline__ void owner_store(TileSummary<TH> &sm, const FillWs &w
 // four workgroups share a CU -- the allocator is at its limit, and the method form of the very same code spilled five
 // registers and ran 25 % slower.)
 // BOUNDS = false (measurement build only): no motion bounds; flagged images are then redone by the general path.
-template <bool DEPTH, int TH, int kReach, int MINW, bool BOUNDS = true, int NEARROWS = 8>
+// SARM (measurement build only, timing arms, fill results WRONG): 1 no summary_add, 2 no summary_store, 3 neither
+template <bool DEPTH, int TH, int kReach, int MINW, bool BOUNDS = true, int NEARROWS = 8, int SARM = 0>
 __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth,
     float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, int *__restrict__ bounds,
-    FillWs ws, int sw)
+    FillWs ws, int sw, int nonce)
 {
     constexpr int NT = 16 * TH;                   // one lane per four owned cells
     constexpr int NP = DEPTH ? 3 : 2;             // planes: (count, vx, vy) or (count * 2^20 + vx, vy)
@@ -1326,9 +1345,9 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
         }
     }
     if (lane < fill) splat(p_cell, p_vx, p_vy, p_vc);          // what is still waiting
-    if (far) {                                 // this image needs the general path
-        far_flag[b % kFlagWords] = 1;
-        far_flag[kFlagWords] = 1;
+    if (far) {                                 // this image is redone by proj_owner_far.  The flag words are NOT cleared
+        far_flag[b % kFlagWords] = nonce;      // before the call: "raised" = "holds this call's nonce" (launcher), so stale
+        far_flag[kFlagWords] = nonce;          // or uninitialised words can at worst cause a needless redo, never a missed one
     }
     __syncthreads();                           // every wave's points are in P (and the tile's motion bound in tile_max)
     if (BOUNDS && tid < 2) bounds[2 * (((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx) + tid] = tile_max[tid];
@@ -1401,9 +1420,9 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
         }
     }
     if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
-        const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
+        const bool hole = (SARM & 1) ? false : summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
         const int any_hole = __syncthreads_or(hole);
-        summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
+        if (!(SARM & 2)) summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
     }
 }
 
@@ -1417,18 +1436,18 @@ __global__ __launch_bounds__(16 * TH) void proj_owner_far(
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth,
     float *__restrict__ count, float *__restrict__ out, const int *__restrict__ far_flag,
-    const int *__restrict__ bounds, FillWs ws)
+    const int *__restrict__ bounds, FillWs ws, int nonce)
 {
     using OT = OwnerTile<DEPTH, TH>;
     constexpr int NT = 16 * TH;
     __shared__ __attribute__((aligned(16))) double P[OT::NP * OT::kPlane];
     __shared__ TileSummary<TH> sm;
-    if (far_flag[kFlagWords] == 0) return;
+    if (far_flag[kFlagWords] != nonce) return;
     const unsigned per_image = (unsigned)tiles_x * tiles_y, ntiles = per_image * batch;
 #pragma unroll 1
     for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = tile / per_image, tx = (tile % per_image) % tiles_x, ty = (tile % per_image) / tiles_x;
-        if (far_flag[b % kFlagWords] == 0) continue;             // wave-uniform: this image was complete
+        if (far_flag[b % kFlagWords] != nonce) continue;         // wave-uniform: this image was complete
         const int tid = tid_now();
         const int tx0 = tx * 64, ty0 = ty * TH;
         OT t;
@@ -1519,6 +1538,8 @@ __global__ __launch_bounds__(256) void proj_fill_summary(
     }
 }
 
+// (One WAVE per flagged tile instead of a 256-thread workgroup -- no workgroup barriers, four times the tiles in
+// flight -- was measured and LOST: 61 us against 29; a tile's holes come in clusters of more than 64.)
 template <int TH>
 __global__ __launch_bounds__(256) void proj_fillhole_carry(
     int W, int H, int tiles_x, int tiles_y, int batch, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch,
@@ -2182,9 +2203,23 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     CallScratch scratch;
     int *flag = nullptr, *bounds = nullptr;
     FillWs ws = {nullptr, nullptr, nullptr, nullptr};
+    // The production pair (proj_owner4 / proj_owner_far) needs no cleared flag words: a flag is "raised" when it holds
+    // this call's nonce -- a process-wide counter, never 0, so consecutive calls (which the pool hands the same block)
+    // never see each other's flags; a stale or uninitialised word equal to the nonce (2^-32) would only cause a
+    // needless redo.  That saves a 5 us memset launch per call.  The measurement build's older kernels keep 0 / 1
+    // flags and the memset.
+    static std::atomic<unsigned> call_counter{0};
+    unsigned nonce_u = call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
+    if (nonce_u == 0) nonce_u = call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
+    const int nonce = (int)nonce_u;
+    bool legacy_flags = false;
+#ifdef MEMC_MEASURE
+    legacy_flags = variant == -10 || variant == -7 || variant == -6 || variant == -30 || variant == -31 || variant == -32 ||
+                   (variant <= -21 && variant >= -29);
+#endif
     if ((want_fast || want_carry) && scratch.alloc(ints * sizeof(int), stream)) {
         int *base = static_cast<int *>(scratch.p);
-        if (hipMemsetAsync(base, 0, kHead * sizeof(int), stream) != hipSuccess) return -1;
+        if (legacy_flags && hipMemsetAsync(base, 0, kHead * sizeof(int), stream) != hipSuccess) return -1;
         if (want_fast) {
             flag = base;
             bounds = base + kHead;
@@ -2263,11 +2298,20 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             constexpr int kWgCu = TH == 16 ? (DEPTH ? 4 : 6) : (TH == 32 ? (DEPTH ? 3 : 4) : 1);
             constexpr int kMinW = (kWgCu * (16 * TH / 64) + 3) / 4 > 8 ? 8 : (kWgCu * (16 * TH / 64) + 3) / 4;
 #ifdef MEMC_MEASURE
-            if (variant <= -40 && variant >= -43) {    // A/B: rows whose fx / depth loads are deferred (kNearRows 0 / 4 / 12 / 16)
+            if (variant <= -50 && variant >= -52) {    // timing arms of the summaries (fill results WRONG)
+#define MEMC_PROJ_SA(SA)                                                                                        \
+                hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW, true, 8, SA>), dim3(walk_grid(ntx, nty, batch, sw)), \
+                                   dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,    \
+                                   a.depth, a.count, a.out, flag, bounds, ws, sw, legacy_flags ? 1 : nonce)
+                if (variant == -50) MEMC_PROJ_SA(1);
+                else if (variant == -51) MEMC_PROJ_SA(2);
+                else MEMC_PROJ_SA(3);
+#undef MEMC_PROJ_SA
+            } else if (variant <= -40 && variant >= -43) {    // A/B: rows whose fx / depth loads are deferred (kNearRows 0 / 4 / 12 / 16)
 #define MEMC_PROJ_NR(NR)                                                                                        \
                 hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW, true, NR>), dim3(walk_grid(ntx, nty, batch, sw)),  \
                                    dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,    \
-                                   a.depth, a.count, a.out, flag, bounds, ws, sw)
+                                   a.depth, a.count, a.out, flag, bounds, ws, sw, legacy_flags ? 1 : nonce)
                 if (variant == -40) MEMC_PROJ_NR(0);
                 else if (variant == -41) MEMC_PROJ_NR(4);
                 else if (variant == -42) MEMC_PROJ_NR(12);
@@ -2276,12 +2320,12 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             } else if (variant == -32)         // A/B: without the motion bounds; flagged images take the general path
                 hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW, false>), dim3(walk_grid(ntx, nty, batch, sw)),
                                    dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,
-                                   a.depth, a.count, a.out, flag, bounds, ws, sw);
+                                   a.depth, a.count, a.out, flag, bounds, ws, sw, 1);
             else
 #endif
             hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(16 * TH), 0,
                                stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
-                               a.out, flag, bounds, ws, sw);
+                               a.out, flag, bounds, ws, sw, legacy_flags ? 1 : nonce);
             own4 = variant != -32;
         }
         if (launch_status() != 0) return -1;
@@ -2289,7 +2333,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             const unsigned pg = persistent_grid(1);
             hipLaunchKernelGGL((proj_owner_far<DEPTH, TH, 24>), dim3(ntiles < pg ? ntiles : pg), dim3(16 * TH), 0, stream, w, h,
                                ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,
-                               bounds, ws);
+                               bounds, ws, nonce);
             if (launch_status() != 0) return -1;
         } else if (!only_part) {
             hipLaunchKernelGGL(proj_redo_zero, dim3(gq), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
@@ -2359,6 +2403,10 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
             th = 16 << ((v - 130) / 10);
             sw = (v - 130) % 10;
             v = -30;
+        } else if (v >= 190 && v < 193) {      // proj_owner4 summary timing arms
+            th = 32;
+            sw = 4;
+            v = -50 - (v - 190);
         } else if (v >= 180 && v < 184) {      // proj_owner4 with kNearRows = 0 / 4 / 12 / 16
             th = 32;
             sw = 4;
