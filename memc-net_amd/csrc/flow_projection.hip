@@ -415,13 +415,15 @@ struct TileSummary {              // LDS
     int col_last[64], row_first[TH], row_last[TH];
 };
 
+// (the summary helpers take the thread index as an argument: a kernel that rebuilds it late -- proj_owner4 -- must not
+// keep threadIdx.x alive in a register just for them)
 template <int TH>
-__device__ __forceinline__ void summary_init(TileSummary<TH> &t)
+__device__ __forceinline__ void summary_init(TileSummary<TH> &t, int tid = threadIdx.x)
 {
-    if (threadIdx.x < 64) t.col_last[threadIdx.x] = -1;
-    if (threadIdx.x < TH) {
-        t.row_first[threadIdx.x] = INT_MAX;
-        t.row_last[threadIdx.x] = -1;
+    if (tid < 64) t.col_last[tid] = -1;
+    if (tid < TH) {
+        t.row_first[tid] = INT_MAX;
+        t.row_last[tid] = -1;
     }
 }
 
@@ -443,7 +445,8 @@ __device__ __forceinline__ int row16_min_i32(int v)
 // one LDS word with atomics serialise); the columns' last non-zero rows span waves and stay LDS atomics.
 // Converged code only.  A barrier must separate summary_init from this, and this from summary_store.
 template <int TH>
-__device__ __forceinline__ bool summary_add(TileSummary<TH> &t, bool inb, const f32x4 &c4, int lx, int ly, int x, int y)
+__device__ __forceinline__ bool summary_add(TileSummary<TH> &t, bool inb, const f32x4 &c4, int lx, int ly, int x, int y,
+                                            int tid = threadIdx.x)
 {
     bool hole = false;
     int first = INT_MAX, last = -1;
@@ -459,7 +462,7 @@ __device__ __forceinline__ bool summary_add(TileSummary<TH> &t, bool inb, const 
     }
     first = row16_min_i32(first);
     last = -row16_min_i32(-last);
-    if ((threadIdx.x & 15) == 15) {                        // one writer per row
+    if ((tid & 15) == 15) {                                // one writer per row
         t.row_first[ly] = first;
         t.row_last[ly] = last;
     }
@@ -468,18 +471,18 @@ __device__ __forceinline__ bool summary_add(TileSummary<TH> &t, bool inb, const 
 
 template <int TH>
 __device__ __forceinline__ void summary_store(const TileSummary<TH> &t, int any_hole, const FillWs &ws, int b, int tx,
-                                              int ty, int W, int H, int ntx, int nty)
+                                              int ty, int W, int H, int ntx, int nty, int tid = threadIdx.x)
 {
     const int tx0 = tx * 64, ty0 = ty * TH;
-    if (threadIdx.x < 64 && tx0 + (int)threadIdx.x < W)
-        ws.up[((int64_t)b * nty + ty) * W + tx0 + threadIdx.x] = t.col_last[threadIdx.x];
-    if (threadIdx.x < TH && ty0 + (int)threadIdx.x < H) {
+    if (tid < 64 && tx0 + (int)tid < W)
+        ws.up[((int64_t)b * nty + ty) * W + tx0 + tid] = t.col_last[tid];
+    if (tid < TH && ty0 + (int)tid < H) {
         // [b][tx][y]: a tile's rows are one contiguous run (row-major [b][y][tx] made these TH scattered 4-byte stores)
-        const int64_t i = ((int64_t)b * ntx + tx) * H + ty0 + threadIdx.x;
-        ws.right[i] = t.row_first[threadIdx.x] == INT_MAX ? -1 : t.row_first[threadIdx.x];
-        ws.left[i] = t.row_last[threadIdx.x];
+        const int64_t i = ((int64_t)b * ntx + tx) * H + ty0 + tid;
+        ws.right[i] = t.row_first[tid] == INT_MAX ? -1 : t.row_first[tid];
+        ws.left[i] = t.row_last[tid];
     }
-    if (threadIdx.x == 0) ws.hole[((int64_t)b * nty + ty) * ntx + tx] = any_hole;
+    if (tid == 0) ws.hole[((int64_t)b * nty + ty) * ntx + tx] = any_hole;
 }
 
 #ifdef MEMC_MEASURE
@@ -1005,9 +1008,11 @@ constexpr int kPtW4 = 66;
 constexpr double kCountUnit = 1048576.0;          // 2^20
 
 // One owned 64 x TH tile: its point planes, window bounds and the wave's register batch of waiting hits.
+// (Used by proj_owner_far.  Always THREE planes there: without a limit on |flow| the sum of vx at a point is not
+// bounded by 2^19, which the packed count * 2^20 + sum(vx) plane of proj_owner4 relies on.)
 template <bool DEPTH, int TH>
 struct OwnerTile {
-    static constexpr int NP = DEPTH ? 3 : 2;      // planes: (count, vx, vy) or (count * 2^20 + vx, vy)
+    static constexpr int NP = 3;                  // planes: count, vx, vy
     static constexpr int kPlane = (TH + 1) * kPtW4;
     static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
     double *P;
@@ -1026,7 +1031,7 @@ struct OwnerTile {
     __device__ __forceinline__ void begin(double *P_, int tx0_, int ty0_, int W, int H, unsigned lane_)
     {
         P = P_;  tx0 = tx0_;  ty0 = ty0_;  lane = lane_;  fill = 0;
-        p_cell = 0;  p_vx = p_vy = p_vc = 0.0f;
+        p_cell = 0;  p_vx = p_vy = 0.0f;  p_vc = 1.0f;         // (FlowProjection: every source counts 1)
         xlo = (float)max(tx0 - 1, 0);
         ylo = (float)max(ty0 - 1, 0);
         xhi_bits = min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1);
@@ -1041,14 +1046,9 @@ struct OwnerTile {
     __device__ __forceinline__ void splat(int cell, float vx, float vy, float vc) const
     {
         double *q = P + cell;
-        if (DEPTH) {
-            lds_add_f64(q, (double)vc);
-            lds_add_f64(q + kPlane, (double)vx);
-            lds_add_f64(q + 2 * kPlane, (double)vy);
-        } else {
-            lds_add_f64(q, (double)vx + kCountUnit);           // one source: count += 1, sum(vx) += vx
-            lds_add_f64(q + kPlane, (double)vy);
-        }
+        lds_add_f64(q, (double)vc);
+        lds_add_f64(q + kPlane, (double)vx);
+        lds_add_f64(q + 2 * kPlane, (double)vy);
     }
     // the four y tests of a quad of sources in row sy
     __device__ __forceinline__ bool rows(bool lv, float syf, const f32x4 &fy4, float (&y2)[4], bool (&wy)[4]) const
@@ -1123,17 +1123,7 @@ struct OwnerTile {
                 float (&dst_x)[5] = rr ? bot[1] : top[1];
                 float (&dst_y)[5] = rr ? bot[2] : top[2];
 #pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    if (DEPTH) {
-                        (pl == 0 ? dst_c : (pl == 1 ? dst_x : dst_y))[i] = (float)v[i];
-                    } else if (pl == 0) {      // A = count * 2^20 + sum(vx): split exactly
-                        const double cnt = __builtin_rint(v[i] * (1.0 / kCountUnit));
-                        dst_c[i] = (float)cnt;
-                        dst_x[i] = (float)__builtin_fma(cnt, -kCountUnit, v[i]);
-                    } else {
-                        dst_y[i] = (float)v[i];
-                    }
-                }
+                for (int i = 0; i < 5; i++) (pl == 0 ? dst_c : (pl == 1 ? dst_x : dst_y))[i] = (float)v[i];
             }
         }
 #pragma unroll
@@ -1211,12 +1201,13 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
     const TileCoord tc = tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, sw);
     if (tc.tx >= tiles_x) return;                 // virtual column of the last stripe
     const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * TH;
-    const int tid = threadIdx.x;
-    summary_init(sm);
-    if (BOUNDS && tid < 2) tile_max[tid] = 0;
+    const int tid0 = threadIdx.x;                 // (thread index of the first half of the kernel, see below)
+    const int wave_index = __builtin_amdgcn_readfirstlane(tid0 / kWave);
+    summary_init(sm, tid0);
+    if (BOUNDS && tid0 < 2) tile_max[tid0] = 0;
     {
         f32x4 *pz = reinterpret_cast<f32x4 *>(P);
-        for (int i = tid; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid0; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // scan loads: see proj_owner2 (slots, far rows, unconditional addresses)
@@ -1230,7 +1221,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
     f32x4 fx[kIts], fy[kIts], dd[kIts];
     int sx[kIts], sy[kIts];
     bool live[kIts];
-    int row = tid / kCols4, c4 = tid % kCols4;
+    int row = tid0 / kCols4, c4 = tid0 % kCols4;
 #pragma unroll
     for (int it = 0; it < kIts; it++) {
         sx[it] = tx0 - kScanPadX + 4 * c4;
@@ -1255,22 +1246,24 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
     const float xlo = (float)max(tx0 - 1, 0), ylo = (float)max(ty0 - 1, 0);
     const int xhi_bits = min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1);
     const int yhi_bits = min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1);
-    const unsigned lane = tid & (kWave - 1);
+    const unsigned lane = tid0 & (kWave - 1);
     // the wave's batch of waiting hits: entry i sits in lane i; `fill` of them are valid (wave-uniform)
     int p_cell = 0;
     float p_vx = 0.0f, p_vy = 0.0f, p_vc = 0.0f;
     unsigned fill = 0;
     bool far = false;
 
+    // (cell, vx, vy as compacted above: cell without its wave-uniform offset, +f instead of v = -f)
+    const int cell0 = (ty0 - 1) * kPtW4 + (tx0 - 1);
     auto splat = [&](int cell, float vx, float vy, float vc) {
-        double *q = P + cell;
+        double *q = P + (cell - cell0);
         if (DEPTH) {
             lds_add_f64(q, (double)vc);
-            lds_add_f64(q + kPlane, (double)vx);
-            lds_add_f64(q + 2 * kPlane, (double)vy);
+            lds_add_f64(q + kPlane, -(double)vx);
+            lds_add_f64(q + 2 * kPlane, -(double)vy);
         } else {
-            lds_add_f64(q, (double)vx + kCountUnit);           // one source: count += 1, sum(vx) += vx
-            lds_add_f64(q + kPlane, (double)vy);
+            lds_add_f64(q, kCountUnit - (double)vx);           // one source: count += 1, sum(vx) += -fx
+            lds_add_f64(q + kPlane, -(double)vy);
         }
     };
 
@@ -1278,8 +1271,10 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
     for (int it = 0; it < kIts; it++) {
         const bool lv = live[it];
         const float syf = (float)sy[it], sxf = (float)sx[it];
-        // the quad lies inside the tile itself (tx0, the pad and sx are multiples of 4: all four sites or none)
-        const bool homeq = lv && (unsigned)(sy[it] - ty0) < (unsigned)TH && (unsigned)(sx[it] - tx0) < 64u;
+        // The quad lies inside the tile itself (tx0, the pad and sx are multiples of 4: all four sites or none) -- only
+        // slots that can hold rows of the tile evaluate this (and the far-source test below) at all.
+        const bool kHomeIt = NT * it / kCols4 < kReach + 1 + TH && (NT * it + NT - 1) / kCols4 >= kReach + 1;   // folds: `it` is unrolled
+        const bool homeq = kHomeIt && lv && (unsigned)(sy[it] - ty0) < (unsigned)TH && (unsigned)(sx[it] - tx0) < 64u;
         float y2[4];
         bool wy[4], rowany = false;
 #pragma unroll
@@ -1300,8 +1295,11 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
         for (int j = 0; j < 4; j++) {
             const float fxv = fxq[j], fyv = fy[it][j];
             const float x2 = (sxf + (float)j) + fxv;           // (float)x + fx, as the reference rounds it
-            const bool nearj = fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach;
-            if (homeq && !nearj) {             // a far source whose home is this tile: the image is redone
+            // A far source (|f| >= kReach) whose home is this tile: the image is redone by proj_owner_far.  The hit
+            // test below does NOT ask for |f| < kReach: an image without a valid far source has only near hits, which
+            // every owner of their point sees (they lie inside its scan region); in an image WITH one the owners may
+            // disagree -- and every tile of that image is recomputed anyway.  Two compares less per scanned source.
+            if (kHomeIt && homeq && !(fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach)) {
                 const bool valid = x2 >= 0.0f && y2[j] >= 0.0f && x2 <= (float)(W - 1) && y2[j] <= (float)(H - 1);
                 far = far || valid;
                 if (BOUNDS && valid) {         // (cold) the tile's bound on its far sources' motion, for proj_owner_far:
@@ -1309,7 +1307,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
                     atomicMax(&tile_max[1], __float_as_int(fabsf(fyv)));
                 }
             }
-            const bool hit = wy[j] && nearj && x2 >= xlo && __float_as_int(x2) < xhi_bits;
+            const bool hit = wy[j] && x2 >= xlo && __float_as_int(x2) < xhi_bits;
             const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
             if (m == 0) continue;              // wave-uniform
             const unsigned n = (unsigned)__builtin_popcountll(m);
@@ -1317,14 +1315,16 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
             // Push the hits to the consecutive lanes fill, fill + 1, ... (cyclically) of the batch.  Lanes without a
             // hit aim at the LAST slot of the cycle, which a hit only takes when all 64 lanes hit (no such lane then).
             const int dst = (int)((fill + (hit ? rank : 63u)) & 63u) << 2;
-            const int py = (int)y2[j] - (ty0 - 1), px = (int)x2 - (tx0 - 1);                 // (garbage without a hit)
-            float vx = -fxv, vy = -fyv, vc = 1.0f;
-            if (DEPTH) {                       // my_lib_kernel.cu:2102-2114
-                vx = -ddq[j] * fxv;
-                vy = -ddq[j] * fyv;
+            // cell = ((int)y2 - (ty0 - 1)) * pitch + (int)x2 - (tx0 - 1); the wave-uniform part is added at the splat
+            const int cell = (int)y2[j] * kPtW4 + (int)x2;                                   // (garbage without a hit)
+            // what travels is +f (or d * f): the sign of v = -f is applied where it is converted to double
+            float vx = fxv, vy = fyv, vc = 1.0f;
+            if (DEPTH) {                       // my_lib_kernel.cu:2102-2114: v = -d * f, count += d
+                vx = ddq[j] * fxv;
+                vy = ddq[j] * fyv;
                 vc = ddq[j] * 1.0f;
             }
-            const int r_cell = __builtin_amdgcn_ds_permute(dst, py * kPtW4 + px);
+            const int r_cell = __builtin_amdgcn_ds_permute(dst, cell);
             const float r_vx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vx)));
             const float r_vy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vy)));
             float r_vc = 1.0f;
@@ -1350,62 +1350,55 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
         far_flag[kFlagWords] = nonce;          // or uninitialised words can at worst cause a needless redo, never a missed one
     }
     __syncthreads();                           // every wave's points are in P (and the tile's motion bound in tile_max)
+    // (from here on the thread index is REBUILT from the wave's index, a scalar, and the lane's rank in the wave:
+    // kept in a VGPR across the scan it was the one value the allocator spilled at 64 registers)
+    const int tid = wave_index * kWave + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if (BOUNDS && tid < 2) bounds[2 * (((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx) + tid] = tile_max[tid];
 
-    // every lane owns four cells of a row: 2x2 box sums of the points of columns c-1 .. c+3, rows cy-1 and cy
+    // Every lane owns four cells of a row: 2x2 box sums of the points of columns c-1 .. c+3, rows cy-1 and cy (border
+    // duplicates as weights 2, see proj_scatter_tiled), summed in DOUBLE -- exact, also for the packed plane:
+    // sum_i w_i (count_i 2^20 + S_i) = (sum w count) 2^20 + sum w S with |sum w S| < 2^19 (at most 2500 sources reach a
+    // 2x2 block, weights <= 4, |v| < kReach) -- then split and rounded to fp32 ONCE per cell (four splits per lane
+    // instead of ten; the reference's fp32 atomics add in arbitrary order anyway).
     const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
     const bool inb = cx < W && cy < H;            // (no early exit: the summary below has a barrier)
-    const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
-    float top[3][5], bot[3][5];                // [count, vx, vy][column], each point sum rounded to fp32 once
+    const double wy0 = (cy == H - 1) ? 2.0 : 1.0;
+    f32x4 ox, oy, oc;
     {
         typedef double f64x2 __attribute__((ext_vector_type(2)));
         const double *r0 = P + (cy - ty0) * kPtW4 + (cx - tx0);   // column offset a multiple of 4: 16-byte pairs
+        double box[NP][4];
 #pragma unroll
         for (int pl = 0; pl < NP; pl++) {
+            const double *a = r0 + pl * kPlane, *c = a + kPtW4;
+            const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
+            const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
+            const double top[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
+            const double bot[5] = {c01[0], c01[1], c23[0], c23[1], c[4]};
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                const double *a = r0 + pl * kPlane + rr * kPtW4;
-                const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
-                const double v[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
-#pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    float (&dst_c)[5] = rr ? bot[0] : top[0];
-                    float (&dst_x)[5] = rr ? bot[1] : top[1];
-                    float (&dst_y)[5] = rr ? bot[2] : top[2];
-                    if (DEPTH) {
-                        (pl == 0 ? dst_c : (pl == 1 ? dst_x : dst_y))[i] = (float)v[i];
-                    } else if (pl == 0) {      // A = count * 2^20 + sum(vx): split exactly
-                        const double cnt = __builtin_rint(v[i] * (1.0 / kCountUnit));
-                        dst_c[i] = (float)cnt;
-                        dst_x[i] = (float)__builtin_fma(cnt, -kCountUnit, v[i]);
-                    } else {
-                        dst_y[i] = (float)v[i];
-                    }
-                }
+            for (int j = 0; j < 4; j++) {
+                const double wx0 = (cx + j == W - 1) ? 2.0 : 1.0;
+                box[pl][j] = __builtin_fma(wy0, __builtin_fma(wx0, bot[j + 1], bot[j]), __builtin_fma(wx0, top[j + 1], top[j]));
             }
         }
-    }
-    f32x4 ox, oy, oc;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
-        float v[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            // the four contributions are added in a fixed order (the reference's order is arbitrary: fp32 atomics)
-            float t = 0.0f;
-            t += wy0 * wx0 * bot[pl][j + 1];
-            t += wy0 * bot[pl][j];
-            t += wx0 * top[pl][j + 1];
-            t += top[pl][j];
-            v[pl] = t;
+        for (int j = 0; j < 4; j++) {
+            float v0, v1, v2;
+            if (DEPTH) {
+                v0 = (float)box[0][j];  v1 = (float)box[1][j];  v2 = (float)box[NP - 1][j];
+            } else {                           // A = count * 2^20 + sum(vx): split exactly
+                const double cnt = __builtin_rint(box[0][j] * (1.0 / kCountUnit));
+                v0 = (float)cnt;
+                v1 = (float)__builtin_fma(cnt, -kCountUnit, box[0][j]);
+                v2 = (float)box[1][j];
+            }
+            if (v0 > 0.0f) {                   // my_lib_kernel.cu:1730-1735; one reciprocal for both components
+                const float inv = 1.0f / v0;   // (<= 1 ulp from the two divisions)
+                v1 = v1 * inv;
+                v2 = v2 * inv;
+            }
+            oc[j] = v0;  ox[j] = v1;  oy[j] = v2;
         }
-        if (v[0] > 0.0f) {                     // my_lib_kernel.cu:1730-1735; one reciprocal for both components
-            const float inv = 1.0f / v[0];     // (<= 1 ulp from the two divisions)
-            v[1] = v[1] * inv;
-            v[2] = v[2] * inv;
-        }
-        oc[j] = v[0];  ox[j] = v[1];  oy[j] = v[2];
     }
     if (inb) {
         float *o = out + b * s1b + (int64_t)cy * s1h + cx, *cn = count + b * scb + (int64_t)cy * sch + cx;
@@ -1420,9 +1413,9 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
         }
     }
     if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
-        const bool hole = (SARM & 1) ? false : summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
+        const bool hole = (SARM & 1) ? false : summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy, tid);
         const int any_hole = __syncthreads_or(hole);
-        if (!(SARM & 2)) summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
+        if (!(SARM & 2)) summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, tid);
     }
 }
 
