@@ -5,7 +5,7 @@ be this repository's classes, and the first operator call on CPU tensors must fa
 error -- i.e. the reference code reached the real HIP binding and nothing fell back.
 
 CPU only; skipped where /root/reference does not exist (the GPU box).  On a GPU the same reference file running on
-the HIP operators is covered by tests/test_gpu_reference_network.py."""
+the HIP operators is covered by tests/test_gpu_network.py."""
 import os
 import sys
 
