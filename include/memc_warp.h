@@ -27,8 +27,9 @@
  *     With zero-filled buffers the results are the reference's.  With anything else they are unspecified,
  *     and in two places differ from the reference's `+=`: the FilterInterpolation backward STORES gradinput3
  *     (each site owns its taps) and the (Depth)FlowProjection backward STORES gradinput1 / gradinput2 (each site
- *     owns its elements) instead of adding to them; FilterInterpolation gradinput1 is added to and gradinput2
- *     assigned, as in the reference;
+ *     owns its elements) instead of adding to them; FilterInterpolation gradinput2 is assigned and gradinput1
+ *     added to, as in the reference -- except for channel counts that are multiples of four (>= 8), whose
+ *     owner-computes kernels STORE gradinput1 too (every cell has exactly one writer);
  *   - `output`, `gradoutput` and `gradinput1` are indexed with input1's b/c/h strides
  *     (my_lib_kernel.cu:1184,1276-1283), `gradinput2`/`gradinput3` with input2's/input3's;
  *   - work is enqueued asynchronously on `stream`; no host synchronisation, no state carried from one call to

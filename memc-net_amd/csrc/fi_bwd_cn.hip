@@ -1,0 +1,907 @@
+// fi_bwd_cn.hip -- FilterInterpolation backward, fs == 4, channel counts that are multiples of four (C >= 8), gfx950.
+//
+// Same operator as fi_bwd_tiled_c3 (filter_interpolation.hip; reference kernel my_lib_kernel.cu:1220-1515), built for
+// many channels.  With C channels a site issues 16 * C scattered adds into gradinput1; issued as global atomics
+// (fi_bwd_direct_fs4) that is 1024 atomics per site at C = 64, and the chip retires ~290 G of them per second
+// whatever the working set (tools/probes/run_probe.py atomics): 163 ms for 8 x 64 x 720 x 1280, a 128-thread CPU's
+// speed.  LDS accumulator planes (the RGB kernel's way) would still cost ~15 clk per wave-add.
+//
+// The observation this file is built on: the scatter PATTERN and its COEFFICIENTS do not depend on the channel.
+//     gradinput1[c][cell] += K(site, tap) * gradoutput[c][site],     K = (bilinear weight of the tap's quadrant) * tap
+//     gradinput3[tap]      = wq * S(site, tap),                       S = sum_c gradoutput[c][site] * input1[c][cell]
+//     gradinput2           = sum_taps (+-w) * S * tap
+// so the pattern is resolved ONCE per tile and then replayed for every channel as a gather:
+//
+//   fi_bwd_taps_c4n    (site tiles, 64 x 16, the forward c4n pipeline: chunks of four channels staged into LDS pixel
+//                       quads while the previous chunk is consumed) accumulates S in registers -- 4 FMAs per LDS
+//                       read -- and writes gradinput3 / gradinput2 (assigned) plus the tile's target bounding box;
+//   fi_bwd_image_owner (CELL tiles, 64 x 16, owner-computes) finds the site tiles whose boxes reach its cells, turns
+//                       their taps into a CSR list per cell in LDS (count -> scan -> fill, LDS integer atomics only),
+//                       then per chunk of four channels stages gradoutput of the contributing sites into LDS and
+//                       every cell replays its list: one ds_read_b128 + 4 FMAs per entry.  The result is STORED to
+//                       gradinput1 with plain 16-byte stores: no global atomics, no read-modify-write, each cell
+//                       written by exactly one workgroup (the caller's zero fill is not relied on).
+//
+// Sites whose window leaves the owner's search window (kOwnRX / kOwnRY site tiles around the site's own tile: motion
+// beyond ~128 px horizontally or ~64 px vertically) are "far": every owner skips them and a third kernel,
+// fi_bwd_far_sites, adds their image gradient with global atomics after the owners have stored theirs (kernel A
+// flags the site tiles that have any; the kernel's other workgroups exit at once).
+#include "memc_common.hpp"
+#include "memc_internal.h"
+#include "memc_tile.hpp"
+#include "memc_fi.hpp"
+#include "memc_scratch.hpp"
+
+namespace memc {
+
+constexpr int kOwnRX = 2, kOwnRY = 4;          // owner search window, in site tiles of 64 x 16
+constexpr int kTileHasFar = 1 << 30;           // in BBox::h of a site tile's target box: some of its sites are far
+
+// one site: does its (clamped) window reach a cell tile outside the search window of the site's own tile?
+__device__ __forceinline__ bool fi_site_far(int x, int y, int ix, int iy, int W, int H)
+{
+    const int tx = x >> 6, ty = y >> 4;
+    const int c0 = max(ix - 1, 0) >> 6, c1 = min(ix + 2, W - 1) >> 6;
+    const int r0 = max(iy - 1, 0) >> 4, r1 = min(iy + 2, H - 1) >> 4;
+    return c0 < tx - kOwnRX || c1 > tx + kOwnRX || r0 < ty - kOwnRY || r1 > ty + kOwnRY;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Rare paths, one site at a time from global memory.
+// ---------------------------------------------------------------------------------------------------------
+// image gradient of a far site: 16 * C global atomics
+__device__ __noinline__ void fi_bwd_site_image_atomics(int x, int y, int W, int H, int C, float *gin1_b, int64_t s1c,
+                                                       int s1h, const float *flow_p, int64_t s2c, const float *tap_p,
+                                                       int64_t s3c, const float *gout_p)
+{
+    const FiSite s = fi_locate(x, y, W, H, flow_p[0], flow_p[s2c]);
+    if (!s.valid) return;
+    for (int k = 0; k < 4; k++) {
+        const int ro = clampi(s.iy - 1 + k, H - 1) * s1h;
+        for (int m = 0; m < 4; m++) {
+            const int co = clampi(s.ix - 1 + m, W - 1);
+            const float wa = m < 2 ? (1 - s.a) : s.a, wb = k < 2 ? (1 - s.b) : s.b;
+            const float kk = (wa * wb) * tap_p[(k * 4 + m) * s3c];
+            for (int c = 0; c < C; c++) atomic_add_f32(gin1_b + c * s1c + ro + co, gout_p[c * s1c] * kk);
+        }
+    }
+}
+
+// tap and flow gradients of one site (a site no band of its tile covered)
+__device__ __noinline__ void fi_bwd_site_taps_cn(int x, int y, int W, int H, int C, const float *in_b, int64_t s1c,
+                                                 int s1h, const float *flow_p, float *g2, int64_t s2c,
+                                                 const float *tap_p, float *g3, int64_t s3c, const float *gout_p)
+{
+    const FiSite s = fi_locate(x, y, W, H, flow_p[0], flow_p[s2c]);
+    if (!s.valid) return;
+    float gx = 0.0f, gy = 0.0f;
+    for (int k = 0; k < 4; k++) {
+        const float *row = in_b + (int64_t)clampi(s.iy - 1 + k, H - 1) * s1h;
+        for (int m = 0; m < 4; m++) {
+            const float *p = row + clampi(s.ix - 1 + m, W - 1);
+            float sv = 0.0f;
+            for (int c = 0; c < C; c++) sv += gout_p[c * s1c] * p[c * s1c];
+            const float wa = m < 2 ? (1 - s.a) : s.a, wb = k < 2 ? (1 - s.b) : s.b;
+            g3[(k * 4 + m) * s3c] = (wa * wb) * sv;
+            const float st = sv * tap_p[(k * 4 + m) * s3c];
+            gx += (m < 2 ? -wb : wb) * st;
+            gy += (k < 2 ? -wa : wa) * st;
+        }
+    }
+    g2[0] = gx;
+    g2[s2c] = gy;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Kernel A: tap and flow gradients.
+// ---------------------------------------------------------------------------------------------------------
+// S[tap][j] += sum over the chunk's four channels of gradoutput * staged image, for the sites in `sel`.
+__device__ __forceinline__ void fi_bwd_taps_accum(const Region &r, const FiSite4 &g, unsigned sel,
+                                                  const f32x4 (&go)[4], int W, int H, const f32x4 *tile,
+                                                  f32x4 (&S)[16])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool on = (sel >> j) & 1;
+        int ro[4], co[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ro[k] = on ? (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch : 0;
+            co[k] = on ? swz_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0) : 0;
+        }
+        // unselected sites still issue their reads (at pixel 0) and add zeros: no control flow in the nest
+        const float g0 = on ? go[0][j] : 0.0f, g1 = on ? go[1][j] : 0.0f, g2 = on ? go[2][j] : 0.0f,
+                    g3 = on ? go[3][j] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            f32x4 v[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) v[m] = tile[ro[k] + co[m]];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                float acc = S[k * 4 + m][j];
+                acc += g0 * v[m][0];  acc += g1 * v[m][1];  acc += g2 * v[m][2];  acc += g3 * v[m][3];
+                S[k * 4 + m][j] = acc;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                 // one site's sixteen reads at a time: S needs the registers
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
+    int W, int H, int C, int tiles_x, int tiles_y, int batch,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
+    const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
+    const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2, float *__restrict__ gin3,
+    BBox *__restrict__ tbox)
+{
+    constexpr int LX = 16;
+    using G = TileGeom<LX>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
+    const int b = tc.b;
+    const unsigned tid = tid_now();
+    const int x = tc.tx * G::kTW + 4 * (int)(tid % LX), y = tc.ty * G::kTH + (int)(tid / LX);
+    const bool inb = x < W && y < H;
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const float *flow_b = flow + b * s2b, *filt_b = filt + b * s3b, *gout_b = gout + b * s1b;
+    float *gin2_b = gin2 + b * s2b, *gin3_b = gin3 + b * s3b;
+    const unsigned o1 = 4u * (unsigned)(ys * s1h + xs), o2 = 4u * (unsigned)(ys * s2h + xs),
+                   o3 = 4u * (unsigned)(ys * s3h + xs);
+    const f32x4 fx4 = ld_stream4_u(flow_b, o2), fy4 = ld_stream4_u(flow_b + s2c, o2);
+
+    FiSite4 g;
+    g.valid = 0;
+    unsigned far = 0;
+    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;          // staging box: every valid site
+    int ncmin = INT_MAX, ncmax = -1, nrmin = INT_MAX, nrmax = -1;      // target box of the sites the owners take
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
+        g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
+        if (inb && s.valid) {
+            g.valid |= 1u << j;
+            const int c0 = max(s.ix - 1, 0), c1 = min(s.ix + 2, W - 1), r0 = max(s.iy - 1, 0), r1 = min(s.iy + 2, H - 1);
+            cmin = min(cmin, c0);  cmax = max(cmax, c1);  rmin = min(rmin, r0);  rmax = max(rmax, r1);
+            if (fi_site_far(x + j, y, s.ix, s.iy, W, H)) {
+                far |= 1u << j;
+            } else {
+                ncmin = min(ncmin, c0);  ncmax = max(ncmax, c1);  nrmin = min(nrmin, r0);  nrmax = max(nrmax, r1);
+            }
+        }
+    }
+    const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
+    BBox near_box = tile_bbox<LX>(ncmin, ncmax, nrmin, nrmax, bb + 16);
+    // h's bit 30: the tile has far sites (fi_bwd_far_sites adds their image gradient after the owners have stored)
+    if (__syncthreads_or(far != 0)) near_box.h |= kTileHasFar;
+    if (tid == 0) tbox[((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx] = near_box;
+    const Bands bands = make_bands<LX>(box);
+    const float *in_b = in1 + b * s1b;
+
+    f32x4 S[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) S[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned done = 0;
+#pragma unroll 1
+    for (int bi = 0; bi < bands.n; bi++) {
+        const Region r = band_region(box, bands, bi);
+        const unsigned sel = inb ? fi_covered(r, g, W, H) & ~done : 0u;
+        if (bi > 0 && !__syncthreads_or(sel != 0)) continue;
+        done |= sel;
+        const StageSlot sl = stage_slots(r);
+        f32x4 go[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) go[c] = ld_stream4_u(gout_b + c * s1c, o1);
+#pragma unroll 1
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            {
+                // not carried across the accumulation (S needs the registers); wave-uniform plane bases + one 32-bit
+                // offset per slot: per-lane 64-bit pointers, strength-reduced over this loop, are what spills here
+                StageRegs<4> sr;
+#pragma unroll
+                for (int it = 0; it < kStageIts; it++) {
+                    const unsigned off = sl.row[it] < r.h
+                                             ? 4u * (unsigned)((r.y0 + sl.row[it]) * s1h + r.x0 + 4 * sl.q[it]) : 0u;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) sr.v[it][c] = ld_cached4_u(in_b + (c0 + c) * s1c, off);
+                }
+                tile_stage_store<4>(r, sl, sr, tile);
+            }
+            __syncthreads();
+            fi_bwd_taps_accum(r, g, sel, go, W, H, tile, S);
+            // the next chunk's gradoutput, once this chunk's has been used (one register set)
+            const int cn = c0 + 4 < C ? c0 + 4 : c0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) go[c] = ld_stream4_u(gout_b + (cn + c) * s1c, o1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: gradinput3 = wq * S, gradinput2 from S * tap; sites that are invalid (or not covered: redone below)
+    // store zeros -- both tensors are fully defined by this kernel.  One tap row at a time, the next row's taps in
+    // flight: all sixteen tap quads at once would not fit next to S.
+    if (inb) {
+        const unsigned live = g.valid & done;
+        const f32x4 fxe = ld_cached4_u(flow_b, o2), fye = ld_cached4_u(flow_b + s2c, o2);
+        f32x4 a4, b4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                      // alpha / beta again (not kept through the channel loop)
+            const FiSite s = fi_locate(x + j, y, W, H, fxe[j], fye[j]);
+            a4[j] = s.a;
+            b4[j] = s.b;
+        }
+        f32x4 gx4 = {0.f, 0.f, 0.f, 0.f}, gy4 = gx4;
+        f32x4 tp[4], tn[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) tp[m] = ld_stream4_u(filt_b + m * s3c, o3);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k < 3) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) tn[m] = ld_stream4_u(filt_b + ((k + 1) * 4 + m) * s3c, o3);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                f32x4 gt;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float a = a4[j], bt = b4[j];
+                    const float wa = m < 2 ? (1 - a) : a, wb = k < 2 ? (1 - bt) : bt;
+                    const float sv = ((live >> j) & 1) ? S[k * 4 + m][j] : 0.0f;
+                    gt[j] = (wa * wb) * sv;
+                    const float st = sv * tp[m][j];
+                    gx4[j] += (m < 2 ? -wb : wb) * st;
+                    gy4[j] += (k < 2 ? -wa : wa) * st;
+                }
+                st_stream4_u(gin3_b + (k * 4 + m) * s3c, o3, gt);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++) tp[m] = tn[m];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        st_stream4_u(gin2_b, o2, gx4);
+        st_stream4_u(gin2_b + s2c, o2, gy4);
+    }
+    unsigned slow = inb ? g.valid & ~done : 0u;            // not coverable within kMaxBands bands: from global memory
+    while (slow) {
+        const int j = __ffs(slow) - 1;
+        slow &= slow - 1;
+        fi_bwd_site_taps_cn(x + j, y, W, H, C, in_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j, s2c,
+                            filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
+    }
+}
+
+// The image gradient of the far sites, after the owners have stored theirs: one workgroup per site tile, gone at once
+// unless kernel A flagged the tile.
+__global__ __launch_bounds__(256) void fi_bwd_far_sites(
+    int W, int H, int C, int tiles_x, int tiles_y, int batch,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
+    const float *__restrict__ flow, const float *__restrict__ filt, const float *__restrict__ gout,
+    float *__restrict__ gin1, const BBox *__restrict__ tbox)
+{
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
+    if (!(tbox[((int64_t)tc.b * tiles_y + tc.ty) * tiles_x + tc.tx].h & kTileHasFar)) return;
+    const int x0 = tc.tx * 64 + 4 * (int)(threadIdx.x % 16), y = tc.ty * 16 + (int)(threadIdx.x / 16);
+    if (x0 >= W || y >= H) return;
+    const float *flow_p = flow + tc.b * s2b + (int64_t)y * s2h + x0;
+    for (int j = 0; j < 4; j++) {
+        const FiSite s = fi_locate(x0 + j, y, W, H, flow_p[j], flow_p[s2c + j]);
+        if (s.valid && fi_site_far(x0 + j, y, s.ix, s.iy, W, H))
+            fi_bwd_site_image_atomics(x0 + j, y, W, H, C, gin1 + tc.b * s1b, s1c, s1h, flow_p + j, s2c,
+                                      filt + tc.b * s3b + (int64_t)y * s3h + x0 + j, s3c,
+                                      gout + tc.b * s1b + (int64_t)y * s1h + x0 + j);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Kernel B: image gradient, owner-computes over 64 x 16 cell tiles, 512 lanes (one workgroup per CU).
+//
+//   1. candidate site tiles (target box reaches this cell tile), from the boxes kernel A left;
+//   2. one pass over their sites (flow only): per-cell tap counts (LDS integer atomics) and the box of the sites that
+//      contribute;
+//   3. one pass over the contributing box (flow + taps): every tap that lands here appends (K, site slot) to its
+//      cell's list.  A list is kListHead entries in a fixed table (slot r of every cell side by side) plus a tail in a
+//      CSR area (exclusive scan of the tail lengths) -- 16 taps per cell on average, but a compressing flow gives
+//      a heavy tail (the benchmark's flow: 9 % of the cells above 24, hot cells above 100);
+//   4. every lane copies the heads of its two cells into REGISTERS for the whole channel loop.  The tails are cut
+//      into segments of kSegLen entries and dealt out to ALL lanes (two per lane, in registers as well): a hot
+//      cell's work is spread over the workgroup instead of serialising its owner;
+//   5. per chunk of four channels: gradoutput of the contributing sites is staged as one float4 per site slot; every
+//      entry is one ds_read_b128 + 4 FMAs; segment sums go through LDS to the owners; then a 4 x 4 transpose inside
+//      lane quads (DPP) and one 16-byte read-modify-write per lane and cell row.
+// A contributing box larger than the staging area, or tails that do not fit (converging flow), are processed in
+// slabs of site rows, each slab one count / fill / replay round.
+//
+// LDS: head table (K fp32, slot u16) -- once the heads are in registers the same bytes hold the staged gradoutput,
+// the segment sums and the segment table -- | tail K, tail slot | one word per cell (cursor : count) | tail offsets |
+// control words.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kOwnThreads = 512;
+constexpr int kOwnCells = 1024;                // 64 x 16
+constexpr int kListHead = 16;                  // entries per cell a lane keeps in registers
+constexpr int kTailCap = 8192;                 // tail entries per slab
+constexpr int kSegLen = 8, kSegCap = 2 * kOwnThreads;      // tail segments: two per lane
+constexpr int kSlotCap = 3072;                 // sites whose gradoutput is staged per slab; slot kSlotCap holds zeros
+constexpr int kOwnCand = (2 * kOwnRX + 1) * (2 * kOwnRY + 1);
+static_assert(kOwnCand <= 64, "one lane per candidate site tile");
+constexpr int kOwnLdsHK = 0, kOwnLdsHS = kOwnLdsHK + kListHead * kOwnCells * 4,
+              kOwnLdsHeadEnd = kOwnLdsHS + kListHead * kOwnCells * 2;
+// aliases of the head table, valid after the heads have been copied to registers
+constexpr int kOwnLdsG = 0, kOwnLdsPart = (kOwnLdsG + (kSlotCap + 1) * 16 + 127) / 128 * 128,
+              kOwnLdsSeg = kOwnLdsPart + kSegCap * 16, kOwnLdsAliasEnd = kOwnLdsSeg + kSegCap * 4;
+static_assert(kOwnLdsAliasEnd <= kOwnLdsHeadEnd, "staging, segment sums and segment table fit the dead head table");
+constexpr int kOwnLdsTK = kOwnLdsHeadEnd, kOwnLdsTS = kOwnLdsTK + kTailCap * 4, kOwnLdsOc = kOwnLdsTS + kTailCap * 2,
+              kOwnLdsPres = kOwnLdsOc + kOwnCells * 4, kOwnLdsToff = kOwnLdsPres + kOwnCells * 4,
+              kOwnLdsCtl = kOwnLdsToff + kOwnCells * 2, kOwnLdsBytes = kOwnLdsCtl + 512;
+constexpr unsigned kHeadEmpty = 0x7fc5a5a5u;   // a NaN payload no coefficient has: an unclaimed head slot
+static_assert(kOwnLdsBytes <= 160 * 1024, "one workgroup per CU");
+
+struct OwnCtl {                                // control words in LDS
+    int cand[64];                              // candidate site tiles: tx | ty << 16
+    int ncand;
+    int ax0, ax1, ay0, ay1;                    // box of the contributing sites
+    unsigned wave_sum[8], wave_sum2[8];
+};
+
+// Which taps of the four sites of one quad land on the cell tile at (tx0, ty0)?  rowm / colm: bit k of site j's mask =
+// tap row / column k lands inside; a site contributes iff both are non-zero.
+struct QuadHits {
+    unsigned rowm[4], colm[4], any;
+    int ix[4], iy[4];
+    float a[4], b[4];
+};
+__device__ __forceinline__ QuadHits own_quad_hits(int x, int y, int W, int H, int tx0, int ty0, f32x4 fx4, f32x4 fy4)
+{
+    QuadHits h;
+    h.any = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
+        h.ix[j] = s.ix; h.iy[j] = s.iy; h.a[j] = s.a; h.b[j] = s.b;
+        unsigned rm = 0, cm = 0;
+        if (s.valid && !fi_site_far(x + j, y, s.ix, s.iy, W, H)) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                rm |= (unsigned)((unsigned)(clampi(s.iy - 1 + k, H - 1) - ty0) < 16u) << k;
+                cm |= (unsigned)((unsigned)(clampi(s.ix - 1 + k, W - 1) - tx0) < 64u) << k;
+            }
+        }
+        const bool hit = rm && cm;
+        h.rowm[j] = hit ? rm : 0;
+        h.colm[j] = hit ? cm : 0;
+        h.any |= hit ? 1u << j : 0u;
+    }
+    return h;
+}
+
+// oc[cell] += 1 << 16 and pres[cell] |= 1 << tap index for every tap of the quad that lands on the tile
+__device__ __forceinline__ void own_count(const QuadHits &h, unsigned *oc, unsigned *pres, int W, int H, int tx0,
+                                          int ty0)
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!((h.any >> j) & 1)) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!((h.rowm[j] >> k) & 1)) continue;
+            const int rc = (clampi(h.iy[j] - 1 + k, H - 1) - ty0) * 64 - tx0;
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                if ((h.colm[j] >> m) & 1) {
+                    const int ci = rc + clampi(h.ix[j] - 1 + m, W - 1);
+                    atomicAdd(oc + ci, 0x10000u);
+                    atomicOr(pres + ci, 1u << (k * 4 + m));          // which tap indices the cell receives
+                }
+        }
+    }
+}
+
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xf, 0xf, true));
+}
+// 4 x 4 transpose inside every aligned group of four lanes: lane i (of the group) gets component i of lanes 0..3
+__device__ __forceinline__ f32x4 quad_transpose(f32x4 v, unsigned my)
+{
+    f32x4 out;
+#define MEMC_QT(K)                                                                                                 \
+    {                                                                                                              \
+        const float t0 = quad_bcast<K>(v[0]), t1 = quad_bcast<K>(v[1]), t2 = quad_bcast<K>(v[2]),                  \
+                    t3 = quad_bcast<K>(v[3]);                                                                      \
+        out[K] = my == 0 ? t0 : (my == 1 ? t1 : (my == 2 ? t2 : t3));                                              \
+    }
+    MEMC_QT(0) MEMC_QT(1) MEMC_QT(2) MEMC_QT(3)
+#undef MEMC_QT
+    return out;
+}
+
+// TR (measurement build): thread 0 accumulates the shader clocks of every phase into trace[blockIdx.x * 16 + ...]
+// (tools/trace_kernel.py fi_bwd_cn): 0 whole life, 1 candidates + count pass, 2 slab recounts, 3 scan, 4 fill,
+// 5 lists -> registers, 6 replay, 7 slab rounds, 8 candidate tiles, 9 tail segments (last slab), 10 site-box area.
+template <bool TR>
+__global__ __launch_bounds__(kOwnThreads) void fi_bwd_image_owner(
+    int W, int H, int C, int tiles_x, int tiles_y, int batch,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
+    const float *__restrict__ flow, const float *__restrict__ filt, const float *__restrict__ gout,
+    float *__restrict__ gin1, const BBox *__restrict__ tbox, unsigned long long *__restrict__ trace)
+{
+    unsigned long long tr_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_t = 0, tr_t0 = 0;
+#define MEMC_TR_BEGIN() do { if (TR) tr_t = __builtin_readcyclecounter(); } while (0)
+#define MEMC_TR_END(slot) do { if (TR) { const unsigned long long n_ = __builtin_readcyclecounter(); tr_acc[slot] += n_ - tr_t; tr_t = n_; } } while (0)
+    if (TR) tr_t0 = __builtin_readcyclecounter();
+    MEMC_TR_BEGIN();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *HK = reinterpret_cast<float *>(smem + kOwnLdsHK);
+    unsigned short *HS = reinterpret_cast<unsigned short *>(smem + kOwnLdsHS);
+    f32x4 *g4 = reinterpret_cast<f32x4 *>(smem + kOwnLdsG);                      // } aliases of the head table
+    f32x4 *part = reinterpret_cast<f32x4 *>(smem + kOwnLdsPart);                 // }
+    unsigned *segtab = reinterpret_cast<unsigned *>(smem + kOwnLdsSeg);          // }
+    float *TK = reinterpret_cast<float *>(smem + kOwnLdsTK);
+    unsigned short *TS = reinterpret_cast<unsigned short *>(smem + kOwnLdsTS);
+    unsigned *oc = reinterpret_cast<unsigned *>(smem + kOwnLdsOc);
+    unsigned *pres = reinterpret_cast<unsigned *>(smem + kOwnLdsPres);
+    unsigned short *toff = reinterpret_cast<unsigned short *>(smem + kOwnLdsToff);
+    OwnCtl *ctl = reinterpret_cast<OwnCtl *>(smem + kOwnLdsCtl);
+    static_assert(sizeof(OwnCtl) <= 512, "control words");
+
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
+    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
+    const unsigned tid = threadIdx.x;
+
+    // this lane's two cells (rows r and r + 8 of the tile) and, after the quad transpose, its channel of four cells;
+    // the channel (my) is folded into the lane's byte offset: 4 * (my * s1c + row * s1h + col)
+    const unsigned my = tid & 3;
+    const int cell_x = tx0 + (int)(tid & 63 & ~3u), cell_y = ty0 + (int)(tid >> 6);
+    const bool st0 = cell_x < W && cell_y < H, st1 = cell_x < W && cell_y + 8 < H;
+    const unsigned wo0 = st0 ? 4u * (unsigned)((int64_t)my * s1c + (int64_t)cell_y * s1h + cell_x) : 0u;
+    const unsigned wo1 = st1 ? 4u * (unsigned)((int64_t)my * s1c + (int64_t)(cell_y + 8) * s1h + cell_x) : 0u;
+    float *gin1_b = gin1 + b * s1b;
+    // gradinput1 is STORED by this kernel (the first slab assigns, later slabs add): cells nobody reaches get zeros
+    auto store_zeros = [&]() {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            if (st0) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + c0 * s1c, wo0)) = z;
+            if (st1) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + c0 * s1c, wo1)) = z;
+        }
+    };
+
+    // 1. candidate site tiles: those of the search window whose target box reaches this cell tile
+    if (tid < 64) {
+        const int dx = (int)tid % (2 * kOwnRX + 1) - kOwnRX, dy = (int)tid / (2 * kOwnRX + 1) - kOwnRY;
+        const int sx = tc.tx + dx, sy = tc.ty + dy;
+        bool hit = false;
+        if ((int)tid < kOwnCand && sx >= 0 && sx < tiles_x && sy >= 0 && sy < tiles_y) {
+            BBox bx = tbox[((int64_t)b * tiles_y + sy) * tiles_x + sx];
+            bx.h &= ~kTileHasFar;
+            hit = bx.w > 0 && bx.x0 < tx0 + 64 && bx.x0 + bx.w > tx0 && bx.y0 < ty0 + 16 && bx.y0 + bx.h > ty0;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (hit) ctl->cand[__popcll(m & ((1ull << tid) - 1ull))] = sx | (sy << 16);
+        if (tid == 0) {
+            ctl->ncand = __popcll(m);
+            ctl->ax0 = INT_MAX;  ctl->ax1 = -1;  ctl->ay0 = INT_MAX;  ctl->ay1 = -1;
+        }
+    }
+    oc[tid] = 0;
+    oc[tid + kOwnThreads] = 0;
+    pres[tid] = 0;
+    pres[tid + kOwnThreads] = 0;
+    __syncthreads();
+    const int ncand = ctl->ncand;
+    if (ncand == 0) {                                      // nobody reaches these cells
+        store_zeros();
+        return;
+    }
+
+    const float *flow_b = flow + b * s2b, *filt_b = filt + b * s3b, *gout_b = gout + b * s1b;
+
+    // 2. counts and the box of the contributing sites (flow only)
+    {
+        int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
+        const int nq = ncand * 256;
+#pragma unroll 2
+        for (int idx = tid; idx < nq; idx += kOwnThreads) {
+            const int t = ctl->cand[idx >> 8], q = idx & 255;
+            const int x = (t & 0xffff) * 64 + 4 * (q & 15), y = (t >> 16) * 16 + (q >> 4);
+            if (x >= W || y >= H) continue;
+            const float *fp = flow_b + (int64_t)y * s2h + x;
+            const QuadHits h = own_quad_hits(x, y, W, H, tx0, ty0, ld_cached4(fp), ld_cached4(fp + s2c));
+            if (h.any) {
+                bx0 = min(bx0, x + __ffs(h.any) - 1);
+                bx1 = max(bx1, x + 31 - __clz(h.any));
+                by0 = min(by0, y);
+                by1 = max(by1, y);
+                own_count(h, oc, pres, W, H, tx0, ty0);
+            }
+        }
+        bx0 = wave_min_i32(bx0);  bx1 = -wave_min_i32(-bx1);  by0 = wave_min_i32(by0);  by1 = -wave_min_i32(-by1);
+        if ((tid & 63) == 0 && bx1 >= 0) {
+            atomicMin(&ctl->ax0, bx0);  atomicMax(&ctl->ax1, bx1);
+            atomicMin(&ctl->ay0, by0);  atomicMax(&ctl->ay1, by1);
+        }
+    }
+    __syncthreads();
+    MEMC_TR_END(1);
+    if (ctl->ax1 < 0) {
+        store_zeros();
+        return;
+    }
+    const int ax0 = ctl->ax0 & ~3, aw = (ctl->ax1 | 3) + 1 - ax0, ay0 = ctl->ay0, ay1 = ctl->ay1;
+    const int nqw = aw >> 2;
+    int rows = max(1, min(ay1 - ay0 + 1, kSlotCap / aw));
+    bool counted = rows == ay1 - ay0 + 1;                  // one slab: the counts above are its counts
+
+#pragma unroll 1
+    for (int y_lo = ay0; y_lo <= ay1;) {
+        const int y_hi = min(y_lo + rows - 1, ay1);
+        const int nqs = (y_hi - y_lo + 1) * nqw;           // float4 slots of this slab's site box (<= 2 per lane)
+        const int i0 = (int)tid, i1 = (int)tid + kOwnThreads;
+        const int r0 = i0 / nqw, q0 = i0 - r0 * nqw, r1 = i1 / nqw, q1 = i1 - r1 * nqw;
+        const bool on0 = i0 < nqs, on1 = i1 < nqs;
+        const int xq0 = ax0 + 4 * q0, yq0 = y_lo + r0, xq1 = ax0 + 4 * q1, yq1 = y_lo + r1;
+        const float *fp0 = flow_b + (on0 ? (int64_t)yq0 * s2h + xq0 : 0);
+        const float *fp1 = flow_b + (on1 ? (int64_t)yq1 * s2h + xq1 : 0);
+
+        if (!counted) {                                    // several slabs: this slab's counts
+            oc[tid] = 0;
+            oc[tid + kOwnThreads] = 0;
+            pres[tid] = 0;
+            pres[tid + kOwnThreads] = 0;
+            __syncthreads();
+            const QuadHits h0 = own_quad_hits(xq0, yq0, W, H, tx0, ty0, ld_cached4(fp0), ld_cached4(fp0 + s2c));
+            const QuadHits h1 = own_quad_hits(xq1, yq1, W, H, tx0, ty0, ld_cached4(fp1), ld_cached4(fp1 + s2c));
+            if (on0 && h0.any) own_count(h0, oc, pres, W, H, tx0, ty0);
+            if (on1 && h1.any) own_count(h1, oc, pres, W, H, tx0, ty0);
+            __syncthreads();
+        }
+        counted = false;
+        MEMC_TR_END(2);
+        if (TR) tr_acc[7]++;
+
+        // 3a. tails: lengths beyond the head table, their exclusive scan (CSR offsets) and their segments.  This lane's
+        //     cells are tid and tid + 512 from here on.  Tails that do not fit: the slab is halved and counted again.
+        const unsigned w0 = oc[tid], w1 = oc[tid + kOwnThreads];
+        const int n0 = (int)(w0 >> 16), n1 = (int)(w1 >> 16);
+        // heads are indexed by tap: one entry per tap index the cell receives; every further one is tail
+        const int tl0 = n0 - __popc(pres[tid]), tl1 = n1 - __popc(pres[tid + kOwnThreads]);
+        const int ns0 = (tl0 + kSegLen - 1) / kSegLen, ns1 = (tl1 + kSegLen - 1) / kSegLen;
+        unsigned toff0, sb0, nseg_total;
+        bool serial_tails;
+        {
+            unsigned incl = (unsigned)(tl0 + tl1), incl2 = (unsigned)(ns0 + ns1);
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(incl, o), up2 = __shfl_up(incl2, o);
+                if ((int)(tid & 63) >= o) {
+                    incl += up;
+                    incl2 += up2;
+                }
+            }
+            if ((tid & 63) == 63) {
+                ctl->wave_sum[tid >> 6] = incl;
+                ctl->wave_sum2[tid >> 6] = incl2;
+            }
+            // head table: unclaimed (become K = 0 on the zero slot when the heads are read)
+            {
+                const f32x4 z4 = {__uint_as_float(kHeadEmpty), __uint_as_float(kHeadEmpty), __uint_as_float(kHeadEmpty),
+                                  __uint_as_float(kHeadEmpty)};
+                f32x4 *k4 = reinterpret_cast<f32x4 *>(HK);
+#pragma unroll
+                for (int i = 0; i < kListHead * kOwnCells / 4 / kOwnThreads; i++) k4[tid + i * kOwnThreads] = z4;
+                unsigned *s2 = reinterpret_cast<unsigned *>(HS);
+                const unsigned zs = (unsigned)kSlotCap | ((unsigned)kSlotCap << 16);
+#pragma unroll
+                for (int i = 0; i < kListHead * kOwnCells / 2 / kOwnThreads; i++) s2[tid + i * kOwnThreads] = zs;
+            }
+            __syncthreads();
+            unsigned base = 0, base2 = 0, total = 0, total2 = 0;
+#pragma unroll
+            for (int w = 0; w < kOwnThreads / 64; w++) {
+                base += w < (int)(tid >> 6) ? ctl->wave_sum[w] : 0u;
+                base2 += w < (int)(tid >> 6) ? ctl->wave_sum2[w] : 0u;
+                total += ctl->wave_sum[w];
+                total2 += ctl->wave_sum2[w];
+            }
+            if (total > (unsigned)kTailCap && rows > 1) {  // workgroup-uniform
+                rows = (rows + 1) / 2;
+                __syncthreads();                           // wave_sum is rewritten by the next round
+                continue;
+            }
+            toff0 = base + incl - (unsigned)(tl0 + tl1);
+            sb0 = base2 + incl2 - (unsigned)(ns0 + ns1);
+            nseg_total = total2;
+            // (a single row of sites can still overflow the tail area in theory: those tails are dropped from the
+            //  lists and ... cannot happen: a row holds at most 320 sites = 5120 taps)
+            serial_tails = total2 > (unsigned)kSegCap;     // more segments than lanes can keep: owners walk their tails
+            toff[tid] = (unsigned short)toff0;
+            toff[tid + kOwnThreads] = (unsigned short)(toff0 + tl0);
+            oc[tid] = w0 & 0xffff0000u;                    // tail cursor 0 : count
+            oc[tid + kOwnThreads] = w1 & 0xffff0000u;
+        }
+        __syncthreads();
+        MEMC_TR_END(3);
+
+        // 3b. the taps of the slab's sites into the lists
+#pragma unroll 1
+        for (int u = 0; u < 2; u++) {
+            if (!(u ? on1 : on0)) continue;
+            const int x = u ? xq1 : xq0, y = u ? yq1 : yq0;
+            const float *fp = u ? fp1 : fp0;
+            const float *tp_p = filt_b + (int64_t)y * s3h + x;
+            const f32x4 fx4 = ld_cached4(fp), fy4 = ld_cached4(fp + s2c);
+            f32x4 tp[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) tp[k] = ld_cached4(tp_p + k * s3c);
+            const QuadHits h = own_quad_hits(x, y, W, H, tx0, ty0, fx4, fy4);
+            if (!h.any) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!((h.any >> j) & 1)) continue;
+                const unsigned short slot = (unsigned short)((y - y_lo) * aw + (x + j - ax0));
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (!((h.rowm[j] >> k) & 1)) continue;
+                    const int rc = (clampi(h.iy[j] - 1 + k, H - 1) - ty0) * 64 - tx0;
+                    const float wb = k < 2 ? (1 - h.b[j]) : h.b[j];
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        if (!((h.colm[j] >> m) & 1)) continue;
+                        const int ci = rc + clampi(h.ix[j] - 1 + m, W - 1);
+                        const float wa = m < 2 ? (1 - h.a[j]) : h.a[j];
+                        const float kv = (wa * wb) * tp[k * 4 + m][j];
+                        // the head slot of this tap index, if nobody has it yet (neighbouring cells then hold
+                        // neighbouring sites in the same slot: conflict-free replay); else the cell's tail
+                        const int hi = (k * 4 + m) * kOwnCells + ci;
+                        if (atomicCAS(reinterpret_cast<unsigned *>(HK) + hi, kHeadEmpty, __float_as_uint(kv)) == kHeadEmpty) {
+                            HS[hi] = slot;
+                        } else {
+                            const int e = (int)toff[ci] + (int)(atomicAdd(oc + ci, 1u) & 0xffffu);
+                            TK[e] = kv;
+                            TS[e] = slot;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        MEMC_TR_END(4);
+
+        // 4. heads of this lane's two cells -> registers; then the head table's bytes become the staging area, the
+        //    segment sums and the segment table
+        float kk0[kListHead], kk1[kListHead];
+        unsigned ss0[kListHead / 2], ss1[kListHead / 2];   // two slots per register (the lists must not spill)
+#pragma unroll
+        for (int t = 0; t < kListHead; t++) {
+            const float k0 = HK[t * kOwnCells + tid], k1 = HK[t * kOwnCells + tid + kOwnThreads];
+            kk0[t] = __float_as_uint(k0) == kHeadEmpty ? 0.0f : k0;
+            kk1[t] = __float_as_uint(k1) == kHeadEmpty ? 0.0f : k1;
+        }
+#pragma unroll
+        for (int t = 0; t < kListHead; t += 2) {
+            ss0[t / 2] = (unsigned)HS[t * kOwnCells + tid] | ((unsigned)HS[(t + 1) * kOwnCells + tid] << 16);
+            ss1[t / 2] = (unsigned)HS[t * kOwnCells + tid + kOwnThreads] |
+                         ((unsigned)HS[(t + 1) * kOwnCells + tid + kOwnThreads] << 16);
+        }
+        __syncthreads();
+        if (tid == 0) g4[kSlotCap] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned sb1 = sb0 + (unsigned)ns0;
+        if (!serial_tails) {                               // the owners describe their tails' segments: start | length << 16
+            for (int i = 0; i < ns0; i++)
+                segtab[sb0 + i] = (toff0 + (unsigned)(i * kSegLen)) | ((unsigned)min(kSegLen, tl0 - i * kSegLen) << 16);
+            for (int i = 0; i < ns1; i++)
+                segtab[sb1 + i] = (toff0 + (unsigned)(tl0 + i * kSegLen)) | ((unsigned)min(kSegLen, tl1 - i * kSegLen) << 16);
+        }
+        __syncthreads();
+        // this lane's two segments (any cells' tails) -> registers
+        float ks0[kSegLen], ks1[kSegLen];
+        unsigned sg0[kSegLen / 2], sg1[kSegLen / 2];
+        const bool has0 = !serial_tails && tid < nseg_total, has1 = !serial_tails && tid + kOwnThreads < nseg_total;
+        {
+            const unsigned d0 = has0 ? segtab[tid] : 0u, d1 = has1 ? segtab[tid + kOwnThreads] : 0u;
+            const int b0 = (int)(d0 & 0xffffu), l0 = (int)(d0 >> 16), b1 = (int)(d1 & 0xffffu), l1 = (int)(d1 >> 16);
+#pragma unroll
+            for (int i = 0; i < kSegLen; i++) {
+                const bool h0 = i < l0, h1 = i < l1;
+                const float k0 = TK[h0 ? b0 + i : 0], k1 = TK[h1 ? b1 + i : 0];
+                const unsigned s0 = TS[h0 ? b0 + i : 0], s1 = TS[h1 ? b1 + i : 0];
+                ks0[i] = h0 ? k0 : 0.0f;
+                ks1[i] = h1 ? k1 : 0.0f;
+                const unsigned z0 = h0 ? s0 : (unsigned)kSlotCap, z1 = h1 ? s1 : (unsigned)kSlotCap;
+                if (i & 1) {
+                    sg0[i / 2] |= z0 << 16;
+                    sg1[i / 2] |= z1 << 16;
+                } else {
+                    sg0[i / 2] = z0;
+                    sg1[i / 2] = z1;
+                }
+            }
+        }
+        const bool any_seg = nseg_total != 0;              // workgroup-uniform
+        MEMC_TR_END(5);
+
+        // 5. replay, four channels at a time.  Wave-uniform plane bases + 32-bit byte offsets (per-lane 64-bit
+        //    pointers would not fit next to the lists: a spilled pointer's reload waits for every load in flight)
+        const unsigned go0 = on0 ? 4u * (unsigned)(yq0 * s1h + xq0) : 0u, go1 = on1 ? 4u * (unsigned)(yq1 * s1h + xq1) : 0u;
+        f32x4 *gd0 = g4 + (on0 ? r0 * aw + 4 * q0 : 0), *gd1 = g4 + (on1 ? r1 * aw + 4 * q1 : 0);
+        f32x4 v0[4], v1[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            v0[c] = ld_cached4_u(gout_b + c * s1c, go0);
+            v1[c] = ld_cached4_u(gout_b + c * s1c, go1);
+        }
+        const bool rmw = y_lo != ay0;                      // workgroup-uniform: a later slab adds to the first one's
+        f32x4 old0 = {0.f, 0.f, 0.f, 0.f}, old1 = old0, nold0 = old0, nold1 = old0;
+        if (rmw) {
+            old0 = ld_cached4_u(gin1_b, wo0);
+            old1 = ld_cached4_u(gin1_b, wo1);
+        }
+        // Two barriers per chunk: [stage chunk i | finish chunk i - 1: segment sums, transpose, store] barrier
+        // [issue the next loads | segments of chunk i -> LDS | heads of chunk i] barrier (the staging area is free).
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;        // head sums of the chunk before
+        auto finish = [&](int cp) {                       // chunk cp's sums are complete: add the segments', store
+            if (!serial_tails && any_seg) {
+                f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
+#pragma unroll 4
+                for (int i = 0; i < ns0; i++) q0 += part[sb0 + i];
+#pragma unroll 4
+                for (int i = 0; i < ns1; i++) q1 += part[sb1 + i];
+                a0 += q0;
+                a1 += q1;
+            }
+            const f32x4 t0 = quad_transpose(a0, my), t1 = quad_transpose(a1, my);
+            if (st0) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + cp * s1c, wo0)) = old0 + t0;
+            if (st1) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + cp * s1c, wo1)) = old1 + t1;
+        };
+#pragma unroll 1
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            if (on0) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) gd0[i] = f32x4{v0[0][i], v0[1][i], v0[2][i], v0[3][i]};
+            }
+            if (on1) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) gd1[i] = f32x4{v1[0][i], v1[1][i], v1[2][i], v1[3][i]};
+            }
+            if (c0 > 0) {
+                finish(c0 - 4);
+                old0 = nold0;
+                old1 = nold1;
+            }
+            __syncthreads();
+            MEMC_TR_END(11);
+            // the next chunk's gradoutput (and, in later slabs, the cells' current values): in flight during the replay
+            // (the last iteration re-reads its own chunk -- harmless, keeps the loads unconditional)
+            const int cn = c0 + 4 < C ? c0 + 4 : c0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                v0[c] = ld_cached4_u(gout_b + (cn + c) * s1c, go0);
+                v1[c] = ld_cached4_u(gout_b + (cn + c) * s1c, go1);
+            }
+            if (rmw) {
+                nold0 = ld_cached4_u(gin1_b + cn * s1c, wo0);
+                nold1 = ld_cached4_u(gin1_b + cn * s1c, wo1);
+            }
+            // keep the slot unpacking inside the loop (hoisted, the 48 LDS addresses spill)
+#pragma unroll
+            for (int i = 0; i < kListHead / 2; i++) asm volatile("" : "+v"(ss0[i]), "+v"(ss1[i]));
+#pragma unroll
+            for (int i = 0; i < kSegLen / 2; i++) asm volatile("" : "+v"(sg0[i]), "+v"(sg1[i]));
+            // ... and the coefficients single: hoisted, the {k, k} pairs of the packed FMAs double them
+#pragma unroll
+            for (int i = 0; i < kListHead; i++) asm volatile("" : "+v"(kk0[i]), "+v"(kk1[i]));
+#pragma unroll
+            for (int i = 0; i < kSegLen; i++) asm volatile("" : "+v"(ks0[i]), "+v"(ks1[i]));
+            // Eight ds_read_b128 are issued back to back, then consumed in order (the scheduling barriers pin that:
+            // left alone, the compiler -- short of registers -- waits for every read before issuing the next).
+#define MEMC_REPLAY8(ACC, KS, SS, T0)                                                                              \
+            {                                                                                                      \
+                f32x4 gq[8];                                                                                       \
+                _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++)                                                   \
+                    gq[i_] = g4[((T0 + i_) & 1) ? SS[(T0 + i_) / 2] >> 16 : SS[(T0 + i_) / 2] & 0xffffu];          \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+                _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) ACC += KS[T0 + i_] * gq[i_];                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+            }
+            static_assert(kSegLen == 8 && kListHead == 16, "the replay is written in batches of eight");
+            if (any_seg && !serial_tails) {                // (workgroup-uniform) segment sums: for their owners
+                f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+                MEMC_REPLAY8(p0, ks0, sg0, 0)
+                if ((tid & ~63u) + kOwnThreads < nseg_total) MEMC_REPLAY8(p1, ks1, sg1, 0)      // wave-uniform
+                if (has0) part[tid] = p0;
+                if (has1) part[tid + kOwnThreads] = p1;
+            }
+            MEMC_TR_END(12);
+            a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            a1 = a0;
+            MEMC_REPLAY8(a0, kk0, ss0, 0)
+            MEMC_REPLAY8(a1, kk1, ss1, 0)
+            MEMC_REPLAY8(a0, kk0, ss0, 8)
+            MEMC_REPLAY8(a1, kk1, ss1, 8)
+#undef MEMC_REPLAY8
+            if (serial_tails) {                            // (converging flow) owners walk their own tails
+                for (int t = 0; t < tl0; t++) a0 += TK[toff0 + t] * g4[TS[toff0 + t]];
+                for (int t = 0; t < tl1; t++) a1 += TK[toff0 + tl0 + t] * g4[TS[toff0 + tl0 + t]];
+            }
+            MEMC_TR_END(13);
+            __syncthreads();
+            MEMC_TR_END(15);
+        }
+        finish(C - 4);
+        __syncthreads();                                   // the segment sums have been read: the next slab may rebuild
+        MEMC_TR_END(6);
+        if (TR && tid == 0) trace[(size_t)blockIdx.x * 16 + 9] = (unsigned long long)nseg_total;
+        y_lo = y_hi + 1;
+    }
+    if (TR && tid == 0) {
+        unsigned long long *t = trace + (size_t)blockIdx.x * 16;
+        t[0] = __builtin_readcyclecounter() - tr_t0;
+        for (int i = 1; i < 8; i++) t[i] = tr_acc[i];
+        for (int i = 11; i < 16; i++) t[i] = tr_acc[i];     // inside the replay: stage + barrier, segments, heads,
+                                                            // barrier, sums + transpose + store + barrier
+        t[8] = (unsigned long long)ncand;
+        t[10] = (unsigned long long)(aw * (ay1 - ay0 + 1));
+    }
+#undef MEMC_TR_BEGIN
+#undef MEMC_TR_END
+}
+
+#ifdef MEMC_MEASURE
+static unsigned long long *g_trace_cn = nullptr;       // gridDim.x * 16 uint64; tools/trace_kernel.py fi_bwd_cn
+extern "C" int memc_debug_set_trace_buffer_cn(void *p)
+{
+    g_trace_cn = static_cast<unsigned long long *>(p);
+    return 0;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------
+// Launcher.  Returns 1 when the call was taken, 0 when it is not for these kernels (the caller falls back to the
+// direct kernel), -1 on a launch error.
+// ---------------------------------------------------------------------------------------------------------
+int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
+                     int s1b, int s1c, int s1h, int s2b, int s2c, int s2h, int s3b, int s3c, int s3h,
+                     const float *input1, const float *input2, const float *input3, const float *gradoutput,
+                     float *gradinput1, float *gradinput2, float *gradinput3)
+{
+    if (channel % 4 != 0 || channel < 8) return 0;
+    if (!plane_fits_u32(w, h, {s1h, s2h, s3h}) ||
+        !vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
+                 {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3}))
+        return 0;
+    if (4LL * (3LL * s1c + (long long)(h - 1) * s1h + w) >= (1LL << 32)) return 0;     // the owner's 4-plane offsets
+    const int ntx = (w + 63) / 64, nty = (h + 15) / 16;
+    if (ntx > 0xffff || nty > 0x7fff) return 0;
+    const unsigned ntiles = (unsigned)ntx * nty * batch;
+    CallScratch scratch;                                   // the site tiles' target boxes
+    if (!scratch.alloc((size_t)ntiles * sizeof(BBox), stream)) return 0;      // e.g. inside a stream capture
+    BBox *tbox = static_cast<BBox *>(scratch.p);
+    hipLaunchKernelGGL(fi_bwd_taps_c4n, dim3(ntiles), dim3(256), tile_lds_bytes<16>() + 64, stream,
+                       w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                       (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2,
+                       gradinput3, tbox);
+#define MEMC_OWNER(TR, TRACE)                                                                                      \
+    do {                                                                                                           \
+        static const bool once = (allow_big_lds(fi_bwd_image_owner<TR>, kOwnLdsBytes), true);                      \
+        (void)once;                                                                                                \
+        hipLaunchKernelGGL(fi_bwd_image_owner<TR>, dim3(ntiles), dim3(kOwnThreads), kOwnLdsBytes, stream,          \
+                           w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,          \
+                           (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input2, input3, gradoutput,         \
+                           gradinput1, tbox, TRACE);                                                               \
+    } while (0)
+#ifdef MEMC_MEASURE
+    if (g_trace_cn) MEMC_OWNER(true, g_trace_cn);
+    else
+#endif
+        MEMC_OWNER(false, nullptr);
+#undef MEMC_OWNER
+    hipLaunchKernelGGL(fi_bwd_far_sites, dim3(ntiles), dim3(256), 0, stream,
+                       w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                       (int64_t)s3b, (int64_t)s3c, s3h, input2, input3, gradoutput, gradinput1, tbox);
+    return launch_status() == 0 ? 1 : -1;
+}
+
+}  // namespace memc

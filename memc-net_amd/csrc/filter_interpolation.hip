@@ -17,6 +17,7 @@
 #include "memc_common.hpp"
 #include "memc_internal.h"
 #include "memc_tile.hpp"
+#include "memc_fi.hpp"
 
 namespace memc {
 
@@ -33,12 +34,6 @@ namespace memc {
 //   4. one dwordx4 store per channel (non-temporal).
 //   C > 4 loops steps 2-4 over chunks of four channels with the taps and site geometry kept in registers.
 // --------------------------------------------------------------------------------------------------
-struct FiSite4 {          // geometry of a lane's four sites
-    int ix[4], iy[4];
-    float a[4], b[4];
-    unsigned valid;       // bit j
-};
-
 // Scalar evaluation of ONE site for channels [0, nch) of `plane0`, everything read from global memory
 // (flow, taps, image): the rare path for sites whose source window is not in the staged LDS region, and the
 // body of the any-filter-size kernel.  Same arithmetic order as the fast path.
@@ -118,18 +113,6 @@ __device__ __forceinline__ void fi_gather(const Region &r, const FiSite4 &g, con
         const f32x4 val = ((1 - a) * (1 - bt)) * TL + (a * (1 - bt)) * TR + ((1 - a) * bt) * BL + (a * bt) * BR;
         res[j] = on ? val : res[j];
     }
-}
-
-// sites of this lane whose (clamped) window lies inside the band
-__device__ __forceinline__ unsigned fi_covered(const Region &r, const FiSite4 &g, int W, int H)
-{
-    unsigned m = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-        if (((g.valid >> j) & 1) &&
-            r.covers(max(g.ix[j] - 1, 0), min(g.ix[j] + 2, W - 1), max(g.iy[j] - 1, 0), min(g.iy[j] + 2, H - 1)))
-            m |= 1u << j;
-    return m;
 }
 
 template <int LX, int NCH, int ABL = 0>
@@ -1752,6 +1735,12 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
     const int tiles_x = (w + kWave - 1) / kWave;
     const int tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
+    int taken = 0;
+#ifdef MEMC_MEASURE
+    const bool direct_only = g_fi_bwd_variant == 40;       // A/B: the direct kernel (global atomics) for any channel count
+#else
+    constexpr bool direct_only = false;
+#endif
     if (filter_size != 4) {
         hipLaunchKernelGGL(fi_bwd_generic, dim3(nwg), dim3(256), 0, stream, w, h, channel, filter_size,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
@@ -1802,6 +1791,10 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
 #undef MEMC_FI_BWD
 #undef MEMC_FI_BWD_P
 #undef MEMC_FI_BWD_ARGS
+    } else if (channel != 3 && !direct_only &&
+               (taken = fi_bwd_cn_launch(stream, w, h, channel, batch, s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h, input1,
+                                         input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)) != 0) {
+        return taken > 0 ? 0 : -1;                         // many channels: fi_bwd_cn.hip
     } else if (channel == 3) {
         hipLaunchKernelGGL((fi_bwd_direct_fs4<3, 4>), dim3(nwg), dim3(256), 0, stream, w, h, channel,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,

@@ -9,6 +9,18 @@
 #pragma once
 #include "memc_warp.h"
 
+#if defined(__cplusplus) && defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+namespace memc {
+// fi_bwd_cn.hip: FilterInterpolation backward for C % 4 == 0, C >= 8, fs == 4 (tap-gradient kernel + owner-computes image
+// gradient).  1: taken, 0: not applicable here (caller falls back), -1: launch error.  Strides as in the C ABI.
+int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
+                     int s1b, int s1c, int s1h, int s2b, int s2c, int s2h, int s3b, int s3c, int s3h,
+                     const float *input1, const float *input2, const float *input3, const float *gradoutput,
+                     float *gradinput1, float *gradinput2, float *gradinput3);
+}  // namespace memc
+#endif
+
 #ifdef MEMC_MEASURE
 #ifdef __cplusplus
 extern "C" {
@@ -24,6 +36,7 @@ void memc_debug_set_bl_cap(int which);           // 2x2-footprint kernels' LDS s
 void memc_debug_set_walk(int stripe_width);      // < 0: each launcher's default; 0: strips; n: stripes n tile columns wide
 int memc_debug_set_trace_buffer(void *device_u64_buffer);        // gridDim.x * 16 slots, written by fi_bwd variant 9
 int memc_debug_set_trace_buffer_proj(void *device_u64_buffer);   // the same for the projection's trace arm
+int memc_debug_set_trace_buffer_cn(void *device_u64_buffer);     // fi_bwd_image_owner's phase clocks; NULL switches them off
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -91,6 +91,59 @@ def test_filter_interpolation(oracle, case):
     close(N(k.grad), g3, "gradinput3", RTOL)
 
 
+def _many_channel_flows(kind, rng, B, H, W):
+    """Flow fields that take fi_bwd_cn.hip's paths one by one (FilterInterpolation backward, C % 4 == 0)."""
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    if kind == "smooth":                       # the common case: a handful of candidate site tiles per cell tile
+        return synth.np_flow(rng, B, H, W, "smooth", 6.0)
+    if kind == "pan":                          # coherent motion of 100 px: the target boxes sit two tiles away
+        f = synth.np_flow(rng, B, H, W, "smooth", 1.5)
+        f[:, 0] += -100.25
+        f[:, 1] += 9.5
+        return f
+    if kind == "far":                          # beyond the owners' search window (> 2 tile columns): global atomics
+        f = synth.np_flow(rng, B, H, W, "smooth", 2.0)
+        f[:, 0, :, W // 2:] -= 170.0
+        return f
+    if kind == "converge":                     # every site lands near one point: lists far beyond the LDS budget
+        f = np.empty((B, 2, H, W), np.float32)
+        f[:, 0] = (W / 2 - xx) * 0.97 + 0.3
+        f[:, 1] = (H / 2 - yy) * 0.97 + 0.3
+        return f
+    if kind == "iid":
+        return synth.np_flow(rng, B, H, W, "iid", 20.0)
+    raise ValueError(kind)
+
+
+MANY = [(2, 8, 70, 200, "smooth"), (1, 16, 96, 384, "pan"), (1, 8, 48, 448, "far"), (1, 8, 64, 192, "converge"),
+        (1, 12, 80, 256, "iid"), (1, 64, 36, 132, "smooth")]
+
+
+@pytest.mark.parametrize("case", MANY, ids=["%dx%dx%dx%d-%s" % c for c in MANY])
+def test_filter_interpolation_backward_many_channels(oracle, case):
+    """C % 4 == 0, C >= 8: tap-gradient kernel + owner-computes image gradient (fi_bwd_cn.hip)."""
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    B, C, H, W, kind = case
+    rng = np.random.default_rng(sum(case[:4]))
+    xn, kn, gn = synth.np_image(rng, B, C, H, W), synth.np_filter(rng, B, H, W), synth.np_image(rng, B, C, H, W)
+    fn = _many_channel_flows(kind, rng, B, H, W)
+    x, f, k = T(xn, True), T(fn, True), T(kn, True)
+    out = FilterInterpolationModule()(x, f, k)
+    out.backward(T(gn))
+    g1, g2, g3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+    close(N(x.grad), g1, "gradinput1", 3 * RTOL)      # a cell can collect hundreds of taps ("converge")
+    close(N(f.grad), g2, "gradinput2", RTOL)
+    close(N(k.grad), g3, "gradinput3", RTOL)
+    # The owner kernels STORE gradinput1 (every cell has exactly one writer; unreached cells get zeros; far sites are
+    # added afterwards): outside a stream capture the result does not depend on what the buffers held before.
+    import my_package._ext.my_lib as my_lib
+    h1, h2, h3 = torch.full_like(x, 7.0), torch.full_like(f, 7.0), torch.full_like(k, 7.0)
+    assert my_lib.FilterInterpolationLayer_gpu_backward(x.detach(), f.detach(), k.detach(), T(gn), h1, h2, h3) == 0
+    close(N(h1), g1, "gradinput1 (stored)", 3 * RTOL)
+    close(N(h2), g2, "gradinput2 (stored)", RTOL)
+    close(N(h3), g3, "gradinput3 (stored)", RTOL)
+
+
 @pytest.mark.parametrize("fs", [2, 3, 6])
 def test_filter_interpolation_other_filter_sizes(oracle, fs):
     """fs = (int)sqrt(channels of input3) (my_lib.c:925); 3 is odd: window [ix, ix+2]."""

@@ -334,6 +334,9 @@ def main():
                          [int(v) for v in args.bwd_variants.split(",") if v])
             bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "iid", "720p")
             bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "video", "720p")
+    if want("fi_bwd_ctx"):
+        bench_fi_bwd(rows, dev, 8, 64, 720, 1280, "smooth", "ctx64")
+        bench_fi_bwd(rows, dev, 4, 64, 256, 448, "smooth", "ctx64 crop")
     if want("proj"):
         bench_projection(rows, dev, 32, 720, 1280, "smooth", "c3",
                          [int(v) for v in args.proj_variants.split(",") if v])

@@ -61,6 +61,11 @@ def atomics_main():
     for rep, shift in ((1, 0), (4, 0), (4, 1), (4, 1280), (2, 1)):
         t = timeit(lambda: lib.probe_atomics(st, 0, 16384, ctypes.c_void_p(d.data_ptr()), n, rep, shift))
         print("atomics n=%d rep=%d shift=%-5d %9.1f us  %7.2f G atomics/s" % (n, rep, shift, t * 1e6, n * rep / t / 1e9), flush=True)
+    # is the coalesced rate the atomic units' or HBM's?  The same pattern over working sets that stay in L2 / MALL
+    for n_small, rep in ((1 << 20, 64), (1 << 23, 16), (1 << 25, 4)):
+        t = timeit(lambda: lib.probe_atomics(st, 0, 16384, ctypes.c_void_p(d.data_ptr()), n_small, rep, 0))
+        print("atomics n=%d (%.0f MB) rep=%d shift=0 %9.1f us  %7.2f G atomics/s" % (
+            n_small, n_small * 4 / 1e6, rep, t * 1e6, n_small * rep / t / 1e9), flush=True)
     t = timeit(lambda: lib.probe_atomics(st, 1, 16384, ctypes.c_void_p(d.data_ptr()), n, 1, 0))
     print("plain float4 += over the same %d elements %9.1f us  %7.1f GB/s (read+write)" % (n, t * 1e6, n * 8 / t / 1e9))
 

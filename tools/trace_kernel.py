@@ -39,8 +39,45 @@ for _code, _th in ((0, 16), (1, 32), (2, 64)):      # proj_owner2 (round 2), til
                                      last=5, th=_th, marks=_PROJ2_MARKS)
 
 
+def fi_bwd_cn():
+    """fi_bwd_image_owner (fi_bwd_cn.hip): accumulated shader clocks per phase, thread 0 of every workgroup."""
+    dev = torch.device("cuda:0")
+    B, C, H, W = 8, 64, 720, 1280
+    kind = sys.argv[2] if len(sys.argv) > 2 else "smooth"
+    t = synth.torch_inputs(dev, B, C, H, W, flow_kind=kind, with_grad=True)
+    x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
+    g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
+    fn = lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3)     # noqa: E731
+    ntiles = ((W + 63) // 64) * ((H + 15) // 16) * B
+    buf = torch.zeros(ntiles * 16, dtype=torch.int64, device=dev)
+    setter = M.lib().memc_debug_set_trace_buffer_cn
+    setter.argtypes = [ctypes.c_void_p]
+    for _ in range(5):
+        fn()
+    assert setter(ctypes.c_void_p(buf.data_ptr())) == 0
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); fn(); b.record(); b.synchronize()
+    setter(ctypes.c_void_p(0))
+    ts = buf.cpu().numpy().reshape(ntiles, 16).astype(np.float64)
+    print("fi_bwd C=%d %dx%dx%d flow=%s: %.1f us by events (both kernels, trace arm), %d workgroups" % (
+        C, B, H, W, kind, a.elapsed_time(b) * 1e3, ntiles))
+    tot = ts[:, 0].mean()
+    print("mean workgroup life %.0f clocks (100 MHz counter ticks if s_memrealtime; see ratio only)" % tot)
+    names = {1: "candidates + count pass", 2: "slab recounts", 3: "scan", 4: "fill", 5: "lists -> registers", 6: "replay (outside the marks below)",
+             11: "  replay: stage + barrier", 12: "  replay: loads issue + segments", 13: "  replay: heads",
+             14: "  replay: barrier (segment sums)", 15: "  replay: sums, transpose, store, barrier"}
+    for i, nm in names.items():
+        print("%-28s %6.1f%%  %10.0f" % (nm, 100 * ts[:, i].mean() / tot, ts[:, i].mean()))
+    print("slab rounds per tile: mean %.2f max %d; candidates mean %.1f; longest list (wave 0, last slab) mean %.1f max %d; "
+          "site box mean %.0f max %d" % (ts[:, 7].mean(), ts[:, 7].max(), ts[:, 8].mean(), ts[:, 9].mean(), ts[:, 9].max(),
+                                         ts[:, 10].mean(), ts[:, 10].max()))
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "fi_bwd"
+    if which == "fi_bwd_cn":
+        return fi_bwd_cn()
     K = KERNELS[which]
     dev = torch.device("cuda:0")
     B, C, H, W = 32, 3, 720, 1280
