@@ -20,7 +20,9 @@
 //                       then per chunk of four channels stages gradoutput of the contributing sites into LDS and
 //                       every cell replays its list: one ds_read_b128 + 4 FMAs per entry.  The result is STORED to
 //                       gradinput1 with plain 16-byte stores: no global atomics, no read-modify-write, each cell
-//                       written by exactly one workgroup (the caller's zero fill is not relied on).
+//                       written by exactly one workgroup.  For this class of channel counts gradinput1 is stored on
+//                       EVERY path (the launcher clears it before falling back to the direct kernel), so a caller
+//                       need not zero-fill it.
 //
 // Sites whose window leaves the owner's search window (kOwnRX / kOwnRY site tiles around the site's own tile: motion
 // beyond ~128 px horizontally or ~64 px vertically) are "far": every owner skips them and a third kernel,
@@ -862,22 +864,40 @@ extern "C" int memc_debug_set_trace_buffer_cn(void *p)
 // Launcher.  Returns 1 when the call was taken, 0 when it is not for these kernels (the caller falls back to the
 // direct kernel), -1 on a launch error.
 // ---------------------------------------------------------------------------------------------------------
+// gradinput1 = 0 over a strided [batch, channel, h, w] view (rows are contiguous)
+__global__ __launch_bounds__(256) void fi_bwd_zero_rows(float *__restrict__ p, int w, int h, int channel, int64_t sb,
+                                                        int64_t sc, int sh)
+{
+    const int64_t row = blockIdx.x;                        // (b * channel + c) * h + y
+    const int y = (int)(row % h), c = (int)((row / h) % channel);
+    float *q = p + (row / h / channel) * sb + c * sc + (int64_t)y * sh;
+    for (int x = threadIdx.x; x < w; x += 256) q[x] = 0.0f;
+}
+
+// Channel counts this file is for.  For them gradinput1 is STORED on every path: when the owner kernels cannot run
+// (odd geometry, no scratch inside a stream capture) the buffer is cleared here before the caller falls back to the
+// accumulating direct kernel.
+bool fi_bwd_cn_class(int channel, int filter_size) { return filter_size == 4 && channel % 4 == 0 && channel >= 8; }
+
 int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                      int s1b, int s1c, int s1h, int s2b, int s2c, int s2h, int s3b, int s3c, int s3h,
                      const float *input1, const float *input2, const float *input3, const float *gradoutput,
-                     float *gradinput1, float *gradinput2, float *gradinput3)
+                     float *gradinput1, float *gradinput2, float *gradinput3, bool force_direct)
 {
-    if (channel % 4 != 0 || channel < 8) return 0;
-    if (!plane_fits_u32(w, h, {s1h, s2h, s3h}) ||
-        !vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
-                 {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3}))
-        return 0;
-    if (4LL * (3LL * s1c + (long long)(h - 1) * s1h + w) >= (1LL << 32)) return 0;     // the owner's 4-plane offsets
+    if (!fi_bwd_cn_class(channel, 4)) return 0;
     const int ntx = (w + 63) / 64, nty = (h + 15) / 16;
-    if (ntx > 0xffff || nty > 0x7fff) return 0;
     const unsigned ntiles = (unsigned)ntx * nty * batch;
     CallScratch scratch;                                   // the site tiles' target boxes
-    if (!scratch.alloc((size_t)ntiles * sizeof(BBox), stream)) return 0;      // e.g. inside a stream capture
+    if (force_direct || !plane_fits_u32(w, h, {s1h, s2h, s3h}) ||
+        !vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
+                 {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3}) ||
+        4LL * (3LL * s1c + (long long)(h - 1) * s1h + w) >= (1LL << 32) ||           // the owner's 4-plane offsets
+        ntx > 0xffff || nty > 0x7fff ||
+        !scratch.alloc((size_t)ntiles * sizeof(BBox), stream)) {                     // e.g. inside a stream capture
+        hipLaunchKernelGGL(fi_bwd_zero_rows, dim3((unsigned)batch * channel * h), dim3(256), 0, stream, gradinput1, w, h,
+                           channel, (int64_t)s1b, (int64_t)s1c, s1h);
+        return launch_status() == 0 ? 0 : -1;
+    }
     BBox *tbox = static_cast<BBox *>(scratch.p);
     hipLaunchKernelGGL(fi_bwd_taps_c4n, dim3(ntiles), dim3(256), tile_lds_bytes<16>() + 64, stream,
                        w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,

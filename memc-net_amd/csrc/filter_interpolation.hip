@@ -1791,9 +1791,10 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
 #undef MEMC_FI_BWD
 #undef MEMC_FI_BWD_P
 #undef MEMC_FI_BWD_ARGS
-    } else if (channel != 3 && !direct_only &&
+    } else if (channel != 3 &&
                (taken = fi_bwd_cn_launch(stream, w, h, channel, batch, s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h, input1,
-                                         input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)) != 0) {
+                                         input2, input3, gradoutput, gradinput1, gradinput2, gradinput3,
+                                         direct_only)) != 0) {
         return taken > 0 ? 0 : -1;                         // many channels: fi_bwd_cn.hip
     } else if (channel == 3) {
         hipLaunchKernelGGL((fi_bwd_direct_fs4<3, 4>), dim3(nwg), dim3(256), 0, stream, w, h, channel,

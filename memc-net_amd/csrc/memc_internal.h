@@ -13,11 +13,13 @@
 #include <hip/hip_runtime.h>
 namespace memc {
 // fi_bwd_cn.hip: FilterInterpolation backward for C % 4 == 0, C >= 8, fs == 4 (tap-gradient kernel + owner-computes image
-// gradient).  1: taken, 0: not applicable here (caller falls back), -1: launch error.  Strides as in the C ABI.
+// gradient).  1: taken, 0: not taken (the caller falls back to the direct kernel; for this class of channel counts
+// gradinput1 has then been cleared: it is STORED on every path), -1: launch error.  Strides as in the C ABI.
+// force_direct: measurement arm -- clear and decline.
 int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                      int s1b, int s1c, int s1h, int s2b, int s2c, int s2h, int s3b, int s3c, int s3h,
                      const float *input1, const float *input2, const float *input3, const float *gradoutput,
-                     float *gradinput1, float *gradinput2, float *gradinput3);
+                     float *gradinput1, float *gradinput2, float *gradinput3, bool force_direct);
 }  // namespace memc
 #endif
 

@@ -116,7 +116,8 @@ def _many_channel_flows(kind, rng, B, H, W):
 
 
 MANY = [(2, 8, 70, 200, "smooth"), (1, 16, 96, 384, "pan"), (1, 8, 48, 448, "far"), (1, 8, 64, 192, "converge"),
-        (1, 12, 80, 256, "iid"), (1, 64, 36, 132, "smooth")]
+        (1, 12, 80, 256, "iid"), (1, 64, 36, 132, "smooth"),
+        (1, 8, 20, 50, "smooth")]          # width not a multiple of 4: cleared, then the direct kernel
 
 
 @pytest.mark.parametrize("case", MANY, ids=["%dx%dx%dx%d-%s" % c for c in MANY])
