@@ -321,25 +321,31 @@ __global__ __launch_bounds__(256) void fi_bwd_far_sites(
 // the segment sums and the segment table -- | tail K, tail slot | one word per cell (cursor : count) | tail offsets |
 // control words.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kOwnThreads = 512;
-constexpr int kOwnCells = 1024;                // 64 x 16
-constexpr int kListHead = 16;                  // entries per cell a lane keeps in registers
-constexpr int kTailCap = 8192;                 // tail entries per slab
-constexpr int kSegLen = 8, kSegCap = 2 * kOwnThreads;      // tail segments: two per lane
-constexpr int kSlotCap = 3072;                 // sites whose gradoutput is staged per slab; slot kSlotCap holds zeros
+constexpr int kListHead = 16;                  // entries per cell a lane keeps in registers (one per tap index)
+constexpr int kSegLen = 8;                     // tail segment length; two segments per lane
+constexpr unsigned kHeadEmpty = 0x7fc5a5a5u;   // a NaN payload no coefficient has: an unclaimed head slot
 constexpr int kOwnCand = (2 * kOwnRX + 1) * (2 * kOwnRY + 1);
 static_assert(kOwnCand <= 64, "one lane per candidate site tile");
-constexpr int kOwnLdsHK = 0, kOwnLdsHS = kOwnLdsHK + kListHead * kOwnCells * 4,
-              kOwnLdsHeadEnd = kOwnLdsHS + kListHead * kOwnCells * 2;
-// aliases of the head table, valid after the heads have been copied to registers
-constexpr int kOwnLdsG = 0, kOwnLdsPart = (kOwnLdsG + (kSlotCap + 1) * 16 + 127) / 128 * 128,
-              kOwnLdsSeg = kOwnLdsPart + kSegCap * 16, kOwnLdsAliasEnd = kOwnLdsSeg + kSegCap * 4;
-static_assert(kOwnLdsAliasEnd <= kOwnLdsHeadEnd, "staging, segment sums and segment table fit the dead head table");
-constexpr int kOwnLdsTK = kOwnLdsHeadEnd, kOwnLdsTS = kOwnLdsTK + kTailCap * 4, kOwnLdsOc = kOwnLdsTS + kTailCap * 2,
-              kOwnLdsPres = kOwnLdsOc + kOwnCells * 4, kOwnLdsToff = kOwnLdsPres + kOwnCells * 4,
-              kOwnLdsCtl = kOwnLdsToff + kOwnCells * 2, kOwnLdsBytes = kOwnLdsCtl + 512;
-constexpr unsigned kHeadEmpty = 0x7fc5a5a5u;   // a NaN payload no coefficient has: an unclaimed head slot
-static_assert(kOwnLdsBytes <= 160 * 1024, "one workgroup per CU");
+
+// Cell tile 64 x TH, 32 * TH lanes (two cells per lane: rows r and r + TH / 2).
+//   TH = 16: 512 lanes, 157 KB of LDS, one workgroup per CU;
+//   TH = 8:  256 lanes,  78 KB, two per CU -- the build / replay phases of one overlap the other's barriers.
+template <int TH>
+struct OwnGeom {
+    static constexpr int kThreads = 32 * TH, kCells = 64 * TH;
+    static constexpr int kTailCap = 8 * kCells;            // tail entries per slab
+    static constexpr int kSegCap = 2 * kThreads;
+    static constexpr int kSlotCap = TH == 16 ? 3072 : 2048;        // sites staged per slab; slot kSlotCap holds zeros
+    static constexpr int kHK = 0, kHS = kHK + kListHead * kCells * 4, kHeadEnd = kHS + kListHead * kCells * 2;
+    // aliases of the head table, valid after the heads have been copied to registers
+    static constexpr int kG = 0, kPart = (kG + (kSlotCap + 1) * 16 + 127) / 128 * 128, kSeg = kPart + kSegCap * 16,
+                         kAliasEnd = kSeg + kSegCap * 4;
+    static_assert(kAliasEnd <= kHeadEnd, "staging, segment sums and segment table fit the dead head table");
+    static_assert(kSlotCap <= 8 * kThreads, "two float4 slots of staging per lane");
+    static constexpr int kTK = kHeadEnd, kTS = kTK + kTailCap * 4, kOc = kTS + kTailCap * 2, kPres = kOc + kCells * 4,
+                         kToff = kPres + kCells * 4, kCtl = kToff + kCells * 2, kBytes = kCtl + 512;
+    static_assert(kBytes * (TH == 16 ? 1 : 2) <= 160 * 1024, "LDS per CU");
+};
 
 struct OwnCtl {                                // control words in LDS
     int cand[64];                              // candidate site tiles: tx | ty << 16
@@ -355,6 +361,7 @@ struct QuadHits {
     int ix[4], iy[4];
     float a[4], b[4];
 };
+template <int TH>
 __device__ __forceinline__ QuadHits own_quad_hits(int x, int y, int W, int H, int tx0, int ty0, f32x4 fx4, f32x4 fy4)
 {
     QuadHits h;
@@ -367,7 +374,7 @@ __device__ __forceinline__ QuadHits own_quad_hits(int x, int y, int W, int H, in
         if (s.valid && !fi_site_far(x + j, y, s.ix, s.iy, W, H)) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                rm |= (unsigned)((unsigned)(clampi(s.iy - 1 + k, H - 1) - ty0) < 16u) << k;
+                rm |= (unsigned)((unsigned)(clampi(s.iy - 1 + k, H - 1) - ty0) < (unsigned)TH) << k;
                 cm |= (unsigned)((unsigned)(clampi(s.ix - 1 + k, W - 1) - tx0) < 64u) << k;
             }
         }
@@ -424,9 +431,9 @@ __device__ __forceinline__ f32x4 quad_transpose(f32x4 v, unsigned my)
 // TR (measurement build): thread 0 accumulates the shader clocks of every phase into trace[blockIdx.x * 16 + ...]
 // (tools/trace_kernel.py fi_bwd_cn): 0 whole life, 1 candidates + count pass, 2 slab recounts, 3 scan, 4 fill,
 // 5 lists -> registers, 6 replay, 7 slab rounds, 8 candidate tiles, 9 tail segments (last slab), 10 site-box area.
-template <bool TR>
-__global__ __launch_bounds__(kOwnThreads) void fi_bwd_image_owner(
-    int W, int H, int C, int tiles_x, int tiles_y, int batch,
+template <int TH, bool TR>
+__global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
+    int W, int H, int C, int tiles_x, int tiles_y, int site_tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ flow, const float *__restrict__ filt, const float *__restrict__ gout,
     float *__restrict__ gin1, const BBox *__restrict__ tbox, unsigned long long *__restrict__ trace)
@@ -436,6 +443,12 @@ __global__ __launch_bounds__(kOwnThreads) void fi_bwd_image_owner(
 #define MEMC_TR_END(slot) do { if (TR) { const unsigned long long n_ = __builtin_readcyclecounter(); tr_acc[slot] += n_ - tr_t; tr_t = n_; } } while (0)
     if (TR) tr_t0 = __builtin_readcyclecounter();
     MEMC_TR_BEGIN();
+    using Gm = OwnGeom<TH>;
+    constexpr int kOwnThreads = Gm::kThreads, kOwnCells = Gm::kCells, kTailCap = Gm::kTailCap, kSegCap = Gm::kSegCap,
+                  kSlotCap = Gm::kSlotCap;
+    constexpr int kOwnLdsHK = Gm::kHK, kOwnLdsHS = Gm::kHS, kOwnLdsG = Gm::kG, kOwnLdsPart = Gm::kPart,
+                  kOwnLdsSeg = Gm::kSeg, kOwnLdsTK = Gm::kTK, kOwnLdsTS = Gm::kTS, kOwnLdsOc = Gm::kOc,
+                  kOwnLdsPres = Gm::kPres, kOwnLdsToff = Gm::kToff, kOwnLdsCtl = Gm::kCtl;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *HK = reinterpret_cast<float *>(smem + kOwnLdsHK);
     unsigned short *HS = reinterpret_cast<unsigned short *>(smem + kOwnLdsHS);
@@ -451,16 +464,16 @@ __global__ __launch_bounds__(kOwnThreads) void fi_bwd_image_owner(
     static_assert(sizeof(OwnCtl) <= 512, "control words");
 
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
-    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
+    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * TH;      // tiles_y counts CELL tiles (rows of TH)
     const unsigned tid = threadIdx.x;
 
-    // this lane's two cells (rows r and r + 8 of the tile) and, after the quad transpose, its channel of four cells;
+    // this lane's two cells (rows r and r + TH / 2 of the tile) and, after the quad transpose, its channel of four cells;
     // the channel (my) is folded into the lane's byte offset: 4 * (my * s1c + row * s1h + col)
     const unsigned my = tid & 3;
     const int cell_x = tx0 + (int)(tid & 63 & ~3u), cell_y = ty0 + (int)(tid >> 6);
-    const bool st0 = cell_x < W && cell_y < H, st1 = cell_x < W && cell_y + 8 < H;
+    const bool st0 = cell_x < W && cell_y < H, st1 = cell_x < W && cell_y + TH / 2 < H;
     const unsigned wo0 = st0 ? 4u * (unsigned)((int64_t)my * s1c + (int64_t)cell_y * s1h + cell_x) : 0u;
-    const unsigned wo1 = st1 ? 4u * (unsigned)((int64_t)my * s1c + (int64_t)(cell_y + 8) * s1h + cell_x) : 0u;
+    const unsigned wo1 = st1 ? 4u * (unsigned)((int64_t)my * s1c + (int64_t)(cell_y + TH / 2) * s1h + cell_x) : 0u;
     float *gin1_b = gin1 + b * s1b;
     // gradinput1 is STORED by this kernel (the first slab assigns, later slabs add): cells nobody reaches get zeros
     auto store_zeros = [&]() {
@@ -474,12 +487,12 @@ __global__ __launch_bounds__(kOwnThreads) void fi_bwd_image_owner(
     // 1. candidate site tiles: those of the search window whose target box reaches this cell tile
     if (tid < 64) {
         const int dx = (int)tid % (2 * kOwnRX + 1) - kOwnRX, dy = (int)tid / (2 * kOwnRX + 1) - kOwnRY;
-        const int sx = tc.tx + dx, sy = tc.ty + dy;
+        const int sx = tc.tx + dx, sy = (ty0 >> 4) + dy;   // site tiles are 64 x 16; site_tiles_y of them per image
         bool hit = false;
-        if ((int)tid < kOwnCand && sx >= 0 && sx < tiles_x && sy >= 0 && sy < tiles_y) {
-            BBox bx = tbox[((int64_t)b * tiles_y + sy) * tiles_x + sx];
+        if ((int)tid < kOwnCand && sx >= 0 && sx < tiles_x && sy >= 0 && sy < site_tiles_y) {
+            BBox bx = tbox[((int64_t)b * site_tiles_y + sy) * tiles_x + sx];
             bx.h &= ~kTileHasFar;
-            hit = bx.w > 0 && bx.x0 < tx0 + 64 && bx.x0 + bx.w > tx0 && bx.y0 < ty0 + 16 && bx.y0 + bx.h > ty0;
+            hit = bx.w > 0 && bx.x0 < tx0 + 64 && bx.x0 + bx.w > tx0 && bx.y0 < ty0 + TH && bx.y0 + bx.h > ty0;
         }
         const unsigned long long m = __ballot(hit);
         if (hit) ctl->cand[__popcll(m & ((1ull << tid) - 1ull))] = sx | (sy << 16);
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(kOwnThreads) void fi_bwd_image_owner(
             const int x = (t & 0xffff) * 64 + 4 * (q & 15), y = (t >> 16) * 16 + (q >> 4);
             if (x >= W || y >= H) continue;
             const float *fp = flow_b + (int64_t)y * s2h + x;
-            const QuadHits h = own_quad_hits(x, y, W, H, tx0, ty0, ld_cached4(fp), ld_cached4(fp + s2c));
+            const QuadHits h = own_quad_hits<TH>(x, y, W, H, tx0, ty0, ld_cached4(fp), ld_cached4(fp + s2c));
             if (h.any) {
                 bx0 = min(bx0, x + __ffs(h.any) - 1);
                 bx1 = max(bx1, x + 31 - __clz(h.any));
@@ -554,8 +567,8 @@ __global__ __launch_bounds__(kOwnThreads) void fi_bwd_image_owner(
             pres[tid] = 0;
             pres[tid + kOwnThreads] = 0;
             __syncthreads();
-            const QuadHits h0 = own_quad_hits(xq0, yq0, W, H, tx0, ty0, ld_cached4(fp0), ld_cached4(fp0 + s2c));
-            const QuadHits h1 = own_quad_hits(xq1, yq1, W, H, tx0, ty0, ld_cached4(fp1), ld_cached4(fp1 + s2c));
+            const QuadHits h0 = own_quad_hits<TH>(xq0, yq0, W, H, tx0, ty0, ld_cached4(fp0), ld_cached4(fp0 + s2c));
+            const QuadHits h1 = own_quad_hits<TH>(xq1, yq1, W, H, tx0, ty0, ld_cached4(fp1), ld_cached4(fp1 + s2c));
             if (on0 && h0.any) own_count(h0, oc, pres, W, H, tx0, ty0);
             if (on1 && h1.any) own_count(h1, oc, pres, W, H, tx0, ty0);
             __syncthreads();
@@ -638,7 +651,7 @@ __global__ __launch_bounds__(kOwnThreads) void fi_bwd_image_owner(
             f32x4 tp[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) tp[k] = ld_cached4(tp_p + k * s3c);
-            const QuadHits h = own_quad_hits(x, y, W, H, tx0, ty0, fx4, fy4);
+            const QuadHits h = own_quad_hits<TH>(x, y, W, H, tx0, ty0, fx4, fy4);
             if (!h.any) continue;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -852,6 +865,8 @@ __global__ __launch_bounds__(kOwnThreads) void fi_bwd_image_owner(
 }
 
 #ifdef MEMC_MEASURE
+static int g_owner_th = 16;                            // A/B: cell tile height of the owner kernel (16 or 8)
+extern "C" void memc_debug_set_owner_th(int th) { g_owner_th = th; }
 static unsigned long long *g_trace_cn = nullptr;       // gridDim.x * 16 uint64; tools/trace_kernel.py fi_bwd_cn
 extern "C" int memc_debug_set_trace_buffer_cn(void *p)
 {
@@ -903,20 +918,27 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                        w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                        (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2,
                        gradinput3, tbox);
-#define MEMC_OWNER(TR, TRACE)                                                                                      \
+#define MEMC_OWNER(TH, TR, TRACE)                                                                                  \
     do {                                                                                                           \
-        static const bool once = (allow_big_lds(fi_bwd_image_owner<TR>, kOwnLdsBytes), true);                      \
+        static const bool once = (allow_big_lds(fi_bwd_image_owner<TH, TR>, OwnGeom<TH>::kBytes), true);           \
         (void)once;                                                                                                \
-        hipLaunchKernelGGL(fi_bwd_image_owner<TR>, dim3(ntiles), dim3(kOwnThreads), kOwnLdsBytes, stream,          \
-                           w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,          \
-                           (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input2, input3, gradoutput,         \
-                           gradinput1, tbox, TRACE);                                                               \
+        const int cty = (h + TH - 1) / TH;                                                                         \
+        hipLaunchKernelGGL((fi_bwd_image_owner<TH, TR>), dim3((unsigned)ntx * cty * batch),                        \
+                           dim3(OwnGeom<TH>::kThreads), OwnGeom<TH>::kBytes, stream, w, h, channel, ntx, cty, nty, \
+                           batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,  \
+                           (int64_t)s3c, s3h, input2, input3, gradoutput, gradinput1, tbox, TRACE);                \
     } while (0)
+    // 64 x 16 cell tiles, one workgroup per CU.  Measured (8 x 64 x 720 x 1280, tools/bench_ops.py --only fi_bwd_ctx on
+    // the measurement build): 4.30 ms for the whole backward; 64 x 8 tiles, two workgroups per CU: 4.40 -- the phases
+    // are LDS- and VALU-throughput bound (SQ counters: LDS active 45 % of the busy cycles, half of that bank
+    // conflicts of the compressing benchmark flow; VALU 40 %), not barrier-bound, so overlap buys nothing and the
+    // smaller tile scans more sites per cell.
 #ifdef MEMC_MEASURE
-    if (g_trace_cn) MEMC_OWNER(true, g_trace_cn);
+    if (g_trace_cn) MEMC_OWNER(16, true, g_trace_cn);
+    else if (g_owner_th == 8) MEMC_OWNER(8, false, nullptr);
     else
 #endif
-        MEMC_OWNER(false, nullptr);
+        MEMC_OWNER(16, false, nullptr);
 #undef MEMC_OWNER
     hipLaunchKernelGGL(fi_bwd_far_sites, dim3(ntiles), dim3(256), 0, stream,
                        w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,

@@ -38,6 +38,7 @@ void memc_debug_set_bl_cap(int which);           // 2x2-footprint kernels' LDS s
 void memc_debug_set_walk(int stripe_width);      // < 0: each launcher's default; 0: strips; n: stripes n tile columns wide
 int memc_debug_set_trace_buffer(void *device_u64_buffer);        // gridDim.x * 16 slots, written by fi_bwd variant 9
 int memc_debug_set_trace_buffer_proj(void *device_u64_buffer);   // the same for the projection's trace arm
+void memc_debug_set_owner_th(int th);            // fi_bwd_image_owner's cell tile height: 16 (default) or 8
 int memc_debug_set_trace_buffer_cn(void *device_u64_buffer);     // fi_bwd_image_owner's phase clocks; NULL switches them off
 
 #pragma GCC visibility pop

@@ -145,6 +145,30 @@ def test_filter_interpolation_backward_many_channels(oracle, case):
     close(N(h3), g3, "gradinput3 (stored)", RTOL)
 
 
+@pytest.mark.parametrize("arm", [("owner_th", 8), ("fi_bwd", 40)], ids=["owner tiles 64x8", "direct kernel"])
+def test_filter_interpolation_backward_many_channels_measurement_arms(oracle, arm):
+    """The A/B arms of the many-channel backward (measurement build): the owner kernel on 64 x 8 cell tiles, and the
+    direct global-atomics kernel it replaced -- both must give the oracle's gradients (from garbage-filled buffers:
+    gradinput1 is stored on every path)."""
+    from tools import measure as M          # forced paths exist in the measurement build only
+    my_lib = M.bound()
+    for case in (MANY[0], MANY[3]):
+        B, C, H, W, kind = case
+        rng = np.random.default_rng(sum(case[:4]))
+        xn, kn, gn = synth.np_image(rng, B, C, H, W), synth.np_filter(rng, B, H, W), synth.np_image(rng, B, C, H, W)
+        fn = _many_channel_flows(kind, rng, B, H, W)
+        g1, g2, g3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+        h1, h2, h3 = (torch.full(s, 3.0, device=dev()) for s in (xn.shape, fn.shape, kn.shape))
+        try:
+            M.set_variant(*arm)
+            assert my_lib.FilterInterpolationLayer_gpu_backward(T(xn), T(fn), T(kn), T(gn), h1, h2, h3) == 0
+        finally:
+            M.reset()
+        close(N(h1), g1, "gradinput1 %s" % (arm,), 3 * RTOL)
+        close(N(h2), g2, "gradinput2 %s" % (arm,), RTOL)
+        close(N(h3), g3, "gradinput3 %s" % (arm,), RTOL)
+
+
 @pytest.mark.parametrize("fs", [2, 3, 6])
 def test_filter_interpolation_other_filter_sizes(oracle, fs):
     """fs = (int)sqrt(channels of input3) (my_lib.c:925); 3 is odd: window [ix, ix+2]."""

@@ -336,6 +336,11 @@ def main():
             bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "video", "720p")
     if want("fi_bwd_ctx"):
         bench_fi_bwd(rows, dev, 8, 64, 720, 1280, "smooth", "ctx64")
+        if M.active:                               # A/B: the owner kernel on 64 x 8 cell tiles (two workgroups per CU)
+            M.set_variant("owner_th", 8)
+            bench_fi_bwd(rows, dev, 8, 64, 720, 1280, "smooth", "ctx64 owner tiles 64x8")
+            M.set_variant("owner_th", 16)
+        bench_fi_bwd(rows, dev, 8, 64, 720, 1280, "iid", "ctx64")
         bench_fi_bwd(rows, dev, 4, 64, 256, 448, "smooth", "ctx64 crop")
     if want("proj"):
         bench_projection(rows, dev, 32, 720, 1280, "smooth", "c3",
