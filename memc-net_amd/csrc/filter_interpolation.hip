@@ -1697,20 +1697,29 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
 #endif  // MEMC_MEASURE
 
     if (filter_size == 4 && vec) {
-        if (channel % 4 == 0 && channel >= 8) MEMC_FI_C4N(0);          // e.g. the 64-channel context warp
-        else if (channel == 3) MEMC_FI_TILED(16, 3, 2);                // default: 64x16 tiles, strip walk
-        else MEMC_FI_TILED(16, 0, 2);
+        if (channel % 4 == 0 && channel >= 8) {                        // e.g. the 64-channel context warp
+            MEMC_PATH("fi_fwd:tiled_c4n");
+            MEMC_FI_C4N(0);
+        } else if (channel == 3) {                                     // default: 64x16 tiles, strip walk
+            MEMC_PATH("fi_fwd:tiled_c3");
+            MEMC_FI_TILED(16, 3, 2);
+        } else {
+            MEMC_PATH("fi_fwd:tiled_chunks");
+            MEMC_FI_TILED(16, 0, 2);
+        }
         return launch_status();
     }
     if (filter_size != 4) {
         const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
         const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
+        MEMC_PATH("fi_fwd:generic");
         hipLaunchKernelGGL(fi_fwd_generic, dim3(nwg), dim3(256), 0, stream, w, h, channel, filter_size,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
         return launch_status();
     }
     // odd widths / unaligned views: scalar direct-gather kernels
+    MEMC_PATH("fi_fwd:direct");
     if (channel == 3) MEMC_FI_FWD_LAUNCH(3, 4);
     else MEMC_FI_FWD_LAUNCH(0, 4);
 #undef MEMC_FI_FWD_LAUNCH
@@ -1742,6 +1751,7 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
     constexpr bool direct_only = false;
 #endif
     if (filter_size != 4) {
+        MEMC_PATH("fi_bwd:generic");
         hipLaunchKernelGGL(fi_bwd_generic, dim3(nwg), dim3(256), 0, stream, w, h, channel, filter_size,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput,
@@ -1754,6 +1764,7 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
                       "the accumulator plane aliases the staged image");
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const unsigned ntiles = (unsigned)ntx * nty * batch;
+        MEMC_PATH("fi_bwd:tiled_c3");
 #define MEMC_FI_BWD_ARGS                                                                                           \
         w, h, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,     \
             (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3
@@ -1795,13 +1806,16 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
                (taken = fi_bwd_cn_launch(stream, w, h, channel, batch, s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h, input1,
                                          input2, input3, gradoutput, gradinput1, gradinput2, gradinput3,
                                          direct_only)) != 0) {
+        MEMC_PATH("fi_bwd:owner");
         return taken > 0 ? 0 : -1;                         // many channels: fi_bwd_cn.hip
     } else if (channel == 3) {
+        MEMC_PATH("fi_bwd:direct");
         hipLaunchKernelGGL((fi_bwd_direct_fs4<3, 4>), dim3(nwg), dim3(256), 0, stream, w, h, channel,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput,
                            gradinput1, gradinput2, gradinput3);
     } else {
+        MEMC_PATH("fi_bwd:direct");
         hipLaunchKernelGGL((fi_bwd_direct_fs4<0, 4>), dim3(nwg), dim3(256), 0, stream, w, h, channel,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput,

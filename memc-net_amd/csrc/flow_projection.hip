@@ -2173,6 +2173,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                        dim3(256), 4 * A::kPlane * 4 + 64, stream, w, h, ntx, snty, sntiles, s1b, s1c, s1h, sdb, sdh,  \
                        scb, sch, a.flow, a.depth, a.count, a.out, FLAG)
     bool only_part = false;                                  // measurement arms that time one piece
+    MEMC_PATH(flag ? (DEPTH ? "dproj_fwd:owner" : "proj_fwd:owner") : (DEPTH ? "dproj_fwd:general" : "proj_fwd:general"));
     if (flag) {
         // fast path: owner-computes (no atomics, fused averaging, hole-filler summaries for free); images with a
         // far source are redone by proj_owner_far behind a device flag (round-1 / ring kernels of the measurement
@@ -2370,6 +2371,7 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
+    MEMC_PATH(DEPTH ? "dproj_fwd:scalar" : "proj_fwd:scalar");
     hipLaunchKernelGGL(proj_zero_scalar, dim3(256 * 8), dim3(256), 0, stream, w, h, batch, (int64_t)s1b, (int64_t)s1c, s1h,
                        (int64_t)scb, sch, count, out);
     hipLaunchKernelGGL(proj_scatter<DEPTH>, dim3(nwg), dim3(256), 0, stream, w, h, tiles_x, tiles_y,
@@ -2399,6 +2401,7 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         const unsigned nwg = walk_grid(ntx, nty, batch, sw);
+        MEMC_PATH(DEPTH ? "dproj_bwd:tiled" : "proj_bwd:tiled");
 #define MEMC_PROJ_BWD(CAP)                                                                                      \
         hipLaunchKernelGGL((proj_bwd_tiled<DEPTH, CAP>), dim3(nwg), dim3(256), (tile_lds_bytes<16, CAP>()), stream, w, \
                            h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow,   \
@@ -2415,6 +2418,7 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
+    MEMC_PATH(DEPTH ? "dproj_bwd:scalar" : "proj_bwd:scalar");
     hipLaunchKernelGGL(proj_bwd<DEPTH>, dim3(nwg), dim3(256), 0, stream, w, h, tiles_x, tiles_y,
                        (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count,
                        fwd_out, gout, gin1, gin2);

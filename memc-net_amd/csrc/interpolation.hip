@@ -364,6 +364,7 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         const unsigned nwg_t = walk_grid(ntx, nty, batch, sw);
+        MEMC_PATH(channel == 3 ? "bl_fwd:tiled_c3" : "bl_fwd:tiled_chunks");
 #define MEMC_BL_FWD(CT, CAP)                                                                                    \
             hipLaunchKernelGGL((bl_fwd_tiled<CT, CAP>), dim3(nwg_t), dim3(256), (tile_lds_bytes<16, CAP>() + g_extra_lds), \
                                stream, w, h, channel, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,          \
@@ -385,6 +386,7 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
+    MEMC_PATH("bl_fwd:direct");
     if (channel == 3)
         hipLaunchKernelGGL(bl_fwd<3>, dim3(nwg), dim3(256), 0, stream, w, h, channel, tiles_x, tiles_y,
                            (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, output);
@@ -407,6 +409,7 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         static_assert(AccT::kPlane * 8 <= 2496 * 16, "the smaller budget still holds the accumulator plane");
+        MEMC_PATH("bl_bwd:tiled_c3");
 #define MEMC_BL_BWD(CAP)                                                                                        \
         hipLaunchKernelGGL(bl_bwd_tiled_c3<CAP>, dim3(walk_grid(ntx, nty, batch, sw)), dim3(256),                  \
                            (tile_lds_bytes<16, CAP>()), stream, w, h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h,  \
@@ -423,6 +426,7 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
+    MEMC_PATH("bl_bwd:direct");
     if (channel == 3)
         hipLaunchKernelGGL(bl_bwd<3>, dim3(nwg), dim3(256), 0, stream, w, h, channel, tiles_x, tiles_y,
                            (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2,

@@ -88,6 +88,13 @@ int bilinear_backward(bool require_c3, memc_stream_t stream, const memc_tensor4 
 
 }  // namespace
 
+#ifdef MEMC_MEASURE
+extern "C" {
+__attribute__((visibility("default"))) const char *g_memc_last_path = "";
+const char *memc_debug_last_path(void) { return g_memc_last_path; }
+}
+#endif
+
 extern "C" {
 
 #ifdef MEMC_MEASURE

@@ -23,6 +23,21 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
 }  // namespace memc
 #endif
 
+// Which kernel family a launcher chose: recorded in the measurement build only (tests assert that a shape took the
+// path it is documented to take), compiled away in the product.
+#ifdef MEMC_MEASURE
+#ifdef __cplusplus
+extern "C" {
+#endif
+extern const char *g_memc_last_path;
+#ifdef __cplusplus
+}
+#endif
+#define MEMC_PATH(name) (g_memc_last_path = (name))
+#else
+#define MEMC_PATH(name) ((void)0)
+#endif
+
 #ifdef MEMC_MEASURE
 #ifdef __cplusplus
 extern "C" {
@@ -39,7 +54,8 @@ void memc_debug_set_walk(int stripe_width);      // < 0: each launcher's default
 int memc_debug_set_trace_buffer(void *device_u64_buffer);        // gridDim.x * 16 slots, written by fi_bwd variant 9
 int memc_debug_set_trace_buffer_proj(void *device_u64_buffer);   // the same for the projection's trace arm
 void memc_debug_set_owner_th(int th);            // fi_bwd_image_owner's cell tile height: 16 (default) or 8
-int memc_debug_set_trace_buffer_cn(void *device_u64_buffer);     // fi_bwd_image_owner's phase clocks; NULL switches them off
+int memc_debug_set_trace_buffer_cn(void *device_u64_buffer);
+const char *memc_debug_last_path(void);          // the kernel family the last launcher call chose, e.g. "fi_fwd:tiled_c3"     // fi_bwd_image_owner's phase clocks; NULL switches them off
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

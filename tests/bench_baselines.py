@@ -54,7 +54,12 @@ def reference_gpu_rows(rows):
     t = synth.torch_inputs(dev, B, C, H, W, flow_kind="smooth", with_grad=True, with_depth=True)
     x, f, k, g, d = t["x"], t["flow"], t["filt"], t["gout"], t["depth"]
     gf = torch.rand_like(f)
-    t64 = synth.torch_inputs(dev, 8, 64, H, W, flow_kind="smooth")
+    t64 = synth.torch_inputs(dev, 8, 64, H, W, flow_kind="smooth", with_grad=True)
+
+    def ours_fi_bwd64():
+        a, b, c, e = t64["x"], t64["flow"], t64["filt"], t64["gout"]
+        g1, g2, g3 = torch.empty_like(a), torch.empty_like(b), torch.empty_like(c)      # as the shipped layer does
+        L.FilterInterpolationLayer_gpu_backward(a, b, c, e, g1, g2, g3)
 
     def ours_fi_bwd():
         g1, g2, g3 = torch.zeros_like(x), torch.empty_like(f), torch.empty_like(k)      # as the shipped layer does
@@ -94,6 +99,8 @@ def reference_gpu_rows(rows):
             ("FilterInterpolation fwd C=64 8x720x1280", lambda: R.filter_interpolation_forward(t64["x"], t64["flow"], t64["filt"]),
              lambda: FilterInterpolationLayer()(t64["x"], t64["flow"], t64["filt"])),
             ("FilterInterpolation bwd C=3 32x720x1280", lambda: R.filter_interpolation_backward(x, f, k, g), ours_fi_bwd),
+            ("FilterInterpolation bwd C=64 8x720x1280",
+             lambda: R.filter_interpolation_backward(t64["x"], t64["flow"], t64["filt"], t64["gout"]), ours_fi_bwd64),
             ("FlowProjection fwd 32x720x1280", lambda: R.flow_projection_forward(f, 0), lambda: ours_fp(0)),
             ("FlowProjection fwd + hole fill", lambda: R.flow_projection_forward(f, 1), lambda: ours_fp(1)),
             ("DepthFlowProjection fwd + hole fill", lambda: R.depth_flow_projection_forward(f, d, 1), lambda: ours_dfp(1)),

@@ -169,6 +169,58 @@ def test_filter_interpolation_backward_many_channels_measurement_arms(oracle, ar
         close(N(h3), g3, "gradinput3 %s" % (arm,), RTOL)
 
 
+def test_shapes_take_the_documented_kernel_paths():
+    """DESIGN.md section 5 says which kernel family a shape takes; the measurement build records the launcher's choice
+    (memc_debug_last_path), so the claim is checked instead of inferred from timings: aligned shapes must not
+    silently drop to the scalar kernels, odd ones must not reach the vector kernels."""
+    import ctypes
+    from tools import measure as M
+    my_lib = M.bound()
+    last = M.lib().memc_debug_last_path
+    last.restype = ctypes.c_char_p
+    rng = np.random.default_rng(5)
+
+    def run(B, C, H, W, fs=4, sliced=False):
+        Wa = W + 1 if sliced else W                     # sliced: views whose rows start at unaligned addresses
+
+        def view(t):
+            return t[..., 1:] if sliced else t
+
+        def buf(ch):
+            return view(torch.zeros(B, ch, H, Wa, device=dev()))
+        x, g = view(T(synth.np_image(rng, B, C, H, Wa))), view(T(synth.np_image(rng, B, C, H, Wa)))
+        f, k = view(T(synth.np_flow(rng, B, H, Wa, "smooth", 2.0))), view(T(synth.np_filter(rng, B, H, Wa, fs)))
+        got = {}
+        out, g1, g2, g3 = buf(C), buf(C), buf(2), buf(fs * fs)
+        assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+        got["fi_fwd"] = last().decode()
+        assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+        got["fi_bwd"] = last().decode()
+        if fs == 4:
+            assert my_lib.InterpolationChLayer_gpu_forward(x, f, out) == 0
+            got["bl_fwd"] = last().decode()
+            assert my_lib.InterpolationChLayer_gpu_backward(x, f, g, g1, g2) == 0
+            got["bl_bwd"] = last().decode()
+            cnt, po, gf = buf(1), buf(2), view(T(synth.np_flow(rng, B, H, Wa, "smooth", 1.0)))
+            assert my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, 1) == 0
+            got["proj_fwd"] = last().decode()
+            assert my_lib.FlowProjectionLayer_gpu_backward(f, cnt, gf, g2) == 0
+            got["proj_bwd"] = last().decode()
+        return got
+
+    assert run(2, 3, 40, 128) == {"fi_fwd": "fi_fwd:tiled_c3", "fi_bwd": "fi_bwd:tiled_c3", "bl_fwd": "bl_fwd:tiled_c3",
+                                  "bl_bwd": "bl_bwd:tiled_c3", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
+    assert run(1, 64, 40, 128) == {"fi_fwd": "fi_fwd:tiled_c4n", "fi_bwd": "fi_bwd:owner", "bl_fwd": "bl_fwd:tiled_chunks",
+                                   "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
+    assert run(1, 5, 40, 128) == {"fi_fwd": "fi_fwd:tiled_chunks", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:tiled_chunks",
+                                  "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
+    # width not a multiple of four, and an aligned width seen through a view that starts one element in
+    for odd in (run(1, 3, 20, 50), run(1, 3, 20, 64, sliced=True)):
+        assert odd == {"fi_fwd": "fi_fwd:direct", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:direct",
+                       "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:scalar", "proj_bwd": "proj_bwd:scalar"}
+    assert run(1, 3, 24, 64, fs=2) == {"fi_fwd": "fi_fwd:generic", "fi_bwd": "fi_bwd:generic"}
+
+
 @pytest.mark.parametrize("fs", [2, 3, 6])
 def test_filter_interpolation_other_filter_sizes(oracle, fs):
     """fs = (int)sqrt(channels of input3) (my_lib.c:925); 3 is odd: window [ix, ix+2]."""

@@ -18,6 +18,8 @@ echo "== bench";   timeout 600 python bench.py 2>&1 | tail -3 | tee "$OUT/bench.
 echo "== bench, strong-scaling shard sizes on one GPU (what rank 0 of an N-GPU run executes: batch 32 / N, HIP graph)"
 for b in 16 8 4; do timeout 300 python bench.py --batch $b --no-cpu-baseline --no-secondary 2>&1 | tail -1 | tee -a "$OUT/bench_shards.log"; done
 echo "== model"; timeout 600 python tools/bench_model.py --json "$OUT/bench_model.json" 2>&1 | tail -2 | tee "$OUT/bench_model.log"
+echo "== many-channel FilterInterpolation backward: phase clocks of the owner kernel (measurement build)"
+timeout 300 python tools/trace_kernel.py fi_bwd_cn 2>&1 | grep -v amdgpu.ids | tee "$OUT/fi_bwd_cn_trace.txt"
 echo "== race screen"; timeout 600 python tools/stress_projection.py 60 2>&1 | tail -3 | tee "$OUT/stress.log"
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprof kernel trace of bench.py (the same command as the bench line above, minus the CPU baseline)"

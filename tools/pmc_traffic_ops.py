@@ -28,6 +28,9 @@ KERNELS = {
     "proj_bwd_tiled<true": (48, SITES),
     "bl_fwd_tiled<3": (32, SITES),                    # x 12 + flow 8 | out 12
     "bl_bwd_tiled_c3": (52, SITES),                   # x 12 + flow 8 + gout 12 | gin1 12 + gin2 8
+    # FilterInterpolation backward, C = 64, batch 8 (fi_bwd_cn.hip): the operator's 912 B/site split over its kernels
+    "fi_bwd_taps_c4n": (4 * (2 * 64 + 2 + 16 + 2 + 16), SITES // 4),     # x, gout, flow, taps | gin2, gin3
+    "fi_bwd_image_owner": (4 * (64 + 64 + 2 + 16), SITES // 4),          # gout, flow, taps | gin1
 }
 
 
@@ -37,7 +40,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     py = sys.executable
-    sweep = [py, os.path.join(ROOT, "tools", "bench_ops.py"), "--only", "fi_fwd,fi_blend,fi_bwd,proj,interp",
+    sweep = [py, os.path.join(ROOT, "tools", "bench_ops.py"), "--only", "fi_fwd,fi_blend,fi_bwd,fi_bwd_ctx,proj,interp",
              "--ctx-only", "--variants=-1", "--json", os.path.join(a.out, "sweep_under_pmc.json")]
     probe = [py, os.path.join(ROOT, "tools", "probes", "run_probe.py"), "copyonly"]
     dbs, cal = {}, {}
