@@ -39,13 +39,40 @@ namespace memc {
 constexpr int kOwnRX = 2, kOwnRY = 4;          // owner search window, in site tiles of 64 x 16
 constexpr int kTileHasFar = 1 << 30;           // in BBox::h of a site tile's target box: some of its sites are far
 
+// The two window shapes the owner kernel serves.  Tap (k, m), k, m < kN, of a site with integer target (ix, iy) lands on
+// cell (clamp(iy + kOff + k), clamp(ix + kOff + m)); its bilinear weight is wa * wb with wa = m < kN / 2 ? 1 - a : a.
+struct FpFilter {                              // FilterInterpolation: 4 x 4 window around the 2 x 2 sample, times a tap
+    static constexpr int kN = 4, kOff = -1;
+    static constexpr bool kTaps = true;
+    static __device__ __forceinline__ FiSite locate(int x, int y, int W, int H, float fx, float fy)
+    {
+        return fi_locate(x, y, W, H, fx, fy);
+    }
+};
+struct FpBilinear {                            // Interpolation / InterpolationCh: the 2 x 2 sample itself
+    static constexpr int kN = 2, kOff = 0;
+    static constexpr bool kTaps = false;
+    static __device__ __forceinline__ FiSite locate(int x, int y, int W, int H, float fx, float fy)
+    {
+        const BlSite b = bl_locate<true>(x, y, W, H, fx, fy);      // R = min(L + 1, W - 1) == clamp(L + 1)
+        FiSite s;
+        s.ix = b.L;  s.iy = b.T;  s.a = b.a;  s.b = b.b;  s.valid = b.valid;
+        return s;
+    }
+};
+
 // one site: does its (clamped) window reach a cell tile outside the search window of the site's own tile?
-__device__ __forceinline__ bool fi_site_far(int x, int y, int ix, int iy, int W, int H)
+template <class FP>
+__device__ __forceinline__ bool site_far(int x, int y, int ix, int iy, int W, int H)
 {
     const int tx = x >> 6, ty = y >> 4;
-    const int c0 = max(ix - 1, 0) >> 6, c1 = min(ix + 2, W - 1) >> 6;
-    const int r0 = max(iy - 1, 0) >> 4, r1 = min(iy + 2, H - 1) >> 4;
+    const int c0 = clampi(ix + FP::kOff, W - 1) >> 6, c1 = clampi(ix + FP::kOff + FP::kN - 1, W - 1) >> 6;
+    const int r0 = clampi(iy + FP::kOff, H - 1) >> 4, r1 = clampi(iy + FP::kOff + FP::kN - 1, H - 1) >> 4;
     return c0 < tx - kOwnRX || c1 > tx + kOwnRX || r0 < ty - kOwnRY || r1 > ty + kOwnRY;
+}
+__device__ __forceinline__ bool fi_site_far(int x, int y, int ix, int iy, int W, int H)
+{
+    return site_far<FpFilter>(x, y, ix, iy, W, H);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -321,29 +348,32 @@ __global__ __launch_bounds__(256) void fi_bwd_far_sites(
 // the segment sums and the segment table -- | tail K, tail slot | one word per cell (cursor : count) | tail offsets |
 // control words.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kListHead = 16;                  // entries per cell a lane keeps in registers (one per tap index)
 constexpr int kSegLen = 8;                     // tail segment length; two segments per lane
 constexpr unsigned kHeadEmpty = 0x7fc5a5a5u;   // a NaN payload no coefficient has: an unclaimed head slot
 constexpr int kOwnCand = (2 * kOwnRX + 1) * (2 * kOwnRY + 1);
 static_assert(kOwnCand <= 64, "one lane per candidate site tile");
 
-// Cell tile 64 x TH, 32 * TH lanes (two cells per lane: rows r and r + TH / 2).
-//   TH = 16: 512 lanes, 157 KB of LDS, one workgroup per CU;
+// Cell tile 64 x TH, 32 * TH lanes (two cells per lane: rows r and r + TH / 2); kHead = kN * kN head slots per cell.
+//   TH = 16: 512 lanes, 157 KB of LDS (4 x 4 window), one workgroup per CU;
 //   TH = 8:  256 lanes,  78 KB, two per CU -- the build / replay phases of one overlap the other's barriers.
-template <int TH>
+template <class FP, int TH>
 struct OwnGeom {
+    static constexpr int kHead = FP::kN * FP::kN;          // entries per cell a lane keeps in registers (one per tap index)
     static constexpr int kThreads = 32 * TH, kCells = 64 * TH;
-    static constexpr int kTailCap = 8 * kCells;            // tail entries per slab
+    static constexpr int kTailCap = (FP::kN == 4 ? 8 : 4) * kCells;      // tail entries per slab
     static constexpr int kSegCap = 2 * kThreads;
     static constexpr int kSlotCap = TH == 16 ? 3072 : 2048;        // sites staged per slab; slot kSlotCap holds zeros
-    static constexpr int kHK = 0, kHS = kHK + kListHead * kCells * 4, kHeadEnd = kHS + kListHead * kCells * 2;
-    // aliases of the head table, valid after the heads have been copied to registers
-    static constexpr int kG = 0, kPart = (kG + (kSlotCap + 1) * 16 + 127) / 128 * 128, kSeg = kPart + kSegCap * 16,
-                         kAliasEnd = kSeg + kSegCap * 4;
-    static_assert(kAliasEnd <= kHeadEnd, "staging, segment sums and segment table fit the dead head table");
+    static constexpr int kHK = 0, kHS = kHK + kHead * kCells * 4, kHeadEnd = kHS + kHead * kCells * 2;
+    // staging area, segment sums, segment table: inside the head table's bytes once the heads have been copied to
+    // registers, if they fit there (4 x 4 window); behind it otherwise
+    static constexpr int kAliasNeed = ((kSlotCap + 1) * 16 + 127) / 128 * 128 + kSegCap * 16 + kSegCap * 4;
+    static constexpr bool kAlias = kAliasNeed <= kHeadEnd;
+    static constexpr int kG = kAlias ? 0 : kHeadEnd, kPart = kG + ((kSlotCap + 1) * 16 + 127) / 128 * 128,
+                         kSeg = kPart + kSegCap * 16, kAliasEnd = kSeg + kSegCap * 4;
     static_assert(kSlotCap <= 8 * kThreads, "two float4 slots of staging per lane");
-    static constexpr int kTK = kHeadEnd, kTS = kTK + kTailCap * 4, kOc = kTS + kTailCap * 2, kPres = kOc + kCells * 4,
-                         kToff = kPres + kCells * 4, kCtl = kToff + kCells * 2, kBytes = kCtl + 512;
+    static constexpr int kTK = kAlias ? kHeadEnd : kAliasEnd, kTS = kTK + kTailCap * 4, kOc = kTS + kTailCap * 2,
+                         kPres = kOc + kCells * 4, kToff = kPres + kCells * 4, kCtl = kToff + kCells * 2,
+                         kBytes = kCtl + 512;
     static_assert(kBytes * (TH == 16 ? 1 : 2) <= 160 * 1024, "LDS per CU");
 };
 
@@ -361,21 +391,21 @@ struct QuadHits {
     int ix[4], iy[4];
     float a[4], b[4];
 };
-template <int TH>
+template <class FP, int TH>
 __device__ __forceinline__ QuadHits own_quad_hits(int x, int y, int W, int H, int tx0, int ty0, f32x4 fx4, f32x4 fy4)
 {
     QuadHits h;
     h.any = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
+        const FiSite s = FP::locate(x + j, y, W, H, fx4[j], fy4[j]);
         h.ix[j] = s.ix; h.iy[j] = s.iy; h.a[j] = s.a; h.b[j] = s.b;
         unsigned rm = 0, cm = 0;
-        if (s.valid && !fi_site_far(x + j, y, s.ix, s.iy, W, H)) {
+        if (s.valid && !site_far<FP>(x + j, y, s.ix, s.iy, W, H)) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                rm |= (unsigned)((unsigned)(clampi(s.iy - 1 + k, H - 1) - ty0) < (unsigned)TH) << k;
-                cm |= (unsigned)((unsigned)(clampi(s.ix - 1 + k, W - 1) - tx0) < 64u) << k;
+            for (int k = 0; k < FP::kN; k++) {
+                rm |= (unsigned)((unsigned)(clampi(s.iy + FP::kOff + k, H - 1) - ty0) < (unsigned)TH) << k;
+                cm |= (unsigned)((unsigned)(clampi(s.ix + FP::kOff + k, W - 1) - tx0) < 64u) << k;
             }
         }
         const bool hit = rm && cm;
@@ -387,6 +417,7 @@ __device__ __forceinline__ QuadHits own_quad_hits(int x, int y, int W, int H, in
 }
 
 // oc[cell] += 1 << 16 and pres[cell] |= 1 << tap index for every tap of the quad that lands on the tile
+template <class FP>
 __device__ __forceinline__ void own_count(const QuadHits &h, unsigned *oc, unsigned *pres, int W, int H, int tx0,
                                           int ty0)
 {
@@ -394,15 +425,15 @@ __device__ __forceinline__ void own_count(const QuadHits &h, unsigned *oc, unsig
     for (int j = 0; j < 4; j++) {
         if (!((h.any >> j) & 1)) continue;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < FP::kN; k++) {
             if (!((h.rowm[j] >> k) & 1)) continue;
-            const int rc = (clampi(h.iy[j] - 1 + k, H - 1) - ty0) * 64 - tx0;
+            const int rc = (clampi(h.iy[j] + FP::kOff + k, H - 1) - ty0) * 64 - tx0;
 #pragma unroll
-            for (int m = 0; m < 4; m++)
+            for (int m = 0; m < FP::kN; m++)
                 if ((h.colm[j] >> m) & 1) {
-                    const int ci = rc + clampi(h.ix[j] - 1 + m, W - 1);
+                    const int ci = rc + clampi(h.ix[j] + FP::kOff + m, W - 1);
                     atomicAdd(oc + ci, 0x10000u);
-                    atomicOr(pres + ci, 1u << (k * 4 + m));          // which tap indices the cell receives
+                    atomicOr(pres + ci, 1u << (k * FP::kN + m));     // which tap indices the cell receives
                 }
         }
     }
@@ -431,7 +462,7 @@ __device__ __forceinline__ f32x4 quad_transpose(f32x4 v, unsigned my)
 // TR (measurement build): thread 0 accumulates the shader clocks of every phase into trace[blockIdx.x * 16 + ...]
 // (tools/trace_kernel.py fi_bwd_cn): 0 whole life, 1 candidates + count pass, 2 slab recounts, 3 scan, 4 fill,
 // 5 lists -> registers, 6 replay, 7 slab rounds, 8 candidate tiles, 9 tail segments (last slab), 10 site-box area.
-template <int TH, bool TR>
+template <class FP, int TH, bool TR>
 __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
     int W, int H, int C, int tiles_x, int tiles_y, int site_tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
@@ -443,7 +474,8 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
 #define MEMC_TR_END(slot) do { if (TR) { const unsigned long long n_ = __builtin_readcyclecounter(); tr_acc[slot] += n_ - tr_t; tr_t = n_; } } while (0)
     if (TR) tr_t0 = __builtin_readcyclecounter();
     MEMC_TR_BEGIN();
-    using Gm = OwnGeom<TH>;
+    using Gm = OwnGeom<FP, TH>;
+    constexpr int kListHead = Gm::kHead;
     constexpr int kOwnThreads = Gm::kThreads, kOwnCells = Gm::kCells, kTailCap = Gm::kTailCap, kSegCap = Gm::kSegCap,
                   kSlotCap = Gm::kSlotCap;
     constexpr int kOwnLdsHK = Gm::kHK, kOwnLdsHS = Gm::kHS, kOwnLdsG = Gm::kG, kOwnLdsPart = Gm::kPart,
@@ -524,13 +556,13 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
             const int x = (t & 0xffff) * 64 + 4 * (q & 15), y = (t >> 16) * 16 + (q >> 4);
             if (x >= W || y >= H) continue;
             const float *fp = flow_b + (int64_t)y * s2h + x;
-            const QuadHits h = own_quad_hits<TH>(x, y, W, H, tx0, ty0, ld_cached4(fp), ld_cached4(fp + s2c));
+            const QuadHits h = own_quad_hits<FP, TH>(x, y, W, H, tx0, ty0, ld_cached4(fp), ld_cached4(fp + s2c));
             if (h.any) {
                 bx0 = min(bx0, x + __ffs(h.any) - 1);
                 bx1 = max(bx1, x + 31 - __clz(h.any));
                 by0 = min(by0, y);
                 by1 = max(by1, y);
-                own_count(h, oc, pres, W, H, tx0, ty0);
+                own_count<FP>(h, oc, pres, W, H, tx0, ty0);
             }
         }
         bx0 = wave_min_i32(bx0);  bx1 = -wave_min_i32(-bx1);  by0 = wave_min_i32(by0);  by1 = -wave_min_i32(-by1);
@@ -567,10 +599,10 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
             pres[tid] = 0;
             pres[tid + kOwnThreads] = 0;
             __syncthreads();
-            const QuadHits h0 = own_quad_hits<TH>(xq0, yq0, W, H, tx0, ty0, ld_cached4(fp0), ld_cached4(fp0 + s2c));
-            const QuadHits h1 = own_quad_hits<TH>(xq1, yq1, W, H, tx0, ty0, ld_cached4(fp1), ld_cached4(fp1 + s2c));
-            if (on0 && h0.any) own_count(h0, oc, pres, W, H, tx0, ty0);
-            if (on1 && h1.any) own_count(h1, oc, pres, W, H, tx0, ty0);
+            const QuadHits h0 = own_quad_hits<FP, TH>(xq0, yq0, W, H, tx0, ty0, ld_cached4(fp0), ld_cached4(fp0 + s2c));
+            const QuadHits h1 = own_quad_hits<FP, TH>(xq1, yq1, W, H, tx0, ty0, ld_cached4(fp1), ld_cached4(fp1 + s2c));
+            if (on0 && h0.any) own_count<FP>(h0, oc, pres, W, H, tx0, ty0);
+            if (on1 && h1.any) own_count<FP>(h1, oc, pres, W, H, tx0, ty0);
             __syncthreads();
         }
         counted = false;
@@ -607,6 +639,7 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
                 f32x4 *k4 = reinterpret_cast<f32x4 *>(HK);
 #pragma unroll
                 for (int i = 0; i < kListHead * kOwnCells / 4 / kOwnThreads; i++) k4[tid + i * kOwnThreads] = z4;
+                static_assert(kListHead * kOwnCells / 4 % kOwnThreads == 0, "head table init");
                 unsigned *s2 = reinterpret_cast<unsigned *>(HS);
                 const unsigned zs = (unsigned)kSlotCap | ((unsigned)kSlotCap << 16);
 #pragma unroll
@@ -646,31 +679,33 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
             if (!(u ? on1 : on0)) continue;
             const int x = u ? xq1 : xq0, y = u ? yq1 : yq0;
             const float *fp = u ? fp1 : fp0;
-            const float *tp_p = filt_b + (int64_t)y * s3h + x;
             const f32x4 fx4 = ld_cached4(fp), fy4 = ld_cached4(fp + s2c);
-            f32x4 tp[16];
+            f32x4 tp[FP::kTaps ? 16 : 1];
+            if (FP::kTaps) {
+                const float *tp_p = filt_b + (int64_t)y * s3h + x;
 #pragma unroll
-            for (int k = 0; k < 16; k++) tp[k] = ld_cached4(tp_p + k * s3c);
-            const QuadHits h = own_quad_hits<TH>(x, y, W, H, tx0, ty0, fx4, fy4);
+                for (int k = 0; k < (FP::kTaps ? 16 : 1); k++) tp[k] = ld_cached4(tp_p + k * s3c);
+            }
+            const QuadHits h = own_quad_hits<FP, TH>(x, y, W, H, tx0, ty0, fx4, fy4);
             if (!h.any) continue;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (!((h.any >> j) & 1)) continue;
                 const unsigned short slot = (unsigned short)((y - y_lo) * aw + (x + j - ax0));
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < FP::kN; k++) {
                     if (!((h.rowm[j] >> k) & 1)) continue;
-                    const int rc = (clampi(h.iy[j] - 1 + k, H - 1) - ty0) * 64 - tx0;
-                    const float wb = k < 2 ? (1 - h.b[j]) : h.b[j];
+                    const int rc = (clampi(h.iy[j] + FP::kOff + k, H - 1) - ty0) * 64 - tx0;
+                    const float wb = k < FP::kN / 2 ? (1 - h.b[j]) : h.b[j];
 #pragma unroll
-                    for (int m = 0; m < 4; m++) {
+                    for (int m = 0; m < FP::kN; m++) {
                         if (!((h.colm[j] >> m) & 1)) continue;
-                        const int ci = rc + clampi(h.ix[j] - 1 + m, W - 1);
-                        const float wa = m < 2 ? (1 - h.a[j]) : h.a[j];
-                        const float kv = (wa * wb) * tp[k * 4 + m][j];
+                        const int ci = rc + clampi(h.ix[j] + FP::kOff + m, W - 1);
+                        const float wa = m < FP::kN / 2 ? (1 - h.a[j]) : h.a[j];
+                        const float kv = FP::kTaps ? (wa * wb) * tp[FP::kTaps ? k * 4 + m : 0][j] : wa * wb;
                         // the head slot of this tap index, if nobody has it yet (neighbouring cells then hold
                         // neighbouring sites in the same slot: conflict-free replay); else the cell's tail
-                        const int hi = (k * 4 + m) * kOwnCells + ci;
+                        const int hi = (k * FP::kN + m) * kOwnCells + ci;
                         if (atomicCAS(reinterpret_cast<unsigned *>(HK) + hi, kHeadEmpty, __float_as_uint(kv)) == kHeadEmpty) {
                             HS[hi] = slot;
                         } else {
@@ -810,33 +845,38 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
             for (int i = 0; i < kListHead; i++) asm volatile("" : "+v"(kk0[i]), "+v"(kk1[i]));
 #pragma unroll
             for (int i = 0; i < kSegLen; i++) asm volatile("" : "+v"(ks0[i]), "+v"(ks1[i]));
-            // Eight ds_read_b128 are issued back to back, then consumed in order (the scheduling barriers pin that:
+            // Up to eight ds_read_b128 are issued back to back, then consumed in order (the scheduling barriers pin that:
             // left alone, the compiler -- short of registers -- waits for every read before issuing the next).
-#define MEMC_REPLAY8(ACC, KS, SS, T0)                                                                              \
+#define MEMC_REPLAY(N, ACC, KS, SS, T0)                                                                            \
             {                                                                                                      \
-                f32x4 gq[8];                                                                                       \
-                _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++)                                                   \
+                f32x4 gq[N];                                                                                       \
+                _Pragma("unroll") for (int i_ = 0; i_ < N; i_++)                                                   \
                     gq[i_] = g4[((T0 + i_) & 1) ? SS[(T0 + i_) / 2] >> 16 : SS[(T0 + i_) / 2] & 0xffffu];          \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
-                _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) ACC += KS[T0 + i_] * gq[i_];                      \
+                _Pragma("unroll") for (int i_ = 0; i_ < N; i_++) ACC += KS[T0 + i_] * gq[i_];                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
             }
-            static_assert(kSegLen == 8 && kListHead == 16, "the replay is written in batches of eight");
+            static_assert(kSegLen == 8 && (kListHead == 16 || kListHead == 4), "the replay's batches");
             if (any_seg && !serial_tails) {                // (workgroup-uniform) segment sums: for their owners
                 f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
-                MEMC_REPLAY8(p0, ks0, sg0, 0)
-                if ((tid & ~63u) + kOwnThreads < nseg_total) MEMC_REPLAY8(p1, ks1, sg1, 0)      // wave-uniform
+                MEMC_REPLAY(8, p0, ks0, sg0, 0)
+                if ((tid & ~63u) + kOwnThreads < nseg_total) MEMC_REPLAY(8, p1, ks1, sg1, 0)    // wave-uniform
                 if (has0) part[tid] = p0;
                 if (has1) part[tid + kOwnThreads] = p1;
             }
             MEMC_TR_END(12);
             a0 = f32x4{0.f, 0.f, 0.f, 0.f};
             a1 = a0;
-            MEMC_REPLAY8(a0, kk0, ss0, 0)
-            MEMC_REPLAY8(a1, kk1, ss1, 0)
-            MEMC_REPLAY8(a0, kk0, ss0, 8)
-            MEMC_REPLAY8(a1, kk1, ss1, 8)
-#undef MEMC_REPLAY8
+            if constexpr (kListHead == 16) {
+                MEMC_REPLAY(8, a0, kk0, ss0, 0)
+                MEMC_REPLAY(8, a1, kk1, ss1, 0)
+                MEMC_REPLAY(8, a0, kk0, ss0, 8)
+                MEMC_REPLAY(8, a1, kk1, ss1, 8)
+            } else {
+                MEMC_REPLAY(4, a0, kk0, ss0, 0)
+                MEMC_REPLAY(4, a1, kk1, ss1, 0)
+            }
+#undef MEMC_REPLAY
             if (serial_tails) {                            // (converging flow) owners walk their own tails
                 for (int t = 0; t < tl0; t++) a0 += TK[toff0 + t] * g4[TS[toff0 + t]];
                 for (int t = 0; t < tl1; t++) a1 += TK[toff0 + tl0 + t] * g4[TS[toff0 + tl0 + t]];
@@ -879,6 +919,164 @@ extern "C" int memc_debug_set_trace_buffer_cn(void *p)
 // Launcher.  Returns 1 when the call was taken, 0 when it is not for these kernels (the caller falls back to the
 // direct kernel), -1 on a launch error.
 // ---------------------------------------------------------------------------------------------------------
+// =========================================================================================================
+// The bilinear warp (Interpolation / InterpolationCh, reference kernel my_lib_kernel.cu:584-670) at many channels: the
+// same three steps with a 2 x 2 window and no taps.
+//   bl_bwd_flow_c4n   flow gradient: the four corner sums S = sum_c gradoutput * input1(corner) accumulated over
+//                     chunks of four staged channels; gradinput2 = gam * (S_TR - S_TL) + ... (assigned); target boxes;
+//   fi_bwd_image_owner<FpBilinear>   image gradient, stored;
+//   bl_bwd_far_sites  the far sites' image gradient.
+// =========================================================================================================
+__device__ __noinline__ void bl_bwd_site_image_atomics(int x, int y, int W, int H, int C, float *gin1_b, int64_t s1c,
+                                                       int s1h, const float *flow_p, int64_t s2c, const float *gout_p)
+{
+    const BlSite s = bl_locate<true>(x, y, W, H, flow_p[0], flow_p[s2c]);
+    if (!s.valid) return;
+    const int oTL = s.T * s1h + s.L, oTR = s.T * s1h + s.R, oBL = s.Bm * s1h + s.L, oBR = s.Bm * s1h + s.R;
+    for (int c = 0; c < C; c++) {
+        const float g = gout_p[c * s1c];
+        float *q = gin1_b + c * s1c;
+        atomic_add_f32(q + oTL, g * ((1 - s.a) * (1 - s.b)));
+        atomic_add_f32(q + oTR, g * (s.a * (1 - s.b)));
+        atomic_add_f32(q + oBL, g * ((1 - s.a) * s.b));
+        atomic_add_f32(q + oBR, g * (s.a * s.b));
+    }
+}
+
+template <int CAP>
+__global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
+    int W, int H, int C, int tiles_x, int tiles_y, int batch,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
+    const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
+    float *__restrict__ gin2, BBox *__restrict__ tbox)
+{
+    constexpr int LX = 16;
+    using G = TileGeom<LX, CAP>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
+    const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
+    const int x = tile_x0 + 4 * (int)(threadIdx.x % LX), y = tile_y0 + (int)(threadIdx.x / LX);
+    const bool inb = x < W && y < H;
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
+    const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s2c);
+    const float *gout_p = gout + b * s1b + (int64_t)ys * s1h + xs;
+
+    BlSite st[4];
+    unsigned far = 0;
+    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;          // staging box: every valid site
+    int ncmin = INT_MAX, ncmax = -1, nrmin = INT_MAX, nrmax = -1;      // target box of the sites the owners take
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        st[j] = bl_locate<true>(x + j, y, W, H, fx4[j], fy4[j]);
+        st[j].valid = st[j].valid && inb;
+        if (st[j].valid) {
+            cmin = min(cmin, st[j].L);  cmax = max(cmax, st[j].R);
+            rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
+            if (site_far<FpBilinear>(x + j, y, st[j].L, st[j].T, W, H)) {
+                far |= 1u << j;
+            } else {
+                ncmin = min(ncmin, st[j].L);  ncmax = max(ncmax, st[j].R);
+                nrmin = min(nrmin, st[j].T);  nrmax = max(nrmax, st[j].Bm);
+            }
+        }
+    }
+    const Region r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    BBox near_box = tile_bbox<LX>(ncmin, ncmax, nrmin, nrmax, bb + 16);
+    if (__syncthreads_or(far != 0)) near_box.h |= kTileHasFar;
+    if (threadIdx.x == 0) tbox[((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx] = near_box;
+
+    int oTL[4], oTR[4], oBL[4], oBR[4];
+    unsigned valid = 0, staged = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const BlSite &s = st[j];
+        const bool in_box = s.valid && r.covers(s.L, s.R, s.T, s.Bm);
+        valid |= (s.valid ? 1u : 0u) << j;
+        staged |= (in_box ? 1u : 0u) << j;
+        const int rT = in_box ? (s.T - r.y0) * r.pitch : 0, rB = in_box ? (s.Bm - r.y0) * r.pitch : 0;
+        const int cL = in_box ? swz_col(s.L - r.x0) : 0, cR = in_box ? swz_col(s.R - r.x0) : 0;
+        oTL[j] = rT + cL;  oTR[j] = rT + cR;  oBL[j] = rB + cL;  oBR[j] = rB + cR;
+    }
+    const float *in_b = in1 + b * s1b;
+    f32x4 sTL = {0.f, 0.f, 0.f, 0.f}, sTR = sTL, sBL = sTL, sBR = sTL;         // corner sums, component = site
+#pragma unroll 1
+    for (int c0 = 0; c0 < C; c0 += 4) {
+        if (c0 > 0) __syncthreads();
+        f32x4 go[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) go[c] = ld_stream4(gout_p + (c0 + c) * s1c);
+#pragma unroll
+        for (int j = 0; j < 4; j++) asm volatile("" : "+v"(oTL[j]), "+v"(oTR[j]), "+v"(oBL[j]), "+v"(oBR[j]));
+        tile_stage<16, 4>(r, in_b + c0 * s1c, s1c, s1h, tile);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool on = (staged >> j) & 1;
+            const f32x4 gj = on ? f32x4{go[0][j], go[1][j], go[2][j], go[3][j]} : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 pTL = tile[oTL[j]], pTR = tile[oTR[j]], pBL = tile[oBL[j]], pBR = tile[oBR[j]];
+            sTL[j] += gj[0] * pTL[0] + gj[1] * pTL[1] + gj[2] * pTL[2] + gj[3] * pTL[3];
+            sTR[j] += gj[0] * pTR[0] + gj[1] * pTR[1] + gj[2] * pTR[2] + gj[3] * pTR[3];
+            sBL[j] += gj[0] * pBL[0] + gj[1] * pBL[1] + gj[2] * pBL[2] + gj[3] * pBL[3];
+            sBR[j] += gj[0] * pBR[0] + gj[1] * pBR[1] + gj[2] * pBR[2] + gj[3] * pBR[3];
+        }
+        if (valid & ~staged) {                             // rare: corners outside the staged box -> global gathers
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {
+                if (!(((valid & ~staged) >> j) & 1)) continue;
+                const BlSite &s = st[j];
+                for (int c = 0; c < 4; c++) {
+                    const float *p = in_b + (c0 + c) * s1c;
+                    const float gv = gout_p[(c0 + c) * s1c + j];
+                    const float vTL = p[s.T * s1h + s.L], vTR = p[s.T * s1h + s.R], vBL = p[s.Bm * s1h + s.L],
+                                vBR = p[s.Bm * s1h + s.R];
+                    // (j is a run-time index here: the four sums go through a select chain, not through scratch)
+                    const f32x4 e = {j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f, j == 3 ? 1.f : 0.f};
+                    sTL += e * (gv * vTL);  sTR += e * (gv * vTR);  sBL += e * (gv * vBL);  sBR += e * (gv * vBR);
+                }
+            }
+        }
+    }
+    if (inb) {
+        f32x4 gx4, gy4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const BlSite &s = st[j];
+            const float x2 = (float)(x + j) + fx4[j], y2 = (float)y + fy4[j];
+            const float gam_x = (float)s.Bm - y2, gam_y = (float)s.R - x2;     // clamped corners, my_lib_kernel.cu:634,652
+            const float vx = gam_x * (sTR[j] - sTL[j]) + (1 - gam_x) * (sBR[j] - sBL[j]);
+            const float vy = gam_y * (sBL[j] - sTL[j]) + (1 - gam_y) * (sBR[j] - sTR[j]);
+            gx4[j] = s.valid ? vx : 0.0f;                  // gradinput2 is ASSIGNED; invalid sites store zeros
+            gy4[j] = s.valid ? vy : 0.0f;
+        }
+        float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
+        st_stream4(g2, gx4);
+        st_stream4(g2 + s2c, gy4);
+    }
+}
+
+__global__ __launch_bounds__(256) void bl_bwd_far_sites(
+    int W, int H, int C, int tiles_x, int tiles_y, int batch,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
+    const float *__restrict__ flow, const float *__restrict__ gout, float *__restrict__ gin1,
+    const BBox *__restrict__ tbox)
+{
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
+    if (!(tbox[((int64_t)tc.b * tiles_y + tc.ty) * tiles_x + tc.tx].h & kTileHasFar)) return;
+    const int x0 = tc.tx * 64 + 4 * (int)(threadIdx.x % 16), y = tc.ty * 16 + (int)(threadIdx.x / 16);
+    if (x0 >= W || y >= H) return;
+    const float *flow_p = flow + tc.b * s2b + (int64_t)y * s2h + x0;
+    for (int j = 0; j < 4; j++) {
+        const BlSite s = bl_locate<true>(x0 + j, y, W, H, flow_p[j], flow_p[s2c + j]);
+        if (s.valid && site_far<FpBilinear>(x0 + j, y, s.L, s.T, W, H))
+            bl_bwd_site_image_atomics(x0 + j, y, W, H, C, gin1 + tc.b * s1b, s1c, s1h, flow_p + j, s2c,
+                                      gout + tc.b * s1b + (int64_t)y * s1h + x0 + j);
+    }
+}
+
 // gradinput1 = 0 over a strided [batch, channel, h, w] view (rows are contiguous)
 __global__ __launch_bounds__(256) void fi_bwd_zero_rows(float *__restrict__ p, int w, int h, int channel, int64_t sb,
                                                         int64_t sc, int sh)
@@ -920,19 +1118,15 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                        gradinput3, tbox);
 #define MEMC_OWNER(TH, TR, TRACE)                                                                                  \
     do {                                                                                                           \
-        static const bool once = (allow_big_lds(fi_bwd_image_owner<TH, TR>, OwnGeom<TH>::kBytes), true);           \
+        using Gm_ = OwnGeom<FpFilter, TH>;                                                                         \
+        static const bool once = (allow_big_lds(fi_bwd_image_owner<FpFilter, TH, TR>, Gm_::kBytes), true);         \
         (void)once;                                                                                                \
         const int cty = (h + TH - 1) / TH;                                                                         \
-        hipLaunchKernelGGL((fi_bwd_image_owner<TH, TR>), dim3((unsigned)ntx * cty * batch),                        \
-                           dim3(OwnGeom<TH>::kThreads), OwnGeom<TH>::kBytes, stream, w, h, channel, ntx, cty, nty, \
+        hipLaunchKernelGGL((fi_bwd_image_owner<FpFilter, TH, TR>), dim3((unsigned)ntx * cty * batch),              \
+                           dim3(Gm_::kThreads), Gm_::kBytes, stream, w, h, channel, ntx, cty, nty,                 \
                            batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,  \
                            (int64_t)s3c, s3h, input2, input3, gradoutput, gradinput1, tbox, TRACE);                \
     } while (0)
-    // 64 x 16 cell tiles, one workgroup per CU.  Measured (8 x 64 x 720 x 1280, tools/bench_ops.py --only fi_bwd_ctx on
-    // the measurement build): 4.30 ms for the whole backward; 64 x 8 tiles, two workgroups per CU: 4.40 -- the phases
-    // are LDS- and VALU-throughput bound (SQ counters: LDS active 45 % of the busy cycles, half of that bank
-    // conflicts of the compressing benchmark flow; VALU 40 %), not barrier-bound, so overlap buys nothing and the
-    // smaller tile scans more sites per cell.
 #ifdef MEMC_MEASURE
     if (g_trace_cn) MEMC_OWNER(16, true, g_trace_cn);
     else if (g_owner_th == 8) MEMC_OWNER(8, false, nullptr);
@@ -943,6 +1137,42 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
     hipLaunchKernelGGL(fi_bwd_far_sites, dim3(ntiles), dim3(256), 0, stream,
                        w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                        (int64_t)s3b, (int64_t)s3c, s3h, input2, input3, gradoutput, gradinput1, tbox);
+    return launch_status() == 0 ? 1 : -1;
+}
+
+// The bilinear warp's backward for the same class of channel counts (C % 4 == 0, C >= 8); same return convention.
+int bl_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
+                     int s1b, int s1c, int s1h, int s2b, int s2c, int s2h,
+                     const float *input1, const float *input2, const float *gradoutput,
+                     float *gradinput1, float *gradinput2, bool force_direct)
+{
+    if (!fi_bwd_cn_class(channel, 4)) return 0;
+    const int ntx = (w + 63) / 64, nty = (h + 15) / 16;
+    const unsigned ntiles = (unsigned)ntx * nty * batch;
+    CallScratch scratch;                                   // the site tiles' target boxes
+    if (force_direct || !plane_fits_u32(w, h, {s1h, s2h}) ||
+        !vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2}) ||
+        4LL * (3LL * s1c + (long long)(h - 1) * s1h + w) >= (1LL << 32) || ntx > 0xffff || nty > 0x7fff ||
+        !scratch.alloc((size_t)ntiles * sizeof(BBox), stream)) {
+        hipLaunchKernelGGL(fi_bwd_zero_rows, dim3((unsigned)batch * channel * h), dim3(256), 0, stream, gradinput1, w, h,
+                           channel, (int64_t)s1b, (int64_t)s1c, s1h);
+        return launch_status() == 0 ? 0 : -1;
+    }
+    BBox *tbox = static_cast<BBox *>(scratch.p);
+    constexpr int kCap = 2496;                             // the forward's staging budget: 39 KiB, 2 x 2 footprint
+    hipLaunchKernelGGL(bl_bwd_flow_c4n<kCap>, dim3(ntiles), dim3(256), (tile_lds_bytes<16, kCap>() + 64), stream,
+                       w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                       input1, input2, gradoutput, gradinput2, tbox);
+    using Gm = OwnGeom<FpBilinear, 16>;
+    static const bool once = (allow_big_lds(fi_bwd_image_owner<FpBilinear, 16, false>, Gm::kBytes), true);
+    (void)once;
+    hipLaunchKernelGGL((fi_bwd_image_owner<FpBilinear, 16, false>), dim3(ntiles), dim3(Gm::kThreads), Gm::kBytes, stream,
+                       w, h, channel, ntx, nty, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c,
+                       s2h, (int64_t)0, (int64_t)0, 0, input2, static_cast<const float *>(nullptr), gradoutput,
+                       gradinput1, tbox, static_cast<unsigned long long *>(nullptr));
+    hipLaunchKernelGGL(bl_bwd_far_sites, dim3(ntiles), dim3(256), 0, stream,
+                       w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                       input2, gradoutput, gradinput1, tbox);
     return launch_status() == 0 ? 1 : -1;
 }
 

@@ -396,6 +396,10 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
     return launch_status();
 }
 
+#ifdef MEMC_MEASURE
+static int g_bl_bwd_direct = 0;                // A/B: the direct (global atomics) kernel for any channel count
+#endif
+
 static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batch, int s1b, int s1c, int s1h,
                          int s2b, int s2c, int s2h, const float *input1, const float *input2,
                          const float *gradoutput, float *gradinput1, float *gradinput2)
@@ -424,6 +428,19 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
 #undef MEMC_BL_BWD
         return launch_status();
     }
+    if (channel != 3) {                                    // many channels: fi_bwd_cn.hip (owner-computes)
+#ifdef MEMC_MEASURE
+        const bool direct_only = g_bl_bwd_direct != 0;
+#else
+        constexpr bool direct_only = false;
+#endif
+        const int taken = bl_bwd_cn_launch(stream, w, h, channel, batch, s1b, s1c, s1h, s2b, s2c, s2h, input1, input2,
+                                           gradoutput, gradinput1, gradinput2, direct_only);
+        if (taken != 0) {
+            MEMC_PATH("bl_bwd:owner");
+            return taken > 0 ? 0 : -1;
+        }
+    }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
     MEMC_PATH("bl_bwd:direct");
@@ -447,6 +464,7 @@ int memc::g_tile_walk_sw = -1;
 int memc::g_extra_lds = 0;
 int memc::g_cap_sel = -1;
 extern "C" void memc_debug_set_bl_cap(int which) { memc::g_cap_sel = which; }
+extern "C" void memc_debug_set_bl_bwd_direct(int on) { memc::g_bl_bwd_direct = on; }
 extern "C" void memc_debug_set_extra_lds(int bytes) { memc::g_extra_lds = bytes > 0 ? bytes : 0; }
 extern "C" void memc_debug_set_walk(int stripe_width) { memc::g_tile_walk_sw = stripe_width; }
 #endif

@@ -20,6 +20,11 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                      int s1b, int s1c, int s1h, int s2b, int s2c, int s2h, int s3b, int s3c, int s3h,
                      const float *input1, const float *input2, const float *input3, const float *gradoutput,
                      float *gradinput1, float *gradinput2, float *gradinput3, bool force_direct);
+// ... and the bilinear warp's backward (Interpolation / InterpolationCh) for the same class of channel counts
+int bl_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
+                     int s1b, int s1c, int s1h, int s2b, int s2c, int s2h,
+                     const float *input1, const float *input2, const float *gradoutput,
+                     float *gradinput1, float *gradinput2, bool force_direct);
 }  // namespace memc
 #endif
 
@@ -53,6 +58,7 @@ void memc_debug_set_bl_cap(int which);           // 2x2-footprint kernels' LDS s
 void memc_debug_set_walk(int stripe_width);      // < 0: each launcher's default; 0: strips; n: stripes n tile columns wide
 int memc_debug_set_trace_buffer(void *device_u64_buffer);        // gridDim.x * 16 slots, written by fi_bwd variant 9
 int memc_debug_set_trace_buffer_proj(void *device_u64_buffer);   // the same for the projection's trace arm
+void memc_debug_set_bl_bwd_direct(int on);       // bilinear backward: 1 = the direct kernel for any channel count
 void memc_debug_set_owner_th(int th);            // fi_bwd_image_owner's cell tile height: 16 (default) or 8
 int memc_debug_set_trace_buffer_cn(void *device_u64_buffer);
 const char *memc_debug_last_path(void);          // the kernel family the last launcher call chose, e.g. "fi_fwd:tiled_c3"     // fi_bwd_image_owner's phase clocks; NULL switches them off

@@ -145,6 +145,39 @@ def test_filter_interpolation_backward_many_channels(oracle, case):
     close(N(h3), g3, "gradinput3 (stored)", RTOL)
 
 
+@pytest.mark.parametrize("case", MANY, ids=["%dx%dx%dx%d-%s" % c for c in MANY])
+def test_interpolation_ch_backward_many_channels(oracle, case):
+    """The bilinear warp's backward for C % 4 == 0, C >= 8: flow-gradient kernel + the owner kernel with a 2 x 2 window
+    (fi_bwd_cn.hip).  Through the module, then through the C ABI from garbage-filled buffers (gradinput1 is stored)."""
+    from my_package.modules.InterpolationChModule import InterpolationChModule
+    import my_package._ext.my_lib as my_lib
+    B, C, H, W, kind = case
+    rng = np.random.default_rng(sum(case[:4]) + 1)
+    xn, gn = synth.np_image(rng, B, C, H, W), synth.np_image(rng, B, C, H, W)
+    fn = _many_channel_flows(kind, rng, B, H, W)
+    x, f = T(xn, True), T(fn, True)
+    out = InterpolationChModule()(x, f)
+    out.backward(T(gn))
+    close(N(out), oracle.interpolation_ch_forward(xn, fn), "forward")
+    g1, g2 = oracle.interpolation_ch_backward(xn, fn, gn)
+    close(N(x.grad), g1, "gradinput1", 3 * RTOL)
+    close(N(f.grad), g2, "gradinput2", 3 * RTOL)
+    h1, h2 = torch.full_like(x, 7.0), torch.full_like(f, 7.0)
+    assert my_lib.InterpolationChLayer_gpu_backward(x.detach(), f.detach(), T(gn), h1, h2) == 0
+    close(N(h1), g1, "gradinput1 (stored)", 3 * RTOL)
+    close(N(h2), g2, "gradinput2 (stored)", 3 * RTOL)
+    from tools import measure as M          # the direct kernel it replaced: same answers from garbage-filled buffers
+    ml = M.bound()
+    try:
+        M.set_variant("bl_bwd_direct", 1)
+        h1.fill_(5.0); h2.fill_(5.0)
+        assert ml.InterpolationChLayer_gpu_backward(x.detach(), f.detach(), T(gn), h1, h2) == 0
+    finally:
+        M.reset()
+    close(N(h1), g1, "gradinput1 (direct arm)", 3 * RTOL)
+    close(N(h2), g2, "gradinput2 (direct arm)", 3 * RTOL)
+
+
 @pytest.mark.parametrize("arm", [("owner_th", 8), ("fi_bwd", 40)], ids=["owner tiles 64x8", "direct kernel"])
 def test_filter_interpolation_backward_many_channels_measurement_arms(oracle, arm):
     """The A/B arms of the many-channel backward (measurement build): the owner kernel on 64 x 8 cell tiles, and the
@@ -211,7 +244,7 @@ def test_shapes_take_the_documented_kernel_paths():
     assert run(2, 3, 40, 128) == {"fi_fwd": "fi_fwd:tiled_c3", "fi_bwd": "fi_bwd:tiled_c3", "bl_fwd": "bl_fwd:tiled_c3",
                                   "bl_bwd": "bl_bwd:tiled_c3", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
     assert run(1, 64, 40, 128) == {"fi_fwd": "fi_fwd:tiled_c4n", "fi_bwd": "fi_bwd:owner", "bl_fwd": "bl_fwd:tiled_chunks",
-                                   "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
+                                   "bl_bwd": "bl_bwd:owner", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
     assert run(1, 5, 40, 128) == {"fi_fwd": "fi_fwd:tiled_chunks", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:tiled_chunks",
                                   "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
     # width not a multiple of four, and an aligned width seen through a view that starts one element in

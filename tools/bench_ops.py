@@ -351,6 +351,12 @@ def main():
             bench_projection(rows, dev, 32, 720, 1280, "video", "c3")
     if want("interp"):
         bench_interp(rows, dev, 32, 3, 720, 1280, "smooth", "720p")
+    if want("interp_ctx"):
+        bench_interp(rows, dev, 8, 64, 720, 1280, "smooth", "ctx64")
+        if M.active:                               # A/B: the direct global-atomics backward it replaced
+            M.set_variant("bl_bwd_direct", 1)
+            bench_interp(rows, dev, 8, 64, 720, 1280, "smooth", "ctx64 DIRECT backward")
+            M.set_variant("bl_bwd_direct", 0)
     # baselines (the CPU oracle, the reference's own kernels on this GPU) live under tests/: tests/bench_baselines.py
     os.makedirs(os.path.dirname(args.json), exist_ok=True)
     json.dump({"device": torch.cuda.get_device_name(0), "lib": measure.version() if M.active else L.version(), "rows": rows}, open(args.json, "w"),
