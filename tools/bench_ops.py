@@ -335,7 +335,8 @@ def main():
             bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "iid", "720p")
             bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "video", "720p")
     if want("fi_bwd_ctx"):
-        bench_fi_bwd(rows, dev, 8, 64, 720, 1280, "smooth", "ctx64")
+        # (measurement build: + variant 40, the direct global-atomics kernel this path replaced -- 163 ms)
+        bench_fi_bwd(rows, dev, 8, 64, 720, 1280, "smooth", "ctx64", [40] if M.active else [])
         if M.active:                               # A/B: the owner kernel on 64 x 8 cell tiles (two workgroups per CU)
             M.set_variant("owner_th", 8)
             bench_fi_bwd(rows, dev, 8, 64, 720, 1280, "smooth", "ctx64 owner tiles 64x8")

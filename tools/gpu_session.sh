@@ -20,6 +20,8 @@ for b in 16 8 4; do timeout 300 python bench.py --batch $b --no-cpu-baseline --n
 echo "== model"; timeout 600 python tools/bench_model.py --json "$OUT/bench_model.json" 2>&1 | tail -2 | tee "$OUT/bench_model.log"
 echo "== many-channel FilterInterpolation backward: phase clocks of the owner kernel (measurement build)"
 timeout 300 python tools/trace_kernel.py fi_bwd_cn 2>&1 | grep -v amdgpu.ids | tee "$OUT/fi_bwd_cn_trace.txt"
+echo "== many-channel backward passes, A/B arms (measurement build: owner tiles 64x8, the direct kernels they replaced)"
+timeout 600 python tools/bench_ops.py --only fi_bwd_ctx,interp_ctx --bwd-variants 40 --json "$OUT/bench_many_channels.json" 2>&1 | grep -v amdgpu.ids | tee "$OUT/bench_many_channels.log"
 echo "== race screen"; timeout 600 python tools/stress_projection.py 60 2>&1 | tail -3 | tee "$OUT/stress.log"
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprof kernel trace of bench.py (the same command as the bench line above, minus the CPU baseline)"
