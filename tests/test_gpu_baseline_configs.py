@@ -62,6 +62,37 @@ def test_config2_adaptive_warp_fwd_bwd_448x256_batch8(kind):
 
 
 @pytest.mark.parametrize("kind", ["smooth", "iid"])
+def test_context_warp_shape_fwd_bwd_64_channels_720p(kind):
+    """The 64-channel context warp of BASELINE config 4's network (MEMC_Net_star.py:281-285), at 720p: forward and the
+    many-channel backward (fi_bwd_cn.hip: owner-computes, no global atomics) against the reference's own kernels.
+    gradinput1 goes in garbage-filled: for this class of channel counts the library stores it."""
+    import my_package._ext.my_lib as L
+    B, C, H, W = 2, 64, 720, 1280
+    t = synth.torch_inputs(dev(), B, C, H, W, flow_kind=kind, seed=44, with_grad=True)
+    x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
+    out = torch.full_like(x, float("nan"))
+    assert L.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+    close(out, R.filter_interpolation_forward(x, f, k), "context warp forward (%s)" % kind)
+    g1, g2, g3 = torch.full_like(x, float("nan")), torch.full_like(f, float("nan")), torch.full_like(k, float("nan"))
+    assert L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+    w1, w2, w3 = R.filter_interpolation_backward(x, f, k, g)
+    # 64 channels of fp32 products per tap sum / per cell: relative tolerance on the larger sums
+    for got, want, what in ((g1, w1, "gradinput1"), (g2, w2, "gradinput2"), (g3, w3, "gradinput3")):
+        err = (got.double() - want.double()).abs()
+        worst = float((err - (ATOL + 5 * RTOL * want.double().abs())).max())
+        assert worst <= 0, "context warp %s (%s): max abs err %.3g (|want| up to %.3g)" % (
+            what, kind, float(err.max()), float(want.abs().max()))
+    # the bilinear warp at the same shape (InterpolationCh)
+    h1, h2 = torch.full_like(x, float("nan")), torch.full_like(f, float("nan"))
+    assert L.InterpolationChLayer_gpu_backward(x, f, g, h1, h2) == 0
+    v1, v2 = R.interpolation_backward(x, f, g, ch=True)
+    for got, want, what in ((h1, v1, "gradinput1"), (h2, v2, "gradinput2")):
+        err = (got.double() - want.double()).abs()
+        worst = float((err - (ATOL + 5 * RTOL * want.double().abs())).max())
+        assert worst <= 0, "bilinear %s (%s): max abs err %.3g" % (what, kind, float(err.max()))
+
+
+@pytest.mark.parametrize("kind", ["smooth", "iid"])
 def test_config3_projection_scatter_1280x720_batch32(kind):
     import my_package._ext.my_lib as L
     B, H, W = 32, 720, 1280
