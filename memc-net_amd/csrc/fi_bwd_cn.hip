@@ -1,4 +1,6 @@
-// fi_bwd_cn.hip -- FilterInterpolation backward, fs == 4, channel counts that are multiples of four (C >= 8), gfx950.
+// fi_bwd_cn.hip -- the scattering backward passes at many channels (C % 4 == 0, C >= 8), gfx950: FilterInterpolation
+// (fs == 4) and, with the same owner kernel on a 2 x 2 window, the bilinear warp (Interpolation / InterpolationCh; the
+// second half of this file).
 //
 // Same operator as fi_bwd_tiled_c3 (filter_interpolation.hip; reference kernel my_lib_kernel.cu:1220-1515), built for
 // many channels.  With C channels a site issues 16 * C scattered adds into gradinput1; issued as global atomics

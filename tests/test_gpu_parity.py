@@ -98,8 +98,8 @@ def _many_channel_flows(kind, rng, B, H, W):
         return synth.np_flow(rng, B, H, W, "smooth", 6.0)
     if kind == "pan":                          # coherent motion of 100 px: the target boxes sit two tiles away
         f = synth.np_flow(rng, B, H, W, "smooth", 1.5)
-        f[:, 0] += -100.25
-        f[:, 1] += 9.5
+        f[:, 0] += -min(100.25, 0.4 * W)
+        f[:, 1] += min(9.5, 0.3 * H)
         return f
     if kind == "far":                          # beyond the owners' search window (> 2 tile columns): global atomics
         f = synth.np_flow(rng, B, H, W, "smooth", 2.0)
@@ -117,7 +117,8 @@ def _many_channel_flows(kind, rng, B, H, W):
 
 MANY = [(2, 8, 70, 200, "smooth"), (1, 16, 96, 384, "pan"), (1, 8, 48, 448, "far"), (1, 8, 64, 192, "converge"),
         (1, 12, 80, 256, "iid"), (1, 64, 36, 132, "smooth"),
-        (1, 8, 20, 50, "smooth")]          # width not a multiple of 4: cleared, then the direct kernel
+        (1, 8, 20, 50, "smooth"),          # width not a multiple of 4: cleared, then the direct kernel
+        (1, 8, 5, 12, "smooth"), (1, 8, 16, 64, "iid"), (3, 8, 33, 68, "pan")]      # tiny, exactly one tile, ragged
 
 
 @pytest.mark.parametrize("case", MANY, ids=["%dx%dx%dx%d-%s" % c for c in MANY])
