@@ -373,6 +373,7 @@ struct OwnGeom {
     static constexpr int kG = kAlias ? 0 : kHeadEnd, kPart = kG + ((kSlotCap + 1) * 16 + 127) / 128 * 128,
                          kSeg = kPart + kSegCap * 16, kAliasEnd = kSeg + kSegCap * 4;
     static_assert(kSlotCap <= 8 * kThreads, "two float4 slots of staging per lane");
+    static_assert(kSlotCap % 256 == 0, "the slot swizzle permutes aligned blocks of 256");
     static constexpr int kTK = kAlias ? kHeadEnd : kAliasEnd, kTS = kTK + kTailCap * 4, kOc = kTS + kTailCap * 2,
                          kPres = kOc + kCells * 4, kToff = kPres + kCells * 4, kCtl = kToff + kCells * 2,
                          kBytes = kCtl + 512;
@@ -440,6 +441,11 @@ __device__ __forceinline__ void own_count(const QuadHits &h, unsigned *oc, unsig
         }
     }
 }
+
+// Staging slots are XOR-swizzled in their low four bits with bits 4..7: a 16-lane group of a ds_read_b128 conflicts when
+// two of its lanes read different slots 16 (or 32) apart, which is exactly what neighbouring cells' sources do under a
+// compressing or expanding flow (slot distance = cell distance * (1 - gradient)).  A bijection of every aligned 256.
+__device__ __forceinline__ int swz_slot(int s) { return s ^ ((s >> 4) & 15); }
 
 template <int K>
 __device__ __forceinline__ float quad_bcast(float v)
@@ -693,7 +699,7 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (!((h.any >> j) & 1)) continue;
-                const unsigned short slot = (unsigned short)((y - y_lo) * aw + (x + j - ax0));
+                const unsigned short slot = (unsigned short)swz_slot((y - y_lo) * aw + (x + j - ax0));
 #pragma unroll
                 for (int k = 0; k < FP::kN; k++) {
                     if (!((h.rowm[j] >> k) & 1)) continue;
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
         // 5. replay, four channels at a time.  Wave-uniform plane bases + 32-bit byte offsets (per-lane 64-bit
         //    pointers would not fit next to the lists: a spilled pointer's reload waits for every load in flight)
         const unsigned go0 = on0 ? 4u * (unsigned)(yq0 * s1h + xq0) : 0u, go1 = on1 ? 4u * (unsigned)(yq1 * s1h + xq1) : 0u;
-        f32x4 *gd0 = g4 + (on0 ? r0 * aw + 4 * q0 : 0), *gd1 = g4 + (on1 ? r1 * aw + 4 * q1 : 0);
+        const int gs0 = on0 ? r0 * aw + 4 * q0 : 0, gs1 = on1 ? r1 * aw + 4 * q1 : 0;      // first of four slots
         f32x4 v0[4], v1[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -812,11 +818,11 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
         for (int c0 = 0; c0 < C; c0 += 4) {
             if (on0) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) gd0[i] = f32x4{v0[0][i], v0[1][i], v0[2][i], v0[3][i]};
+                for (int i = 0; i < 4; i++) g4[swz_slot(gs0 + i)] = f32x4{v0[0][i], v0[1][i], v0[2][i], v0[3][i]};
             }
             if (on1) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) gd1[i] = f32x4{v1[0][i], v1[1][i], v1[2][i], v1[3][i]};
+                for (int i = 0; i < 4; i++) g4[swz_slot(gs1 + i)] = f32x4{v1[0][i], v1[1][i], v1[2][i], v1[3][i]};
             }
             if (c0 > 0) {
                 finish(c0 - 4);

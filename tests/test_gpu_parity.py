@@ -554,6 +554,36 @@ def test_stream_capture_and_replay(oracle):
     close(N(pout), oracle.flow_projection_forward(d["flow"], 1)[0], "captured projection")
 
 
+def test_stream_capture_many_channel_backward(oracle):
+    """Inside a stream capture nothing may be allocated: the many-channel backward passes then clear gradinput1 themselves
+    and take the direct kernels -- same gradients, replayable, still independent of what the buffers held."""
+    import my_package._ext.my_lib as my_lib
+    B, C, H, W = 1, 8, 40, 128
+    rng = np.random.default_rng(77)
+    xn, kn, gn = synth.np_image(rng, B, C, H, W), synth.np_filter(rng, B, H, W), synth.np_image(rng, B, C, H, W)
+    fn = synth.np_flow(rng, B, H, W, "smooth", 5.0)
+    x, f, k, g = T(xn), T(fn), T(kn), T(gn)
+    g1, g2, g3 = torch.full_like(x, 9.0), torch.full_like(f, 9.0), torch.full_like(k, 9.0)
+    h1, h2 = torch.full_like(x, 9.0), torch.full_like(f, 9.0)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+            assert my_lib.InterpolationChLayer_gpu_backward(x, f, g, h1, h2) == 0
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    w1, w2, w3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+    close(N(g1), w1, "captured FI gradinput1", 3 * RTOL)
+    close(N(g2), w2, "captured FI gradinput2", RTOL)
+    close(N(g3), w3, "captured FI gradinput3", RTOL)
+    v1, v2 = oracle.interpolation_ch_backward(xn, fn, gn)
+    close(N(h1), v1, "captured bilinear gradinput1", 3 * RTOL)
+    close(N(h2), v2, "captured bilinear gradinput2", 3 * RTOL)
+
+
 def test_concurrent_streams_projection(oracle):
     """Two streams running the projection fast path at the same time must not share far-source flags."""
     import my_package._ext.my_lib as my_lib
