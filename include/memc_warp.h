@@ -28,10 +28,10 @@
  *     and in two places differ from the reference's `+=`: the FilterInterpolation backward STORES gradinput3
  *     (each site owns its taps) and the (Depth)FlowProjection backward STORES gradinput1 / gradinput2 (each site
  *     owns its elements) instead of adding to them; FilterInterpolation gradinput2 is assigned and gradinput1
- *     added to, as in the reference -- except for channel counts that are multiples of four (>= 8) with the
- *     4x4 filter, for which gradinput1 is STORED as well, on every path (owner-computes kernels: every cell
- *     has exactly one writer), so that a caller may skip that memset; the same holds for the gradinput1 of the
- *     Interpolation(Ch) backward at those channel counts;
+ *     added to, as in the reference -- except with four or more channels and the 4x4 filter, for which
+ *     gradinput1 is STORED as well, on every path (owner-computes kernels: every cell has exactly one writer),
+ *     so that a caller may skip that memset; the same holds for the gradinput1 of the Interpolation(Ch) backward
+ *     with four or more channels;
  *   - `output`, `gradoutput` and `gradinput1` are indexed with input1's b/c/h strides
  *     (my_lib_kernel.cu:1184,1276-1283), `gradinput2`/`gradinput3` with input2's/input3's;
  *   - work is enqueued asynchronously on `stream`; no host synchronisation, no state carried from one call to

@@ -1,4 +1,4 @@
-// fi_bwd_cn.hip -- the scattering backward passes at many channels (C % 4 == 0, C >= 8), gfx950: FilterInterpolation
+// fi_bwd_cn.hip -- the scattering backward passes at many channels (C >= 4), gfx950: FilterInterpolation
 // (fs == 4) and, with the same owner kernel on a 2 x 2 window, the bilinear warp (Interpolation / InterpolationCh; the
 // second half of this file).
 //
@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
         const StageSlot sl = stage_slots(r);
         f32x4 go[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) go[c] = ld_stream4_u(gout_b + c * s1c, o1);
+        for (int c = 0; c < 4; c++) {
+            const f32x4 gl = ld_stream4_u(gout_b + min(c, C - 1) * s1c, o1);
+            go[c] = c < C ? gl : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll 1
         for (int c0 = 0; c0 < C; c0 += 4) {
             {
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
                     const unsigned off = sl.row[it] < r.h
                                              ? 4u * (unsigned)((r.y0 + sl.row[it]) * s1h + r.x0 + 4 * sl.q[it]) : 0u;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) sr.v[it][c] = ld_cached4_u(in_b + (c0 + c) * s1c, off);
+                    for (int c = 0; c < 4; c++) sr.v[it][c] = ld_cached4_u(in_b + min(c0 + c, C - 1) * s1c, off);
                 }
                 tile_stage_store<4>(r, sl, sr, tile);
             }
@@ -246,7 +249,10 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
             // the next chunk's gradoutput, once this chunk's has been used (one register set)
             const int cn = c0 + 4 < C ? c0 + 4 : c0;
 #pragma unroll
-            for (int c = 0; c < 4; c++) go[c] = ld_stream4_u(gout_b + (cn + c) * s1c, o1);
+            for (int c = 0; c < 4; c++) {                  // a ragged last chunk: channels past C contribute zeros
+                const f32x4 gl = ld_stream4_u(gout_b + min(cn + c, C - 1) * s1c, o1);
+                go[c] = cn + c < C ? gl : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             __syncthreads();
         }
     }
@@ -519,6 +525,7 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
     auto store_zeros = [&]() {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         for (int c0 = 0; c0 < C; c0 += 4) {
+            if (c0 + (int)my >= C) continue;               // ragged last chunk: this lane's channel does not exist
             if (st0) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + c0 * s1c, wo0)) = z;
             if (st1) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + c0 * s1c, wo1)) = z;
         }
@@ -788,12 +795,12 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
         f32x4 v0[4], v1[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            v0[c] = ld_cached4_u(gout_b + c * s1c, go0);
-            v1[c] = ld_cached4_u(gout_b + c * s1c, go1);
+            v0[c] = ld_cached4_u(gout_b + min(c, C - 1) * s1c, go0);
+            v1[c] = ld_cached4_u(gout_b + min(c, C - 1) * s1c, go1);
         }
         const bool rmw = y_lo != ay0;                      // workgroup-uniform: a later slab adds to the first one's
         f32x4 old0 = {0.f, 0.f, 0.f, 0.f}, old1 = old0, nold0 = old0, nold1 = old0;
-        if (rmw) {
+        if (rmw && (int)my < C) {
             old0 = ld_cached4_u(gin1_b, wo0);
             old1 = ld_cached4_u(gin1_b, wo1);
         }
@@ -811,8 +818,9 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
                 a1 += q1;
             }
             const f32x4 t0 = quad_transpose(a0, my), t1 = quad_transpose(a1, my);
-            if (st0) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + cp * s1c, wo0)) = old0 + t0;
-            if (st1) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + cp * s1c, wo1)) = old1 + t1;
+            const bool ch_ok = cp + (int)my < C;           // ragged last chunk: this lane's channel may not exist
+            if (st0 && ch_ok) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + cp * s1c, wo0)) = old0 + t0;
+            if (st1 && ch_ok) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + cp * s1c, wo1)) = old1 + t1;
         };
 #pragma unroll 1
         for (int c0 = 0; c0 < C; c0 += 4) {
@@ -836,12 +844,14 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
             const int cn = c0 + 4 < C ? c0 + 4 : c0;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                v0[c] = ld_cached4_u(gout_b + (cn + c) * s1c, go0);
-                v1[c] = ld_cached4_u(gout_b + (cn + c) * s1c, go1);
+                v0[c] = ld_cached4_u(gout_b + min(cn + c, C - 1) * s1c, go0);     // (channels past C: never stored)
+                v1[c] = ld_cached4_u(gout_b + min(cn + c, C - 1) * s1c, go1);
             }
             if (rmw) {
-                nold0 = ld_cached4_u(gin1_b + cn * s1c, wo0);
-                nold1 = ld_cached4_u(gin1_b + cn * s1c, wo1);
+                if (cn + (int)my < C) {
+                    nold0 = ld_cached4_u(gin1_b + cn * s1c, wo0);
+                    nold1 = ld_cached4_u(gin1_b + cn * s1c, wo1);
+                }
             }
             // keep the slot unpacking inside the loop (hoisted, the 48 LDS addresses spill)
 #pragma unroll
@@ -893,7 +903,7 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
             __syncthreads();
             MEMC_TR_END(15);
         }
-        finish(C - 4);
+        finish((C - 1) / 4 * 4);
         __syncthreads();                                   // the segment sums have been read: the next slab may rebuild
         MEMC_TR_END(6);
         if (TR && tid == 0) trace[(size_t)blockIdx.x * 16 + 9] = (unsigned long long)nseg_total;
@@ -1016,10 +1026,22 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
         if (c0 > 0) __syncthreads();
         f32x4 go[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) go[c] = ld_stream4(gout_p + (c0 + c) * s1c);
+        for (int c = 0; c < 4; c++) {                      // a ragged last chunk: channels past C contribute zeros
+            const f32x4 gl = ld_stream4(gout_p + min(c0 + c, C - 1) * s1c);
+            go[c] = c0 + c < C ? gl : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) asm volatile("" : "+v"(oTL[j]), "+v"(oTR[j]), "+v"(oBL[j]), "+v"(oBR[j]));
-        tile_stage<16, 4>(r, in_b + c0 * s1c, s1c, s1h, tile);
+        {
+            const float *plane[4];
+            int hs[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                plane[c] = in_b + min(c0 + c, C - 1) * s1c;
+                hs[c] = s1h;
+            }
+            tile_stage_planes<16, 4>(r, plane, hs, tile);
+        }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -1036,7 +1058,7 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
             for (int j = 0; j < 4; j++) {
                 if (!(((valid & ~staged) >> j) & 1)) continue;
                 const BlSite &s = st[j];
-                for (int c = 0; c < 4; c++) {
+                for (int c = 0; c < 4 && c0 + c < C; c++) {
                     const float *p = in_b + (c0 + c) * s1c;
                     const float gv = gout_p[(c0 + c) * s1c + j];
                     const float vTL = p[s.T * s1h + s.L], vTR = p[s.T * s1h + s.R], vBL = p[s.Bm * s1h + s.L],
@@ -1095,10 +1117,11 @@ __global__ __launch_bounds__(256) void fi_bwd_zero_rows(float *__restrict__ p, i
     for (int x = threadIdx.x; x < w; x += 256) q[x] = 0.0f;
 }
 
-// Channel counts this file is for.  For them gradinput1 is STORED on every path: when the owner kernels cannot run
+// Channel counts this file is for: four and more (chunks of four staged channels, a ragged last chunk padded with zeros;
+// RGB has its own kernels, one or two channels are few atomics).  For them gradinput1 is STORED on every path: when the owner kernels cannot run
 // (odd geometry, no scratch inside a stream capture) the buffer is cleared here before the caller falls back to the
 // accumulating direct kernel.
-bool fi_bwd_cn_class(int channel, int filter_size) { return filter_size == 4 && channel % 4 == 0 && channel >= 8; }
+bool fi_bwd_cn_class(int channel, int filter_size) { return filter_size == 4 && channel >= 4; }
 
 int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                      int s1b, int s1c, int s1h, int s2b, int s2c, int s2h, int s3b, int s3c, int s3h,
@@ -1148,7 +1171,7 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
     return launch_status() == 0 ? 1 : -1;
 }
 
-// The bilinear warp's backward for the same class of channel counts (C % 4 == 0, C >= 8); same return convention.
+// The bilinear warp's backward for the same class of channel counts (C >= 4); same return convention.
 int bl_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                      int s1b, int s1c, int s1h, int s2b, int s2c, int s2h,
                      const float *input1, const float *input2, const float *gradoutput,

@@ -39,10 +39,10 @@ class _FilterInterpolationFunction(Function):
     def backward(ctx, gradoutput):
         input1, input2, input3 = ctx.saved_tensors
         gradoutput = f32c(gradoutput)
-        # accumulation target: zero-filled (reference :46) -- except for channel counts that are multiples of four
-        # (>= 8) with the 4x4 filter: the library STORES gradinput1 for those on every path (include/memc_warp.h),
+        # accumulation target: zero-filled (reference :46) -- except for four and more channels
+        # with the 4x4 filter: the library STORES gradinput1 for those on every path (include/memc_warp.h),
         # and the memset would be a fifth of the call's traffic
-        stored = input1.size(1) % 4 == 0 and input1.size(1) >= 8 and input3.size(1) == 16
+        stored = input1.size(1) >= 4 and input3.size(1) == 16
         gradinput1 = torch.empty_like(input1) if stored else torch.zeros_like(input1)
         # the reference zero-fills these two as well (:47-48); the backward kernels DEFINE every element of them
         # (invalid sites store zero; tests/test_gpu_parity.py::test_backward_defines_flow_and_tap_gradients), so

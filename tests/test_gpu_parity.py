@@ -118,7 +118,9 @@ def _many_channel_flows(kind, rng, B, H, W):
 MANY = [(2, 8, 70, 200, "smooth"), (1, 16, 96, 384, "pan"), (1, 8, 48, 448, "far"), (1, 8, 64, 192, "converge"),
         (1, 12, 80, 256, "iid"), (1, 64, 36, 132, "smooth"),
         (1, 8, 20, 50, "smooth"),          # width not a multiple of 4: cleared, then the direct kernel
-        (1, 8, 5, 12, "smooth"), (1, 8, 16, 64, "iid"), (3, 8, 33, 68, "pan")]      # tiny, exactly one tile, ragged
+        (1, 8, 5, 12, "smooth"), (1, 8, 16, 64, "iid"), (3, 8, 33, 68, "pan"),      # tiny, exactly one tile, ragged
+        (1, 4, 40, 128, "smooth"), (2, 5, 40, 132, "smooth"), (1, 6, 24, 64, "iid"), (1, 7, 70, 200, "converge")]
+# (the last four: one chunk; ragged last chunks of 1, 2 and 3 channels)
 
 
 @pytest.mark.parametrize("case", MANY, ids=["%dx%dx%dx%d-%s" % c for c in MANY])
@@ -246,8 +248,8 @@ def test_shapes_take_the_documented_kernel_paths():
                                   "bl_bwd": "bl_bwd:tiled_c3", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
     assert run(1, 64, 40, 128) == {"fi_fwd": "fi_fwd:tiled_c4n", "fi_bwd": "fi_bwd:owner", "bl_fwd": "bl_fwd:tiled_chunks",
                                    "bl_bwd": "bl_bwd:owner", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
-    assert run(1, 5, 40, 128) == {"fi_fwd": "fi_fwd:tiled_chunks", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:tiled_chunks",
-                                  "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
+    assert run(1, 5, 40, 128) == {"fi_fwd": "fi_fwd:tiled_chunks", "fi_bwd": "fi_bwd:owner", "bl_fwd": "bl_fwd:tiled_chunks",
+                                  "bl_bwd": "bl_bwd:owner", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
     # width not a multiple of four, and an aligned width seen through a view that starts one element in
     for odd in (run(1, 3, 20, 50), run(1, 3, 20, 64, sliced=True)):
         assert odd == {"fi_fwd": "fi_fwd:direct", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:direct",
