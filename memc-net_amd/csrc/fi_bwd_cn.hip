@@ -961,6 +961,19 @@ __device__ __noinline__ void bl_bwd_site_image_atomics(int x, int y, int W, int 
     }
 }
 
+// corner sums of one site over nch channels, everything from global memory (a site whose corners are not staged)
+__device__ __noinline__ f32x4 bl_corner_sums_global(const float *plane0, const float *gout_site, int64_t s1c, int nch,
+                                                    int oTL, int oTR, int oBL, int oBR)
+{
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nch; c++) {
+        const float *p = plane0 + c * s1c;
+        const float gv = gout_site[c * s1c];
+        q[0] += gv * p[oTL];  q[1] += gv * p[oTR];  q[2] += gv * p[oBL];  q[3] += gv * p[oBR];
+    }
+    return q;
+}
+
 template <int CAP>
 __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
     int W, int H, int C, int tiles_x, int tiles_y, int batch,
@@ -1021,32 +1034,42 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
     }
     const float *in_b = in1 + b * s1b;
     f32x4 sTL = {0.f, 0.f, 0.f, 0.f}, sTR = sTL, sBL = sTL, sBR = sTL;         // corner sums, component = site
-#pragma unroll 1
-    for (int c0 = 0; c0 < C; c0 += 4) {
-        if (c0 > 0) __syncthreads();
-        f32x4 go[4];
+    // Software-pipelined over chunks of four channels (the forward's fi_fwd_tiled_c4n scheme): the next chunk's image
+    // rows and gradoutput are on their way to registers while this one is consumed from LDS.  A ragged last chunk
+    // reads the last plane again and multiplies it by zero.
+    const StageSlot sl = stage_slots(r);
+    StageRegs<4> sr;
+    f32x4 go[4];
+    auto fetch = [&](int c0) {
+        const float *plane[4];
+        int hs[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {                      // a ragged last chunk: channels past C contribute zeros
+        for (int c = 0; c < 4; c++) {
+            plane[c] = in_b + min(c0 + c, C - 1) * s1c;
+            hs[c] = s1h;
+        }
+        tile_stage_load_planes<4>(r, sl, plane, hs, sr);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
             const f32x4 gl = ld_stream4(gout_p + min(c0 + c, C - 1) * s1c);
             go[c] = c0 + c < C ? gl : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int c0 = 0; c0 < C; c0 += 4) {
+        tile_stage_store<4>(r, sl, sr, tile);
+        f32x4 gc[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) gc[c] = go[c];
+        __syncthreads();
+        fetch(c0 + 4 < C ? c0 + 4 : c0);                   // (the last iteration re-reads its own chunk: harmless)
 #pragma unroll
         for (int j = 0; j < 4; j++) asm volatile("" : "+v"(oTL[j]), "+v"(oTR[j]), "+v"(oBL[j]), "+v"(oBR[j]));
-        {
-            const float *plane[4];
-            int hs[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                plane[c] = in_b + min(c0 + c, C - 1) * s1c;
-                hs[c] = s1h;
-            }
-            tile_stage_planes<16, 4>(r, plane, hs, tile);
-        }
-        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const bool on = (staged >> j) & 1;
-            const f32x4 gj = on ? f32x4{go[0][j], go[1][j], go[2][j], go[3][j]} : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 gj = on ? f32x4{gc[0][j], gc[1][j], gc[2][j], gc[3][j]} : f32x4{0.f, 0.f, 0.f, 0.f};
             const f32x4 pTL = tile[oTL[j]], pTR = tile[oTR[j]], pBL = tile[oBL[j]], pBR = tile[oBR[j]];
             sTL[j] += gj[0] * pTL[0] + gj[1] * pTL[1] + gj[2] * pTL[2] + gj[3] * pTL[3];
             sTR[j] += gj[0] * pTR[0] + gj[1] * pTR[1] + gj[2] * pTR[2] + gj[3] * pTR[3];
@@ -1054,21 +1077,16 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
             sBR[j] += gj[0] * pBR[0] + gj[1] * pBR[1] + gj[2] * pBR[2] + gj[3] * pBR[3];
         }
         if (valid & ~staged) {                             // rare: corners outside the staged box -> global gathers
-#pragma unroll 1
-            for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {                  // (compile-time j: a run-time index would put st[] in scratch)
                 if (!(((valid & ~staged) >> j) & 1)) continue;
-                const BlSite &s = st[j];
-                for (int c = 0; c < 4 && c0 + c < C; c++) {
-                    const float *p = in_b + (c0 + c) * s1c;
-                    const float gv = gout_p[(c0 + c) * s1c + j];
-                    const float vTL = p[s.T * s1h + s.L], vTR = p[s.T * s1h + s.R], vBL = p[s.Bm * s1h + s.L],
-                                vBR = p[s.Bm * s1h + s.R];
-                    // (j is a run-time index here: the four sums go through a select chain, not through scratch)
-                    const f32x4 e = {j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f, j == 3 ? 1.f : 0.f};
-                    sTL += e * (gv * vTL);  sTR += e * (gv * vTR);  sBL += e * (gv * vBL);  sBR += e * (gv * vBR);
-                }
+                const f32x4 q = bl_corner_sums_global(in_b + c0 * s1c, gout_p + c0 * s1c + j, s1c, min(4, C - c0),
+                                                      st[j].T * s1h + st[j].L, st[j].T * s1h + st[j].R,
+                                                      st[j].Bm * s1h + st[j].L, st[j].Bm * s1h + st[j].R);
+                sTL[j] += q[0];  sTR[j] += q[1];  sBL[j] += q[2];  sBR[j] += q[3];
             }
         }
+        __syncthreads();
     }
     if (inb) {
         f32x4 gx4, gy4;
