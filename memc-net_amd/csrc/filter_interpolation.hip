@@ -186,15 +186,21 @@ __device__ __forceinline__ void fi_fwd_chunk(
 // on their way to registers while the current chunk is gathered from LDS, so the round trip hides behind
 // ~1 us of FMA work per chunk (at C = 64 the operator is about as VALU-bound as it is HBM-bound).
 // --------------------------------------------------------------------------------------------------
-template <int SW>                              // 0: one tile column per XCD strip; 2 / 4: stripes SW tile columns wide
-__global__ __launch_bounds__(256, 2) void fi_fwd_tiled_c4n(
+// NT = 512 (measurement arm 32): 64 x 32 tiles, one workgroup of 512 lanes per CU instead of two of 256 -- the same waves
+// per CU, and the staged box covers 1.5x its sites instead of 1.8x (PMC: the 64 x 16 tiles read the image 2.0 times,
+// nothing is shared between neighbouring tiles through the L2s: they drift apart in their chunk loops).  Measured
+// 1698 us against 1132 us (8 x 64 x 720 x 1280): two independent workgroups cover each other's barriers, one of eight
+// waves stalls the whole CU at every one of them -- the box traffic is not what binds this kernel.
+template <int SW, int NT = 256>                // SW 0: one tile column per XCD strip; 2 / 4: stripes SW tile columns wide
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
     float *__restrict__ out)
 {
     constexpr int LX = 16;
-    using G = TileGeom<LX>;
+    constexpr int CAP = NT == 256 ? 3072 : 3584;
+    using G = TileGeom<LX, CAP, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
@@ -229,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void fi_fwd_tiled_c4n(
             rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
         }
     }
-    const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
-    const Bands bands = make_bands<LX>(box);
+    const BBox box = tile_bbox<LX, NT>(cmin, cmax, rmin, rmax, bb);
+    const Bands bands = make_bands<LX, true, CAP>(box);
     const float *in_b = in1 + b * s1b;
     float *out_p = out + b * s1b + (int64_t)y * s1h + x;
     unsigned done = 0;
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void fi_fwd_tiled_c4n(
         done |= sel;
         // band 0 also writes the out-of-range sites (they copy the input pixel)
         const unsigned wr = sel | (bi == 0 && inb ? ~g.valid & 0xFu : 0u);
-        const StageSlot sl = stage_slots(r);
+        const StageSlot sl = stage_slots<NT>(r);
         StageRegs<4> sr;
         tile_stage_load<4>(r, sl, in_b, s1c, s1h, sr);
 #pragma unroll 1
@@ -1604,13 +1610,17 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, \
                            s3h, input1, input2, input3, output);                                           \
     } while (0)
-#define MEMC_FI_C4N(SW)                                                                                        \
+#define MEMC_FI_C4N(SW) MEMC_FI_C4N_NT(SW, 256)
+#define MEMC_FI_C4N_NT(SW, NT)                                                                             \
     do {                                                                                                   \
-        using G = TileGeom<16>;                                                                            \
+        using G = TileGeom<16, (NT == 256 ? 3072 : 3584), NT>;                                             \
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                        \
-        hipLaunchKernelGGL(fi_fwd_tiled_c4n<SW>, dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) *  \
-                                                              (SW ? SW : 1)) * nty * batch),                \
-                           dim3(256), tile_lds_bytes<16>(), stream, w, h, channel, ntx, nty, (int64_t)s1b,    \
+        const int lds = G::kCapPx * 16 + 4 * 4 * (NT / 64);                                                \
+        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT>, lds), true);                     \
+        (void)once;                                                                                        \
+        hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
+                                                                    (SW ? SW : 1)) * nty * batch),          \
+                           dim3(NT), lds, stream, w, h, channel, ntx, nty, (int64_t)s1b,                   \
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c,    \
                            s3h, input1, input2, input3, output);                                           \
     } while (0)
@@ -1689,6 +1699,8 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             MEMC_FI_C4N(2);
         } else if (variant == 31 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N(4);
+        } else if (variant == 32 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N_NT(0, 512);                        // 64 x 32 tiles, 512 lanes
         } else {
             handled = false;
         }
@@ -1724,6 +1736,7 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
     else MEMC_FI_FWD_LAUNCH(0, 4);
 #undef MEMC_FI_FWD_LAUNCH
 #undef MEMC_FI_C4N
+#undef MEMC_FI_C4N_NT
 #undef MEMC_FI_TILED
 #undef MEMC_FI_TILED_A
     return launch_status();

@@ -109,9 +109,9 @@ inline bool vec4_ok(int w, std::initializer_list<long> strides, std::initializer
 // Tile geometry: 256 threads, LX lanes per tile row, 4 sites per lane.
 // CAP: the LDS budget in pixel quads.  3072 px * 16 B = 48 KiB -> 3 workgroups per CU (the 4x4-window kernels, whose
 // boxes need it); the 2x2-footprint kernels stage smaller boxes and trade budget for workgroups per CU.
-template <int LX, int CAP = 3072>
+template <int LX, int CAP = 3072, int NT = 256>
 struct TileGeom {
-    static constexpr int kThreads = 256;
+    static constexpr int kThreads = NT;                // 256: 64 x 16 tiles; 512: 64 x 32 (less box halo per site)
     static constexpr int kTW = 4 * LX;                 // tile width  (sites)
     static constexpr int kTH = kThreads / LX;          // tile height (sites)
     static constexpr int kPitch = kTW + 32;            // LDS row pitch in pixels; multiple of 16 (swizzle span)
@@ -235,10 +235,10 @@ struct Bands {
 };
 
 // Workgroup-wide box of the lanes' boxes (DPP / readlane reduction + one barrier), not clipped.
-template <int LX>
-__device__ __forceinline__ BBox tile_bbox(int cmin, int cmax, int rmin, int rmax, int *bb /* 16 ints in LDS */)
+template <int LX, int NT = 256>
+__device__ __forceinline__ BBox tile_bbox(int cmin, int cmax, int rmin, int rmax, int *bb /* 4 ints per wave in LDS */)
 {
-    using G = TileGeom<LX>;
+    using G = TileGeom<LX, 3072, NT>;
     cmin = wave_min_i32(cmin);
     cmax = -wave_min_i32(-cmax);
     rmin = wave_min_i32(rmin);
@@ -277,10 +277,10 @@ __device__ __forceinline__ BBox tile_bbox(int cmin, int cmax, int rmin, int rmax
 }
 
 // DYN = false: fixed 96 x 32 geometry (kernels whose accumulator planes have a compile-time pitch)
-template <int LX, bool DYN = true>
+template <int LX, bool DYN = true, int CAP = 3072>
 __device__ __forceinline__ Bands make_bands(const BBox &b)
 {
-    using G = TileGeom<LX>;
+    using G = TileGeom<LX, CAP>;
     Bands d;
     d.bw = min(b.w, G::kPitch);
     d.pitch = DYN ? max((d.bw + 15) & ~15, 16) : G::kPitch;
@@ -316,13 +316,14 @@ struct StageSlot {
     int row[kStageIts], q[kStageIts];      // q = float4 column; row >= r.h marks an empty slot
 };
 
+template <int NT = 256>
 __device__ __forceinline__ StageSlot stage_slots(const Region &r)
 {
     StageSlot s;
     const int wq = max(r.w >> 2, 1);
     const unsigned tid = tid_now();
     int row = tid / wq, q = tid % wq;          // one run-time division per kernel
-    const int drow = 256 / wq, dq = 256 % wq;
+    const int drow = NT / wq, dq = NT % wq;
 #pragma unroll
     for (int it = 0; it < kStageIts; it++) {
         s.row[it] = r.w > 0 ? row : r.h;
