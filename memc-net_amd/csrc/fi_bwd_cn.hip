@@ -27,7 +27,7 @@
 //                       need not zero-fill it.
 //
 // Sites whose window leaves the owner's search window (kOwnRX / kOwnRY site tiles around the site's own tile: motion
-// beyond ~128 px horizontally or ~64 px vertically) are "far": every owner skips them and a third kernel,
+// beyond ~192 px horizontally or ~64 px vertically) are "far": every owner skips them and a third kernel,
 // fi_bwd_far_sites, adds their image gradient with global atomics after the owners have stored theirs (kernel A
 // flags the site tiles that have any; the kernel's other workgroups exit at once).
 #include "memc_common.hpp"
@@ -38,7 +38,7 @@
 
 namespace memc {
 
-constexpr int kOwnRX = 2, kOwnRY = 4;          // owner search window, in site tiles of 64 x 16
+constexpr int kOwnRX = 3, kOwnRY = 4;          // owner search window, in site tiles of 64 x 16 (7 x 9 = 63 candidates: one wave)
 constexpr int kTileHasFar = 1 << 30;           // in BBox::h of a site tile's target box: some of its sites are far
 
 // The two window shapes the owner kernel serves.  Tap (k, m), k, m < kN, of a site with integer target (ix, iy) lands on

@@ -101,9 +101,9 @@ def _many_channel_flows(kind, rng, B, H, W):
         f[:, 0] += -min(100.25, 0.4 * W)
         f[:, 1] += min(9.5, 0.3 * H)
         return f
-    if kind == "far":                          # beyond the owners' search window (> 2 tile columns): global atomics
+    if kind == "far":                          # beyond the owners' search window (> 3 tile columns): global atomics
         f = synth.np_flow(rng, B, H, W, "smooth", 2.0)
-        f[:, 0, :, W // 2:] -= 170.0
+        f[:, 0, :, W // 2:] -= 0.47 * W                    # (still valid: |flow| < W / 2)
         return f
     if kind == "converge":                     # every site lands near one point: lists far beyond the LDS budget
         f = np.empty((B, 2, H, W), np.float32)
@@ -115,7 +115,7 @@ def _many_channel_flows(kind, rng, B, H, W):
     raise ValueError(kind)
 
 
-MANY = [(2, 8, 70, 200, "smooth"), (1, 16, 96, 384, "pan"), (1, 8, 48, 448, "far"), (1, 8, 64, 192, "converge"),
+MANY = [(2, 8, 70, 200, "smooth"), (1, 16, 96, 384, "pan"), (1, 8, 48, 512, "far"), (1, 8, 64, 192, "converge"),
         (1, 12, 80, 256, "iid"), (1, 64, 36, 132, "smooth"),
         (1, 8, 20, 50, "smooth"),          # width not a multiple of 4: cleared, then the direct kernel
         (1, 8, 5, 12, "smooth"), (1, 8, 16, 64, "iid"), (3, 8, 33, 68, "pan"),      # tiny, exactly one tile, ragged
