@@ -556,6 +556,50 @@ def test_stream_capture_and_replay(oracle):
     close(N(pout), oracle.flow_projection_forward(d["flow"], 1)[0], "captured projection")
 
 
+def test_many_channel_backward_on_strided_views(oracle):
+    """The owner kernels index every tensor through its own batch / channel / row strides: channel slices of wider
+    tensors, rows of wider images (16-byte aligned, so still the vector path), all strides different."""
+    import my_package._ext.my_lib as my_lib
+    from tools import measure as M
+    B, C, H, W = 2, 8, 40, 128
+    rng = np.random.default_rng(91)
+    xn, kn, gn = synth.np_image(rng, B, C, H, W), synth.np_filter(rng, B, H, W), synth.np_image(rng, B, C, H, W)
+    fn = synth.np_flow(rng, B, H, W, "smooth", 5.0)
+
+    def wide(a, cpad, wpad, fill=7.0):
+        """a copy of `a` living inside a tensor with cpad extra channels in front and wpad extra columns behind"""
+        big = torch.full((a.shape[0], a.shape[1] + cpad, a.shape[2], a.shape[3] + wpad), fill, device=dev())
+        v = big[:, cpad:, :, :a.shape[3]]
+        v.copy_(T(a))
+        return big, v
+    _, x = wide(xn, 2, 4)
+    _, f = wide(fn, 1, 8)
+    _, k = wide(kn, 3, 12)
+    g = wide(gn, 2, 4)[1]                                   # gradoutput shares input1's strides (the contract)
+    b1, g1 = wide(np.zeros_like(xn), 2, 4)
+    b2, g2 = wide(np.zeros_like(fn), 1, 8)
+    b3, g3 = wide(np.zeros_like(kn), 3, 12)
+    assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+    w1, w2, w3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+    close(N(g1), w1, "strided gradinput1", 3 * RTOL)
+    close(N(g2), w2, "strided gradinput2", RTOL)
+    close(N(g3), w3, "strided gradinput3", RTOL)
+    for big in (b1, b2, b3):                                # nothing written outside the views
+        assert float(big[:, 0].min()) == 7.0 and float(big[..., -1].min()) == 7.0
+    h1, h2 = wide(np.zeros_like(xn), 2, 4)[1], wide(np.zeros_like(fn), 1, 8)[1]
+    assert my_lib.InterpolationChLayer_gpu_backward(x, f, g, h1, h2) == 0
+    v1, v2 = oracle.interpolation_ch_backward(xn, fn, gn)
+    close(N(h1), v1, "strided bilinear gradinput1", 3 * RTOL)
+    close(N(h2), v2, "strided bilinear gradinput2", 3 * RTOL)
+    # and they really took the owner path
+    ml = M.bound()
+    import ctypes
+    last = M.lib().memc_debug_last_path
+    last.restype = ctypes.c_char_p
+    assert ml.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0 and last().decode() == "fi_bwd:owner"
+    assert ml.InterpolationChLayer_gpu_backward(x, f, g, h1, h2) == 0 and last().decode() == "bl_bwd:owner"
+
+
 def test_stream_capture_many_channel_backward(oracle):
     """Inside a stream capture nothing may be allocated: the many-channel backward passes then clear gradinput1 themselves
     and take the direct kernels -- same gradients, replayable, still independent of what the buffers held."""
