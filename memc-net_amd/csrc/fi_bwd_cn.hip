@@ -77,6 +77,33 @@ __device__ __forceinline__ bool fi_site_far(int x, int y, int ix, int iy, int W,
     return site_far<FpFilter>(x, y, ix, iy, W, H);
 }
 
+// What the owners cull by: the target bounding box of every 64 x 4 STRIP of sites (one wave of a producer's site tile:
+// 16 lanes x 4 sites per row, 4 rows), four per site tile; tbox[(tile * 4 + strip)].  BBox::h of a tile's strip 0 also
+// carries kTileHasFar.  A lane passes the box of its own near sites (or an empty one); one wave-level reduction, no
+// barrier.
+__device__ __forceinline__ void strip_box_store(BBox *tbox, int64_t tile, int cmin, int cmax, int rmin, int rmax,
+                                                bool tile_has_far)
+{
+    cmin = wave_min_i32(cmin);
+    cmax = -wave_min_i32(-cmax);
+    rmin = wave_min_i32(rmin);
+    rmax = -wave_min_i32(-rmax);
+    const unsigned tid = threadIdx.x;
+    if ((tid & 63) == 0) {
+        BBox bx;
+        if (cmin > cmax) {
+            bx.x0 = bx.y0 = bx.w = bx.h = 0;
+        } else {
+            bx.x0 = cmin & ~3;
+            bx.w = (cmax | 3) + 1 - bx.x0;
+            bx.y0 = rmin;
+            bx.h = rmax + 1 - rmin;
+        }
+        if (tid == 0 && tile_has_far) bx.h |= kTileHasFar;
+        tbox[tile * 4 + (tid >> 6)] = bx;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Rare paths, one site at a time from global memory.
 // ---------------------------------------------------------------------------------------------------------
@@ -205,10 +232,10 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
         }
     }
     const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
-    BBox near_box = tile_bbox<LX>(ncmin, ncmax, nrmin, nrmax, bb + 16);
-    // h's bit 30: the tile has far sites (fi_bwd_far_sites adds their image gradient after the owners have stored)
-    if (__syncthreads_or(far != 0)) near_box.h |= kTileHasFar;
-    if (tid == 0) tbox[((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx] = near_box;
+    // the strips' target boxes; h's bit 30 of strip 0: the tile has far sites (fi_bwd_far_sites adds their image gradient
+    // after the owners have stored)
+    strip_box_store(tbox, ((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx, ncmin, ncmax, nrmin, nrmax,
+                    __syncthreads_or(far != 0) != 0);
     const Bands bands = make_bands<LX>(box);
     const float *in_b = in1 + b * s1b;
 
@@ -320,7 +347,7 @@ __global__ __launch_bounds__(256) void fi_bwd_far_sites(
     float *__restrict__ gin1, const BBox *__restrict__ tbox)
 {
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
-    if (!(tbox[((int64_t)tc.b * tiles_y + tc.ty) * tiles_x + tc.tx].h & kTileHasFar)) return;
+    if (!(tbox[(((int64_t)tc.b * tiles_y + tc.ty) * tiles_x + tc.tx) * 4].h & kTileHasFar)) return;
     const int x0 = tc.tx * 64 + 4 * (int)(threadIdx.x % 16), y = tc.ty * 16 + (int)(threadIdx.x / 16);
     if (x0 >= W || y >= H) return;
     const float *flow_p = flow + tc.b * s2b + (int64_t)y * s2h + x0;
@@ -387,8 +414,7 @@ struct OwnGeom {
 };
 
 struct OwnCtl {                                // control words in LDS
-    int cand[64];                              // candidate site tiles: tx | ty << 16
-    int ncand;
+    int ncand;                                 // candidate site strips (their list lives in the tail-offset area)
     int ax0, ax1, ay0, ay1;                    // box of the contributing sites
     unsigned wave_sum[8], wave_sum2[8];
 };
@@ -425,7 +451,8 @@ __device__ __forceinline__ QuadHits own_quad_hits(int x, int y, int W, int H, in
     return h;
 }
 
-// oc[cell] += 1 << 16 and pres[cell] |= 1 << tap index for every tap of the quad that lands on the tile
+// pres[cell] |= 1 << tap index for every tap of the quad that lands on the tile; oc[cell] += 1 << 16 for those whose
+// index was already there (the cell's tail length)
 template <class FP>
 __device__ __forceinline__ void own_count(const QuadHits &h, unsigned *oc, unsigned *pres, int W, int H, int tx0,
                                           int ty0)
@@ -441,8 +468,9 @@ __device__ __forceinline__ void own_count(const QuadHits &h, unsigned *oc, unsig
             for (int m = 0; m < FP::kN; m++)
                 if ((h.colm[j] >> m) & 1) {
                     const int ci = rc + clampi(h.ix[j] + FP::kOff + m, W - 1);
-                    atomicAdd(oc + ci, 0x10000u);
-                    atomicOr(pres + ci, 1u << (k * FP::kN + m));     // which tap indices the cell receives
+                    // the first tap of this index at the cell will get the head slot; every further one is tail
+                    const unsigned bit = 1u << (k * FP::kN + m);
+                    if (atomicOr(pres + ci, bit) & bit) atomicAdd(oc + ci, 0x10000u);
                 }
         }
     }
@@ -531,22 +559,37 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
         }
     };
 
-    // 1. candidate site tiles: those of the search window whose target box reaches this cell tile
-    if (tid < 64) {
-        const int dx = (int)tid % (2 * kOwnRX + 1) - kOwnRX, dy = (int)tid / (2 * kOwnRX + 1) - kOwnRY;
+    // 1. candidate site strips (64 x 4 sites, four per site tile): those of the search window whose target box reaches
+    //    this cell tile.  One lane per strip; the list (tx | ty << 12 | strip << 28) lives where the tail offsets will.
+    int *cand = reinterpret_cast<int *>(toff);
+    static_assert(kOwnCand * 4 <= 256 && kOwnCand * 4 * 4 <= 64 * TH * 2, "one lane per strip; the list fits the toff area");
+    if (tid < 256) {
+        const int tile_i = (int)tid >> 2, strip = (int)tid & 3;
+        const int dx = tile_i % (2 * kOwnRX + 1) - kOwnRX, dy = tile_i / (2 * kOwnRX + 1) - kOwnRY;
         const int sx = tc.tx + dx, sy = (ty0 >> 4) + dy;   // site tiles are 64 x 16; site_tiles_y of them per image
         bool hit = false;
-        if ((int)tid < kOwnCand && sx >= 0 && sx < tiles_x && sy >= 0 && sy < site_tiles_y) {
-            BBox bx = tbox[((int64_t)b * site_tiles_y + sy) * tiles_x + sx];
+        if (tile_i < kOwnCand && sx >= 0 && sx < tiles_x && sy >= 0 && sy < site_tiles_y) {
+            BBox bx = tbox[(((int64_t)b * site_tiles_y + sy) * tiles_x + sx) * 4 + strip];
             bx.h &= ~kTileHasFar;
             hit = bx.w > 0 && bx.x0 < tx0 + 64 && bx.x0 + bx.w > tx0 && bx.y0 < ty0 + TH && bx.y0 + bx.h > ty0;
         }
         const unsigned long long m = __ballot(hit);
-        if (hit) ctl->cand[__popcll(m & ((1ull << tid) - 1ull))] = sx | (sy << 16);
+        if ((tid & 63) == 0) ctl->wave_sum[tid >> 6] = (unsigned)__popcll(m);
+        // ranks inside the wave now, the waves' offsets after the barrier
+        const int rank = __popcll(m & ((1ull << (tid & 63)) - 1ull));
+        const int word = sx | (sy << 12) | (strip << 28);
+        __syncthreads();
+        if (hit) {
+            int base = 0;
+            for (int w = 0; w < (int)(tid >> 6); w++) base += (int)ctl->wave_sum[w];
+            cand[base + rank] = word;
+        }
         if (tid == 0) {
-            ctl->ncand = __popcll(m);
+            ctl->ncand = (int)(ctl->wave_sum[0] + ctl->wave_sum[1] + ctl->wave_sum[2] + ctl->wave_sum[3]);
             ctl->ax0 = INT_MAX;  ctl->ax1 = -1;  ctl->ay0 = INT_MAX;  ctl->ay1 = -1;
         }
+    } else {
+        __syncthreads();
     }
     oc[tid] = 0;
     oc[tid + kOwnThreads] = 0;
@@ -564,11 +607,11 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
     // 2. counts and the box of the contributing sites (flow only)
     {
         int bx0 = INT_MAX, bx1 = -1, by0 = INT_MAX, by1 = -1;
-        const int nq = ncand * 256;
+        const int nq = ncand * 64;                         // 64 quads per strip
 #pragma unroll 2
         for (int idx = tid; idx < nq; idx += kOwnThreads) {
-            const int t = ctl->cand[idx >> 8], q = idx & 255;
-            const int x = (t & 0xffff) * 64 + 4 * (q & 15), y = (t >> 16) * 16 + (q >> 4);
+            const int t = cand[idx >> 6], q = idx & 63;
+            const int x = (t & 0xfff) * 64 + 4 * (q & 15), y = ((t >> 12) & 0xffff) * 16 + ((t >> 28) & 3) * 4 + (q >> 4);
             if (x >= W || y >= H) continue;
             const float *fp = flow_b + (int64_t)y * s2h + x;
             const QuadHits h = own_quad_hits<FP, TH>(x, y, W, H, tx0, ty0, ld_cached4(fp), ld_cached4(fp + s2c));
@@ -627,9 +670,8 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
         // 3a. tails: lengths beyond the head table, their exclusive scan (CSR offsets) and their segments.  This lane's
         //     cells are tid and tid + 512 from here on.  Tails that do not fit: the slab is halved and counted again.
         const unsigned w0 = oc[tid], w1 = oc[tid + kOwnThreads];
-        const int n0 = (int)(w0 >> 16), n1 = (int)(w1 >> 16);
-        // heads are indexed by tap: one entry per tap index the cell receives; every further one is tail
-        const int tl0 = n0 - __popc(pres[tid]), tl1 = n1 - __popc(pres[tid + kOwnThreads]);
+        // heads are indexed by tap: one entry per tap index the cell receives; the counts are of the further ones (tails)
+        const int tl0 = (int)(w0 >> 16), tl1 = (int)(w1 >> 16);
         const int ns0 = (tl0 + kSegLen - 1) / kSegLen, ns1 = (tl1 + kSegLen - 1) / kSegLen;
         unsigned toff0, sb0, nseg_total;
         bool serial_tails;
@@ -1016,9 +1058,8 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
         }
     }
     const Region r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
-    BBox near_box = tile_bbox<LX>(ncmin, ncmax, nrmin, nrmax, bb + 16);
-    if (__syncthreads_or(far != 0)) near_box.h |= kTileHasFar;
-    if (threadIdx.x == 0) tbox[((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx] = near_box;
+    strip_box_store(tbox, ((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx, ncmin, ncmax, nrmin, nrmax,
+                    __syncthreads_or(far != 0) != 0);
 
     int oTL[4], oTR[4], oBL[4], oBR[4];
     unsigned valid = 0, staged = 0;
@@ -1113,7 +1154,7 @@ __global__ __launch_bounds__(256) void bl_bwd_far_sites(
     const BBox *__restrict__ tbox)
 {
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
-    if (!(tbox[((int64_t)tc.b * tiles_y + tc.ty) * tiles_x + tc.tx].h & kTileHasFar)) return;
+    if (!(tbox[(((int64_t)tc.b * tiles_y + tc.ty) * tiles_x + tc.tx) * 4].h & kTileHasFar)) return;
     const int x0 = tc.tx * 64 + 4 * (int)(threadIdx.x % 16), y = tc.ty * 16 + (int)(threadIdx.x / 16);
     if (x0 >= W || y >= H) return;
     const float *flow_p = flow + tc.b * s2b + (int64_t)y * s2h + x0;
@@ -1154,8 +1195,8 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
         !vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
                  {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3}) ||
         4LL * (3LL * s1c + (long long)(h - 1) * s1h + w) >= (1LL << 32) ||           // the owner's 4-plane offsets
-        ntx > 0xffff || nty > 0x7fff ||
-        !scratch.alloc((size_t)ntiles * sizeof(BBox), stream)) {                     // e.g. inside a stream capture
+        ntx > 0xfff || nty > 0x7fff ||
+        !scratch.alloc((size_t)ntiles * 4 * sizeof(BBox), stream)) {                 // e.g. inside a stream capture
         hipLaunchKernelGGL(fi_bwd_zero_rows, dim3((unsigned)batch * channel * h), dim3(256), 0, stream, gradinput1, w, h,
                            channel, (int64_t)s1b, (int64_t)s1c, s1h);
         return launch_status() == 0 ? 0 : -1;
@@ -1201,8 +1242,8 @@ int bl_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
     CallScratch scratch;                                   // the site tiles' target boxes
     if (force_direct || !plane_fits_u32(w, h, {s1h, s2h}) ||
         !vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2}) ||
-        4LL * (3LL * s1c + (long long)(h - 1) * s1h + w) >= (1LL << 32) || ntx > 0xffff || nty > 0x7fff ||
-        !scratch.alloc((size_t)ntiles * sizeof(BBox), stream)) {
+        4LL * (3LL * s1c + (long long)(h - 1) * s1h + w) >= (1LL << 32) || ntx > 0xfff || nty > 0x7fff ||
+        !scratch.alloc((size_t)ntiles * 4 * sizeof(BBox), stream)) {
         hipLaunchKernelGGL(fi_bwd_zero_rows, dim3((unsigned)batch * channel * h), dim3(256), 0, stream, gradinput1, w, h,
                            channel, (int64_t)s1b, (int64_t)s1c, s1h);
         return launch_status() == 0 ? 0 : -1;

@@ -69,7 +69,7 @@ def fi_bwd_cn():
              14: "  replay: barrier (segment sums)", 15: "  replay: sums, transpose, store, barrier"}
     for i, nm in names.items():
         print("%-28s %6.1f%%  %10.0f" % (nm, 100 * ts[:, i].mean() / tot, ts[:, i].mean()))
-    print("slab rounds per tile: mean %.2f max %d; candidates mean %.1f; longest list (wave 0, last slab) mean %.1f max %d; "
+    print("slab rounds per tile: mean %.2f max %d; candidate strips (64 x 4 sites) mean %.1f; longest list (wave 0, last slab) mean %.1f max %d; "
           "site box mean %.0f max %d" % (ts[:, 7].mean(), ts[:, 7].max(), ts[:, 8].mean(), ts[:, 9].mean(), ts[:, 9].max(),
                                          ts[:, 10].mean(), ts[:, 10].max()))
 
