@@ -16,11 +16,13 @@
 //
 //   fi_bwd_taps_c4n    (site tiles, 64 x 16, the forward c4n pipeline: chunks of four channels staged into LDS pixel
 //                       quads while the previous chunk is consumed) accumulates S in registers -- 4 FMAs per LDS
-//                       read -- and writes gradinput3 / gradinput2 (assigned) plus the tile's target bounding box;
-//   fi_bwd_image_owner (CELL tiles, 64 x 16, owner-computes) finds the site tiles whose boxes reach its cells, turns
-//                       their taps into a CSR list per cell in LDS (count -> scan -> fill, LDS integer atomics only),
-//                       then per chunk of four channels stages gradoutput of the contributing sites into LDS and
-//                       every cell replays its list: one ds_read_b128 + 4 FMAs per entry.  The result is STORED to
+//                       read -- and writes gradinput3 / gradinput2 (assigned) plus the target bounding boxes of the
+//                       tile's four 64 x 4 strips of sites;
+//   fi_bwd_image_owner (CELL tiles, 64 x 16, owner-computes) finds the site strips whose boxes reach its cells, turns
+//                       their taps into a list per cell in LDS (a head table indexed by tap + a CSR tail; LDS integer
+//                       atomics only), keeps the lists in registers, then per chunk of four channels stages
+//                       gradoutput of the contributing sites into LDS and every cell replays its list: one
+//                       ds_read_b128 + 4 FMAs per entry.  The result is STORED to
 //                       gradinput1 with plain 16-byte stores: no global atomics, no read-modify-write, each cell
 //                       written by exactly one workgroup.  For this class of channel counts gradinput1 is stored on
 //                       EVERY path (the launcher clears it before falling back to the direct kernel), so a caller
@@ -38,7 +40,7 @@
 
 namespace memc {
 
-constexpr int kOwnRX = 3, kOwnRY = 4;          // owner search window, in site tiles of 64 x 16 (7 x 9 = 63 candidates: one wave)
+constexpr int kOwnRX = 3, kOwnRY = 4;          // owner search window, in site tiles of 64 x 16: 7 x 9 tiles, 252 strips
 constexpr int kTileHasFar = 1 << 30;           // in BBox::h of a site tile's target box: some of its sites are far
 
 // The two window shapes the owner kernel serves.  Tap (k, m), k, m < kN, of a site with integer target (ix, iy) lands on
