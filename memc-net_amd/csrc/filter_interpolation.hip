@@ -191,7 +191,9 @@ __device__ __forceinline__ void fi_fwd_chunk(
 // nothing is shared between neighbouring tiles through the L2s: they drift apart in their chunk loops).  Measured
 // 1698 us against 1132 us (8 x 64 x 720 x 1280): two independent workgroups cover each other's barriers, one of eight
 // waves stalls the whole CU at every one of them -- the box traffic is not what binds this kernel.
-template <int SW, int NT = 256>                // SW 0: one tile column per XCD strip; 2 / 4: stripes SW tile columns wide
+// RAGGED: any channel count >= 4 -- the last chunk re-reads the last plane for the channels it does not have and does not
+// store them (a separate instantiation: the C % 4 == 0 kernel, at 239 registers, is left exactly as it was).
+template <int SW, int NT = 256, bool RAGGED = false>       // SW 0: one tile column per XCD strip; 2 / 4: stripes
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
@@ -251,7 +253,21 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
         const unsigned wr = sel | (bi == 0 && inb ? ~g.valid & 0xFu : 0u);
         const StageSlot sl = stage_slots<NT>(r);
         StageRegs<4> sr;
-        tile_stage_load<4>(r, sl, in_b, s1c, s1h, sr);
+        auto stage_load = [&](int cb) {
+            if (!RAGGED) {
+                tile_stage_load<4>(r, sl, in_b + cb * s1c, s1c, s1h, sr);
+            } else {                                       // planes past the last one: the last one again
+                const float *plane[4];
+                int hs[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    plane[c] = in_b + min(cb + c, C - 1) * s1c;
+                    hs[c] = s1h;
+                }
+                tile_stage_load_planes<4>(r, sl, plane, hs, sr);
+            }
+        };
+        stage_load(0);
 #pragma unroll 1
         for (int c0 = 0; c0 < C; c0 += 4) {
             tile_stage_store<4>(r, sl, sr, tile);
@@ -259,7 +275,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
             // next chunk's rows: in flight while this chunk is gathered (the last iteration re-reads its own
             // chunk -- harmless, keeps the loads unconditional)
             const int cn = c0 + 4 < C ? c0 + 4 : c0;
-            tile_stage_load<4>(r, sl, in_b + cn * s1c, s1c, s1h, sr);
+            stage_load(cn);
             // keep the loop-invariant tap splats / LDS addresses inside the loop (see fi_fwd_tiled_fs4)
 #pragma unroll
             for (int k = 0; k < 16; k++)
@@ -275,6 +291,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
             if (wr & ~g.valid) {                           // out-of-range sites copy the input pixel
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
+                    if (RAGGED && c0 + c >= C) continue;
                     const f32x4 own = ld_cached4(plane0 + c * s1c + (int64_t)y * s1h + x);
 #pragma unroll
                     for (int j = 0; j < 4; j++)
@@ -283,13 +300,15 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
             }
             if (wr == 0xFu) {
 #pragma unroll
-                for (int c = 0; c < 4; c++) st_stream4(o + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
+                for (int c = 0; c < 4; c++)
+                    if (!RAGGED || c0 + c < C) st_stream4(o + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
             } else if (wr) {                               // a lane whose sites are split over bands
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if ((wr >> j) & 1) {
 #pragma unroll
-                        for (int c = 0; c < 4; c++) o[c * s1c + j] = res[j][c];
+                        for (int c = 0; c < 4; c++)
+                            if (!RAGGED || c0 + c < C) o[c * s1c + j] = res[j][c];
                     }
             }
             __syncthreads();
@@ -1610,15 +1629,15 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, \
                            s3h, input1, input2, input3, output);                                           \
     } while (0)
-#define MEMC_FI_C4N(SW) MEMC_FI_C4N_NT(SW, 256)
-#define MEMC_FI_C4N_NT(SW, NT)                                                                             \
+#define MEMC_FI_C4N(SW) MEMC_FI_C4N_NT(SW, 256, false)
+#define MEMC_FI_C4N_NT(SW, NT, RAG)                                                                             \
     do {                                                                                                   \
         using G = TileGeom<16, (NT == 256 ? 3072 : 3584), NT>;                                             \
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                        \
         const int lds = G::kCapPx * 16 + 4 * 4 * (NT / 64);                                                \
-        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT>, lds), true);                     \
+        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG>, lds), true);                     \
         (void)once;                                                                                        \
-        hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
+        hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT, RAG>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
                                                                     (SW ? SW : 1)) * nty * batch),          \
                            dim3(NT), lds, stream, w, h, channel, ntx, nty, (int64_t)s1b,                   \
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c,    \
@@ -1700,7 +1719,7 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
         } else if (variant == 31 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N(4);
         } else if (variant == 32 && channel % 4 == 0 && channel >= 8) {
-            MEMC_FI_C4N_NT(0, 512);                        // 64 x 32 tiles, 512 lanes
+            MEMC_FI_C4N_NT(0, 512, false);                 // 64 x 32 tiles, 512 lanes
         } else {
             handled = false;
         }
@@ -1715,6 +1734,9 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
         } else if (channel == 3) {                                     // default: 64x16 tiles, strip walk
             MEMC_PATH("fi_fwd:tiled_c3");
             MEMC_FI_TILED(16, 3, 2);
+        } else if (channel >= 4) {                                     // any other count from four up: the same pipeline,
+            MEMC_PATH("fi_fwd:tiled_c4n_ragged");                      // ragged last chunk
+            MEMC_FI_C4N_NT(0, 256, true);
         } else {
             MEMC_PATH("fi_fwd:tiled_chunks");
             MEMC_FI_TILED(16, 0, 2);
