@@ -556,6 +556,33 @@ def test_stream_capture_and_replay(oracle):
     close(N(pout), oracle.flow_projection_forward(d["flow"], 1)[0], "captured projection")
 
 
+def test_many_channel_backward_random_shapes(oracle):
+    """Twelve seeded random shapes (batch, channels 4..13, ragged heights / widths -- multiples of four and not --,
+    five flow kinds): both many-channel backward passes against the oracle, from garbage-filled buffers."""
+    import my_package._ext.my_lib as my_lib
+    rng = np.random.default_rng(20260927)
+    kinds = ["smooth", "pan", "far", "converge", "iid"]
+    for _ in range(12):
+        B, C = int(rng.integers(1, 3)), int(rng.integers(4, 14))
+        H, W = int(rng.integers(5, 90)), int(rng.integers(3, 60)) * 4 + (int(rng.integers(0, 4)) if rng.random() < 0.25 else 0)
+        kind = kinds[int(rng.integers(0, len(kinds)))]
+        xn, kn, gn = synth.np_image(rng, B, C, H, W), synth.np_filter(rng, B, H, W), synth.np_image(rng, B, C, H, W)
+        fn = _many_channel_flows(kind, rng, B, H, W)
+        what = "%dx%dx%dx%d %s" % (B, C, H, W, kind)
+        x, f, k, g = T(xn), T(fn), T(kn), T(gn)
+        g1, g2, g3 = torch.full_like(x, -3.0), torch.full_like(f, -3.0), torch.full_like(k, -3.0)
+        assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+        w1, w2, w3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+        close(N(g1), w1, "gradinput1 " + what, 3 * RTOL)
+        close(N(g2), w2, "gradinput2 " + what, 3 * RTOL)
+        close(N(g3), w3, "gradinput3 " + what, 3 * RTOL)
+        h1, h2 = torch.full_like(x, -3.0), torch.full_like(f, -3.0)
+        assert my_lib.InterpolationChLayer_gpu_backward(x, f, g, h1, h2) == 0
+        v1, v2 = oracle.interpolation_ch_backward(xn, fn, gn)
+        close(N(h1), v1, "bilinear gradinput1 " + what, 3 * RTOL)
+        close(N(h2), v2, "bilinear gradinput2 " + what, 3 * RTOL)
+
+
 def test_many_channel_backward_on_strided_views(oracle):
     """The owner kernels index every tensor through its own batch / channel / row strides: channel slices of wider
     tensors, rows of wider images (16-byte aligned, so still the vector path), all strides different."""
