@@ -407,6 +407,330 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_tiled_c3_persistent(
     }   // tiles
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 3: the image gradient in ONE LDS round instead of three.
+//
+// What the round-1/2 kernel (fi_bwd_tiled_c3, now a measurement arm) spends after its HBM-bound phase 1 is LDS
+// atomic work: 48 ds_add_f64 per site (16 taps x 3 colours) into ONE fp64 plane that the colours take in turn --
+// adds, barrier, flush, barrier, three times.  ds_add_f32 is an emulated path on this chip (0.33 lane-ops/clk/CU),
+// 64-bit integer adds are the fastest LDS atomic there is (9.0; ds_add_f64: 6.7), so the three colours of a
+// contribution are accumulated as 23-bit fixed-point numbers packed into TWO 64-bit words per cell:
+//
+//     word A = n0 * 2^26 + (n2 >> 11)            word B = n1 * 2^26 + (n2 & 2047)
+//
+// with n_c = round(g_c * wq * tap * 2^(22 - e)), |n_c| <= 2^22, where 2^e bounds every contribution of the TILE:
+// 2^e > (the tile's largest |gradoutput|) x (its largest |tap|), by less than a factor two (the bilinear weights
+// are <= 1).  Integer adds are exact and associative: a cell's sums come out bit-identical whatever order the LDS
+// retires them in (the reference's fp32 atomics do not), scaling the inputs by a power of two scales the result by
+// exactly that power, and nothing can overflow -- one site puts at most 9 of its 16 taps into one cell (the image
+// corner, where the clamp folds 3 x 3 window positions), so a tile adds at most 1024 x 9 < 2^14 numbers to a cell:
+// |sum n0| < 2^36 (word A holds 38 signed bits above bit 26), |sum (n2 >> 11)| < 2^25 (26-bit signed field),
+// sum (n2 & 2047) < 2^25 (26-bit unsigned field).  Every contribution is rounded once, to a multiple of 2^(e - 22)
+// <= 2^-21 x (the tile's largest possible contribution) -- about fp32's own resolution of that largest contribution;
+// a cell's error is at most (its number of contributions) x 2^(e - 23).  32 adds per site instead of 48, both planes
+// flushed in one pass: one round of adds / barrier / flush.
+// A tile whose gradoutput or taps are not all finite takes per-site global atomics instead (NaN / Inf then land
+// exactly where the reference puts them); a tile whose bound is zero has nothing to add.
+// ---------------------------------------------------------------------------------------------------------
+struct PkAcc {
+    static constexpr int kMagic = 0x4B400000;                                  // bits of 1.5 * 2^23
+    static constexpr int kShift = 26, kSplit = 11;
+};
+// A plane has the band's geometry: r.h rows of r.pitch 64-bit slots (pitch 96, 80 or 64: a multiple of 16 slots, so
+// every row starts on the same bank).  Column c of a row is stored at (c & 3) * (pitch / 4) + (c >> 2): cells 4 apart
+// (the sites of neighbouring lanes) are adjacent 8-byte slots -- see AccT in memc_tile.hpp.
+__device__ __forceinline__ int pk_col(int c, int quarter) { return (c & 3) * quarter + (c >> 2); }
+
+__device__ __forceinline__ void lds_add_u64(unsigned long long *p, unsigned long long v)
+{
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_u64
+}
+
+// exponent e with |v| < 2^e for the non-negative float whose bits are `bits` (finite, non-zero), kept inside
+// [-100, 128] so that every power of two formed from it is a normal float
+__device__ __forceinline__ int pk_exponent(int bits)
+{
+    int e;
+    (void)frexpf(__int_as_float(bits), &e);
+    return max(e, -100);
+}
+
+// The 32 ds_add_u64 of the sites in `fast`.  sg = 2^(11 - e_g), st = 2^(11 - e_t): |g * sg| < 2^11, |w * st| <= 2^11.
+__device__ __forceinline__ void fi_bwd_adds_pk(const Region &r, unsigned fast, FiSite4 &g, const f32x4 (&tp)[16],
+                                               const f32x4 (&go)[3], float sg, float st,
+                                               unsigned long long *accA, unsigned long long *accB, int W, int H)
+{
+    const float magic = __int_as_float(PkAcc::kMagic);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!((fast >> j) & 1)) continue;
+        // keep the cell addresses and weights inside the caller's loops (hoisted, they spill)
+        asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
+        int ro[4], co[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ro[k] = (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch;
+            co[k] = pk_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0, r.pitch >> 2);
+        }
+        const float a = g.a[j], bt = g.b[j];
+        const float wq[4] = {st * ((1 - a) * (1 - bt)), st * (a * (1 - bt)), st * ((1 - a) * bt), st * (a * bt)};
+        const float g0 = sg * go[0][j], g1 = sg * go[1][j], g2 = sg * go[2][j];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const float w = wq[(k >> 1) * 2 + (m >> 1)] * tp[k * 4 + m][j];
+                const int n0 = __float_as_int(fmaf(g0, w, magic)) - PkAcc::kMagic;
+                const int n1 = __float_as_int(fmaf(g1, w, magic)) - PkAcc::kMagic;
+                const int n2 = __float_as_int(fmaf(g2, w, magic)) - PkAcc::kMagic;
+                const long long A = ((long long)n0 << PkAcc::kShift) + (long long)(n2 >> PkAcc::kSplit);
+                const long long B = ((long long)n1 << PkAcc::kShift) | (long long)(n2 & ((1 << PkAcc::kSplit) - 1));
+                lds_add_u64(accA + ro[k] + co[m], (unsigned long long)A);
+                lds_add_u64(accB + ro[k] + co[m], (unsigned long long)B);
+            }
+    }
+}
+
+// Unpacks every cell of the band and adds its three colours to gradinput1 (row-coalesced global atomics: the boxes of
+// neighbouring tiles overlap).  The 256 lanes walk the box's cells in row-major order, so a wave's 64 cells are one
+// run of a row (256 contiguous bytes per colour) and, in the planes, 4 x 8 consecutive slots: conflict-free.
+// inv = 2^(e_g + e_t - 22) as a double (the float may not exist).
+__device__ __forceinline__ void fi_bwd_flush_pk(const Region &r, const unsigned long long *accA,
+                                                const unsigned long long *accB, double inv, float *gin1_b,
+                                                int64_t s1c, int s1h)
+{
+    const unsigned tid = tid_now();
+    const int w = max(r.w, 1), total = r.w * r.h;
+    int row = tid / w, col = tid % w;                      // one run-time division per band
+    const int drow = 256 / w, dcol = 256 % w;
+    const uintptr_t b0 = pin_sgpr(gin1_b), b1 = pin_sgpr(gin1_b + s1c), b2 = pin_sgpr(gin1_b + 2 * s1c);
+    constexpr int kBatch = 4;
+#pragma unroll 1
+    for (int base = 0; base < total; base += 256 * kBatch) {
+        long long A[kBatch], B[kBatch];
+        unsigned off[kBatch];
+        bool on[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            on[u] = row < r.h;
+            const int slot = (on[u] ? row : 0) * r.pitch + pk_col(col, r.pitch >> 2);
+            A[u] = (long long)accA[slot];
+            B[u] = (long long)accB[slot];
+            off[u] = 4u * (unsigned)((r.y0 + row) * s1h + r.x0 + col);
+            col += dcol;
+            row += drow + (col >= w ? 1 : 0);
+            col -= col >= w ? w : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            if (!on[u] || (A[u] | B[u]) == 0) continue;
+            const long long c0 = (A[u] + (1LL << (PkAcc::kShift - 1))) >> PkAcc::kShift;
+            const long long sa = A[u] - (c0 << PkAcc::kShift);
+            const long long c1 = B[u] >> PkAcc::kShift;
+            const long long lb = B[u] & ((1LL << PkAcc::kShift) - 1);
+            const long long c2 = (sa << PkAcc::kSplit) + lb;
+            const float v0 = (float)((double)c0 * inv), v1 = (float)((double)c1 * inv), v2 = (float)((double)c2 * inv);
+            if (v0 != 0.0f) (void)__builtin_amdgcn_global_atomic_fadd_f32(reinterpret_cast<MEMC_GLOBAL float *>(b0 + off[u]), v0);
+            if (v1 != 0.0f) (void)__builtin_amdgcn_global_atomic_fadd_f32(reinterpret_cast<MEMC_GLOBAL float *>(b1 + off[u]), v1);
+            if (v2 != 0.0f) (void)__builtin_amdgcn_global_atomic_fadd_f32(reinterpret_cast<MEMC_GLOBAL float *>(b2 + off[u]), v2);
+        }
+    }
+}
+
+// the image gradient of ONE site with global atomics (tiles with a non-finite gradoutput or tap)
+__device__ __noinline__ void fi_bwd_site_image_atomics(int x, int y, int W, int H, float *gin1_b, int64_t s1c, int s1h,
+                                                       const float *flow_p, int64_t s2c, const float *tap_p,
+                                                       int64_t s3c, const float *gout_p)
+{
+    const FiSite s = fi_locate(x, y, W, H, flow_p[0], flow_p[s2c]);
+    if (!s.valid) return;
+    for (int c = 0; c < 3; c++) {
+        const float gv = gout_p[c * s1c];
+        float *q = gin1_b + c * s1c;
+        for (int k = 0; k < 4; k++) {
+            const int jj = clampi(s.iy - 1 + k, H - 1) * s1h;
+            for (int m = 0; m < 4; m++) {
+                const float wa = m < 2 ? (1 - s.a) : s.a, wb = k < 2 ? (1 - s.b) : s.b;
+                atomic_add_f32(q + jj + clampi(s.ix - 1 + m, W - 1), gv * wa * wb * tap_p[(k * 4 + m) * s3c]);
+            }
+        }
+    }
+}
+
+// largest value of a non-negative int over the wave (float bit patterns of |x| order like ints; NaN sorts last)
+__device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
+
+// ALIAS: the two planes alias the staged image (48 KiB per workgroup; the planes are zeroed after phase 1, behind a
+// barrier).  !ALIAS: image (2496 pixel quads) and planes (2 x 2496 slots) side by side, 78 KiB -- still two workgroups
+// per CU, which is what the 193 registers allow anyway -- so that a wave goes from its tap / flow gradients straight on
+// to its LDS adds: no barrier and no zeroing pass between the two, the adds of one wave overlap the gathers and
+// stores of the others, and the tile is two barriers long (staged; accumulated) instead of eight.
+template <bool ALIAS>
+struct PkGeom {
+    static constexpr int kCap = ALIAS ? 3072 : 2496;                   // pixel quads staged = slots per plane
+    static constexpr int kImageBytes = kCap * 16, kPlaneBytes = kCap * 8;
+    static constexpr int kLds = (ALIAS ? kImageBytes : kImageBytes + 2 * kPlaneBytes) + 128;
+};
+
+template <int MINW, bool ALIAS, bool TR>
+__global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
+    int W, int H, int tiles_x, int tiles_y, int batch,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
+    const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
+    const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2,
+    float *__restrict__ gin3)
+{
+    constexpr int LX = 16;
+    using PG = PkGeom<ALIAS>;
+    using G = TileGeom<LX, PG::kCap>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    unsigned long long *const accA = reinterpret_cast<unsigned long long *>(smem + (ALIAS ? 0 : PG::kImageBytes));
+    unsigned long long *const accB = accA + PG::kCap;
+    int *bb = reinterpret_cast<int *>(smem + PG::kLds - 128);            // 16 ints: boxes; 8 ints: maxima
+    int *mx = bb + 16;
+
+    trace_mark<TR>(0);
+    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
+    const int b = tc.b;
+    const unsigned tid = tid_now();
+    const int x = tc.tx * G::kTW + 4 * (int)(tid % LX), y = tc.ty * G::kTH + (int)(tid / LX);
+    const bool inb = x < W && y < H;
+    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const float *flow_b = flow + b * s2b, *filt_b = filt + b * s3b, *gout_b = gout + b * s1b;
+    float *gin2_b = gin2 + b * s2b, *gin3_b = gin3 + b * s3b;
+    const unsigned o1 = 4u * (unsigned)(ys * s1h + xs), o2 = 4u * (unsigned)(ys * s2h + xs),
+                   o3 = 4u * (unsigned)(ys * s3h + xs);
+    f32x4 go[3], tp[16];
+    const f32x4 fx4 = ld_stream4_u(flow_b, o2), fy4 = ld_stream4_u(flow_b + s2c, o2);
+#pragma unroll
+    for (int c = 0; c < 3; c++) go[c] = ld_stream4_u(gout_b + c * s1c, o1);
+#pragma unroll
+    for (int k = 0; k < 16; k++) tp[k] = ld_stream4_u(filt_b + k * s3c, o3);
+    if (TR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    trace_mark<TR>(1);                                         // inputs have arrived
+
+    FiSite4 g;
+    g.valid = 0;
+    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
+        g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
+        if (inb && s.valid) {
+            g.valid |= 1u << j;
+            cmin = min(cmin, max(s.ix - 1, 0));  cmax = max(cmax, min(s.ix + 2, W - 1));
+            rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
+        }
+    }
+    {                                          // the tile's largest |gradoutput| and |tap| (bit patterns), per wave;
+        int mg = 0, mt = 0;                    // handed over by the barrier inside tile_bbox
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) mg = max(mg, __float_as_int(go[c][j]) & 0x7FFFFFFF);
+#pragma unroll
+            for (int k = 0; k < 16; k++) mt = max(mt, __float_as_int(tp[k][j]) & 0x7FFFFFFF);
+        }
+        mg = wave_max_i32(inb ? mg : 0);
+        mt = wave_max_i32(inb ? mt : 0);
+        if ((tid & (kWave - 1)) == 0) {
+            mx[(tid / kWave) * 2] = mg;
+            mx[(tid / kWave) * 2 + 1] = mt;
+        }
+    }
+    const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
+    const Bands bands = make_bands<LX, !ALIAS, PG::kCap>(box);
+    int mg = max(max(mx[0], mx[2]), max(mx[4], mx[6])), mt = max(max(mx[1], mx[3]), max(mx[5], mx[7]));
+    mg = __builtin_amdgcn_readfirstlane(mg);
+    mt = __builtin_amdgcn_readfirstlane(mt);
+    // 0: nothing to add (every contribution of this tile is zero); 2: Inf / NaN among the inputs -- per-site global
+    // atomics; 1: the packed planes
+    const int mode = (mg == 0 || mt == 0) ? 0 : ((mg >= 0x7F800000 || mt >= 0x7F800000) ? 2 : 1);
+    // block exponent: 2^(eg + et) > (largest |gradoutput|) x (largest |tap|), off by less than a factor two -- the
+    // mantissas' product tells whether the sum of the two exponents is one too many
+    const int eg = pk_exponent(mode == 1 ? mg : 0x3F800000);
+    int et = pk_exponent(mode == 1 ? mt : 0x3F800000);
+    {
+        int e0, e1;
+        const float mm = frexpf(__int_as_float(mode == 1 ? mg : 0x3F800000), &e0) *
+                         frexpf(__int_as_float(mode == 1 ? mt : 0x3F800000), &e1);
+        if (mm < 0.4999f && et > -100) et -= 1;
+    }
+    const float *in_b = in1 + b * s1b;
+    float *gin1_b = gin1 + b * s1b;
+    unsigned done = 0;
+    trace_mark<TR>(2);                                         // bounding box known
+    fi_bwd_zero_invalid(inb, g.valid, gin2_b, s2c, o2, gin3_b, s3c, o3);
+#pragma unroll 1
+    for (int bi = 0; bi < bands.n; bi++) {
+    const Region r = band_region(box, bands, bi);
+    const unsigned fast = inb ? fi_covered(r, g, W, H) & ~done : 0u;
+    // later bands run only if some site still needs them; the vote is also the barrier that frees the LDS
+    if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
+    done |= fast;
+    auto zero_planes = [&]() {                 // the rows of both planes that the band uses
+        f32x4 *pa = reinterpret_cast<f32x4 *>(accA), *pb = reinterpret_cast<f32x4 *>(accB);
+        const int n = r.h * (r.pitch >> 1);                    // float4 per plane
+        for (int i = (int)tid_now(); i < n; i += 256) {
+            pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (!ALIAS && mode == 1) {                 // planes beside the image: zeroed while the staging loads are in flight
+        const StageSlot sl = stage_slots(r);
+        StageRegs<3> sr;
+        tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);
+        zero_planes();
+        tile_stage_store<3>(r, sl, sr, tile);
+    } else {
+        tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
+    }
+    __syncthreads();
+    if (bi == 0) trace_mark<TR>(3);                            // image staged
+    fi_bwd_phase1<0>(r, fast, g, tp, go, tile, W, H, gin2_b, s2c, o2, gin3_b, s3c, o3);
+    if (fast != 0xFu) {                        // mixed quads (rare): their tap gradients, site by site
+        unsigned todo = fast;
+        while (todo) {
+            const int j = __ffs(todo) - 1;
+            todo &= todo - 1;
+            fi_bwd_site_taps(x + j, y, W, H, in_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j, s2c,
+                             filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
+        }
+    }
+    if (bi == 0) trace_mark<TR>(4);                            // phase 1 done (this wave)
+    if (mode == 2) {
+        unsigned todo = fast;
+        while (todo) {
+            const int j = __ffs(todo) - 1;
+            todo &= todo - 1;
+            fi_bwd_site_image_atomics(x + j, y, W, H, gin1_b, s1c, s1h, flow_b + o2 / 4 + j, s2c,
+                                      filt_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
+        }
+    }
+    if (mode != 1) continue;                   // (workgroup-uniform)
+    if (ALIAS) {
+        __syncthreads();                       // everybody is done reading the image: the LDS becomes the planes
+        zero_planes();
+        __syncthreads();
+        if (bi == 0) trace_mark<TR>(5);                        // planes zeroed
+    }
+    fi_bwd_adds_pk(r, fast, g, tp, go, ldexpf(1.0f, 11 - eg), ldexpf(1.0f, 11 - et), accA, accB, W, H);
+    __syncthreads();
+    if (bi == 0) trace_mark<TR>(6);                            // accumulated
+    fi_bwd_flush_pk(r, accA, accB, ldexp(1.0, eg + et - 22), gin1_b, s1c, s1h);
+    if (bi == 0) trace_mark<TR>(7);                            // flushed
+    }   // bands
+    trace_mark<TR>(12);
+    unsigned slow = inb ? g.valid & ~done : 0u;            // not coverable within kMaxBands bands
+    while (slow) {                            // rare: redone from global memory with global atomics
+        const int j = __ffs(slow) - 1;
+        slow &= slow - 1;
+        fi_bwd_site_scalar(x + j, y, W, H, 3, 4, in_b, gin1_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j,
+                           s2c, filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
+    }
+}
+
 // 1: taken, 0: not this kernel's case (the caller falls back to the direct kernel), -1: launch error.  `variant`
 // selects a measurement arm (measurement build only; the product passes -1).
 int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
@@ -436,6 +760,13 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
         const unsigned grid = ntiles < persistent_grid(2) ? ntiles : persistent_grid(2);                           \
         hipLaunchKernelGGL(fi_bwd_tiled_c3_persistent<PF>, dim3(grid), dim3(256), lds, stream, MEMC_FI_BWD_ARGS);  \
     } while (0)
+#define MEMC_FI_BWD_PK(MINW, AL, TR)                                                                               \
+    do {                                                                                                           \
+        static const bool once = (allow_big_lds(fi_bwd_c3_pk<MINW, AL, TR>, PkGeom<AL>::kLds), true);              \
+        (void)once;                                                                                                \
+        hipLaunchKernelGGL((fi_bwd_c3_pk<MINW, AL, TR>), dim3(ntiles), dim3(256), PkGeom<AL>::kLds, stream,        \
+                           MEMC_FI_BWD_ARGS);                                                                      \
+    } while (0)
 #ifdef MEMC_MEASURE
     switch (variant) {
     case 1: MEMC_FI_BWD(1); break;
@@ -450,6 +781,10 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
         break;
     case 10: MEMC_FI_BWD_P(true); break;
     case 11: MEMC_FI_BWD_P(false); break;
+    case 20: MEMC_FI_BWD_PK(2, true, false); break;        // packed planes aliasing the image
+    case 21: MEMC_FI_BWD_PK(2, false, false); break;       // packed planes beside the image
+    case 28: MEMC_FI_BWD_PK(2, true, true); break;         // + timestamps
+    case 29: MEMC_FI_BWD_PK(2, false, true); break;
     default: MEMC_FI_BWD(0);
     }
 #else
@@ -458,6 +793,7 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
 #endif
 #undef MEMC_FI_BWD
 #undef MEMC_FI_BWD_P
+#undef MEMC_FI_BWD_PK
 #undef MEMC_FI_BWD_ARGS
     return launch_status() == 0 ? 1 : -1;
 }

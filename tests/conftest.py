@@ -30,3 +30,26 @@ def hip_lib_path():
         import __graft_entry__
         __graft_entry__.build()
     return path
+
+
+def pytest_sessionstart(session):
+    """A fresh record of observed parity errors per session (tests/_parity.py)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _parity
+    try:
+        os.remove(_parity.log_path())
+    except OSError:
+        pass
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import json
+    import _parity
+    summary = _parity.summarise()
+    if summary:
+        try:
+            with open(os.path.splitext(_parity.log_path())[0] + ".json", "w") as f:
+                json.dump({"rule": "abs 1e-4 where |want| <= 10, max(1e-4, rtol * |want|) beyond",
+                           "tests": summary}, f, indent=1, sort_keys=True)
+        except OSError:
+            pass

@@ -22,7 +22,8 @@ from tools import synth                    # noqa: E402
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not R.available(), reason="oracle/_ref/libmemc_ref_gpu.so not built")]
-ATOL, RTOL = 1e-4, 1e-5                    # as tests/test_gpu_parity.py
+import _parity as P                        # noqa: E402
+ATOL, RTOL = P.ATOL, P.RTOL                # the rule and the record of observed errors: tests/_parity.py
 
 
 def dev():
@@ -31,12 +32,8 @@ def dev():
     return torch.device("cuda:0")
 
 
-def close(got, want, what):
-    assert got.shape == want.shape, what
-    err = (got.double() - want.double()).abs()
-    bound = ATOL + RTOL * want.double().abs()
-    worst = float((err - bound).max())
-    assert worst <= 0, "%s: max abs err %.3g (|want| up to %.3g)" % (what, float(err.max()), float(want.abs().max()))
+def close(got, want, what, rtol=RTOL):
+    return P.close(got, want, what, rtol)
 
 
 @pytest.mark.parametrize("kind", ["smooth", "iid"])
@@ -76,20 +73,15 @@ def test_context_warp_shape_fwd_bwd_64_channels_720p(kind):
     g1, g2, g3 = torch.full_like(x, float("nan")), torch.full_like(f, float("nan")), torch.full_like(k, float("nan"))
     assert L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
     w1, w2, w3 = R.filter_interpolation_backward(x, f, k, g)
-    # 64 channels of fp32 products per tap sum / per cell: relative tolerance on the larger sums
+    # 64 channels of fp32 products per tap sum / per cell (|gradinput3| reaches ~16): the common rule, 1e-4 abs up to 10
     for got, want, what in ((g1, w1, "gradinput1"), (g2, w2, "gradinput2"), (g3, w3, "gradinput3")):
-        err = (got.double() - want.double()).abs()
-        worst = float((err - (ATOL + 5 * RTOL * want.double().abs())).max())
-        assert worst <= 0, "context warp %s (%s): max abs err %.3g (|want| up to %.3g)" % (
-            what, kind, float(err.max()), float(want.abs().max()))
+        close(got, want, "context warp %s (%s)" % (what, kind))
     # the bilinear warp at the same shape (InterpolationCh)
     h1, h2 = torch.full_like(x, float("nan")), torch.full_like(f, float("nan"))
     assert L.InterpolationChLayer_gpu_backward(x, f, g, h1, h2) == 0
     v1, v2 = R.interpolation_backward(x, f, g, ch=True)
     for got, want, what in ((h1, v1, "gradinput1"), (h2, v2, "gradinput2")):
-        err = (got.double() - want.double()).abs()
-        worst = float((err - (ATOL + 5 * RTOL * want.double().abs())).max())
-        assert worst <= 0, "bilinear %s (%s): max abs err %.3g" % (what, kind, float(err.max()))
+        close(got, want, "bilinear %s (%s)" % (what, kind))
 
 
 @pytest.mark.parametrize("kind", ["smooth", "iid"])

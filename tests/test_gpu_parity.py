@@ -1,9 +1,10 @@
 """Parity of the HIP path (through the C ABI / the drop-in modules) with the CPU oracle.  GPU only.
 
-Tolerance: BASELINE.json's north_star states "within 1e-4 abs float tolerance"; every comparison below is
-`max |hip - oracle| <= 1e-4` (ATOL), plus a relative term RTOL = 1e-5 only where values are sums of many
-scattered contributions whose magnitude exceeds 10 (fp32 atomics add in a different order than the oracle's
-sequential loop).  Integer-valued results (FlowProjection's `count`) must match bit-for-bit.
+Tolerance: BASELINE.json's north_star states "within 1e-4 abs float tolerance"; every comparison below goes through
+tests/_parity.py: `|hip - oracle| <= 1e-4` wherever |oracle| <= 10, a relative term (1e-5 unless stated) only beyond
+(sums of many scattered contributions: fp32 atomics add in a different order than the oracle's sequential loop), and
+the observed maximum of every check is recorded (gpurun_out/parity_errors.json, copied to profiles/ per round).
+Integer-valued results (FlowProjection's `count`) must match bit-for-bit.
 """
 import glob
 import os
@@ -12,12 +13,15 @@ import numpy as np
 import pytest
 import torch
 
-from tools import synth
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _parity as P                        # noqa: E402
+from tools import synth                    # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-ATOL = 1e-4
-RTOL = 1e-5
+ATOL = P.ATOL
+RTOL = P.RTOL
 
 
 def dev():
@@ -35,13 +39,9 @@ def N(t):
     return t.detach().cpu().numpy()
 
 
-def close(got, want, what, rtol=0.0):
-    got = np.asarray(got); want = np.asarray(want)
-    assert got.shape == want.shape, what
-    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
-    bound = ATOL + rtol * np.abs(want)
-    worst = float((err - bound).max()) if err.size else 0.0
-    assert worst <= 0, "%s: max abs err %.3g (|want| up to %.3g)" % (what, float(err.max()), float(np.abs(want).max()))
+def close(got, want, what, rtol=RTOL):
+    """tests/_parity.py: 1e-4 abs where |want| <= 10, max(1e-4, rtol * |want|) beyond; the observed error is recorded."""
+    return P.close(np.asarray(got), np.asarray(want), what, rtol if rtol else RTOL)
 
 
 CASES = [
@@ -89,6 +89,101 @@ def test_filter_interpolation(oracle, case):
     close(N(x.grad), g1, "gradinput1", RTOL)
     close(N(f.grad), g2, "gradinput2", RTOL)
     close(N(k.grad), g3, "gradinput3", RTOL)
+
+
+C3_ARMS = [-1, 20, 21, 0]
+C3_ARM_IDS = ["product", "packed planes aliasing the image", "packed planes beside the image", "fp64 plane per colour (rounds 1-2)"]
+C3_FLOWS = [(2, 100, 132, "smooth", 8.0), (1, 96, 256, "smooth", 25.0), (1, 64, 192, "converge", None),
+            (2, 64, 256, "iid", 20.0), (1, 48, 64, "zero", None), (1, 37, 52, "smooth", 3.0)]
+
+
+def _c3_inputs(case, seed=0, signed=False):
+    B, H, W, kind, sigma = case
+    rng = np.random.default_rng(1000 + seed + H + W)
+    if kind == "converge":
+        fn = _many_channel_flows("converge", rng, B, H, W)
+    else:
+        fn = synth.np_flow(rng, B, H, W, kind, sigma)
+    xn, kn, gn = synth.np_image(rng, B, 3, H, W), synth.np_filter(rng, B, H, W), synth.np_image(rng, B, 3, H, W)
+    if signed:
+        kn = (rng.standard_normal(kn.shape) * 0.3).astype(np.float32)
+        gn = rng.standard_normal(gn.shape).astype(np.float32)
+    return xn, fn, kn, gn
+
+
+def _c3_backward(my_lib, xn, fn, kn, gn, fill=0.0):
+    h1 = torch.full(xn.shape, fill, device=dev())
+    h2, h3 = torch.full(fn.shape, 3.0, device=dev()), torch.full(kn.shape, 3.0, device=dev())      # defined by the kernel
+    assert my_lib.FilterInterpolationLayer_gpu_backward(T(xn), T(fn), T(kn), T(gn), h1, h2, h3) == 0
+    return N(h1), N(h2), N(h3)
+
+
+@pytest.mark.parametrize("arm", C3_ARMS, ids=C3_ARM_IDS)
+def test_filter_interpolation_backward_rgb_arms(oracle, arm):
+    """The RGB backward (fi_bwd_c3.hip) -- the product's kernel and the arms kept beside it in the measurement build -- on
+    smooth, banded (box beyond the LDS budget), converging (hundreds of taps per cell), i.i.d. (scalar fallback sites),
+    zero and odd-sized flows, with positive and with signed gradients / taps."""
+    from tools import measure as M          # forced paths exist in the measurement build only
+    my_lib = M.bound()
+    try:
+        M.set_variant("fi_bwd", arm)
+        for ci, case in enumerate(C3_FLOWS):
+            for signed in (False, True):
+                xn, fn, kn, gn = _c3_inputs(case, ci, signed)
+                g1, g2, g3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+                h1, h2, h3 = _c3_backward(my_lib, xn, fn, kn, gn, fill=0.5)
+                tag = "%s signed=%d arm %d" % (case, signed, arm)
+                close(h1, g1 + 0.5, "gradinput1 += " + tag, 3 * RTOL)
+                close(h2, g2, "gradinput2 " + tag, RTOL)
+                close(h3, g3, "gradinput3 " + tag, RTOL)
+    finally:
+        M.reset()
+
+
+@pytest.mark.parametrize("arm", C3_ARMS[:3], ids=C3_ARM_IDS[:3])
+def test_filter_interpolation_backward_rgb_scaling_and_special_values(oracle, arm):
+    """Properties of the packed fixed-point accumulation (fi_bwd_c3.hip): (a) scaling gradoutput or the taps by a power
+    of two scales gradinput1 by exactly that power (the tile's block exponent moves with it: same integers);
+    (b) a zero gradoutput leaves gradinput1 untouched; (c) NaN / Inf in gradoutput or in a tap land exactly where the
+    reference puts them (the tile takes per-site atomics) and nowhere else; (d) huge and tiny magnitudes."""
+    from tools import measure as M
+    my_lib = M.bound()
+    case = (2, 80, 192, "smooth", 6.0)
+    xn, fn, kn, gn = _c3_inputs(case, 7, signed=True)
+    try:
+        M.set_variant("fi_bwd", arm)
+        base = _c3_backward(my_lib, xn, fn, kn, gn)[0]
+        close(base, oracle.filter_interpolation_backward(xn, fn, kn, gn)[0], "gradinput1 base", 3 * RTOL)
+        for sg, st in ((2.0 ** 40, 1.0), (2.0 ** -40, 1.0), (1.0, 2.0 ** 30), (2.0 ** -20, 2.0 ** -30), (2.0 ** 60, 2.0 ** 50)):
+            got = _c3_backward(my_lib, xn, fn, (kn * np.float32(st)), (gn * np.float32(sg)))[0]
+            want = (base.astype(np.float64) * sg * st).astype(np.float32)
+            assert np.array_equal(got, want), "power-of-two scaling (%g, %g) is not exact: max rel %.3g" % (
+                sg, st, float(np.max(np.abs(got - want) / (np.abs(want) + 1e-300))))
+        # (b)
+        h1 = _c3_backward(my_lib, xn, fn, kn, np.zeros_like(gn), fill=0.25)[0]
+        assert np.array_equal(h1, np.full_like(h1, 0.25)), "zero gradoutput must add nothing"
+        # (c)
+        g_bad, k_bad = gn.copy(), kn.copy()
+        g_bad[0, 1, 10, 20] = np.nan
+        g_bad[0, 2, 50, 100] = np.inf
+        k_bad[1, 5, 30, 60] = -np.inf
+        k_bad[1, 9, 70, 150] = np.nan
+        w1, w2, w3 = oracle.filter_interpolation_backward(xn, fn, k_bad, g_bad)
+        h1, h2, h3 = _c3_backward(my_lib, xn, fn, k_bad, g_bad)
+        assert np.array_equal(np.isnan(h1), np.isnan(w1)), "NaN cells of gradinput1: %d vs %d" % (np.isnan(h1).sum(), np.isnan(w1).sum())
+        assert np.array_equal(np.isinf(h1), np.isinf(w1)), "Inf cells of gradinput1"
+        assert 0 < np.isnan(w1).sum() < 200
+        close(h1, w1, "gradinput1 with NaN / Inf inputs", 3 * RTOL)
+        # (d) magnitudes far from 1: relative accuracy against the oracle in float64 terms
+        for sg, st in ((3.7e12, 5.1e-3), (1.3e-17, 9.0e-9)):
+            kk, gg = (kn * np.float32(st)), (gn * np.float32(sg))
+            want = oracle.filter_interpolation_backward(xn, fn, kk, gg)[0].astype(np.float64)
+            got = _c3_backward(my_lib, xn, fn, kk, gg)[0].astype(np.float64)
+            scale = float(np.abs(want).max())
+            assert float(np.abs(got - want).max()) <= 1e-5 * scale, "magnitudes (%g, %g): %.3g of the largest gradient" % (
+                sg, st, float(np.abs(got - want).max()) / scale)
+    finally:
+        M.reset()
 
 
 def _many_channel_flows(kind, rng, B, H, W):

@@ -18,7 +18,8 @@ from oracle import ref_gpu as R            # noqa: E402
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not R.available(), reason="oracle/_ref/libmemc_ref_gpu.so not built")]
-ATOL, RTOL = 1e-4, 1e-5                    # as tests/test_gpu_parity.py
+import _parity as P                        # noqa: E402
+ATOL, RTOL = P.ATOL, P.RTOL                # the rule and the record of observed errors: tests/_parity.py
 
 
 def T(a):
@@ -29,10 +30,8 @@ def N(t):
     return t.detach().cpu().numpy()
 
 
-def close(got, want, what):
-    err = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
-    bound = ATOL + RTOL * np.abs(want)
-    assert float((err - bound).max()) <= 0, "%s: max abs err %.3g" % (what, float(err.max()))
+def close(got, want, what, rtol=RTOL):
+    return P.close(got, want, what, rtol)
 
 
 @pytest.mark.parametrize("case", RC.REF_CASES, ids=[RC.name(c) for c in RC.REF_CASES])

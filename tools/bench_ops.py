@@ -332,8 +332,8 @@ def main():
         if not args.quick:
             bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "smooth", "720p",
                          [int(v) for v in args.bwd_variants.split(",") if v])
-            bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "iid", "720p")
-            bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "video", "720p")
+            bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "iid", "720p", [int(v) for v in args.bwd_variants.split(",") if v])
+            bench_fi_bwd(rows, dev, 32, 3, 720, 1280, "video", "720p", [int(v) for v in args.bwd_variants.split(",") if v])
     if want("fi_bwd_ctx"):
         # (measurement build: + variant 40, the direct global-atomics kernel this path replaced -- 163 ms)
         bench_fi_bwd(rows, dev, 8, 64, 720, 1280, "smooth", "ctx64", [40] if M.active else [])

@@ -26,6 +26,15 @@ KERNELS = {
                           (4, "phase 1 (taps/flow grads)"), (5, "zero plane"), (6, "adds c0"), (7, "flush c0"),
                           (8, "adds c1"), (9, "flush c1"), (10, "adds c2"), (11, "flush c2"),
                           (12, "later bands / tail")]),
+    # round 3: packed fixed-point planes, one LDS round (fi_bwd_c3.hip): planes aliasing the image / beside it
+    "fi_bwd_pk_alias": dict(setter="memc_debug_set_trace_buffer", op="fi_bwd", variant=28, last=12,
+                            marks=[(1, "load inputs"), (2, "locate + bbox + block exponent"), (3, "stage image"),
+                                   (4, "phase 1 (taps/flow grads)"), (5, "barrier + zero planes + barrier"),
+                                   (6, "packed adds + barrier"), (7, "flush (3 colours)"), (12, "later bands / tail")]),
+    "fi_bwd_pk": dict(setter="memc_debug_set_trace_buffer", op="fi_bwd", variant=29, last=12,
+                      marks=[(1, "load inputs"), (2, "locate + bbox + block exponent"), (3, "stage image + zero planes"),
+                             (4, "phase 1 (taps/flow grads)"), (6, "packed adds + barrier"), (7, "flush (3 colours)"),
+                             (12, "later bands / tail")]),
     "proj": dict(setter="memc_debug_set_trace_buffer_proj", op="projection", variant=-7, last=5, th=16,
                  marks=[(1, "issue scan loads + zero P + barrier"), (2, "wait for the loads"),
                         (3, "scan: locate + fp64 splat (wave 0)"), (4, "barrier (slowest wave)"),
@@ -83,7 +92,7 @@ def main():
     B, C, H, W = 32, 3, 720, 1280
     t = synth.torch_inputs(dev, B, C, H, W, flow_kind="smooth", with_grad=True)
     x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
-    if which == "fi_bwd":
+    if which.startswith("fi_bwd"):
         g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
         fn = lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3)     # noqa: E731
     else:
