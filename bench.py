@@ -31,9 +31,13 @@ for _p in (ROOT, os.path.join(ROOT, "memc-net_amd")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_BPS = 8.0e12           # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md: 8 TB/s; ~6.3 achievable)
-BYTES_PER_SITE = {               # ALGORITHMIC bytes per output site, every tensor touched once (DESIGN.md)
+BYTES_PER_SITE = {               # ALGORITHMIC bytes per output site, every tensor touched once (SURVEY.md 8d, DESIGN.md 3)
     "fi_fwd": lambda C, fs: 4 * (2 * C + 2 + fs * fs),
+    "fi_bwd": lambda C, fs: 4 * (3 * C + 2 * (2 + fs * fs)),
+    "proj_fwd": lambda C, fs: 20,
+    "depth_proj_fwd": lambda C, fs: 24,
 }
+CHECK_TOLERANCE = 1e-4           # BASELINE.json: "outputs within 1e-4 of reference"
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -108,7 +112,9 @@ def timed_steps(step_fn, steps, warmup, world, device):
 # CPU baseline (rank 0, N = 1 only): the oracle -- a port of the reference's CPU code -- on a bounded sample
 # ----------------------------------------------------------------------------------------------------------
 def cpu_baseline(x, flow, filt, target_seconds=12.0):
-    """Times oracle.filter_interpolation_forward on the first few frames of the SAME tensors the GPU ran on."""
+    """Times oracle.filter_interpolation_forward on the first few frames of the SAME tensors the GPU ran on.
+    Returns (the cpu_baseline object, the oracle's output for those frames) -- the second is what the GPU result of
+    the timed launches is checked against."""
     import numpy as np
     from oracle import memc_oracle as O          # checker / baseline only -- never on the product path
     O.build()
@@ -117,16 +123,26 @@ def cpu_baseline(x, flow, filt, target_seconds=12.0):
     xs, fs_, ks = (t[:nb].cpu().numpy() for t in (x, flow, filt))
     sites = nb * xs.shape[2] * xs.shape[3]
     O.filter_interpolation_forward(xs[:1], fs_[:1], ks[:1])     # page in
-    reps, spent = 0, 0.0
+    reps, spent, want = 0, 0.0, None
     while spent < target_seconds and reps < 200:
         t0 = time.perf_counter()
-        O.filter_interpolation_forward(xs, fs_, ks)
+        want = O.filter_interpolation_forward(xs, fs_, ks)
         spent += time.perf_counter() - t0
         reps += 1
     assert np.isfinite(spent)
     return {"value": round(sites * reps / spent / 1e6, 2), "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "sample": "oracle FilterInterpolation fwd, first %d frames of the GPU batch (%dx%dx%dx%d), %d reps, "
-                      "%.1f s, OpenMP over batch x rows" % (nb, nb, xs.shape[1], xs.shape[2], xs.shape[3], reps, spent)}
+                      "%.1f s, OpenMP over batch x rows" % (nb, nb, xs.shape[1], xs.shape[2], xs.shape[3], reps, spent)}, want
+
+
+def check_against_oracle(out, want):
+    """The output of the timed launches (first frames) against the oracle result the cpu_baseline leg computed."""
+    import numpy as np
+    nb = want.shape[0]
+    got = out[:nb].cpu().numpy()
+    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+    return {"max_abs_err": err, "frames": int(nb), "tolerance": CHECK_TOLERANCE, "ok": bool(err <= CHECK_TOLERANCE),
+            "against": "oracle (CPU restatement of my_lib.c), same input tensors as the timed launches"}
 
 
 def kernel_source_hash():
@@ -149,10 +165,10 @@ def load_traffic(workload_key):
         data = json.load(open(path))
         rec = data.get(workload_key)
         if rec is None or rec.get("kernel_source_hash") != kernel_source_hash():
-            return None
-        return rec.get("hbm_bytes_per_launch")
+            return None, None
+        return rec.get("hbm_bytes_per_launch"), "profiles/traffic.json@%s" % rec.get("kernel_source_hash")
     except (OSError, ValueError):
-        return None
+        return None, None
 
 
 def copy_calibration(device, nbytes, iters=20):
@@ -173,6 +189,79 @@ def copy_calibration(device, nbytes, iters=20):
     return 8.0 * n / (ts[len(ts) // 2] * 1e-3)
 
 
+def _avg_launch_s(fn, torch, device, warm=15, iters=40, burst=1):
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a0, a1 in ev:
+        a0.record()
+        for _ in range(burst):
+            fn()
+        a1.record()
+    torch.cuda.synchronize(device)
+    return sum(a0.elapsed_time(a1) for a0, a1 in ev) / len(ev) / burst / 1e3
+
+
+def secondary_rows(my_lib, synth, torch, device, seed):
+    """The other BASELINE configs, OUTSIDE the timed region (rank 0, N = 1): per-launch HIP-event averages and the
+    fraction of the 8 TB/s HBM peak their ALGORITHMIC bytes amount to.  Launches shorter than ~0.2 ms are timed in
+    bursts of 20 between two events (one launch between two events mostly measures the host's enqueue cost)."""
+    rows = {}
+
+    def row(name, op, C, sites, seconds, note=None):
+        nbytes = BYTES_PER_SITE[op](C, 4) * sites
+        rows[name] = {"avg_launch_us": round(seconds * 1e6, 2), "mpixels_s": round(sites / seconds / 1e6, 1),
+                      "algorithmic_bytes_per_launch": nbytes, "frac": round(nbytes / seconds / HBM_PEAK_BPS, 4)}
+        if note:
+            rows[name]["note"] = note
+
+    # config 2: fused adaptive warp fwd + bwd, 448 x 256 (Vimeo septuplet), batch 8
+    t = synth.torch_inputs(device, 8, 3, 256, 448, flow_kind="smooth", seed=seed + 2, with_grad=True)
+    out = torch.zeros_like(t["x"])
+    g1, g2, g3 = torch.zeros_like(t["x"]), torch.zeros_like(t["flow"]), torch.zeros_like(t["filt"])
+    sites = 8 * 256 * 448
+    row("config2_fi_fwd_8x3x256x448", "fi_fwd", 3, sites, _avg_launch_s(
+        lambda: my_lib.FilterInterpolationLayer_gpu_forward(t["x"], t["flow"], t["filt"], out), torch, device, burst=20),
+        "bursts of 20")
+    row("config2_fi_bwd_8x3x256x448", "fi_bwd", 3, sites, _avg_launch_s(
+        lambda: my_lib.FilterInterpolationLayer_gpu_backward(t["x"], t["flow"], t["filt"], t["gout"], g1, g2, g3),
+        torch, device, burst=20), "bursts of 20")
+    del t, out, g1, g2, g3
+    # the backward at the headline size (the only channel count the reference back-propagates through)
+    t = synth.torch_inputs(device, 32, 3, 720, 1280, flow_kind="smooth", seed=seed + 6, with_grad=True)
+    g1, g2, g3 = torch.zeros_like(t["x"]), torch.zeros_like(t["flow"]), torch.zeros_like(t["filt"])
+    row("fi_bwd_32x3x720x1280", "fi_bwd", 3, 32 * 720 * 1280, _avg_launch_s(
+        lambda: my_lib.FilterInterpolationLayer_gpu_backward(t["x"], t["flow"], t["filt"], t["gout"], g1, g2, g3),
+        torch, device))
+    del g1, g2, g3
+    # config 3: FlowProjection / DepthFlowProjection scatter, 1280 x 720, batch 32 (same flow; + depth)
+    f = t["flow"]
+    del t
+    dep = torch.rand((32, 1, 720, 1280), device=device) + 0.1
+    cnt, po = torch.zeros((32, 1, 720, 1280), device=device), torch.zeros_like(f)
+    sites = 32 * 720 * 1280
+    for fill in (0, 1):
+        row("config3_flow_projection_fwd_fillhole%d_32x720x1280" % fill, "proj_fwd", 0, sites, _avg_launch_s(
+            lambda: my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, fill), torch, device, burst=4), "bursts of 4")
+    row("config3_depth_flow_projection_fwd_fillhole1_32x720x1280", "depth_proj_fwd", 0, sites, _avg_launch_s(
+        lambda: my_lib.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, po, 1), torch, device, burst=4), "bursts of 4")
+    del f, dep, cnt, po
+    # config 5: 4K adaptive warp forward, batch 8
+    t = synth.torch_inputs(device, 8, 3, 2160, 3840, flow_kind="smooth", seed=seed + 5)
+    out = torch.zeros_like(t["x"])
+    row("config5_fi_fwd_8x3x2160x3840", "fi_fwd", 3, 8 * 2160 * 3840, _avg_launch_s(
+        lambda: my_lib.FilterInterpolationLayer_gpu_forward(t["x"], t["flow"], t["filt"], out), torch, device, iters=20))
+    del t, out
+    # the 64-channel context warp of config 4's network (MEMC_Net_star.py:281-285), batch 8
+    t = synth.torch_inputs(device, 8, 64, 720, 1280, flow_kind="smooth", seed=seed + 4)
+    out = torch.zeros_like(t["x"])
+    row("context_warp_fi_fwd_8x64x720x1280", "fi_fwd", 64, 8 * 720 * 1280, _avg_launch_s(
+        lambda: my_lib.FilterInterpolationLayer_gpu_forward(t["x"], t["flow"], t["filt"], out), torch, device, iters=20))
+    del t, out
+    torch.cuda.empty_cache()
+    return rows
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,12 +274,18 @@ def main(argv=None):
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
                     help="graph: the K timed steps are one captured HIP graph replay (auto: below 8 M sites per launch)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the i.i.d.-flow row and the copy calibration")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the rows outside the timed region (i.i.d. flow, the other BASELINE configs, copy calibration)")
+    ap.add_argument("--input-sets", type=int, default=0,
+                    help="input sets the launches rotate over (0 = automatic: 1 when a launch moves >= 1 GB, else enough "
+                         "to cycle >= 1.4 GB, at least 4 -- a small shard re-launched on the same tensors would be served "
+                         "by the 256 MB Infinity Cache, and its 'HBM fraction' would not be one)")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--flow", default="smooth", choices=["smooth", "iid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work the cpu_baseline leg is bounded to")
     # plumbing test of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, gloo instead of
     # RCCL, which refuses two ranks on one device): the line it prints is NOT a measurement
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
@@ -226,24 +321,31 @@ def main(argv=None):
     B = plan["items"]                           # this rank's shard
     if B == 0:
         raise SystemExit("rank %d has no frame pair (global batch %d over %d ranks)" % (rank, cfg["batch"], world))
-    t = synth.torch_inputs(device, B, C, H, W, fs=fs, flow_kind=args.flow, seed=plan["seed"])
-    x, flow, filt = t["x"], t["flow"], t["filt"]
-    out = torch.zeros_like(x)                 # caller-allocated, caller-zeroed (reference contract)
+    sites_per_launch = B * H * W
+    alg_bytes = BYTES_PER_SITE["fi_fwd"](C, fs) * sites_per_launch
+    nsets = args.input_sets if args.input_sets > 0 else (1 if alg_bytes >= 1e9 else max(4, -(-1400000000 // alg_bytes)))
+    sets = []
+    for k in range(nsets):                      # set 0 is the one the oracle check and the CPU baseline look at
+        t = synth.torch_inputs(device, B, C, H, W, fs=fs, flow_kind=args.flow, seed=plan["seed"] + 7919 * k)
+        sets.append((t["x"], t["flow"], t["filt"], torch.zeros_like(t["x"])))   # caller-allocated, caller-zeroed output
+    x, flow, filt, out = sets[0]
     steps, warmup = cfg["steps"], cfg["warmup"]
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    counter = [0]
 
     def step(i):
         # one pass of the hot path over the batch; events sit on the stream the kernel is launched on
+        xi, fi, ki, oi = sets[counter[0] % nsets]
+        counter[0] += 1
         if i is not None:
             starts[i].record()
-        err = my_lib.FilterInterpolationLayer_gpu_forward(x, flow, filt, out)
+        err = my_lib.FilterInterpolationLayer_gpu_forward(xi, fi, ki, oi)
         if i is not None:
             stops[i].record()
         if err != 0:
             raise RuntimeError("FilterInterpolationLayer_gpu_forward returned %d" % err)
 
-    sites_per_launch = B * H * W
     use_graph = args.launch == "graph" or (args.launch == "auto" and sites_per_launch < 8_000_000)
     for _ in range(args.prewarm):
         step(None)
@@ -278,13 +380,32 @@ def main(argv=None):
             worst = float(tt.item())
         avg_kernel_s = g0.elapsed_time(g1) / steps / 1e3
     else:
-        worst, _local = timed_steps(step, steps, warmup, world, device)
+        worst, local = timed_steps(step, steps, warmup, world, device)
         kernel_ms = [a.elapsed_time(b) for a, b in zip(starts, stops)]
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
-    alg_bytes = BYTES_PER_SITE["fi_fwd"](C, fs) * sites_per_launch
     achieved = alg_bytes / avg_kernel_s                                 # B/s, this rank's dominant kernel
     total_sites = plan["global_batch"] * H * W                          # all ranks' sites per step
     value = total_sites * steps / worst / 1e6
+    dist_seen = None
+    if world > 1:
+        # what the collective layer actually saw (evidence fields; nothing here is on the data path)
+        import torch.distributed as dist
+        gdev = device if dist.get_backend() == "nccl" else torch.device("cpu")      # gloo gathers host tensors only
+        mine = torch.tensor([local / steps * 1e3, avg_kernel_s * 1e6, float(B)], dtype=torch.float64, device=gdev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        rows = [g.tolist() for g in gathered]
+        dist_seen = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                     "per_rank_ms_per_step": [round(r[0], 4) for r in rows],
+                     "per_rank_avg_launch_us": [round(r[1], 2) for r in rows],
+                     "per_rank_items": [int(r[2]) for r in rows],
+                     "collectives": "1 broadcast of 7 int64 (configuration), 2 barriers, 1 max all-reduce of one double "
+                                    "(time), 1 all-gather of 3 doubles (this record); none between the two barriers"}
+        if dist.get_backend() == "nccl":
+            try:
+                dist_seen["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:                   # noqa: BLE001 -- version lookup is evidence only
+                pass
 
     secondary = None
     if rank == 0 and world == 1 and not args.no_secondary:
@@ -304,10 +425,13 @@ def main(argv=None):
         secondary = {"iid_flow": {"avg_launch_us": round(iid_s * 1e6, 2), "mpixels_s": round(sites_per_launch / iid_s / 1e6, 1),
                                   "frac": round(alg_bytes / iid_s / HBM_PEAK_BPS, 4)},
                      "copy_Bps": copy_calibration(device, alg_bytes)}
+        if B == 32 and (C, H, W) == (3, 720, 1280):      # the default run: + the other BASELINE configs
+            del sets[1:]
+            secondary["rows"] = secondary_rows(my_lib, synth, torch, device, plan["seed"])
 
     if rank == 0:
         workload = "FilterInterpolation fwd fs=4 C=%d batch=%d %dx%d fp32 flow=%s" % (C, cfg["batch"], W, H, args.flow)
-        traffic = load_traffic(workload) if B == cfg["batch"] else None        # (per-launch counters of the full batch)
+        traffic, traffic_source = load_traffic(workload) if B == cfg["batch"] else (None, None)   # (full batch only)
         line = {
             "metric": "Mpixels/s adaptive-warp fwd @720p batch32",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -316,10 +440,11 @@ def main(argv=None):
             "data": "synthetic" if not args.share_gpu else "synthetic; PLUMBING TEST (ranks share a GPU), not a measurement",
             "config": {"workload": workload, "batch_per_gpu": B, "global_batch": plan["global_batch"],
                        "prewarm_launches": args.prewarm, "launch": "hip_graph" if use_graph else "eager",
+                       "input_sets": nsets,
                        "sharding": "independent frame pairs, contiguous shards per rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BPS, 4),
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "fi_fwd", "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(avg_kernel_s * 1e6, 2)},
         }
@@ -328,9 +453,22 @@ def main(argv=None):
             line["roofline"]["achievable_peak"] = round(secondary["copy_Bps"] / 1e9, 1)
             line["roofline"]["frac_of_achievable"] = round(achieved / secondary["copy_Bps"], 4)
             line["secondary"] = {"iid_flow": secondary["iid_flow"]}
+            line["secondary"].update(secondary.get("rows", {}))
+        if dist_seen:
+            line["dist"] = dist_seen
+        failed = None
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(x, flow, filt)
+            # the timed launches' own output (input set 0 is relaunched so that `out` holds its result whatever the
+            # rotation ended on) against the oracle result the baseline leg computes anyway
+            my_lib.FilterInterpolationLayer_gpu_forward(x, flow, filt, out)
+            torch.cuda.synchronize(device)
+            line["cpu_baseline"], want = cpu_baseline(x, flow, filt, args.cpu_seconds)
+            line["check"] = check_against_oracle(out, want)
+            if not line["check"]["ok"]:
+                failed = "output differs from the oracle by %.3g (> %g)" % (line["check"]["max_abs_err"], CHECK_TOLERANCE)
         print(json.dumps(line), flush=True)
+        if failed:
+            raise SystemExit("bench.py: " + failed)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

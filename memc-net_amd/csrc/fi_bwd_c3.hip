@@ -560,19 +560,29 @@ __device__ __noinline__ void fi_bwd_site_image_atomics(int x, int y, int W, int 
 // largest value of a non-negative int over the wave (float bit patterns of |x| order like ints; NaN sorts last)
 __device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
 
-// ALIAS: the two planes alias the staged image (48 KiB per workgroup; the planes are zeroed after phase 1, behind a
-// barrier).  !ALIAS: image (2496 pixel quads) and planes (2 x 2496 slots) side by side, 78 KiB -- still two workgroups
-// per CU, which is what the 193 registers allow anyway -- so that a wave goes from its tap / flow gradients straight on
-// to its LDS adds: no barrier and no zeroing pass between the two, the adds of one wave overlap the gathers and
-// stores of the others, and the tile is two barriers long (staged; accumulated) instead of eight.
-template <bool ALIAS>
+// The two planes alias the staged image (48 KiB per workgroup, 3072 cells: 96 x 32, 80 x 38 or 64 x 48 by the band's
+// width -- DYN; the fixed 96 x 32 of rounds 1-2 is kept as an arm).
+//
+// ORDER 0 / 1 (arms 20 / 22; 0 = fixed 96 x 32 geometry): image first, as rounds 1-2 had it -- stage, barrier, phase 1 (tap
+//   and flow gradients from the staged image), barrier, zero the planes, barrier, adds, barrier, flush.
+// ORDER 2: image gradient FIRST.  The adds need no image, so the planes are zeroed while the tile's input loads are
+//   still in flight, the adds start as soon as the box is known, and the image rows -- requested before the adds --
+//   arrive in registers while the LDS is busy with adds and flush; they are written to the LDS behind the flush and
+//   phase 1 ends the tile with its stores.  Against ORDER 1 the tile's serial chain loses the zeroing pass with its two
+//   barriers and the staging round trip:  load -> box -> adds -> flush -> (image is already here) -> phase 1.
+//   (The staged rows are touched once before the flush: vmcnt is in order, and a wait behind the flush's conditional
+//   atomics could only be vmcnt(0).)
+// Measured and dropped (session r03_s1): image and planes side by side (78 KiB, 2496 cells each; adds straight
+// behind phase 1 without a barrier) -- 1743 us against 1605 for the aliased planes at 720p (i.i.d. flow: 3462 vs
+// 2688): the smaller budget sweeps more tiles in two bands, and the adds overlapped nothing (a wave's adds + barrier
+// took as long as barrier + zero + barrier + adds).
 struct PkGeom {
-    static constexpr int kCap = ALIAS ? 3072 : 2496;                   // pixel quads staged = slots per plane
-    static constexpr int kImageBytes = kCap * 16, kPlaneBytes = kCap * 8;
-    static constexpr int kLds = (ALIAS ? kImageBytes : kImageBytes + 2 * kPlaneBytes) + 128;
+    static constexpr int kCap = 3072;                                  // pixel quads staged = slots per plane
+    static constexpr int kImageBytes = kCap * 16;
+    static constexpr int kLds = kImageBytes + 128;
 };
 
-template <int MINW, bool ALIAS, bool TR>
+template <int MINW, int ORDER, bool TR>
 __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
     int W, int H, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
@@ -581,13 +591,14 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
     float *__restrict__ gin3)
 {
     constexpr int LX = 16;
-    using PG = PkGeom<ALIAS>;
+    constexpr bool DYN = ORDER != 0, P2FIRST = ORDER == 2;
+    using PG = PkGeom;
     using G = TileGeom<LX, PG::kCap>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
-    unsigned long long *const accA = reinterpret_cast<unsigned long long *>(smem + (ALIAS ? 0 : PG::kImageBytes));
+    unsigned long long *const accA = reinterpret_cast<unsigned long long *>(smem);   // the planes alias the image
     unsigned long long *const accB = accA + PG::kCap;
-    int *bb = reinterpret_cast<int *>(smem + PG::kLds - 128);            // 16 ints: boxes; 8 ints: maxima
+    int *bb = reinterpret_cast<int *>(smem + PG::kImageBytes);           // 16 ints: boxes; 8 ints: maxima
     int *mx = bb + 16;
 
     trace_mark<TR>(0);
@@ -607,6 +618,14 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
     for (int c = 0; c < 3; c++) go[c] = ld_stream4_u(gout_b + c * s1c, o1);
 #pragma unroll
     for (int k = 0; k < 16; k++) tp[k] = ld_stream4_u(filt_b + k * s3c, o3);
+    auto zero_planes = [&](int cells) {        // the first `cells` slots of both planes (whole 16-byte units)
+        f32x4 *pa = reinterpret_cast<f32x4 *>(accA), *pb = reinterpret_cast<f32x4 *>(accB);
+        for (int i = (int)tid_now(); i < (cells >> 1); i += 256) {
+            pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (P2FIRST) zero_planes(PG::kCap);        // while the loads are in flight
     if (TR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     trace_mark<TR>(1);                                         // inputs have arrived
 
@@ -640,7 +659,7 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
         }
     }
     const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
-    const Bands bands = make_bands<LX, !ALIAS, PG::kCap>(box);
+    const Bands bands = make_bands<LX, DYN, PG::kCap>(box);
     int mg = max(max(mx[0], mx[2]), max(mx[4], mx[6])), mt = max(max(mx[1], mx[3]), max(mx[5], mx[7]));
     mg = __builtin_amdgcn_readfirstlane(mg);
     mt = __builtin_amdgcn_readfirstlane(mt);
@@ -657,11 +676,33 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
                          frexpf(__int_as_float(mode == 1 ? mt : 0x3F800000), &e1);
         if (mm < 0.4999f && et > -100) et -= 1;
     }
+    const float sg = ldexpf(1.0f, 11 - eg), st = ldexpf(1.0f, 11 - et);
+    const double inv = ldexp(1.0, eg + et - 22);
     const float *in_b = in1 + b * s1b;
     float *gin1_b = gin1 + b * s1b;
     unsigned done = 0;
     trace_mark<TR>(2);                                         // bounding box known
     fi_bwd_zero_invalid(inb, g.valid, gin2_b, s2c, o2, gin3_b, s3c, o3);
+    auto image_atomics = [&](unsigned todo) {  // mode 2
+        while (todo) {
+            const int j = __ffs(todo) - 1;
+            todo &= todo - 1;
+            fi_bwd_site_image_atomics(x + j, y, W, H, gin1_b, s1c, s1h, flow_b + o2 / 4 + j, s2c,
+                                      filt_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
+        }
+    };
+    auto phase1 = [&](const Region &r, unsigned fast) {
+        fi_bwd_phase1<0>(r, fast, g, tp, go, tile, W, H, gin2_b, s2c, o2, gin3_b, s3c, o3);
+        if (fast != 0xFu) {                    // mixed quads (rare): their tap gradients, site by site
+            unsigned todo = fast;
+            while (todo) {
+                const int j = __ffs(todo) - 1;
+                todo &= todo - 1;
+                fi_bwd_site_taps(x + j, y, W, H, in_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j, s2c,
+                                 filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
+            }
+        }
+    };
 #pragma unroll 1
     for (int bi = 0; bi < bands.n; bi++) {
     const Region r = band_region(box, bands, bi);
@@ -669,56 +710,51 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
     // later bands run only if some site still needs them; the vote is also the barrier that frees the LDS
     if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
     done |= fast;
-    auto zero_planes = [&]() {                 // the rows of both planes that the band uses
-        f32x4 *pa = reinterpret_cast<f32x4 *>(accA), *pb = reinterpret_cast<f32x4 *>(accB);
-        const int n = r.h * (r.pitch >> 1);                    // float4 per plane
-        for (int i = (int)tid_now(); i < n; i += 256) {
-            pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    if (!ALIAS && mode == 1) {                 // planes beside the image: zeroed while the staging loads are in flight
+    if (P2FIRST) {
         const StageSlot sl = stage_slots(r);
         StageRegs<3> sr;
-        tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);
-        zero_planes();
+        tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);         // in flight during adds and flush
+        if (mode == 1) {
+            if (bi > 0) {                      // (band 0: zeroed at the top, ordered by the barrier of tile_bbox)
+                zero_planes(r.h * r.pitch);
+                __syncthreads();
+            }
+            fi_bwd_adds_pk(r, fast, g, tp, go, sg, st, accA, accB, W, H);
+            __syncthreads();
+            if (bi == 0) trace_mark<TR>(3);                    // accumulated
+#pragma unroll
+            for (int it = 0; it < kStageIts; it++)             // the staged rows have landed long ago: take the wait
+#pragma unroll                                                 // here, not behind the flush's atomics
+                for (int c = 0; c < 3; c++)
+                    asm volatile("" : "+v"(sr.v[it][c][0]), "+v"(sr.v[it][c][1]), "+v"(sr.v[it][c][2]), "+v"(sr.v[it][c][3]));
+            fi_bwd_flush_pk(r, accA, accB, inv, gin1_b, s1c, s1h);
+            __syncthreads();                   // the planes have been read: the LDS becomes the image
+            if (bi == 0) trace_mark<TR>(4);                    // flushed
+        } else if (mode == 2) {
+            image_atomics(fast);
+        }
         tile_stage_store<3>(r, sl, sr, tile);
-    } else {
-        tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
+        __syncthreads();
+        if (bi == 0) trace_mark<TR>(5);                        // image staged
+        phase1(r, fast);
+        if (bi == 0) trace_mark<TR>(6);                        // phase 1 done (this wave)
+        continue;
     }
+    tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
     __syncthreads();
     if (bi == 0) trace_mark<TR>(3);                            // image staged
-    fi_bwd_phase1<0>(r, fast, g, tp, go, tile, W, H, gin2_b, s2c, o2, gin3_b, s3c, o3);
-    if (fast != 0xFu) {                        // mixed quads (rare): their tap gradients, site by site
-        unsigned todo = fast;
-        while (todo) {
-            const int j = __ffs(todo) - 1;
-            todo &= todo - 1;
-            fi_bwd_site_taps(x + j, y, W, H, in_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j, s2c,
-                             filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
-        }
-    }
+    phase1(r, fast);
     if (bi == 0) trace_mark<TR>(4);                            // phase 1 done (this wave)
-    if (mode == 2) {
-        unsigned todo = fast;
-        while (todo) {
-            const int j = __ffs(todo) - 1;
-            todo &= todo - 1;
-            fi_bwd_site_image_atomics(x + j, y, W, H, gin1_b, s1c, s1h, flow_b + o2 / 4 + j, s2c,
-                                      filt_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
-        }
-    }
+    if (mode == 2) image_atomics(fast);
     if (mode != 1) continue;                   // (workgroup-uniform)
-    if (ALIAS) {
-        __syncthreads();                       // everybody is done reading the image: the LDS becomes the planes
-        zero_planes();
-        __syncthreads();
-        if (bi == 0) trace_mark<TR>(5);                        // planes zeroed
-    }
-    fi_bwd_adds_pk(r, fast, g, tp, go, ldexpf(1.0f, 11 - eg), ldexpf(1.0f, 11 - et), accA, accB, W, H);
+    __syncthreads();                           // everybody is done reading the image: the LDS becomes the planes
+    zero_planes(r.h * r.pitch);
+    __syncthreads();
+    if (bi == 0) trace_mark<TR>(5);                            // planes zeroed
+    fi_bwd_adds_pk(r, fast, g, tp, go, sg, st, accA, accB, W, H);
     __syncthreads();
     if (bi == 0) trace_mark<TR>(6);                            // accumulated
-    fi_bwd_flush_pk(r, accA, accB, ldexp(1.0, eg + et - 22), gin1_b, s1c, s1h);
+    fi_bwd_flush_pk(r, accA, accB, inv, gin1_b, s1c, s1h);
     if (bi == 0) trace_mark<TR>(7);                            // flushed
     }   // bands
     trace_mark<TR>(12);
@@ -762,9 +798,7 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
     } while (0)
 #define MEMC_FI_BWD_PK(MINW, AL, TR)                                                                               \
     do {                                                                                                           \
-        static const bool once = (allow_big_lds(fi_bwd_c3_pk<MINW, AL, TR>, PkGeom<AL>::kLds), true);              \
-        (void)once;                                                                                                \
-        hipLaunchKernelGGL((fi_bwd_c3_pk<MINW, AL, TR>), dim3(ntiles), dim3(256), PkGeom<AL>::kLds, stream,        \
+        hipLaunchKernelGGL((fi_bwd_c3_pk<MINW, AL, TR>), dim3(ntiles), dim3(256), PkGeom::kLds, stream,            \
                            MEMC_FI_BWD_ARGS);                                                                      \
     } while (0)
 #ifdef MEMC_MEASURE
@@ -781,10 +815,11 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
         break;
     case 10: MEMC_FI_BWD_P(true); break;
     case 11: MEMC_FI_BWD_P(false); break;
-    case 20: MEMC_FI_BWD_PK(2, true, false); break;        // packed planes aliasing the image
-    case 21: MEMC_FI_BWD_PK(2, false, false); break;       // packed planes beside the image
-    case 28: MEMC_FI_BWD_PK(2, true, true); break;         // + timestamps
-    case 29: MEMC_FI_BWD_PK(2, false, true); break;
+    case 20: MEMC_FI_BWD_PK(2, 0, false); break;           // packed planes, image first, fixed 96 x 32 geometry
+    case 22: MEMC_FI_BWD_PK(2, 1, false); break;           // packed planes, image first, dynamic pitch
+    case 23: MEMC_FI_BWD_PK(2, 2, false); break;           // packed planes, image gradient first
+    case 27: MEMC_FI_BWD_PK(2, 1, true); break;            // + timestamps
+    case 28: MEMC_FI_BWD_PK(2, 2, true); break;
     default: MEMC_FI_BWD(0);
     }
 #else

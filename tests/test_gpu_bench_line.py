@@ -1,0 +1,52 @@
+"""bench.py's own line: the self-check against the oracle, the evidence fields, and -- where the box has two GPUs --
+the real RCCL path (one process per GPU, backend "nccl").  GPU only."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_checks_its_own_output_against_the_oracle():
+    """A short run of the default workload's code path (2 frame pairs): the line carries `check` (max-abs error of the
+    timed launches' output against the oracle, must be <= 1e-4), `roofline`, `cpu_baseline`, `traffic_source`, and the
+    input sets it rotated over (a 2-frame launch moves 177 MB: eight sets)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "2", "--steps", "6", "--warmup", "2",
+                        "--prewarm", "4", "--no-secondary", "--cpu-seconds", "0.5", "--launch", "eager"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = _line(r.stdout)
+    assert line["check"]["ok"] and line["check"]["max_abs_err"] <= 1e-4 and line["check"]["frames"] == 2
+    assert line["config"]["input_sets"] >= 4
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["frac"] > 0
+    assert "traffic_source" in line["roofline"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+    assert line["n_gpus"] == 1 and line["dtype"] == "f32" and line["vs_baseline"] is None
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the lease of this pool has one")
+def test_two_ranks_over_rccl():
+    """The N > 1 path as the driver launches it: one process per GPU, backend nccl (= RCCL), strong scaling.  The line
+    must say what the collective layer saw."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--prewarm", "20"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = _line(r.stdout)
+    d = line["dist"]
+    assert d["backend"] == "nccl" and d["world_size_seen"] == 2
+    assert d["per_rank_items"] == [16, 16] and len(d["per_rank_ms_per_step"]) == 2
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["global_batch"] == 32

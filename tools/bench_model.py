@@ -85,7 +85,20 @@ def main(argv=None):
         return networks.interpolate_pairs(net, frames[0], frames[1])
 
     with torch.no_grad():
-        worst, _ = bench.timed_steps(lambda i: interpolate_batch(), a.steps, a.warmup, world, dev)
+        worst, local = bench.timed_steps(lambda i: interpolate_batch(), a.steps, a.warmup, world, dev)
+    dist_seen = None
+    if world > 1:                                      # what the collective layer saw (evidence; not on the data path)
+        import torch.distributed as dist
+        gdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        mine = torch.tensor([local / a.steps * 1e3, bcast_s], dtype=torch.float64, device=gdev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        dist_seen = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                     "per_rank_ms_per_step": [round(float(g[0]), 2) for g in gathered],
+                     "weight_broadcast": {"messages": msgs, "bytes": int(nbytes),
+                                          "per_rank_seconds": [round(float(g[1]), 4) for g in gathered],
+                                          "GBps_slowest_rank": round(nbytes / max(float(g[1]) for g in gathered) / 1e9, 2)}}
+    with torch.no_grad():
 
         # share of the step spent inside the hot-path operators: one extra untimed pass with events around them
         spans, originals = [], {}
@@ -129,6 +142,8 @@ def main(argv=None):
                 "hot_path_ops_ms": {k: round(v, 3) for k, v in sorted(per_op.items())},
                 "hot_path_ops_calls": len(spans),
                 "hot_path_share_of_step": round(sum(per_op.values()) / pass_ms, 4), "instrumented_pass_ms": round(pass_ms, 2)}
+        if dist_seen:
+            line["dist"] = dist_seen
         print(json.dumps(line), flush=True)
         if a.json:
             json.dump(line, open(a.json, "w"), indent=1)
