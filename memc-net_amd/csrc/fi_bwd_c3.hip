@@ -1,8 +1,15 @@
-// fi_bwd_c3.hip -- FilterInterpolation backward, RGB (C == 3), fs == 4: the LDS-tiled kernels.
+// fi_bwd_c3.hip -- FilterInterpolation backward, RGB (C == 3), fs == 4: the LDS-tiled kernel.
 //
 // Replaces my_package/src/my_lib_kernel.cu:1220-1518 (kernel) / :1571-1627 (launcher) of the reference for the only
 // channel count its networks back-propagate through (networks/MEMC_Net_star.py:266-277; the context warps are
-// detached, :285).  Semantics: SURVEY.md appendix A.2.
+// detached, :285).  Semantics: SURVEY.md appendix A.2.  Same tile / box machinery as the forward kernel:
+//   * streams (flow, 16 tap planes, 3 gradoutput planes) as dwordx4;
+//   * the image gradient -- 48 scattered adds per site -- is accumulated in LDS (packed fixed point, below) and
+//     flushed once per cell with row-coalesced global atomics (neighbouring tiles' boxes overlap);
+//   * the image box is staged into LDS pixel quads for the tap and flow gradients: gradinput3 (each site owns its
+//     taps) is stored once per site as dwordx4, gradinput2 is assigned;
+//   * sites whose window no band covers are redone by fi_bwd_site_scalar with global atomics.
+// The kernel of rounds 1-2 (one fp64 plane per colour) lives on as a measurement arm: arms/fi_bwd_c3_arms.hip.
 #include "memc_common.hpp"
 #include "memc_internal.h"
 #include "memc_tile.hpp"
@@ -10,62 +17,21 @@
 
 namespace memc {
 
-// --------------------------------------------------------------------------------------------------
-// Backward, fs == 4, RGB, LDS-tiled and vectorised.  Same tile / box machinery as the forward kernel:
-//   * streams (flow, 16 tap planes, 3 gradoutput planes) as dwordx4;
-//   * the image box is staged into LDS pixel quads (needed for the tap and flow gradients);
-//   * the image gradient -- 48 scattered adds per site -- goes, one colour channel at a time, into transposed fp64
-//     LDS accumulator planes (ds_add_f64: twenty times the rate of ds_add_f32 on this chip; AccT in
-//     memc_tile.hpp) and is flushed once per cell, rounded to fp32, with row-coalesced global atomics;
-//   * gradinput3 (each site owns its taps) is stored once per site as dwordx4 (the caller zero-fills it);
-//     gradinput2 is assigned.
-// Sites whose window is not staged are redone by fi_bwd_site_scalar with global atomics.
-// --------------------------------------------------------------------------------------------------
-// Per-workgroup phase timestamps (shader clock) for tools/trace_kernel.py; written by the ABL == 9 arm only.
+// Per-workgroup phase timestamps (shader clock) for tools/trace_kernel.py: the TR = true instantiation exists in the
+// measurement build only.
+#ifdef MEMC_MEASURE
 __device__ unsigned long long *g_trace_buf = nullptr;
-constexpr int kTraceSlots = 16;
+#endif
 template <bool ON>
 __device__ __forceinline__ void trace_mark(int slot)
 {
-    if (ON && threadIdx.x == 0) g_trace_buf[(size_t)blockIdx.x * kTraceSlots + slot] = __builtin_readcyclecounter();
+#ifdef MEMC_MEASURE
+    if (ON && threadIdx.x == 0) g_trace_buf[(size_t)blockIdx.x * 16 + slot] = __builtin_readcyclecounter();
+#else
+    static_assert(!ON, "timestamps: measurement build only");
+    (void)slot;
+#endif
 }
-
-// ABL != 0 are MEASUREMENT arms (tools/bench_ops.py --bwd-variants; their results are wrong by construction):
-//   1 no fp64 LDS adds (zero + flush kept; zero cells are not flushed)   2 no phase 2 at all
-//   3 phase 1 without its LDS reads                                      5 flush with plain stores
-//   4 accumulate but never flush (plane re-zeroed instead)
-//   9 production + phase timestamps
-// gradinput3 and gradinput2 of ONE site straight from global memory (mixed quads of the tiled backward: some of a
-// lane's four sites belong to another band or are invalid).  Assigns both, like the tiled path; the image
-// gradient of such a site still goes through the tiled phase 2.
-__device__ __noinline__ void fi_bwd_site_taps(int x, int y, int W, int H, const float *in_b, int64_t s1c, int s1h,
-                                              const float *flow_p, float *g2, int64_t s2c, const float *tap_p,
-                                              float *g3, int64_t s3c, const float *gout_p)
-{
-    const FiSite s = fi_locate(x, y, W, H, flow_p[0], flow_p[s2c]);
-    if (!s.valid) return;
-    const float g0 = gout_p[0], g1 = gout_p[s1c], gc2 = gout_p[2 * s1c];
-    float gx = 0.0f, gy = 0.0f;
-    for (int k = 0; k < 4; k++) {
-        const float *row = in_b + (int64_t)clampi(s.iy - 1 + k, H - 1) * s1h;
-        for (int m = 0; m < 4; m++) {
-            const float *p = row + clampi(s.ix - 1 + m, W - 1);
-            float sv = 0.0f;
-            sv += g0 * p[0];  sv += g1 * p[s1c];  sv += gc2 * p[2 * s1c];
-            const float wa = m < 2 ? (1 - s.a) : s.a, wb = k < 2 ? (1 - s.b) : s.b;
-            g3[(k * 4 + m) * s3c] = (wa * wb) * sv;
-            const float st = sv * tap_p[(k * 4 + m) * s3c];
-            gx += (m < 2 ? -wb : wb) * st;
-            gy += (k < 2 ? -wa : wa) * st;
-        }
-    }
-    g2[0] = gx;
-    g2[s2c] = gy;
-}
-
-struct FiBwdIn {
-    f32x4 fx, fy, go[3], tp[16];
-};
 
 // Phase 1 of one band: tap and flow gradients of the sites in `fast` from the staged image.
 // With s = sum_c g_c * in_c(tap cell) (3 FMAs per tap), and q the tap's quadrant:
@@ -73,23 +39,6 @@ struct FiBwdIn {
 // where wq = {(1-a)(1-b), a(1-b), (1-a)b, ab}, cx = {-(1-b), (1-b), -b, b}, cy = {-(1-a), -a, (1-a), a}.
 // (The reference sums per channel first -- same value up to fp32 re-association, ~1e-7 relative.)
 // Tap rows are the outer loop so that only one row of tap gradients (4 float4) is live at a time.
-// gradinput2 / gradinput3 are fully DEFINED by the backward kernels (the Python layer hands them over
-// uninitialised -- their memsets were 72 B/site, a seventh of the call): a quad that contains an invalid site
-// first stores zeros to its 16 + 2 float4; its valid sites are then stored site by site (fi_bwd_site_taps), by the
-// same lane and therefore after these.  Quads of four valid sites are stored by phase 1 or by fi_bwd_site_taps.
-__device__ __forceinline__ void fi_bwd_zero_invalid(bool inb, unsigned valid, float *gin2_b, int64_t s2c, unsigned o2,
-                                                    float *gin3_b, int64_t s3c, unsigned o3)
-{
-    if (!inb || valid == 0xFu) return;         // rare (image borders, |flow| guard): ordinary 64-bit addressing
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    float *q3 = gin3_b + (o3 >> 2), *q2 = gin2_b + (o2 >> 2);
-#pragma unroll 1
-    for (int k = 0; k < 16; k++) *reinterpret_cast<f32x4 *>(q3 + k * s3c) = z;
-    *reinterpret_cast<f32x4 *>(q2) = z;
-    *reinterpret_cast<f32x4 *>(q2 + s2c) = z;
-}
-
-template <int ABL>
 __device__ __forceinline__ void fi_bwd_phase1(const Region &r, unsigned fast, FiSite4 &g, f32x4 (&tp)[16],
                                               const f32x4 (&go)[3], const f32x4 *tile, int W, int H,
                                               float *gin2_b, int64_t s2c, unsigned o2, float *gin3_b, int64_t s3c,
@@ -125,7 +74,7 @@ __device__ __forceinline__ void fi_bwd_phase1(const Region &r, unsigned fast, Fi
             for (int j = 0; j < 4; j++) {
                 const float a = g.a[j], bt = g.b[j];
                 const int co = swz_col(clampi(g.ix[j] - 1 + m, W - 1) - r.x0);
-                const f32x4 pix = ABL == 3 ? f32x4{a, bt, a, bt} : tile[ro[j] + co];
+                const f32x4 pix = tile[ro[j] + co];
                 float sv = 0.0f;
                 sv += go[0][j] * pix[0];  sv += go[1][j] * pix[1];  sv += go[2][j] * pix[2];
                 const float wa = m < 2 ? (1 - a) : a, wb = k < 2 ? (1 - bt) : bt;
@@ -139,272 +88,6 @@ __device__ __forceinline__ void fi_bwd_phase1(const Region &r, unsigned fast, Fi
     }
     st_stream4_u(gin2_b, o2, gx4);             // gradinput2 is ASSIGNED
     st_stream4_u(gin2_b + s2c, o2, gy4);
-}
-
-// The 16 ds_add_f64 of channel c of the sites in `fast` into the transposed plane `acc` (AccT, memc_tile.hpp).
-template <int ABL>
-__device__ __forceinline__ void fi_bwd_adds(const Region &r, unsigned fast, FiSite4 &g, const f32x4 (&tp)[16],
-                                            const f32x4 (&go)[3], int c, double *acc, int W, int H)
-{
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (ABL == 1 || !((fast >> j) & 1)) continue;
-        // keep the cell addresses and weights inside the caller's loops (hoisted, they spill)
-        asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
-        int ro[4], co[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            ro[k] = (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * AccT::kPitch;
-            co[k] = acct_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0);
-        }
-        const float a = g.a[j], bt = g.b[j];
-        const float gv = c == 0 ? go[0][j] : (c == 1 ? go[1][j] : go[2][j]);
-        const float wq[4] = {gv * (1 - a) * (1 - bt), gv * a * (1 - bt), gv * (1 - a) * bt, gv * a * bt};
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-                lds_add_f64(acc + ro[k] + co[m], (double)(wq[(k >> 1) * 2 + (m >> 1)] * tp[k * 4 + m][j]));
-    }
-}
-
-// One 64x16 tile per workgroup; 48 KiB of LDS: the staged image, then ONE accumulator plane that the colour
-// channels take in turn.  Measured on MI355X, 720p batch 32 (tools/bench_ops.py --bwd-variants):
-//   this kernel, 2 workgroups / CU (209 VGPRs)                                  1.82 ms
-//   MINW = 3: 3 workgroups / CU at 168 VGPRs (152 B of spills)        (arm 16)  1.93 ms
-//   persistent, 2 / CU, next tile's inputs prefetched during phase 2  (arm 10)  1.83 ms (2.09 with this phase 1)
-//   persistent without the prefetch                                   (arm 11)  1.83 ms (1.98)
-//   second workgroup of every CU delayed by half a tile; wave priority rising through phase 2      no change
-//   no phase 2 at all                                                 (arm 2)   1.05 - 1.3 ms (the HBM floor)
-// i.e. the time is phase 1 (HBM bound) PLUS the LDS-atomic work of phase 2, however the two are arranged: what
-// is left to gain is in the number and the conflict rate of the ds_add_f64 (768 wave-instructions per tile at
-// ~15 clk), not in latency hiding.
-template <int ABL, int MINW = 2>
-__global__ __launch_bounds__(256, MINW) void fi_bwd_tiled_c3(
-    int W, int H, int tiles_x, int tiles_y, int batch,
-    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
-    const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
-    const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2,
-    float *__restrict__ gin3)
-{
-    constexpr int LX = 16;
-    constexpr bool TR = ABL == 9;
-    using G = TileGeom<LX>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
-    double *const acc = reinterpret_cast<double *>(smem);        // aliases the image: phase 2 needs taps only
-    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
-
-    trace_mark<TR>(0);
-    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
-    const int b = tc.b;
-    const unsigned tid = tid_now();
-    const int x = tc.tx * G::kTW + 4 * (int)(tid % LX), y = tc.ty * G::kTH + (int)(tid / LX);
-    const bool inb = x < W && y < H;
-    const int xs = min(x, W - 4), ys = min(y, H - 1);
-    // wave-uniform plane bases + one 32-bit byte offset per tensor (see ld_stream4_u)
-    const float *flow_b = flow + b * s2b, *filt_b = filt + b * s3b, *gout_b = gout + b * s1b;
-    float *gin2_b = gin2 + b * s2b, *gin3_b = gin3 + b * s3b;
-    const unsigned o1 = 4u * (unsigned)(ys * s1h + xs), o2 = 4u * (unsigned)(ys * s2h + xs),
-                   o3 = 4u * (unsigned)(ys * s3h + xs);
-    f32x4 go[3], tp[16];
-    const f32x4 fx4 = ld_stream4_u(flow_b, o2), fy4 = ld_stream4_u(flow_b + s2c, o2);
-#pragma unroll
-    for (int c = 0; c < 3; c++) go[c] = ld_stream4_u(gout_b + c * s1c, o1);
-#pragma unroll
-    for (int k = 0; k < 16; k++) tp[k] = ld_stream4_u(filt_b + k * s3c, o3);
-    if (TR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    trace_mark<TR>(1);                                         // inputs have arrived
-
-    FiSite4 g;
-    g.valid = 0;
-    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const FiSite s = fi_locate(x + j, y, W, H, fx4[j], fy4[j]);
-        g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
-        if (inb && s.valid) {
-            g.valid |= 1u << j;
-            cmin = min(cmin, max(s.ix - 1, 0));  cmax = max(cmax, min(s.ix + 2, W - 1));
-            rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
-        }
-    }
-    const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
-    const Bands bands = make_bands<LX, false>(box);
-    const float *in_b = in1 + b * s1b;
-    float *gin1_b = gin1 + b * s1b;
-    unsigned done = 0;
-    trace_mark<TR>(2);                                         // bounding box known
-    fi_bwd_zero_invalid(inb, g.valid, gin2_b, s2c, o2, gin3_b, s3c, o3);
-#pragma unroll 1
-    for (int bi = 0; bi < bands.n; bi++) {
-    const Region r = band_region(box, bands, bi);
-    const unsigned fast = inb ? fi_covered(r, g, W, H) & ~done : 0u;
-    // later bands run only if some site still needs them; the vote is also the barrier that frees the LDS
-    if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
-    done |= fast;
-    tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
-    __syncthreads();
-    if (bi == 0) trace_mark<TR>(3);                            // image staged
-    fi_bwd_phase1<ABL>(r, fast, g, tp, go, tile, W, H, gin2_b, s2c, o2, gin3_b, s3c, o3);
-    if (fast != 0xFu) {                        // mixed quads (rare): their tap gradients, site by site
-        unsigned todo = fast;
-        while (todo) {
-            const int j = __ffs(todo) - 1;
-            todo &= todo - 1;
-            fi_bwd_site_taps(x + j, y, W, H, in_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j, s2c,
-                             filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
-        }
-    }
-    __syncthreads();                           // everybody is done reading the image: the LDS becomes `acc`
-    if (bi == 0) trace_mark<TR>(4);                            // phase 1 done
-    if (ABL == 2) continue;
-    acct_zero<1>(acc);
-    __syncthreads();
-    if (bi == 0) trace_mark<TR>(5);                            // plane zeroed
-#pragma unroll 1
-    for (int c = 0; c < 3; c++) {
-        fi_bwd_adds<ABL>(r, fast, g, tp, go, c, acc, W, H);
-        __syncthreads();
-        if (bi == 0) trace_mark<TR>(6 + 2 * c);                // channel c accumulated
-        if (ABL == 4) acct_zero<1>(acc);                            // measurement: accumulate, never flush
-        else acct_flush_zero<ABL == 5>(r, acc, gin1_b + c * s1c, s1h);    // leaves the plane zeroed for the next channel
-        __syncthreads();
-        if (bi == 0) trace_mark<TR>(7 + 2 * c);                // channel c flushed
-    }
-    }   // bands
-    trace_mark<TR>(12);
-    unsigned slow = inb ? g.valid & ~done : 0u;            // not coverable within kMaxBands bands
-    while (slow) {                            // rare: redone from global memory with global atomics
-        const int j = __ffs(slow) - 1;
-        slow &= slow - 1;
-        fi_bwd_site_scalar(x + j, y, W, H, 3, 4, in_b, gin1_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j,
-                           s2c, filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
-    }
-}
-
-// Persistent variant (measurement arms 10 / 11): 2 workgroups per CU walk the tiles w, w + grid, ... (grid % 8 == 0:
-// a workgroup stays on its XCD's chunk of the strip order); phase 1 of all bands, then -- arm 10 -- the 21 float4 of
-// per-site inputs of the NEXT tile are requested so that they arrive while phase 2 runs on the LDS (two planes, the
-// flush of one channel overlapping the adds of the next).  No faster than one tile per workgroup (table above).
-template <bool PREFETCH>
-__global__ __launch_bounds__(256, 2) void fi_bwd_tiled_c3_persistent(
-    int W, int H, int tiles_x, int tiles_y, int batch,
-    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
-    const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
-    const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2,
-    float *__restrict__ gin3)
-{
-    constexpr int LX = 16;
-    using G = TileGeom<LX>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
-    double *const plane0 = reinterpret_cast<double *>(smem);     // plane i at plane0 + i * AccT::kPlane
-    int *bb = reinterpret_cast<int *>(smem + 2 * AccT::kPlane * 8);
-    const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
-
-    // requests the per-site inputs of tile `v` (always a valid tile: loads stay unconditional)
-    auto request = [&](unsigned v, FiBwdIn &in) {
-        const TileCoord tc = strip_walk(v, ntiles, tiles_x, tiles_y, batch);
-        const unsigned tid = tid_now();
-        const int xs = min(tc.tx * G::kTW + 4 * (int)(tid % LX), W - 4), ys = min(tc.ty * G::kTH + (int)(tid / LX), H - 1);
-        const float *flow_b = flow + tc.b * s2b, *filt_b = filt + tc.b * s3b, *gout_b = gout + tc.b * s1b;
-        const unsigned o1 = 4u * (unsigned)(ys * s1h + xs), o2 = 4u * (unsigned)(ys * s2h + xs),
-                       o3 = 4u * (unsigned)(ys * s3h + xs);
-        in.fx = ld_stream4_u(flow_b, o2);
-        in.fy = ld_stream4_u(flow_b + s2c, o2);
-#pragma unroll
-        for (int c = 0; c < 3; c++) in.go[c] = ld_stream4_u(gout_b + c * s1c, o1);
-#pragma unroll
-        for (int k = 0; k < 16; k++) in.tp[k] = ld_stream4_u(filt_b + k * s3c, o3);
-    };
-
-    unsigned v = blockIdx.x;
-    FiBwdIn nx;
-    if (PREFETCH) request(v, nx);
-#pragma unroll 1
-    for (;;) {
-    FiBwdIn in;
-    if (PREFETCH) in = nx; else request(v, in);
-    const TileCoord tc = strip_walk(v, ntiles, tiles_x, tiles_y, batch);
-    const int b = tc.b;
-    const unsigned tid = tid_now();        // (and W, H below) opaque per tile: nothing derived from them is hoisted
-    const int x = tc.tx * G::kTW + 4 * (int)(tid % LX), y = tc.ty * G::kTH + (int)(tid / LX);
-    const bool inb = x < W && y < H;
-    const int xs = min(x, W - 4), ys = min(y, H - 1);
-    const float *flow_b = flow + b * s2b, *filt_b = filt + b * s3b, *gout_b = gout + b * s1b;
-    float *gin2_b = gin2 + b * s2b, *gin3_b = gin3 + b * s3b;
-    const unsigned o1 = 4u * (unsigned)(ys * s1h + xs), o2 = 4u * (unsigned)(ys * s2h + xs),
-                   o3 = 4u * (unsigned)(ys * s3h + xs);
-    FiSite4 g;
-    g.valid = 0;
-    int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
-    int Wl = W, Hl = H;
-    asm volatile("" : "+s"(Wl), "+s"(Hl));
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const FiSite s = fi_locate(x + j, y, Wl, Hl, in.fx[j], in.fy[j]);
-        g.ix[j] = s.ix; g.iy[j] = s.iy; g.a[j] = s.a; g.b[j] = s.b;
-        if (inb && s.valid) {
-            g.valid |= 1u << j;
-            cmin = min(cmin, max(s.ix - 1, 0));  cmax = max(cmax, min(s.ix + 2, W - 1));
-            rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
-        }
-    }
-    const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
-    const Bands bands = make_bands<LX, false>(box);
-    const float *in_b = in1 + b * s1b;
-    float *gin1_b = gin1 + b * s1b;
-    fi_bwd_zero_invalid(inb, g.valid, gin2_b, s2c, o2, gin3_b, s3c, o3);
-    unsigned done = 0, fastbits = 0;                           // fastbits: 4 bits per band, the sites it owns
-#pragma unroll 1
-    for (int bi = 0; bi < bands.n; bi++) {
-        const Region r = band_region(box, bands, bi);
-        const unsigned fast = inb ? fi_covered(r, g, W, H) & ~done : 0u;
-        if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
-        done |= fast;
-        fastbits |= fast << (4 * bi);
-        tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
-        __syncthreads();
-        fi_bwd_phase1<0>(r, fast, g, in.tp, in.go, tile, W, H, gin2_b, s2c, o2, gin3_b, s3c, o3);
-        if (fast != 0xFu) {                    // mixed quads (rare): their tap gradients, site by site
-            unsigned todo = fast;
-            while (todo) {
-                const int j = __ffs(todo) - 1;
-                todo &= todo - 1;
-                fi_bwd_site_taps(x + j, y, W, H, in_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j, s2c,
-                                 filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
-            }
-        }
-        __syncthreads();                       // everybody is done reading the image
-    }
-    // next tile's inputs: in flight during phase 2 (the last iteration re-requests its own tile: unconditional)
-    const unsigned vn = v + gridDim.x;
-    if (PREFETCH) request(vn < ntiles ? vn : v, nx);
-    acct_zero<2>(plane0);                      // the image was here; every flush below leaves its plane zeroed again
-    __syncthreads();
-#pragma unroll 1
-    for (int bi = 0; bi < bands.n; bi++) {
-        const unsigned fast = (fastbits >> (4 * bi)) & 0xFu;
-        if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
-        const Region r = band_region(box, bands, bi);
-#pragma unroll 1
-        for (int c = 0; c < 4; c++) {          // channel c accumulates while channel c - 1 is flushed
-            if (c > 0) acct_flush_zero<false>(r, plane0 + ((c - 1) & 1) * AccT::kPlane, gin1_b + (c - 1) * s1c, s1h);
-            if (c < 3) fi_bwd_adds<0>(r, fast, g, in.tp, in.go, c, plane0 + (c & 1) * AccT::kPlane, W, H);
-            __syncthreads();
-        }
-    }
-    unsigned slow = inb ? g.valid & ~done : 0u;
-    while (slow) {
-        const int j = __ffs(slow) - 1;
-        slow &= slow - 1;
-        fi_bwd_site_scalar(x + j, y, W, H, 3, 4, in_b, gin1_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j,
-                           s2c, filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
-    }
-    if (vn >= ntiles) break;
-    v = vn;
-    }   // tiles
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -560,30 +243,30 @@ __device__ __noinline__ void fi_bwd_site_image_atomics(int x, int y, int W, int 
 // largest value of a non-negative int over the wave (float bit patterns of |x| order like ints; NaN sorts last)
 __device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
 
-// The two planes alias the staged image (48 KiB per workgroup, 3072 cells: 96 x 32, 80 x 38 or 64 x 48 by the band's
-// width -- DYN; the fixed 96 x 32 of rounds 1-2 is kept as an arm).
-//
-// ORDER 0 / 1 (arms 20 / 22; 0 = fixed 96 x 32 geometry): image first, as rounds 1-2 had it -- stage, barrier, phase 1 (tap
-//   and flow gradients from the staged image), barrier, zero the planes, barrier, adds, barrier, flush.
-// ORDER 2: image gradient FIRST.  The adds need no image, so the planes are zeroed while the tile's input loads are
-//   still in flight, the adds start as soon as the box is known, and the image rows -- requested before the adds --
-//   arrive in registers while the LDS is busy with adds and flush; they are written to the LDS behind the flush and
-//   phase 1 ends the tile with its stores.  Against ORDER 1 the tile's serial chain loses the zeroing pass with its two
-//   barriers and the staging round trip:  load -> box -> adds -> flush -> (image is already here) -> phase 1.
-//   (The staged rows are touched once before the flush: vmcnt is in order, and a wait behind the flush's conditional
-//   atomics could only be vmcnt(0).)
-// Measured and dropped (session r03_s1): image and planes side by side (78 KiB, 2496 cells each; adds straight
-// behind phase 1 without a barrier) -- 1743 us against 1605 for the aliased planes at 720p (i.i.d. flow: 3462 vs
-// 2688): the smaller budget sweeps more tiles in two bands, and the adds overlapped nothing (a wave's adds + barrier
-// took as long as barrier + zero + barrier + adds).
+// One 64 x 16 tile of sites per workgroup; 48 KiB of LDS: the two packed planes, then -- the same bytes -- the staged
+// image (3072 cells: 96 x 32, 80 x 38 or 64 x 48 by the band's width).  The image gradient comes FIRST: its adds need
+// no image, so
+//   * the planes are zeroed while the tile's 21 input float4 per lane are still in flight;
+//   * the adds start as soon as the box is known; the image rows, requested just before, arrive in registers while
+//     the LDS is busy with adds and flush (they are touched once before the flush: vmcnt is in order, and a wait
+//     placed behind the flush's conditional atomics could only be vmcnt(0));
+//   * the rows go to the LDS behind the flush, and phase 1 (tap and flow gradients from the staged image) ends the
+//     tile with its stores.
+// Serial chain of a tile: load -> box -> adds -> flush -> (image is already here) -> phase 1: four barriers.
+// Measured, 720p batch 32, smooth / i.i.d. flow / 448 x 256 batch 8 (profiles/r03_fi_bwd_c3_arms.txt; one box, one process):
+//   rounds 1-2: fp64 plane per colour, three rounds of adds / flush      1777 / 2977 /  98.1 us
+//   packed planes, image first, fixed 96 x 32 geometry                   1545 / 2594 /  85.6
+//   packed planes, image first, pitch by the band's width                1364 / 1985 /  71.5
+//   packed planes, image gradient first (this kernel)                    1312 / 1929 /  71.4
+//   planes beside the image (78 KiB; adds straight behind phase 1)       1743 / 3462 /  90.1   (two-band sweeps; no overlap won)
 struct PkGeom {
     static constexpr int kCap = 3072;                                  // pixel quads staged = slots per plane
     static constexpr int kImageBytes = kCap * 16;
     static constexpr int kLds = kImageBytes + 128;
 };
 
-template <int MINW, int ORDER, bool TR>
-__global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
+template <bool TR>
+__global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
     int W, int H, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
@@ -591,7 +274,6 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
     float *__restrict__ gin3)
 {
     constexpr int LX = 16;
-    constexpr bool DYN = ORDER != 0, P2FIRST = ORDER == 2;
     using PG = PkGeom;
     using G = TileGeom<LX, PG::kCap>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -625,7 +307,7 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
             pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    if (P2FIRST) zero_planes(PG::kCap);        // while the loads are in flight
+    zero_planes(PG::kCap);                     // while the loads are in flight
     if (TR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     trace_mark<TR>(1);                                         // inputs have arrived
 
@@ -659,7 +341,7 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
         }
     }
     const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
-    const Bands bands = make_bands<LX, DYN, PG::kCap>(box);
+    const Bands bands = make_bands<LX, true, PG::kCap>(box);
     int mg = max(max(mx[0], mx[2]), max(mx[4], mx[6])), mt = max(max(mx[1], mx[3]), max(mx[5], mx[7]));
     mg = __builtin_amdgcn_readfirstlane(mg);
     mt = __builtin_amdgcn_readfirstlane(mt);
@@ -692,7 +374,7 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
         }
     };
     auto phase1 = [&](const Region &r, unsigned fast) {
-        fi_bwd_phase1<0>(r, fast, g, tp, go, tile, W, H, gin2_b, s2c, o2, gin3_b, s3c, o3);
+        fi_bwd_phase1(r, fast, g, tp, go, tile, W, H, gin2_b, s2c, o2, gin3_b, s3c, o3);
         if (fast != 0xFu) {                    // mixed quads (rare): their tap gradients, site by site
             unsigned todo = fast;
             while (todo) {
@@ -710,52 +392,33 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
     // later bands run only if some site still needs them; the vote is also the barrier that frees the LDS
     if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
     done |= fast;
-    if (P2FIRST) {
-        const StageSlot sl = stage_slots(r);
-        StageRegs<3> sr;
-        tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);         // in flight during adds and flush
-        if (mode == 1) {
-            if (bi > 0) {                      // (band 0: zeroed at the top, ordered by the barrier of tile_bbox)
-                zero_planes(r.h * r.pitch);
-                __syncthreads();
-            }
-            fi_bwd_adds_pk(r, fast, g, tp, go, sg, st, accA, accB, W, H);
+    const StageSlot sl = stage_slots(r);
+    StageRegs<3> sr;
+    tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);         // in flight during adds and flush
+    if (mode == 1) {
+        if (bi > 0) {                      // (band 0: zeroed at the top, ordered by the barrier of tile_bbox)
+            zero_planes(r.h * r.pitch);
             __syncthreads();
-            if (bi == 0) trace_mark<TR>(3);                    // accumulated
-#pragma unroll
-            for (int it = 0; it < kStageIts; it++)             // the staged rows have landed long ago: take the wait
-#pragma unroll                                                 // here, not behind the flush's atomics
-                for (int c = 0; c < 3; c++)
-                    asm volatile("" : "+v"(sr.v[it][c][0]), "+v"(sr.v[it][c][1]), "+v"(sr.v[it][c][2]), "+v"(sr.v[it][c][3]));
-            fi_bwd_flush_pk(r, accA, accB, inv, gin1_b, s1c, s1h);
-            __syncthreads();                   // the planes have been read: the LDS becomes the image
-            if (bi == 0) trace_mark<TR>(4);                    // flushed
-        } else if (mode == 2) {
-            image_atomics(fast);
         }
-        tile_stage_store<3>(r, sl, sr, tile);
+        fi_bwd_adds_pk(r, fast, g, tp, go, sg, st, accA, accB, W, H);
         __syncthreads();
-        if (bi == 0) trace_mark<TR>(5);                        // image staged
-        phase1(r, fast);
-        if (bi == 0) trace_mark<TR>(6);                        // phase 1 done (this wave)
-        continue;
+        if (bi == 0) trace_mark<TR>(3);                    // accumulated
+#pragma unroll
+        for (int it = 0; it < kStageIts; it++)             // the staged rows have landed long ago: take the wait
+#pragma unroll                                                 // here, not behind the flush's atomics
+            for (int c = 0; c < 3; c++)
+                asm volatile("" : "+v"(sr.v[it][c][0]), "+v"(sr.v[it][c][1]), "+v"(sr.v[it][c][2]), "+v"(sr.v[it][c][3]));
+        fi_bwd_flush_pk(r, accA, accB, inv, gin1_b, s1c, s1h);
+        __syncthreads();                   // the planes have been read: the LDS becomes the image
+        if (bi == 0) trace_mark<TR>(4);                    // flushed
+    } else if (mode == 2) {
+        image_atomics(fast);
     }
-    tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
+    tile_stage_store<3>(r, sl, sr, tile);
     __syncthreads();
-    if (bi == 0) trace_mark<TR>(3);                            // image staged
+    if (bi == 0) trace_mark<TR>(5);                        // image staged
     phase1(r, fast);
-    if (bi == 0) trace_mark<TR>(4);                            // phase 1 done (this wave)
-    if (mode == 2) image_atomics(fast);
-    if (mode != 1) continue;                   // (workgroup-uniform)
-    __syncthreads();                           // everybody is done reading the image: the LDS becomes the planes
-    zero_planes(r.h * r.pitch);
-    __syncthreads();
-    if (bi == 0) trace_mark<TR>(5);                            // planes zeroed
-    fi_bwd_adds_pk(r, fast, g, tp, go, sg, st, accA, accB, W, H);
-    __syncthreads();
-    if (bi == 0) trace_mark<TR>(6);                            // accumulated
-    fi_bwd_flush_pk(r, accA, accB, inv, gin1_b, s1c, s1h);
-    if (bi == 0) trace_mark<TR>(7);                            // flushed
+    if (bi == 0) trace_mark<TR>(6);                        // phase 1 done (this wave)
     }   // bands
     trace_mark<TR>(12);
     unsigned slow = inb ? g.valid & ~done : 0u;            // not coverable within kMaxBands bands
@@ -766,8 +429,7 @@ __global__ __launch_bounds__(256, MINW) void fi_bwd_c3_pk(
                            s2c, filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
     }
 }
-
-// 1: taken, 0: not this kernel's case (the caller falls back to the direct kernel), -1: launch error.  `variant`
+// 1: taken, 0: geometry not 16-byte aligned (the caller takes the direct kernel), -1: launch error.  `variant` >= 0
 // selects a measurement arm (measurement build only; the product passes -1).
 int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
                      int s1b, int s1c, int s1h, int s2b, int s2c, int s2h, int s3b, int s3c, int s3h,
@@ -779,67 +441,38 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
                  {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3}))
         return 0;
     using G = TileGeom<16>;
-    static_assert(AccT::kPlane * 8 <= G::kCapPx * 16 && G::kPitch <= AccT::kMaxW && G::kRows <= AccT::kRows,
-                  "the accumulator plane aliases the staged image");
     const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
     const unsigned ntiles = (unsigned)ntx * nty * batch;
-#define MEMC_FI_BWD_ARGS                                                                                           \
-    w, h, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,         \
-        (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3
-#define MEMC_FI_BWD(ABL)                                                                                           \
-    hipLaunchKernelGGL(fi_bwd_tiled_c3<ABL>, dim3(ntiles), dim3(256), tile_lds_bytes<16>(), stream, MEMC_FI_BWD_ARGS)
-#define MEMC_FI_BWD_P(PF)                                                                                          \
-    do {                                                                                                           \
-        const int lds = 2 * AccT::kPlane * 8 + 64;                                                                 \
-        static const bool once = (allow_big_lds(fi_bwd_tiled_c3_persistent<PF>, lds), true);                       \
-        (void)once;                                                                                                \
-        const unsigned grid = ntiles < persistent_grid(2) ? ntiles : persistent_grid(2);                           \
-        hipLaunchKernelGGL(fi_bwd_tiled_c3_persistent<PF>, dim3(grid), dim3(256), lds, stream, MEMC_FI_BWD_ARGS);  \
-    } while (0)
-#define MEMC_FI_BWD_PK(MINW, AL, TR)                                                                               \
-    do {                                                                                                           \
-        hipLaunchKernelGGL((fi_bwd_c3_pk<MINW, AL, TR>), dim3(ntiles), dim3(256), PkGeom::kLds, stream,            \
-                           MEMC_FI_BWD_ARGS);                                                                      \
-    } while (0)
+#define MEMC_FI_BWD_PK(TR)                                                                                         \
+    hipLaunchKernelGGL(fi_bwd_c3_pk<TR>, dim3(ntiles), dim3(256), PkGeom::kLds, stream, w, h, ntx, nty, batch,     \
+                       (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,             \
+                       (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)
 #ifdef MEMC_MEASURE
-    switch (variant) {
-    case 1: MEMC_FI_BWD(1); break;
-    case 2: MEMC_FI_BWD(2); break;
-    case 3: MEMC_FI_BWD(3); break;
-    case 4: MEMC_FI_BWD(4); break;
-    case 5: MEMC_FI_BWD(5); break;
-    case 9: MEMC_FI_BWD(9); break;
-    case 16:                                               // three workgroups per CU: 168 VGPRs, spills
-        hipLaunchKernelGGL((fi_bwd_tiled_c3<0, 3>), dim3(ntiles), dim3(256), tile_lds_bytes<16>(), stream,
-                           MEMC_FI_BWD_ARGS);
-        break;
-    case 10: MEMC_FI_BWD_P(true); break;
-    case 11: MEMC_FI_BWD_P(false); break;
-    case 20: MEMC_FI_BWD_PK(2, 0, false); break;           // packed planes, image first, fixed 96 x 32 geometry
-    case 22: MEMC_FI_BWD_PK(2, 1, false); break;           // packed planes, image first, dynamic pitch
-    case 23: MEMC_FI_BWD_PK(2, 2, false); break;           // packed planes, image gradient first
-    case 27: MEMC_FI_BWD_PK(2, 1, true); break;            // + timestamps
-    case 28: MEMC_FI_BWD_PK(2, 2, true); break;
-    default: MEMC_FI_BWD(0);
+    if (variant == 28) {                                   // + timestamps
+        MEMC_FI_BWD_PK(true);
+        return launch_status() == 0 ? 1 : -1;
+    }
+    if (variant >= 0) {                                    // arms/fi_bwd_c3_arms.hip
+        const int r = fi_bwd_c3_arm_launch(variant, stream, w, h, ntx, nty, batch, s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c,
+                                           s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3);
+        if (r != 0) return r;
     }
 #else
     (void)variant;
-    MEMC_FI_BWD(0);
 #endif
-#undef MEMC_FI_BWD
-#undef MEMC_FI_BWD_P
+    MEMC_FI_BWD_PK(false);
 #undef MEMC_FI_BWD_PK
-#undef MEMC_FI_BWD_ARGS
     return launch_status() == 0 ? 1 : -1;
 }
 
 }  // namespace memc
 
 #ifdef MEMC_MEASURE
-// device buffer of gridDim.x * 16 uint64 for the timestamp arm (fi_bwd variant 9); tools/trace_kernel.py
+// device buffer of gridDim.x * 16 uint64 for the timestamp arms (fi_bwd variants 9 and 28); tools/trace_kernel.py
 extern "C" int memc_debug_set_trace_buffer(void *p)
 {
     unsigned long long *q = (unsigned long long *)p;
-    return hipMemcpyToSymbol(HIP_SYMBOL(memc::g_trace_buf), &q, sizeof(q)) == hipSuccess ? 0 : -1;
+    const int a = hipMemcpyToSymbol(HIP_SYMBOL(memc::g_trace_buf), &q, sizeof(q)) == hipSuccess ? 0 : -1;
+    return a == 0 ? memc::fi_bwd_c3_arms_set_trace_buffer(q) : a;
 }
 #endif

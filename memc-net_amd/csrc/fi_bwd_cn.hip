@@ -391,13 +391,17 @@ constexpr int kOwnCand = (2 * kOwnRX + 1) * (2 * kOwnRY + 1);
 static_assert(kOwnCand <= 64, "one lane per candidate site tile");
 
 // Cell tile 64 x TH, 32 * TH lanes (two cells per lane: rows r and r + TH / 2); kHead = kN * kN head slots per cell.
-//   TH = 16: 512 lanes, 157 KB of LDS (4 x 4 window), one workgroup per CU;
-//   TH = 8:  256 lanes,  78 KB, two per CU -- the build / replay phases of one overlap the other's barriers.
+//   TH = 16: 512 lanes, 157 KB of LDS (4 x 4 window), one workgroup per CU.
+//   (TH = 8 -- 256 lanes, 78 KB, two per CU -- was measured in round 2, +2 ... -2 %, and is no longer built: its tail
+//   area, 4096 entries, is smaller than one row of candidate sites can need, see the assertion below.)
 template <class FP, int TH>
 struct OwnGeom {
     static constexpr int kHead = FP::kN * FP::kN;          // entries per cell a lane keeps in registers (one per tap index)
     static constexpr int kThreads = 32 * TH, kCells = 64 * TH;
     static constexpr int kTailCap = (FP::kN == 4 ? 8 : 4) * kCells;      // tail entries per slab
+    // the slab loop halves its rows until a slab's tails fit; ONE row of sites -- (2 kOwnRX + 1) site tiles of 64 sites,
+    // kHead taps each -- is as far as it can go, so that must fit whatever the search window is widened to
+    static_assert((2 * kOwnRX + 1) * 64 * kHead <= kTailCap, "one row of candidate sites must fit the tail area");
     static constexpr int kSegCap = 2 * kThreads;
     static constexpr int kSlotCap = TH == 16 ? 3072 : 2048;        // sites staged per slab; slot kSlotCap holds zeros
     static constexpr int kHK = 0, kHS = kHK + kHead * kCells * 4, kHeadEnd = kHS + kHead * kCells * 2;
@@ -721,8 +725,8 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
             toff0 = base + incl - (unsigned)(tl0 + tl1);
             sb0 = base2 + incl2 - (unsigned)(ns0 + ns1);
             nseg_total = total2;
-            // (a single row of sites can still overflow the tail area in theory: those tails are dropped from the
-            //  lists and ... cannot happen: a row holds at most 320 sites = 5120 taps)
+            // (rows == 1 always fits: a row holds at most (2 kOwnRX + 1) * 64 = 448 sites = 7168 taps of the 8192 entries --
+            //  asserted in OwnGeom)
             serial_tails = total2 > (unsigned)kSegCap;     // more segments than lanes can keep: owners walk their tails
             toff[tid] = (unsigned short)toff0;
             toff[tid + kOwnThreads] = (unsigned short)(toff0 + tl0);
@@ -967,8 +971,6 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
 }
 
 #ifdef MEMC_MEASURE
-static int g_owner_th = 16;                            // A/B: cell tile height of the owner kernel (16 or 8)
-extern "C" void memc_debug_set_owner_th(int th) { g_owner_th = th; }
 static unsigned long long *g_trace_cn = nullptr;       // gridDim.x * 16 uint64; tools/trace_kernel.py fi_bwd_cn
 extern "C" int memc_debug_set_trace_buffer_cn(void *p)
 {
@@ -1221,7 +1223,6 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
     } while (0)
 #ifdef MEMC_MEASURE
     if (g_trace_cn) MEMC_OWNER(16, true, g_trace_cn);
-    else if (g_owner_th == 8) MEMC_OWNER(8, false, nullptr);
     else
 #endif
         MEMC_OWNER(16, false, nullptr);

@@ -83,4 +83,49 @@ __device__ __noinline__ inline void fi_bwd_site_scalar(int x, int y, int W, int 
     g2[s2c] = boty;
 }
 
+
+// gradinput3 and gradinput2 of ONE site straight from global memory (mixed quads of the tiled RGB backward: some of a
+// lane's four sites belong to another band or are invalid).  Assigns both, like the tiled path; the image
+// gradient of such a site still goes through the tile's LDS planes.
+__device__ __noinline__ inline void fi_bwd_site_taps(int x, int y, int W, int H, const float *in_b, int64_t s1c, int s1h,
+                                              const float *flow_p, float *g2, int64_t s2c, const float *tap_p,
+                                              float *g3, int64_t s3c, const float *gout_p)
+{
+    const FiSite s = fi_locate(x, y, W, H, flow_p[0], flow_p[s2c]);
+    if (!s.valid) return;
+    const float g0 = gout_p[0], g1 = gout_p[s1c], gc2 = gout_p[2 * s1c];
+    float gx = 0.0f, gy = 0.0f;
+    for (int k = 0; k < 4; k++) {
+        const float *row = in_b + (int64_t)clampi(s.iy - 1 + k, H - 1) * s1h;
+        for (int m = 0; m < 4; m++) {
+            const float *p = row + clampi(s.ix - 1 + m, W - 1);
+            float sv = 0.0f;
+            sv += g0 * p[0];  sv += g1 * p[s1c];  sv += gc2 * p[2 * s1c];
+            const float wa = m < 2 ? (1 - s.a) : s.a, wb = k < 2 ? (1 - s.b) : s.b;
+            g3[(k * 4 + m) * s3c] = (wa * wb) * sv;
+            const float st = sv * tap_p[(k * 4 + m) * s3c];
+            gx += (m < 2 ? -wb : wb) * st;
+            gy += (k < 2 ? -wa : wa) * st;
+        }
+    }
+    g2[0] = gx;
+    g2[s2c] = gy;
+}
+
+// gradinput2 / gradinput3 are fully DEFINED by the backward kernels (the Python layer hands them over
+// uninitialised -- their memsets were 72 B/site, a seventh of the call): a quad that contains an invalid site
+// first stores zeros to its 16 + 2 float4; its valid sites are then stored site by site (fi_bwd_site_taps), by the
+// same lane and therefore after these.  Quads of four valid sites are stored by phase 1 or by fi_bwd_site_taps.
+__device__ __forceinline__ void fi_bwd_zero_invalid(bool inb, unsigned valid, float *gin2_b, int64_t s2c, unsigned o2,
+                                                    float *gin3_b, int64_t s3c, unsigned o3)
+{
+    if (!inb || valid == 0xFu) return;         // rare (image borders, |flow| guard): ordinary 64-bit addressing
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    float *q3 = gin3_b + (o3 >> 2), *q2 = gin2_b + (o2 >> 2);
+#pragma unroll 1
+    for (int k = 0; k < 16; k++) *reinterpret_cast<f32x4 *>(q3 + k * s3c) = z;
+    *reinterpret_cast<f32x4 *>(q2) = z;
+    *reinterpret_cast<f32x4 *>(q2 + s2c) = z;
+}
+
 }  // namespace memc

@@ -12,8 +12,8 @@
 #if defined(__cplusplus) && defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 namespace memc {
-// fi_bwd_cn.hip: FilterInterpolation backward for C % 4 == 0, C >= 8, fs == 4 (tap-gradient kernel + owner-computes image
-// gradient).  1: taken, 0: not taken (the caller falls back to the direct kernel; for this class of channel counts
+// fi_bwd_cn.hip: FilterInterpolation backward for C >= 4 (a ragged last chunk is padded), fs == 4 (tap-gradient kernel +
+// owner-computes image gradient).  1: taken, 0: not taken (the caller falls back to the direct kernel; for this class of channel counts
 // gradinput1 has then been cleared: it is STORED on every path), -1: launch error.  Strides as in the C ABI.
 // force_direct: measurement arm -- clear and decline.
 int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
@@ -26,6 +26,14 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
                      int s1b, int s1c, int s1h, int s2b, int s2c, int s2h, int s3b, int s3c, int s3h,
                      const float *input1, const float *input2, const float *input3, const float *gradoutput,
                      float *gradinput1, float *gradinput2, float *gradinput3, int variant);
+#ifdef MEMC_MEASURE
+// arms/fi_bwd_c3_arms.hip (measurement build only): the kernels of rounds 1-2 and their ablation arms
+int fi_bwd_c3_arm_launch(int variant, hipStream_t stream, int w, int h, int ntx, int nty, int batch,
+                         int s1b, int s1c, int s1h, int s2b, int s2c, int s2h, int s3b, int s3c, int s3h,
+                         const float *input1, const float *input2, const float *input3, const float *gradoutput,
+                         float *gradinput1, float *gradinput2, float *gradinput3);
+int fi_bwd_c3_arms_set_trace_buffer(unsigned long long *device_buffer);
+#endif
 // ... and the bilinear warp's backward (Interpolation / InterpolationCh) for the same class of channel counts
 int bl_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                      int s1b, int s1c, int s1h, int s2b, int s2c, int s2h,
@@ -65,7 +73,6 @@ void memc_debug_set_walk(int stripe_width);      // < 0: each launcher's default
 int memc_debug_set_trace_buffer(void *device_u64_buffer);        // gridDim.x * 16 slots, written by fi_bwd variant 9
 int memc_debug_set_trace_buffer_proj(void *device_u64_buffer);   // the same for the projection's trace arm
 void memc_debug_set_bl_bwd_direct(int on);       // bilinear backward: 1 = the direct kernel for any channel count
-void memc_debug_set_owner_th(int th);            // fi_bwd_image_owner's cell tile height: 16 (default) or 8
 int memc_debug_set_trace_buffer_cn(void *device_u64_buffer);
 const char *memc_debug_last_path(void);          // the kernel family the last launcher call chose, e.g. "fi_fwd:tiled_c3"     // fi_bwd_image_owner's phase clocks; NULL switches them off
 

@@ -145,8 +145,10 @@ def test_product_library_has_no_measurement_arms(hip_lib_path):
     # the tiled FI forward exists in exactly its production instantiations (ABL == 0 is the last template argument)
     fwd = [k for k in kernels if "16fi_fwd_tiled_fs4" in k]
     assert fwd and all(k.split("EEEv")[0].endswith("Li0") for k in fwd), fwd
-    bwd = [k for k in kernels if "15fi_bwd_tiled_c3" in k]
-    assert bwd == [k for k in bwd if "ILi0ELi2EEE" in k], bwd
+    # the RGB backward: the packed-plane kernel without timestamps, and none of the round-1/2 kernels (arms/)
+    assert not [k for k in kernels if "15fi_bwd_tiled_c3" in k]
+    bwd = [k for k in kernels if "12fi_bwd_c3_pk" in k]
+    assert bwd and all("ILb0EEE" in k for k in bwd), bwd
 
 
 def test_measurement_library_is_separate_and_says_so(hip_lib_path):

@@ -337,10 +337,6 @@ def main():
     if want("fi_bwd_ctx"):
         # (measurement build: + variant 40, the direct global-atomics kernel this path replaced -- 163 ms)
         bench_fi_bwd(rows, dev, 8, 64, 720, 1280, "smooth", "ctx64", [40] if M.active else [])
-        if M.active:                               # A/B: the owner kernel on 64 x 8 cell tiles (two workgroups per CU)
-            M.set_variant("owner_th", 8)
-            bench_fi_bwd(rows, dev, 8, 64, 720, 1280, "smooth", "ctx64 owner tiles 64x8")
-            M.set_variant("owner_th", 16)
         bench_fi_bwd(rows, dev, 8, 64, 720, 1280, "iid", "ctx64")
         bench_fi_bwd(rows, dev, 4, 64, 256, 448, "smooth", "ctx64 crop")
     if want("proj"):

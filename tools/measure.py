@@ -26,7 +26,6 @@ _SETTERS = {
     "walk": "memc_debug_set_walk",
     "extra_lds": "memc_debug_set_extra_lds",
     "bl_cap": "memc_debug_set_bl_cap",
-    "owner_th": "memc_debug_set_owner_th",
     "bl_bwd_direct": "memc_debug_set_bl_bwd_direct",
 }
 
@@ -88,4 +87,4 @@ def set_variant(op, variant):
 
 def reset():
     for op in _SETTERS:
-        set_variant(op, 0 if op in ("extra_lds", "bl_bwd_direct") else (16 if op == "owner_th" else -1))
+        set_variant(op, 0 if op in ("extra_lds", "bl_bwd_direct") else -1)

@@ -26,11 +26,7 @@ KERNELS = {
                           (4, "phase 1 (taps/flow grads)"), (5, "zero plane"), (6, "adds c0"), (7, "flush c0"),
                           (8, "adds c1"), (9, "flush c1"), (10, "adds c2"), (11, "flush c2"),
                           (12, "later bands / tail")]),
-    # round 3: packed fixed-point planes, one LDS round (fi_bwd_c3.hip): image first / image gradient first
-    "fi_bwd_pk1": dict(setter="memc_debug_set_trace_buffer", op="fi_bwd", variant=27, last=12,
-                       marks=[(1, "load inputs"), (2, "locate + bbox + block exponent"), (3, "stage image"),
-                              (4, "phase 1 (taps/flow grads)"), (5, "barrier + zero planes + barrier"),
-                              (6, "packed adds + barrier"), (7, "flush (3 colours)"), (12, "later bands / tail")]),
+    # round 3 (the product kernel + timestamps): packed fixed-point planes, image gradient first (fi_bwd_c3.hip)
     "fi_bwd_pk2": dict(setter="memc_debug_set_trace_buffer", op="fi_bwd", variant=28, last=12,
                        marks=[(1, "load inputs (planes zeroed meanwhile)"), (2, "locate + bbox + block exponent"),
                               (3, "request image rows; packed adds + barrier"), (4, "flush (3 colours) + barrier"),
