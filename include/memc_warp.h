@@ -76,6 +76,14 @@ typedef struct memc_tensor4 {
 /* Library / build identification: returns a static string such as "memc_hip 0.1 gfx950". */
 const char *memc_hip_version(void);
 
+/* Does the backward of this operator STORE gradinput1 (1) or ACCUMULATE into it like the reference's atomicAdd (0)?
+ * filter_size: FilterInterpolation's fs (e.g. 4); 0 for Interpolation / InterpolationCh.
+ * The reference accumulates for every channel count (my_lib_kernel.cu:1276, :690) and its callers hand over a
+ * zero-filled buffer; both contracts give the same result on a zero-filled buffer.  This library accumulates for
+ * one to three channels (RGB) and stores for four and more (fs == 4 or the bilinear warp): a caller that wants to
+ * skip the zero fill, or that accumulates several calls into one buffer, asks here instead of copying the rule. */
+int memc_gradinput1_is_stored(int filter_size, int channel);
+
 /* ======================================================================================================
  * Layer entry points -- replace my_lib_cuda.h:37-117 (implemented in the reference by my_lib_cuda.c).
  * ==================================================================================================== */

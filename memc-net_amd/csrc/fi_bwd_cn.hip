@@ -156,8 +156,10 @@ __device__ __noinline__ void fi_bwd_site_taps_cn(int x, int y, int W, int H, int
 // Kernel A: tap and flow gradients.
 // ---------------------------------------------------------------------------------------------------------
 // S[tap][j] += sum over the chunk's four channels of gradoutput * staged image, for the sites in `sel`.
+// Sites not in `sel` read the ZERO pixel quad kept behind the staged image (index `zero`) and add 0 * 0: reading a
+// staged pixel instead would turn an Inf / NaN there into 0 * Inf = NaN in the sums of sites it has nothing to do with.
 __device__ __forceinline__ void fi_bwd_taps_accum(const Region &r, const FiSite4 &g, unsigned sel,
-                                                  const f32x4 (&go)[4], int W, int H, const f32x4 *tile,
+                                                  const f32x4 (&go)[4], int W, int H, const f32x4 *tile, int zero,
                                                   f32x4 (&S)[16])
 {
 #pragma unroll
@@ -166,10 +168,10 @@ __device__ __forceinline__ void fi_bwd_taps_accum(const Region &r, const FiSite4
         int ro[4], co[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            ro[k] = on ? (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch : 0;
+            ro[k] = on ? (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch : zero;
             co[k] = on ? swz_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0) : 0;
         }
-        // unselected sites still issue their reads (at pixel 0) and add zeros: no control flow in the nest
+        // unselected sites still issue their reads (at the zero pixel) and add zeros: no control flow in the nest
         const float g0 = on ? go[0][j] : 0.0f, g1 = on ? go[1][j] : 0.0f, g2 = on ? go[2][j] : 0.0f,
                     g3 = on ? go[3][j] : 0.0f;
 #pragma unroll
@@ -200,6 +202,8 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+    constexpr int kZeroPx = G::kCapPx + 4;                 // a pixel quad of zeros behind the staged image and the boxes
+    if (threadIdx.x == 0) tile[kZeroPx] = f32x4{0.f, 0.f, 0.f, 0.f};     // (visible after tile_bbox's barrier)
 
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
     const int b = tc.b;
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
                 tile_stage_store<4>(r, sl, sr, tile);
             }
             __syncthreads();
-            fi_bwd_taps_accum(r, g, sel, go, W, H, tile, S);
+            fi_bwd_taps_accum(r, g, sel, go, W, H, tile, kZeroPx, S);
             // the next chunk's gradoutput, once this chunk's has been used (one register set)
             const int cn = c0 + 4 < C ? c0 + 4 : c0;
 #pragma unroll
@@ -1032,6 +1036,8 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+    constexpr int kZeroPx = G::kCapPx + 4;                 // a pixel quad of zeros behind the staged image and the boxes
+    if (threadIdx.x == 0) tile[kZeroPx] = f32x4{0.f, 0.f, 0.f, 0.f};     // (visible after tile_region's barrier)
 
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
@@ -1073,7 +1079,8 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
         const bool in_box = s.valid && r.covers(s.L, s.R, s.T, s.Bm);
         valid |= (s.valid ? 1u : 0u) << j;
         staged |= (in_box ? 1u : 0u) << j;
-        const int rT = in_box ? (s.T - r.y0) * r.pitch : 0, rB = in_box ? (s.Bm - r.y0) * r.pitch : 0;
+        // (sites outside the staged box read the zero pixel quad: 0 * Inf would be NaN)
+        const int rT = in_box ? (s.T - r.y0) * r.pitch : kZeroPx, rB = in_box ? (s.Bm - r.y0) * r.pitch : kZeroPx;
         const int cL = in_box ? swz_col(s.L - r.x0) : 0, cR = in_box ? swz_col(s.R - r.x0) : 0;
         oTL[j] = rT + cL;  oTR[j] = rT + cR;  oBL[j] = rB + cL;  oBR[j] = rB + cR;
     }

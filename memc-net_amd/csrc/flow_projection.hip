@@ -2108,6 +2108,11 @@ struct ProjArgs {
     float *count, *out;
 };
 
+// The far-source flags carry a per-call nonce instead of being cleared: ONE process-wide counter for every
+// instantiation of run_proj_fwd (a function-local static would give FlowProjection and DepthFlowProjection their own
+// counters, and two calls handed the same scratch block could carry the same nonce: a needless whole-image redo).
+static std::atomic<unsigned> g_proj_call_counter{0};
+
 // vectorised forward: owner-computes fast path + the general path behind its far flag (+ hole filling), with the
 // tile height TH of the owner kernel and the filler.  variant: measurement build only (-1 otherwise).
 template <bool DEPTH, int TH>
@@ -2142,9 +2147,8 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     // never see each other's flags; a stale or uninitialised word equal to the nonce (2^-32) would only cause a
     // needless redo.  That saves a 5 us memset launch per call.  The measurement build's older kernels keep 0 / 1
     // flags and the memset.
-    static std::atomic<unsigned> call_counter{0};
-    unsigned nonce_u = call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
-    if (nonce_u == 0) nonce_u = call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
+    unsigned nonce_u = g_proj_call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
+    if (nonce_u == 0) nonce_u = g_proj_call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
     const int nonce = (int)nonce_u;
     bool legacy_flags = false;
 #ifdef MEMC_MEASURE

@@ -103,6 +103,11 @@ const char *memc_hip_version(void) { return "memc_hip 0.2 gfx950 MEASUREMENT BUI
 const char *memc_hip_version(void) { return "memc_hip 0.2 gfx950"; }
 #endif
 
+int memc_gradinput1_is_stored(int filter_size, int channel)
+{
+    return memc::fi_bwd_cn_class(channel, filter_size == 0 ? 4 : filter_size) ? 1 : 0;
+}
+
 int InterpolationLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
                                    const memc_tensor4 *input2, const memc_tensor4 *output)
 { return bilinear_forward(true, stream, input1, input2, output); }

@@ -42,6 +42,16 @@ def version():
     return _lib.memc_hip_version().decode()
 
 
+_lib.memc_gradinput1_is_stored.restype = ctypes.c_int
+_lib.memc_gradinput1_is_stored.argtypes = [ctypes.c_int, ctypes.c_int]
+
+
+def gradinput1_is_stored(filter_size, channel):
+    """The library's own answer (include/memc_warp.h): does the backward store gradinput1 (no zero fill needed) or
+    accumulate into it?  filter_size 0 = Interpolation / InterpolationCh."""
+    return bool(_lib.memc_gradinput1_is_stored(int(filter_size), int(channel)))
+
+
 def _describe(t, name):
     if not isinstance(t, torch.Tensor):
         raise TypeError("%s: expected a torch.Tensor, got %s" % (name, type(t).__name__))

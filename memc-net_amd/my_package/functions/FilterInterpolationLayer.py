@@ -39,10 +39,10 @@ class _FilterInterpolationFunction(Function):
     def backward(ctx, gradoutput):
         input1, input2, input3 = ctx.saved_tensors
         gradoutput = f32c(gradoutput)
-        # accumulation target: zero-filled (reference :46) -- except for four and more channels
-        # with the 4x4 filter: the library STORES gradinput1 for those on every path (include/memc_warp.h),
-        # and the memset would be a fifth of the call's traffic
-        stored = input1.size(1) >= 4 and input3.size(1) == 16
+        # accumulation target: zero-filled (reference :46) -- except where the library says it STORES gradinput1 on
+        # every path (four and more channels with the 4x4 filter; include/memc_warp.h: memc_gradinput1_is_stored):
+        # the memset would be a fifth of the call's traffic
+        stored = my_lib.gradinput1_is_stored(int(input3.size(1) ** 0.5 + 1e-6), input1.size(1))     # fs as my_lib.c:925
         gradinput1 = torch.empty_like(input1) if stored else torch.zeros_like(input1)
         # the reference zero-fills these two as well (:47-48); the backward kernels DEFINE every element of them
         # (invalid sites store zero; tests/test_gpu_parity.py::test_backward_defines_flow_and_tap_gradients), so

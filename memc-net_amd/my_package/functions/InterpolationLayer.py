@@ -32,7 +32,7 @@ def _make_bilinear_function(label, fwd_name, bwd_name):
             gradoutput = f32c(gradoutput)
             # accumulation target, zero-filled (reference :40-41) -- except for four and more channels,
             # for which the library STORES it on every path (include/memc_warp.h)
-            stored = input1.size(1) >= 4
+            stored = my_lib.gradinput1_is_stored(0, input1.size(1))     # the library's own rule (include/memc_warp.h)
             gradinput1 = torch.empty_like(input1) if stored else torch.zeros_like(input1)
             gradinput2 = torch.empty_like(input2)               # assigned at every site (invalid: 0)
             check(bwd(input1, input2, gradoutput, gradinput1, gradinput2), bwd_name)

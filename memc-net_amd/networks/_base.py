@@ -57,8 +57,11 @@ class MEMCNetBase(nn.Module):
         with what is now `align_corners=True`; the reference's unmodified code under a current PyTorch -- and this
         class by default -- samples with `align_corners=False`, which shifts the x4 flow upsampling and the U-Net
         upsamplings by up to 1.5 pixels and visibly degrades the interpolated frames.  Loading weights into a model
-        built with the default therefore warns (once per model); pass `align_corners=True` for published weights."""
-        if not self.align_corners and not getattr(self, "_warned_align_corners", False):
+        built with the default therefore warns (once per model); pass `align_corners=True` for published weights.
+        Checkpoints trained WITH this code at align_corners=False are fine: silence the note with
+        `model.warn_align_corners = False` (or `load_state_dict(..., warn_align_corners=False)`)."""
+        warn = kwargs.pop("warn_align_corners", getattr(self, "warn_align_corners", True))
+        if warn and not self.align_corners and not getattr(self, "_warned_align_corners", False):
             self._warned_align_corners = True
             warnings.warn("%s was built with align_corners=False (what the reference's code does under current "
                           "PyTorch).  Checkpoints published with MEMC-Net were trained with PyTorch 0.2 "
