@@ -182,14 +182,13 @@ __device__ __forceinline__ void fi_fwd_chunk(
 // waves stalls the whole CU at every one of them -- the box traffic is not what binds this kernel.
 // RAGGED: any channel count >= 4 -- the last chunk re-reads the last plane for the channels it does not have and does not
 // store them (a separate instantiation: the C % 4 == 0 kernel, at 239 registers, is left exactly as it was).
-template <int SW, int NT = 256, bool RAGGED = false>       // SW 0: one tile column per XCD strip; 2 / 4: stripes
+template <int SW, int NT = 256, bool RAGGED = false, int LX = 16>   // SW 0: one tile column per XCD strip; 2 / 4: stripes
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
     float *__restrict__ out)
 {
-    constexpr int LX = 16;
     constexpr int CAP = NT == 256 ? 3072 : 3584;
     using G = TileGeom<LX, CAP, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1174,14 +1173,15 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
                            s3h, input1, input2, input3, output);                                           \
     } while (0)
 #define MEMC_FI_C4N(SW) MEMC_FI_C4N_NT(SW, 256, false)
-#define MEMC_FI_C4N_NT(SW, NT, RAG)                                                                             \
+#define MEMC_FI_C4N_NT(SW, NT, RAG) MEMC_FI_C4N_LX(SW, NT, RAG, 16)
+#define MEMC_FI_C4N_LX(SW, NT, RAG, LX)                                                                         \
     do {                                                                                                   \
-        using G = TileGeom<16, (NT == 256 ? 3072 : 3584), NT>;                                             \
+        using G = TileGeom<LX, (NT == 256 ? 3072 : 3584), NT>;                                             \
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                        \
         const int lds = G::kCapPx * 16 + 4 * 4 * (NT / 64);                                                \
-        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG>, lds), true);                     \
+        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG, LX>, lds), true);                 \
         (void)once;                                                                                        \
-        hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT, RAG>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
+        hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT, RAG, LX>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
                                                                     (SW ? SW : 1)) * nty * batch),          \
                            dim3(NT), lds, stream, w, h, channel, ntx, nty, (int64_t)s1b,                   \
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c,    \
@@ -1264,6 +1264,10 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             MEMC_FI_C4N(4);
         } else if (variant == 32 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N_NT(0, 512, false);                 // 64 x 32 tiles, 512 lanes
+        } else if (variant == 33 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N_LX(0, 256, false, 8);              // 32 x 32 tiles: the box of a square tile is the least dilated
+        } else if (variant == 34 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N_LX(4, 256, false, 8);              // ... in stripes four tile columns wide
         } else {
             handled = false;
         }
@@ -1303,6 +1307,7 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
 #undef MEMC_FI_FWD_LAUNCH
 #undef MEMC_FI_C4N
 #undef MEMC_FI_C4N_NT
+#undef MEMC_FI_C4N_LX
 #undef MEMC_FI_TILED
 #undef MEMC_FI_TILED_A
     return launch_status();
