@@ -66,8 +66,6 @@ __device__ __noinline__ void fi_site_scalar(int x, int y, int W, int H, int nch,
 // compile-time unrolled (run-time indexed vectors would live in scratch) and the hot path is branch-free:
 // a site whose window is not staged still issues its 16 LDS reads (at pixel 0, harmless) and is redone
 // afterwards by fi_site_scalar (at the end of the kernel, once for all channels).
-__device__ __forceinline__ float a_dummy(int v) { return __int_as_float(v); }   // ablation arm only
-
 // Gather + blend of the sites selected by `sel` (bit j) from the staged band; other sites keep their `res`.
 // Branch-free: unselected sites still issue their 16 LDS reads (at pixel 0, harmless).
 template <int LX, int NCH>
@@ -104,7 +102,7 @@ __device__ __forceinline__ void fi_gather(const Region &r, const FiSite4 &g, con
     }
 }
 
-template <int LX, int NCH, int ABL = 0>
+template <int LX, int NCH>
 __device__ __forceinline__ void fi_gather_store(
     const Region &r, const FiSite4 &g, const f32x4 (&tp)[16], bool inb, int x, int y, int W, int H,
     const float *__restrict__ plane0, float *__restrict__ out_p, int64_t s1c, int s1h, const f32x4 *tile)
@@ -132,7 +130,7 @@ __device__ __forceinline__ void fi_gather_store(
         for (int k = 0; k < 4; k++) {
             f32x4 v[4];
 #pragma unroll
-            for (int m = 0; m < 4; m++) v[m] = ABL == 2 ? f32x4{a_dummy(ro[k]), a_dummy(co[m]), 0.f, 0.f} : tile[ro[k] + co[m]];
+            for (int m = 0; m < 4; m++) v[m] = tile[ro[k] + co[m]];
             if (k < 2) {
                 TL += v[0] * tp[k * 4 + 0][j];  TL += v[1] * tp[k * 4 + 1][j];
                 TR += v[2] * tp[k * 4 + 2][j];  TR += v[3] * tp[k * 4 + 3][j];
@@ -158,14 +156,14 @@ __device__ __forceinline__ void fi_gather_store(
         st_stream4(out_p + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
 }
 
-template <int LX, int NCH, int ABL = 0>
+template <int LX, int NCH>
 __device__ __forceinline__ void fi_fwd_chunk(
     const Region &r, const FiSite4 &g, const f32x4 (&tp)[16], bool inb, int x, int y, int W, int H,
     const float *__restrict__ plane0, float *__restrict__ out_p, int64_t s1c, int s1h, f32x4 *tile)
 {
-    if (ABL != 3) tile_stage<LX, NCH>(r, plane0, s1c, s1h, tile);
+    tile_stage<LX, NCH>(r, plane0, s1c, s1h, tile);
     __syncthreads();
-    fi_gather_store<LX, NCH, ABL>(r, g, tp, inb, x, y, W, H, plane0, out_p, s1c, s1h, tile);
+    fi_gather_store<LX, NCH>(r, g, tp, inb, x, y, W, H, plane0, out_p, s1c, s1h, tile);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -312,9 +310,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
 
 // CT == 3: RGB, one chunk; CT == 0: any channel count, chunks of four.  MINW = waves per SIMD the register
 // allocator must leave room for (3 <-> 168 VGPRs, matching the 3 workgroups per CU the 48 KiB of LDS admit).
-// ABL (measurement arms): 1 = hardware-ordered tiles, 4 = row-major chunk per XCD (both still correct);
-// 2 = skip the LDS gathers, 3 = skip the staging loads (results WRONG, timing only).
-template <int LX, int CT, int MINW, int ABL>
+// WALK: how workgroups map to tiles -- 0 = column strips dealt to the XCDs (the product); the others exist in the
+// measurement build only (same results): 1 = hardware order, 4 = row-major chunk per XCD, 5 / 6 = stripes 2 / 4 tile
+// columns wide (PMC: profiles/r03_pmc_headline_stripes.txt -- 7.6 % less traffic, 4.6 % slower).
+// (Round 1-2 also timed, and dropped: an L2 prefetch of a future tile's flow 32 / 64 / 96 positions ahead (+6 %: the XCD's
+// L2 turns over in ~6 us, the lines are gone before use); the second half of the tap planes requested behind the staging
+// loads (+-0.3 %); the kernel without its LDS gathers (526 us) / without its staging loads: DESIGN.md section 4.)
+template <int LX, int CT, int MINW, int WALK>
 __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
@@ -327,14 +329,14 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
 
     int tx, ty, b;
-    if (ABL == 4) {                                        // row-major chunks per XCD (measurement arm)
+    if (WALK == 4) {                                       // row-major chunks per XCD (measurement arm)
         const unsigned t = xcd_chunked_id(blockIdx.x, gridDim.x);
         tx = t % tiles_x;  ty = (t / tiles_x) % tiles_y;  b = t / (tiles_x * tiles_y);
-    } else if (ABL == 1) {                                 // hardware order (measurement arm)
+    } else if (WALK == 1) {                                // hardware order (measurement arm)
         const unsigned t = blockIdx.x;
         tx = t % tiles_x;  ty = (t / tiles_x) % tiles_y;  b = t / (tiles_x * tiles_y);
-    } else if (ABL == 5 || ABL == 6) {                     // stripes 2 / 4 tile columns wide
-        const TileCoord tc = ABL == 5 ? stripe_walk<2>(blockIdx.x, gridDim.x, tiles_x, tiles_y)
+    } else if (WALK == 5 || WALK == 6) {                   // stripes 2 / 4 tile columns wide
+        const TileCoord tc = WALK == 5 ? stripe_walk<2>(blockIdx.x, gridDim.x, tiles_x, tiles_y)
                                       : stripe_walk<4>(blockIdx.x, gridDim.x, tiles_x, tiles_y);
         tx = tc.tx;  ty = tc.ty;  b = tc.b;
         if (tx >= tiles_x) return;
@@ -355,32 +357,9 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     const float *tap_p = filt + b * s3b + (int64_t)ys * s3h + xs;
     const f32x4 fx4 = ld_stream4(flow_p);
     const f32x4 fy4 = ld_stream4(flow_p + s2c);
-    // ABL == 11 (and the production RGB path once measured): only the first 8 tap planes go out now; the
-    // other 8 are issued AFTER the staging loads, so that the wait for the staged rows (vmcnt counts in issue
-    // order) leaves half of the tap stream in flight under the LDS writes and the barrier.
-    constexpr bool kSplitTaps = (ABL == 11) && CT == 3 && LX == 16;
     f32x4 tp[16];
 #pragma unroll
-    for (int k = 0; k < (kSplitTaps ? 8 : 16); k++) tp[k] = ld_stream4(tap_p + k * s3c);
-
-    // L2 prefetch of a FUTURE tile's flow (measurement arms ABL 7/9/10 only -- see DESIGN.md: it LOSES).  The flow -> box -> staging chain is the only
-    // serial dependency of a tile; its first link is a full HBM miss.  The tile that this XCD will start
-    // ~kAhead workgroups from now gets its 8 KiB of flow pulled into the XCD's L2 here, behind this tile's own
-    // loads (no extra traffic: the bytes are read from HBM exactly once, just earlier).
-    // One dword per 128-B line is enough to fetch the line: the tile's flow is 16 rows x 2 components x 256 B
-    // = 64 lines = one dword per lane of one wave-instruction (every wave issues the same one; 1 VGPR).
-    float pf = 0.0f;
-    if (ABL == 7 || ABL == 9 || ABL == 10) {
-        constexpr unsigned kAhead = ABL == 7 ? 32 : (ABL == 9 ? 64 : 96);
-        const int pa = strip_ahead(blockIdx.x, gridDim.x, kAhead);
-        const TileCoord fc = strip_at(pa < 0 ? 0 : pa, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
-        const int l = threadIdx.x & (kWave - 1);
-        const int px = min(fc.tx * G::kTW + (l & 1) * 32, W - 4);
-        const int py = min(fc.ty * G::kTH + ((l & 31) >> 1), H - 1);
-        // past the end of the walk: re-read this tile's own flow (harmless; keeps the load unconditional)
-        const float *pp = pa < 0 ? flow_p : flow + fc.b * s2b + (l >> 5) * s2c + (int64_t)py * s2h + px;
-        pf = *pp;
-    }
+    for (int k = 0; k < 16; k++) tp[k] = ld_stream4(tap_p + k * s3c);
 
     // 2. site geometry and this lane's source box
     FiSite4 g;
@@ -405,18 +384,7 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     // 3./4. channels, four at a time
     const float *in_b = in1 + b * s1b;
     float *out_p = out + b * s1b + (int64_t)y * s1h + x;
-    if constexpr (kSplitTaps) {
-        const StageSlot sl = stage_slots(r);
-        StageRegs<3> sr;
-        tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);
-        // the address depends (vacuously) on the region so that the scheduler cannot hoist these loads
-        const float *tap_late = tap_p + (r.w < 0 ? 1 : 0);
-#pragma unroll
-        for (int k = 8; k < 16; k++) tp[k] = ld_stream4(tap_late + k * s3c);
-        tile_stage_store<3>(r, sl, sr, tile);
-        __syncthreads();
-        fi_gather_store<LX, 3, ABL>(r, g, tp, inb, x, y, W, H, in_b, out_p, s1c, s1h, tile);
-    } else if (CT == 3 && ABL == 0) {
+    if (CT == 3) {
         // production RGB path: band loop, results kept in registers until every band has run
         f32x4 res[4];
 #pragma unroll
@@ -453,8 +421,6 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
             for (int c = 0; c < 3; c++)
                 st_stream4(out_p + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
         }
-    } else if (CT == 3) {
-        fi_fwd_chunk<LX, 3, ABL>(r, g, tp, inb, x, y, W, H, in_b, out_p, s1c, s1h, tile);
     } else {
         int c0 = 0;
 #pragma unroll 1
@@ -491,7 +457,6 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
         slow &= slow - 1;
         fi_site_scalar(x + j, y, W, H, C, 4, in_b, s1c, s1h, flow_p + j, s2c, tap_p + j, s3c, out_p + j);
     }
-    asm volatile("" ::"v"(pf));               // the prefetch load must be issued; its value is unused
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -925,44 +890,8 @@ __global__ __launch_bounds__(256) void fi_fwd_generic(
 }
 
 #ifdef MEMC_MEASURE
-// --------------------------------------------------------------------------------------------------
-// Measurement arm only (bench_ops.py): a kernel with the REFERENCE's structure -- block (32,16), one
-// thread per site, taps re-read from global for every channel, no streaming hints, blockIdx-ordered
-// tiles -- to show what a straight port achieves on MI355X.  Never selected by the product path.
-// --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void fi_fwd_refshape(
-    int W, int H, int C, int fs,
-    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
-    const float *in1, const float *flow, const float *filt, float *out)
-{
-    const int x = blockIdx.x * 32 + threadIdx.x;
-    const int y = blockIdx.y * 16 + threadIdx.y;
-    const int b = blockIdx.z;
-    if (x >= W || y >= H) return;
-    const float *flow_b = flow + b * s2b + (int64_t)y * s2h + x;
-    const float fx = flow_b[0], fy = flow_b[s2c];
-    const FiSite s = fi_locate(x, y, W, H, fx, fy);
-    const float *tap_p = filt + b * s3b + (int64_t)y * s3h + x;
-    const float *in_b = in1 + b * s1b;
-    float *out_p = out + b * s1b + (int64_t)y * s1h + x;
-    if (s.valid) {
-        const int L = s.ix + 1 - fs / 2, T = s.iy + 1 - fs / 2, R = L + fs, Bm = T + fs;
-        for (int c = 0; c < C; c++) {
-            const float *p = in_b + c * s1c;
-            const float TL = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, T, s.iy, L, s.ix);
-            const float TR = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, T, s.iy, s.ix + 1, R - 1);
-            const float BL = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, s.iy + 1, Bm - 1, L, s.ix);
-            const float BR = fi_quad_sum(p, s1h, W, H, tap_p, s3c, fs, L, T, s.iy + 1, Bm - 1, s.ix + 1, R - 1);
-            out_p[c * s1c] = (1 - s.a) * (1 - s.b) * TL + s.a * (1 - s.b) * TR +
-                             (1 - s.a) * s.b * BL + s.a * s.b * BR;
-        }
-    } else {
-        const float *p = in_b + (int64_t)y * s1h + x;
-        for (int c = 0; c < C; c++) out_p[c * s1c] = p[c * s1c];
-    }
-}
-
-#endif  // MEMC_MEASURE
+#include "arms/fi_fwd_arms.hpp"           // fi_fwd_refshape: measurement build only
+#endif
 
 // --------------------------------------------------------------------------------------------------
 // Backward, fs == 4, direct.  Per valid site (my_lib_kernel.cu:1248-1515):
@@ -1163,11 +1092,11 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
     // production path: LDS-tiled, 16 B per lane (needs 4-element-aligned geometry)
     const bool vec = vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h}, {input1, input2, input3, output});
 #define MEMC_FI_TILED(LX, CT, MINW)   MEMC_FI_TILED_A(LX, CT, MINW, 0)
-#define MEMC_FI_TILED_A(LX, CT, MINW, ABL)                                                                      \
+#define MEMC_FI_TILED_A(LX, CT, MINW, WALK)                                                                     \
     do {                                                                                                   \
         using G = TileGeom<LX>;                                                                            \
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                        \
-        hipLaunchKernelGGL((fi_fwd_tiled_fs4<LX, CT, MINW, ABL>), dim3((unsigned)ntx * nty * batch), dim3(256), \
+        hipLaunchKernelGGL((fi_fwd_tiled_fs4<LX, CT, MINW, WALK>), dim3((unsigned)ntx * nty * batch), dim3(256), \
                            tile_lds_bytes<LX>(), stream, w, h, channel, ntx, nty, (int64_t)s1b,            \
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, \
                            s3h, input1, input2, input3, output);                                           \
@@ -1231,10 +1160,6 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             if (channel == 3) MEMC_FI_TILED(16, 3, 3); else MEMC_FI_TILED(16, 0, 3);
         } else if (variant == 8 && channel == 3) {
             MEMC_FI_TILED_A(16, 3, 2, 1);
-        } else if (variant == 9 && channel == 3) {
-            MEMC_FI_TILED_A(16, 3, 2, 2);
-        } else if (variant == 10 && channel == 3) {
-            MEMC_FI_TILED_A(16, 3, 2, 3);
         } else if (variant == 11 && channel == 3) {
             MEMC_FI_TILED_A(16, 3, 3, 4);
         } else if ((variant == 15 || variant == 16 || variant == 17) && channel == 3) {
@@ -1242,22 +1167,14 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
             const int sw = variant == 15 ? 2 : 4;
             const unsigned grid = (unsigned)((ntx + sw - 1) / sw * sw) * nty * batch;
-#define MEMC_FI_STRIPE(ABL, MINW)                                                                              \
-            hipLaunchKernelGGL((fi_fwd_tiled_fs4<16, 3, MINW, ABL>), dim3(grid), dim3(256), tile_lds_bytes<16>(),  \
+#define MEMC_FI_STRIPE(WALK, MINW)                                                                             \
+            hipLaunchKernelGGL((fi_fwd_tiled_fs4<16, 3, MINW, WALK>), dim3(grid), dim3(256), tile_lds_bytes<16>(), \
                                stream, w, h, channel, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,     \
                                (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output)
             if (variant == 15) MEMC_FI_STRIPE(5, 2);
             else if (variant == 16) MEMC_FI_STRIPE(6, 2);
             else MEMC_FI_STRIPE(4, 2);                     // 17: row-major chunk per XCD at 2 waves/SIMD
 #undef MEMC_FI_STRIPE
-        } else if (variant == 18 && channel == 3) {
-            MEMC_FI_TILED_A(16, 3, 2, 7);                  // flow prefetch 32 / 64 / 96 positions ahead (18/19/20)
-        } else if (variant == 19 && channel == 3) {
-            MEMC_FI_TILED_A(16, 3, 2, 9);
-        } else if (variant == 20 && channel == 3) {
-            MEMC_FI_TILED_A(16, 3, 2, 10);
-        } else if (variant == 21 && channel == 3) {
-            MEMC_FI_TILED_A(16, 3, 2, 11);                 // split tap stream around the staging loads
         } else if (variant == 30 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N(2);
         } else if (variant == 31 && channel % 4 == 0 && channel >= 8) {

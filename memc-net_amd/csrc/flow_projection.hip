@@ -487,497 +487,9 @@ __device__ __forceinline__ void summary_store(const TileSummary<TH> &t, int any_
 }
 
 #ifdef MEMC_MEASURE
-// ---- measurement build only: proj_owner2 (LDS compaction rings, three planes) and proj_owner3 (persistent) ----
-// ABL / TRACE: measurement build only (timing arms, results WRONG for ABL != 0): 1 no scan, 2 no fp64 adds,
-// 3 no read-out, 4 no halo loads (own tile only), 5 no loads and no scan; TRACE: per-workgroup phase timestamps.
-template <bool DEPTH, int TH, int kReach, int ABL = 0, bool TRACE = false>
-__global__ __launch_bounds__(16 * TH) void proj_owner2(
-    int W, int H, int tiles_x, int tiles_y,
-    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
-    const float *__restrict__ flow, const float *__restrict__ depth,
-    float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, FillWs ws, int sw)
-{
-    constexpr int NT = 16 * TH, NW = NT / kWave;      // one lane per four owned cells
-    constexpr int kPtH = TH + 1, kPlane = kPtH * kPtW;
-    constexpr int kScanPadX = kReach + 4;         // dilated tile: columns, kept 4-aligned
-    constexpr int kScanW = 64 + 2 * kScanPadX;    // source columns
-    constexpr int kScanH = TH + 2 * kReach + 1;   // source rows: [ty0 - kReach - 1, ty0 + TH + kReach)
-    constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + NT - 1) / NT;
-    constexpr int kRing = 128;                    // entries per wave; at most 63 + 64 wait at any time
-    static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
-    constexpr int kPlanes = ABL == 6 ? 2 : 3;     // (timing arm 6: two planes -> 52 KiB at TH = 32, three workgroups per CU)
-    __shared__ __attribute__((aligned(16))) double P[kPlanes * kPlane];
-    __shared__ __attribute__((aligned(16))) f32x4 ring[NW * kRing];
-    __shared__ TileSummary<TH> sm;                // for the hole filler, when one follows (ws.up != nullptr)
-
-    const TileCoord tc = tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, sw);
-    if (tc.tx >= tiles_x) return;                 // virtual column of the last stripe
-    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * TH;
-    const int tid = threadIdx.x;
-    trace_mark_proj<TRACE>(0);
-    summary_init(sm);
-    {
-        f32x4 *pz = reinterpret_cast<f32x4 *>(P);
-        for (int i = tid; i < kPlanes * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    // scan: kCols4 float4 columns x kScanH rows of slots, kIts per lane; all loads first.  Slot -> (row, column) by
-    // one division and increments, addresses as wave-uniform base + 32-bit lane offset.
-    // Slot `it` of the NT lanes covers scan rows [NT it / kCols4, (NT it + NT - 1) / kCols4]; the tile is rows
-    // [kReach + 1, kReach + 1 + TH): the slot is "far" when all of its rows are at least kNearRows away from the
-    // tile -- such rows almost never pass the row test, so only their fy is requested up front (fx / depth follow
-    // inside the branch if they do): the scan moves several times the tile's own bytes through the CU's 64 B/clk
-    // L1 path, which is a bound of its own.
-    constexpr int kNearRows = 8;
-    auto far_it = [](int it) {
-        const int first = NT * it / kCols4, last = (NT * it + NT - 1) / kCols4;
-        return last <= kReach + 1 - kNearRows || first >= kReach + 1 + TH + kNearRows;
-    };
-    const float *flow_b = flow + b * s1b;
-    const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
-    f32x4 fx[kIts], fy[kIts], dd[kIts];
-    int sx[kIts], sy[kIts];
-    bool live[kIts];
-    int row = tid / kCols4, c4 = tid % kCols4;
-#pragma unroll
-    for (int it = 0; it < kIts; it++) {
-        sx[it] = tx0 - kScanPadX + 4 * c4;
-        sy[it] = ty0 - kReach - 1 + row;
-        live[it] = row < kScanH && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
-        if (ABL == 4)                          // (timing arm: the tile's own sources only)
-            live[it] = live[it] && (unsigned)(sy[it] - ty0) < (unsigned)TH && (unsigned)(sx[it] - tx0) < 64u;
-        // dead slots read the plane's first pixels (unconditional loads)
-        const unsigned off = live[it] ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
-        if (ABL == 5) {
-            fx[it] = fy[it] = dd[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {
-            fy[it] = ld_cached4_u(flow_b + s1c, off);
-            if (!far_it(it)) {
-                fx[it] = ld_cached4_u(flow_b, off);
-                if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
-            }
-        }
-        row += NT / kCols4;                    // the next slot of this lane is NT further on
-        c4 += NT % kCols4;
-        if (c4 >= kCols4) {
-            c4 -= kCols4;
-            row++;
-        }
-    }
-    __syncthreads();                           // P is zero
-    trace_mark_proj<TRACE>(1);                 // loads issued, P zeroed
-    if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    trace_mark_proj<TRACE>(2);                 // loads arrived
-
-    // wave-uniform window bounds.  A source is a hit when its point (T, L) = ((int)y2, (int)x2) lies in the window
-    // and the site is valid (x2, y2 inside the image, my_lib_kernel.cu:1670): x2 >= max(tx0 - 1, 0) and
-    // x2 < tx0 + 64 and x2 <= W - 1.  For x2 >= 0 the float order is the order of the bit patterns, so the last two
-    // are ONE integer compare against min(bits(tx0 + 64), bits(W - 1) + 1).
-    const float xlo = (float)max(tx0 - 1, 0), ylo = (float)max(ty0 - 1, 0);
-    const int xhi_bits = min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1);
-    const int yhi_bits = min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1);
-    const int lane = tid & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
-    f32x4 *const my_ring = ring + wave * kRing;
-    unsigned head = 0, tail = 0;               // wave-uniform ring positions
-    bool far = false;
-
-    // all 64 lanes splat one waiting entry each
-    auto flush64 = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the entries are other lanes' LDS writes
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const f32x4 e = my_ring[(head + lane) & (kRing - 1)];
-        double *q = P + __float_as_int(e[0]);
-        if (ABL == 2) {
-            asm volatile("" ::"v"(q), "v"(e[1]), "v"(e[2]), "v"(e[3]));
-        } else {
-            lds_add_f64(q, (double)e[1]);
-            lds_add_f64(q + kPlane, (double)e[2]);
-            if (kPlanes == 3) lds_add_f64(q + 2 * kPlane, (double)e[3]);
-        }
-        head += kWave;
-    };
-
-#pragma unroll
-    for (int it = 0; it < kIts; it++) {
-        if (ABL == 1 || ABL == 5) {            // (timing arm: no scan; the loads stay)
-            asm volatile("" ::"v"(fx[it]), "v"(fy[it]), "v"(dd[it]));
-            continue;
-        }
-        const bool lv = live[it];
-        const float syf = (float)sy[it], sxf = (float)sx[it];
-        // the quad lies inside the tile itself (tx0, the pad and sx are multiples of 4: all four sites or none)
-        const bool homeq = lv && (unsigned)(sy[it] - ty0) < (unsigned)TH && (unsigned)(sx[it] - tx0) < 64u;
-        float y2[4];
-        bool wy[4], rowany = false;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            y2[j] = syf + fy[it][j];
-            wy[j] = lv && y2[j] >= ylo && __float_as_int(y2[j]) < yhi_bits;
-            rowany = rowany || wy[j];
-        }
-        // rows farther from the tile than the local motion: the whole wave leaves after the four y tests
-        if (__builtin_amdgcn_ballot_w64(rowany || homeq) == 0) continue;
-        f32x4 fxq = fx[it], ddq = dd[it];
-        if (far_it(it)) {                      // rare: requested only now (and consumed inside this branch)
-            const unsigned off = lv ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
-            fxq = ld_cached4_u(flow_b, off);
-            if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float fxv = fxq[j], fyv = fy[it][j];
-            const float x2 = (sxf + (float)j) + fxv;           // (float)x + fx, as the reference rounds it
-            const bool nearj = fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach;
-            if (homeq && !nearj) {             // a far source whose home is this tile: the image takes the general path
-                const bool valid = x2 >= 0.0f && y2[j] >= 0.0f && x2 <= (float)(W - 1) && y2[j] <= (float)(H - 1);
-                far = far || valid;
-            }
-            const bool hit = wy[j] && nearj && x2 >= xlo && __float_as_int(x2) < xhi_bits;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-            if (m == 0) continue;              // wave-uniform
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            if (hit) {
-                const int py = (int)y2[j] - (ty0 - 1), px = (int)x2 - (tx0 - 1);
-                float vx = -fxv, vy = -fyv, vc = 1.0f;
-                if (DEPTH) {                   // my_lib_kernel.cu:2102-2114
-                    vx = -ddq[j] * fxv;
-                    vy = -ddq[j] * fyv;
-                    vc = ddq[j] * 1.0f;
-                }
-                my_ring[(tail + rank) & (kRing - 1)] = f32x4{__int_as_float(py * kPtW + px), vx, vy, vc};
-            }
-            tail += (unsigned)__builtin_popcountll(m);
-            if (tail - head >= (unsigned)kWave) flush64();
-        }
-    }
-    {                                          // what is still waiting (< 64 entries)
-        const unsigned n = tail - head;
-        if (n != 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if ((unsigned)lane < n) {
-                const f32x4 e = my_ring[(head + lane) & (kRing - 1)];
-                double *q = P + __float_as_int(e[0]);
-                lds_add_f64(q, (double)e[1]);
-                lds_add_f64(q + kPlane, (double)e[2]);
-                if (kPlanes == 3) lds_add_f64(q + 2 * kPlane, (double)e[3]);
-            }
-        }
-    }
-    if (far) {                                 // this image needs the general path
-        far_flag[b % kFlagWords] = 1;
-        far_flag[kFlagWords] = 1;
-    }
-    trace_mark_proj<TRACE>(3);                 // scan + splat done (wave 0)
-    __syncthreads();                           // every wave's points are in P
-    trace_mark_proj<TRACE>(4);                 // all waves done
-
-    // every lane owns four cells of a row
-    const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
-    const bool inb = cx < W && cy < H;            // (no early exit: the summary below has a barrier)
-    const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
-    f32x4 ox, oy, oc;
-    // The lane's four cells need the point sums of columns c-1 .. c+3 of two rows, per plane: read them once as
-    // 2 x (two 16-byte pairs + one double) instead of 16 single doubles -- lanes are four cells apart, which for
-    // 8-byte reads is a 4-way bank conflict.
-    double top[3][5], bot[3][5];               // [plane][column c-1 .. c+3], rows cy-1 and cy
-    if (ABL == 3) {
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++)
-#pragma unroll
-            for (int i = 0; i < 5; i++) top[pl][i] = bot[pl][i] = 0.0;
-    } else {
-        const int col0 = cx - tx0;             // P column of cell cx-1 (a multiple of 4: 16-byte aligned pairs)
-        const double *r0 = P + (cy - ty0) * kPtW + col0, *r1 = r0 + kPtW;
-        typedef double f64x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            const double *a = r0 + (pl % kPlanes) * kPlane, *c = r1 + (pl % kPlanes) * kPlane;
-            const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
-            const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
-            top[pl][0] = a01[0]; top[pl][1] = a01[1]; top[pl][2] = a23[0]; top[pl][3] = a23[1]; top[pl][4] = a[4];
-            bot[pl][0] = c01[0]; bot[pl][1] = c01[1]; bot[pl][2] = c23[0]; bot[pl][3] = c23[1]; bot[pl][4] = c[4];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
-        float v[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            // the four contributions are rounded to fp32 one by one and added in a fixed order (the
-            // reference's order is arbitrary: fp32 atomics)
-            float t = 0.0f;
-            t += wy0 * wx0 * (float)bot[pl][j + 1];
-            t += wy0 * (float)bot[pl][j];
-            t += wx0 * (float)top[pl][j + 1];
-            t += (float)top[pl][j];
-            v[pl] = t;
-        }
-        if (v[2] > 0.0f) {                     // my_lib_kernel.cu:1730-1735; one reciprocal for both components
-            const float inv = 1.0f / v[2];     // (<= 1 ulp from the two divisions)
-            v[0] = v[0] * inv;
-            v[1] = v[1] * inv;
-        }
-        ox[j] = v[0];  oy[j] = v[1];  oc[j] = v[2];
-    }
-    if (inb) {
-        float *o = out + b * s1b + (int64_t)cy * s1h + cx;
-        *reinterpret_cast<f32x4 *>(o) = ox;    // plain stores: pass 3 (hole fill) re-reads them
-        *reinterpret_cast<f32x4 *>(o + s1c) = oy;
-        *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
-    }
-    trace_mark_proj<TRACE>(5);                 // outputs stored (issued)
-    if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
-        const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
-        const int any_hole = __syncthreads_or(hole);
-        summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
-    }
-}
-
-// --------------------------------------------------------------------------------------------------
-// proj_owner3: proj_owner2 as a PERSISTENT, software-pipelined kernel.
-// Measured on proj_owner2 (tools/bench_ops.py arms 200..251, tools/trace_kernel.py proj2_32): without any scan work
-// the kernel still takes 178 us where its stores alone take 82 -- the scan's loads are issued at the start of a
-// workgroup's life and nothing is in flight while it tests, splats and reads out (39 % of a workgroup's life is
-// "issue the loads, wait for them"): with 2 - 4 workgroups per CU the bytes in flight average ~30 KB per CU, a
-// quarter of what the latency needs.  Here WGCU workgroups per CU walk the tiles of their XCD's chunk of the stripe
-// order (tile positions p, p + grid, ...; grid % 8 == 0) and the NEXT tile's flow is requested before the current
-// tile is scanned, into a second register set (the loop is unrolled by two so that the sets swap by name).
-// --------------------------------------------------------------------------------------------------
-template <bool DEPTH, int TH, int kReach, int WGCU>
-__global__ __launch_bounds__(16 * TH, (16 * TH / 256) * WGCU) void proj_owner3(
-    int W, int H, int tiles_x, int tiles_y, unsigned npos,
-    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
-    const float *__restrict__ flow, const float *__restrict__ depth,
-    float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, FillWs ws, int sw)
-{
-    constexpr int NT = 16 * TH, NW = NT / kWave;
-    constexpr int kPtH = TH + 1, kPlane = kPtH * kPtW;
-    constexpr int kScanPadX = kReach + 4, kScanW = 64 + 2 * kScanPadX, kScanH = TH + 2 * kReach + 1;
-    constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + NT - 1) / NT;
-    constexpr int kRing = 128;
-    constexpr int kNearRows = 8;
-    static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
-    __shared__ __attribute__((aligned(16))) double P[3 * kPlane];
-    __shared__ __attribute__((aligned(16))) f32x4 ring[NW * kRing];
-    __shared__ TileSummary<TH> sm;
-
-    // What is prefetched one tile ahead is the fy plane of the scan region only: the row test needs nothing else,
-    // and two full register sets (fy + fx [+ depth], twice) do not fit the 128 VGPRs that 16 waves per CU leave a
-    // lane -- the allocator then spills freshly loaded values, which waits for them on the spot.  fx (and depth) of
-    // the rows near the tile are requested at the start of the tile's own turn, ahead of the P zeroing, the next
-    // tile's fy requests and the barrier.
-    struct Regs {
-        f32x4 fy[kIts];
-    };
-    auto far_it = [](int it) {                 // see proj_owner2
-        const int first = NT * it / kCols4, last = (NT * it + NT - 1) / kCols4;
-        return last <= kReach + 1 - kNearRows || first >= kReach + 1 + TH + kNearRows;
-    };
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    f32x4 *const my_ring = ring + wave * kRing;
-    // (threadIdx through an opaque asm, once per tile and phase: everything derived from it -- slot rows, columns,
-    // byte offsets -- would otherwise be hoisted out of the tile loop and kept, i.e. spilled, kernel-wide)
-
-    // position of the next real tile of this workgroup's walk (stripes have virtual columns past the image)
-    auto real_from = [&](unsigned p) {
-        while (p < npos && tile_walk(p, npos, tiles_x, tiles_y, sw).tx >= tiles_x) p += gridDim.x;
-        return p;
-    };
-    // slot `it` of this lane in the scan region of the tile at (tx0, ty0)
-    auto slot = [&](int tid, int it, int tx0, int ty0, int &sx, int &sy, bool &live) {
-        const int s = it * NT + tid, row = s / kCols4, c4 = s - row * kCols4;
-        sx = tx0 - kScanPadX + 4 * c4;
-        sy = ty0 - kReach - 1 + row;
-        live = row < kScanH && sx >= 0 && sx < W && sy >= 0 && sy < H;            // W % 4 == 0
-    };
-    auto request = [&](unsigned p, Regs &r) {
-        const TileCoord tc = tile_walk(p, npos, tiles_x, tiles_y, sw);
-        const float *flow_b = flow + tc.b * s1b;
-        const int tid = tid_now();
-#pragma unroll
-        for (int it = 0; it < kIts; it++) {
-            int sx, sy;
-            bool live;
-            slot(tid, it, tc.tx * 64, tc.ty * TH, sx, sy, live);
-            const unsigned off = live ? 4u * (unsigned)(sy * s1h + sx) : 0u;      // dead slots read pixel 0
-            r.fy[it] = ld_cached4_u(flow_b + s1c, off);
-        }
-    };
-
-    // one tile: `cur` holds its flow (requested one tile earlier); the flow of the tile at `pn` goes into `nxt`
-    auto process = [&](unsigned p, Regs &cur, unsigned pn, Regs &nxt) {
-        const TileCoord tc = tile_walk(p, npos, tiles_x, tiles_y, sw);
-        const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * TH;
-        const float *flow_b = flow + b * s1b;
-        const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
-        const int tid = tid_now();
-        const int lane = tid & (kWave - 1);
-        f32x4 cfx[kIts], cdd[kIts];            // this tile's fx / depth, rows near the tile
-#pragma unroll
-        for (int it = 0; it < kIts; it++) {
-            if (far_it(it)) continue;
-            int sx, sy;
-            bool lv;
-            slot(tid, it, tx0, ty0, sx, sy, lv);
-            cfx[it] = ld_cached4_u(flow_b, lv ? 4u * (unsigned)(sy * s1h + sx) : 0u);
-            if (DEPTH) cdd[it] = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy * sdh + sx) : 0u);
-        }
-        summary_init(sm);
-        {
-            f32x4 *pz = reinterpret_cast<f32x4 *>(P);
-            for (int i = tid; i < 3 * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        request(pn, nxt);                      // in flight while this tile is scanned, splatted and read out
-        __syncthreads();                       // P is zero
-
-        const float xlo = (float)max(tx0 - 1, 0), ylo = (float)max(ty0 - 1, 0);
-        const int xhi_bits = min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1);
-        const int yhi_bits = min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1);
-        unsigned head = 0, tail = 0;
-        bool far = false;
-        auto splat = [&](unsigned n) {         // the first n (<= 64) waiting entries, one per lane
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if ((unsigned)lane < n) {
-                const f32x4 e = my_ring[(head + lane) & (kRing - 1)];
-                double *q = P + __float_as_int(e[0]);
-                lds_add_f64(q, (double)e[1]);
-                lds_add_f64(q + kPlane, (double)e[2]);
-                lds_add_f64(q + 2 * kPlane, (double)e[3]);
-            }
-            head += n;
-        };
-#pragma unroll
-        for (int it = 0; it < kIts; it++) {
-            int sx, sy;
-            bool lv;
-            slot(tid, it, tx0, ty0, sx, sy, lv);
-            const float syf = (float)sy, sxf = (float)sx;
-            const bool homeq = lv && (unsigned)(sy - ty0) < (unsigned)TH && (unsigned)(sx - tx0) < 64u;
-            float y2[4];
-            bool wy[4], rowany = false;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                y2[j] = syf + cur.fy[it][j];
-                wy[j] = lv && y2[j] >= ylo && __float_as_int(y2[j]) < yhi_bits;
-                rowany = rowany || wy[j];
-            }
-            if (__builtin_amdgcn_ballot_w64(rowany || homeq) == 0) continue;
-            f32x4 fxq = cfx[it], ddq = cdd[it];
-            if (far_it(it)) {
-                const unsigned off = lv ? 4u * (unsigned)(sy * s1h + sx) : 0u;
-                fxq = ld_cached4_u(flow_b, off);
-                if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy * sdh + sx) : 0u);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float fxv = fxq[j], fyv = cur.fy[it][j];
-                const float x2 = (sxf + (float)j) + fxv;
-                const bool nearj = fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach;
-                if (homeq && !nearj) {
-                    const bool valid = x2 >= 0.0f && y2[j] >= 0.0f && x2 <= (float)(W - 1) && y2[j] <= (float)(H - 1);
-                    far = far || valid;
-                }
-                const bool hit = wy[j] && nearj && x2 >= xlo && __float_as_int(x2) < xhi_bits;
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-                if (m == 0) continue;
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (hit) {
-                    const int py = (int)y2[j] - (ty0 - 1), px = (int)x2 - (tx0 - 1);
-                    float vx = -fxv, vy = -fyv, vc = 1.0f;
-                    if (DEPTH) {
-                        vx = -ddq[j] * fxv;
-                        vy = -ddq[j] * fyv;
-                        vc = ddq[j] * 1.0f;
-                    }
-                    my_ring[(tail + rank) & (kRing - 1)] = f32x4{__int_as_float(py * kPtW + px), vx, vy, vc};
-                }
-                tail += (unsigned)__builtin_popcountll(m);
-                if (tail - head >= (unsigned)kWave) splat(kWave);
-            }
-        }
-        if (tail != head) splat(tail - head);
-        if (far) {
-            far_flag[b % kFlagWords] = 1;
-            far_flag[kFlagWords] = 1;
-        }
-        __syncthreads();                       // every wave's points are in P
-
-        const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
-        const bool inb = cx < W && cy < H;
-        const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
-        // one plane at a time (the next tile's flow occupies a register set of its own: reading all three planes'
-        // thirty doubles at once would not fit beside it)
-        f32x4 val[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            typedef double f64x2 __attribute__((ext_vector_type(2)));
-            const double *a = P + pl * kPlane + (cy - ty0) * kPtW + (cx - tx0), *c = a + kPtW;
-            const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
-            const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
-            const double top[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
-            const double bot[5] = {c01[0], c01[1], c23[0], c23[1], c[4]};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
-                float t = 0.0f;                // same order as proj_owner2
-                t += wy0 * wx0 * (float)bot[j + 1];
-                t += wy0 * (float)bot[j];
-                t += wx0 * (float)top[j + 1];
-                t += (float)top[j];
-                val[pl][j] = t;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        f32x4 ox, oy, oc;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float v0 = val[0][j], v1 = val[1][j];
-            const float v2 = val[2][j];
-            if (v2 > 0.0f) {
-                const float inv = 1.0f / v2;
-                v0 = v0 * inv;
-                v1 = v1 * inv;
-            }
-            ox[j] = v0;  oy[j] = v1;  oc[j] = v2;
-        }
-        if (inb) {
-            float *o = out + b * s1b + (int64_t)cy * s1h + cx;
-            *reinterpret_cast<f32x4 *>(o) = ox;
-            *reinterpret_cast<f32x4 *>(o + s1c) = oy;
-            *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
-        }
-        if (ws.up) {
-            const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
-            const int any_hole = __syncthreads_or(hole);
-            summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
-        }
-        __syncthreads();                       // P, the summary and the rings are rebuilt by the next tile
-    };
-
-    unsigned p = real_from(blockIdx.x);
-    if (p >= npos) return;
-    Regs ra, rb;
-    request(p, ra);
-#pragma unroll 1
-    for (;;) {
-        unsigned pn = real_from(p + gridDim.x);
-        process(p, ra, pn < npos ? pn : p, rb);             // (past the end: re-request this tile -- unconditional loads)
-        if (pn >= npos) break;
-        p = pn;
-        pn = real_from(p + gridDim.x);
-        process(p, rb, pn < npos ? pn : p, ra);
-        if (pn >= npos) break;
-        p = pn;
-    }
-}
-
+#define MEMC_PROJ_ARMS_PART_A
+#include "arms/proj_owner_arms.hpp"      // proj_owner2, proj_owner3: superseded, measurement build only
+#undef MEMC_PROJ_ARMS_PART_A
 #endif  // MEMC_MEASURE
 
 // --------------------------------------------------------------------------------------------------
@@ -1176,9 +688,10 @@ __device__ __forceinline__ void owner_store(TileSummary<TH> &sm, const FillWs &w
 // (Written out rather than built from OwnerTile's methods: at 64 VGPRs -- eight waves per SIMD, which is what lets
 // four workgroups share a CU -- the allocator is at its limit, and the method form of the very same code spilled five
 // registers and ran 25 % slower.)
-// BOUNDS = false (measurement build only): no motion bounds; flagged images are then redone by the general path.
-// SARM (measurement build only, timing arms, fill results WRONG): 1 no summary_add, 2 no summary_store, 3 neither
-template <bool DEPTH, int TH, int kReach, int MINW, bool BOUNDS = true, int NEARROWS = 8, int SARM = 0>
+// (Round 2 measured three knobs of this kernel that are no longer built: rows whose fx / depth loads are deferred --
+// 0 / 4 / 12 / 16 instead of 8: equal / equal / 245 us / 245 us; no motion bounds, flagged images through the general path:
+// four more normally idle launches; timing arms of the summaries: ~20 us of the call with hole filling.)
+template <bool DEPTH, int TH, int kReach, int MINW>
 __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
@@ -1205,14 +718,14 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
     const int tid0 = threadIdx.x;                 // (thread index of the first half of the kernel, see below)
     const int wave_index = __builtin_amdgcn_readfirstlane(tid0 / kWave);
     summary_init(sm, tid0);
-    if (BOUNDS && tid0 < 2) tile_max[tid0] = 0;
+    if (tid0 < 2) tile_max[tid0] = 0;
     {
         f32x4 *pz = reinterpret_cast<f32x4 *>(P);
         for (int i = tid0; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     // scan loads: see proj_owner2 (slots, far rows, unconditional addresses)
-    constexpr int kNearRows = NEARROWS;
+    constexpr int kNearRows = 8;
     auto far_it = [](int it) {
         const int first = NT * it / kCols4, last = (NT * it + NT - 1) / kCols4;
         return last <= kReach + 1 - kNearRows || first >= kReach + 1 + TH + kNearRows;
@@ -1303,7 +816,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
             if (kHomeIt && homeq && !(fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach)) {
                 const bool valid = x2 >= 0.0f && y2[j] >= 0.0f && x2 <= (float)(W - 1) && y2[j] <= (float)(H - 1);
                 far = far || valid;
-                if (BOUNDS && valid) {         // (cold) the tile's bound on its far sources' motion, for proj_owner_far:
+                if (valid) {                   // (cold) the tile's bound on its far sources' motion, for proj_owner_far:
                     atomicMax(&tile_max[0], __float_as_int(fabsf(fxv)));      // non-negative floats order like their bits
                     atomicMax(&tile_max[1], __float_as_int(fabsf(fyv)));
                 }
@@ -1354,7 +867,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
     // (from here on the thread index is REBUILT from the wave's index, a scalar, and the lane's rank in the wave:
     // kept in a VGPR across the scan it was the one value the allocator spilled at 64 registers)
     const int tid = wave_index * kWave + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if (BOUNDS && tid < 2) bounds[2 * (((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx) + tid] = tile_max[tid];
+    if (tid < 2) bounds[2 * (((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx) + tid] = tile_max[tid];
 
     // Every lane owns four cells of a row: 2x2 box sums of the points of columns c-1 .. c+3, rows cy-1 and cy (border
     // duplicates as weights 2, see proj_scatter_tiled), summed in DOUBLE -- exact, also for the packed plane:
@@ -1414,9 +927,9 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
         }
     }
     if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
-        const bool hole = (SARM & 1) ? false : summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy, tid);
+        const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy, tid);
         const int any_hole = __syncthreads_or(hole);
-        if (!(SARM & 2)) summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, tid);
+        summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, tid);
     }
 }
 
@@ -1615,186 +1128,9 @@ __global__ __launch_bounds__(256) void proj_fillhole_carry(
 }
 
 #ifdef MEMC_MEASURE
-// ---- round-1 owner kernel, kept as the A/B arm of proj_owner2 (variants -10 / -7 / -6) ----
-
-template <bool DEPTH, int kReach, bool TRACE = false>
-__global__ __launch_bounds__(256) void proj_owner(
-    int W, int H, int tiles_x, int tiles_y,
-    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
-    const float *__restrict__ flow, const float *__restrict__ depth,
-    float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, FillWs ws)
-{
-    constexpr int kScanPadX = kReach + 4;         // dilated tile: columns, kept 4-aligned
-    constexpr int kScanW = 64 + 2 * kScanPadX;    // source columns
-    constexpr int kScanH = 16 + 2 * kReach + 1;   // source rows: [ty0 - kReach - 1, ty0 + 16 + kReach)
-    constexpr int kPtH = 17;                      // point window 65 x 17
-    __shared__ __attribute__((aligned(16))) double P[3 * kPtH * kPtW];
-    const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, gridDim.x / (tiles_x * tiles_y));
-    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * 16;
-    trace_mark_proj<TRACE>(0);
-    __shared__ TileSummary<16> sm;                   // for the hole filler, when one follows (ws.up != nullptr)
-    summary_init(sm);
-    {
-        static_assert((3 * kPtH * kPtW) % 2 == 0, "P is zeroed 16 bytes at a time");
-        f32x4 *pz = reinterpret_cast<f32x4 *>(P);
-        for (int i = threadIdx.x; i < 3 * kPtH * kPtW / 2; i += 256) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    // scan: kScanW / 4 float4 columns x kScanH rows of slots, kIts per lane; all loads first.  Slot -> (row,
-    // column) by one division and increments, addresses as wave-uniform base + 32-bit lane offset (the address
-    // arithmetic of this prologue was a quarter of the kernel's VALU instructions, and VALU is its bound).
-    constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + 255) / 256;
-    // slot `it` of the 256 lanes covers scan rows [256 it / kCols4, (256 it + 255) / kCols4]; the tile is rows
-    // [kReach + 1, kReach + 17): the slot is "far" when all of its rows are at least kNearRows away from the tile
-    constexpr int kNearRows = 8;
-    auto far_it = [](int it) {
-        const int first = 256 * it / kCols4, last = (256 * it + 255) / kCols4;
-        return last <= kReach + 1 - kNearRows || first >= kReach + 17 + kNearRows;
-    };
-    const float *flow_b = flow + b * s1b;
-    const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
-    f32x4 fx[kIts], fy[kIts], dd[kIts];
-    int sx[kIts], sy[kIts];
-    bool live[kIts];
-    int row = (int)threadIdx.x / kCols4, c4 = (int)threadIdx.x % kCols4;
-#pragma unroll
-    for (int it = 0; it < kIts; it++) {
-        sx[it] = tx0 - kScanPadX + 4 * c4;
-        sy[it] = ty0 - kReach - 1 + row;
-        live[it] = row < kScanH && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
-        // dead slots read the plane's first pixels (unconditional loads)
-        const unsigned off = live[it] ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
-        fy[it] = ld_cached4_u(flow_b + s1c, off);
-        // Rows more than ~8 px from the tile (the first and last two slots of a lane) almost never pass the row
-        // test below: only their fy is requested here, fx / depth follow inside the branch if they do.  The scan
-        // moves 7.6x the tile's own bytes through the CU's 64 B/clk L1 path, which is a bound of its own.
-        if (!far_it(it)) {
-            fx[it] = ld_cached4_u(flow_b, off);
-            if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
-        }
-        row += 256 / kCols4;                   // the next slot of this lane is 256 further on
-        c4 += 256 % kCols4;
-        if (c4 >= kCols4) {
-            c4 -= kCols4;
-            row++;
-        }
-    }
-    __syncthreads();                           // P is zero
-    trace_mark_proj<TRACE>(1);                 // loads issued, P zeroed
-    if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    trace_mark_proj<TRACE>(2);                 // loads arrived
-    bool far = false;
-#pragma unroll
-    for (int it = 0; it < kIts; it++) {
-        if (!live[it]) continue;
-        const bool home_row = sy[it] >= ty0 && sy[it] < ty0 + 16;
-        // conservative row test first (one pixel of slack covers the rounding of y + fy): a wave scans ~2.5 rows
-        // of the dilated tile, and in the rows farther from the tile than the local motion no lane can land --
-        // the whole wave then skips the per-source work (VALU is what bounds this kernel)
-        if (!home_row) {
-            const float lo = (float)(ty0 - 2 - sy[it]), hi = (float)(ty0 + 17 - sy[it]);
-            const f32x4 f = fy[it];
-            if (!((f[0] >= lo && f[0] < hi) || (f[1] >= lo && f[1] < hi) || (f[2] >= lo && f[2] < hi) ||
-                  (f[3] >= lo && f[3] < hi)))
-                continue;
-        }
-        f32x4 fxq = fx[it], ddq = dd[it];
-        if (far_it(it)) {                      // rare: requested only now (and consumed inside this branch)
-            const unsigned off = 4u * (unsigned)(sy[it] * s1h + sx[it]);
-            fxq = ld_cached4_u(flow_b, off);
-            if (DEPTH) ddq = ld_cached4_u(depth_b, 4u * (unsigned)(sy[it] * sdh + sx[it]));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int x = sx[it] + j, y = sy[it];
-            const float fxv = fxq[j], fyv = fy[it][j];
-            const BlSite s = bl_locate<false>(x, y, W, H, fxv, fyv);
-            if (!s.valid) continue;
-            const bool near = fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach;
-            if (!near) {
-                far = far || (home_row && x >= tx0 && x < tx0 + 64);
-                continue;
-            }
-            const int py = s.T - (ty0 - 1), px = s.L - (tx0 - 1);
-            if ((unsigned)py < (unsigned)kPtH && (unsigned)px < 65u) {
-                float vx = -fxv, vy = -fyv, vc = 1.0f;
-                if (DEPTH) {
-                    vx = -ddq[j] * fxv;
-                    vy = -ddq[j] * fyv;
-                    vc = ddq[j] * 1.0f;
-                }
-                double *q = P + py * kPtW + px;
-                lds_add_f64(q, (double)vx);
-                lds_add_f64(q + kPtH * kPtW, (double)vy);
-                lds_add_f64(q + 2 * kPtH * kPtW, (double)vc);
-            }
-        }
-    }
-    if (far) {                                 // this image needs the general path
-        far_flag[b % kFlagWords] = 1;
-        far_flag[kFlagWords] = 1;
-    }
-    trace_mark_proj<TRACE>(3);                 // scan + splat done (wave 0)
-    __syncthreads();
-    trace_mark_proj<TRACE>(4);                 // all waves done
-
-    // every lane owns four cells of a row
-    const int cx = tx0 + 4 * (threadIdx.x % 16), cy = ty0 + threadIdx.x / 16;
-    const bool inb = cx < W && cy < H;            // (no early exit: the summary below has a barrier)
-    const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
-    f32x4 ox, oy, oc;
-    // The lane's four cells need the point sums of columns c-1 .. c+3 of two rows, per plane: read them once as
-    // 2 x (two 16-byte pairs + one double) instead of 16 single doubles -- lanes are four cells apart, which for
-    // 8-byte reads is a 4-way bank conflict, and this read-out was most of the kernel's LDS time.
-    double top[3][5], bot[3][5];               // [plane][column c-1 .. c+3], rows cy-1 and cy
-    {
-        const int col0 = cx - tx0;             // P column of cell cx-1 (a multiple of 4: 16-byte aligned pairs)
-        const double *r0 = P + (cy - ty0) * kPtW + col0, *r1 = r0 + kPtW;
-        typedef double f64x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            const double *a = r0 + pl * kPtH * kPtW, *c = r1 + pl * kPtH * kPtW;
-            const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
-            const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
-            top[pl][0] = a01[0]; top[pl][1] = a01[1]; top[pl][2] = a23[0]; top[pl][3] = a23[1]; top[pl][4] = a[4];
-            bot[pl][0] = c01[0]; bot[pl][1] = c01[1]; bot[pl][2] = c23[0]; bot[pl][3] = c23[1]; bot[pl][4] = c[4];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
-        float v[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            // the four contributions are rounded to fp32 one by one and added in a fixed order (the
-            // reference's order is arbitrary: fp32 atomics)
-            float t = 0.0f;
-            t += wy0 * wx0 * (float)bot[pl][j + 1];
-            t += wy0 * (float)bot[pl][j];
-            t += wx0 * (float)top[pl][j + 1];
-            t += (float)top[pl][j];
-            v[pl] = t;
-        }
-        if (v[2] > 0.0f) {                     // my_lib_kernel.cu:1730-1735; one reciprocal for both components
-            const float inv = 1.0f / v[2];     // (<= 1 ulp from the two divisions; VALU is this kernel's bound)
-            v[0] = v[0] * inv;
-            v[1] = v[1] * inv;
-        }
-        ox[j] = v[0];  oy[j] = v[1];  oc[j] = v[2];
-    }
-    if (inb) {
-        float *o = out + b * s1b + (int64_t)cy * s1h + cx;
-        *reinterpret_cast<f32x4 *>(o) = ox;    // plain stores: pass 3 (hole fill) re-reads them
-        *reinterpret_cast<f32x4 *>(o + s1c) = oy;
-        *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
-    }
-    trace_mark_proj<TRACE>(5);                 // outputs stored (issued)
-    if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
-        const bool hole = summary_add(sm, inb, oc, 4 * (threadIdx.x % 16), threadIdx.x / 16, cx, cy);
-        const int any_hole = __syncthreads_or(hole);
-        summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y);
-    }
-}
+#define MEMC_PROJ_ARMS_PART_B
+#include "arms/proj_owner_arms.hpp"      // proj_owner (round 1): superseded, measurement build only
+#undef MEMC_PROJ_ARMS_PART_B
 #endif  // MEMC_MEASURE
 
 // general path, queued behind proj_owner: each kernel returns at once unless a far source was seen
@@ -2152,7 +1488,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     const int nonce = (int)nonce_u;
     bool legacy_flags = false;
 #ifdef MEMC_MEASURE
-    legacy_flags = variant == -10 || variant == -7 || variant == -6 || variant == -30 || variant == -31 || variant == -32 ||
+    legacy_flags = variant == -10 || variant == -7 || variant == -6 || variant == -30 || variant == -31 ||
                    (variant <= -21 && variant >= -29);
 #endif
     if ((want_fast || want_carry) && scratch.alloc(ints * sizeof(int), stream)) {
@@ -2236,36 +1572,10 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             // workgroups per CU at TH = 32 (2 planes, 35 KiB), the depth operator 3 (53 KiB)
             constexpr int kWgCu = TH == 16 ? (DEPTH ? 4 : 6) : (TH == 32 ? (DEPTH ? 3 : 4) : 1);
             constexpr int kMinW = (kWgCu * (16 * TH / 64) + 3) / 4 > 8 ? 8 : (kWgCu * (16 * TH / 64) + 3) / 4;
-#ifdef MEMC_MEASURE
-            if (variant <= -50 && variant >= -52) {    // timing arms of the summaries (fill results WRONG)
-#define MEMC_PROJ_SA(SA)                                                                                        \
-                hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW, true, 8, SA>), dim3(walk_grid(ntx, nty, batch, sw)), \
-                                   dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,    \
-                                   a.depth, a.count, a.out, flag, bounds, ws, sw, legacy_flags ? 1 : nonce)
-                if (variant == -50) MEMC_PROJ_SA(1);
-                else if (variant == -51) MEMC_PROJ_SA(2);
-                else MEMC_PROJ_SA(3);
-#undef MEMC_PROJ_SA
-            } else if (variant <= -40 && variant >= -43) {    // A/B: rows whose fx / depth loads are deferred (kNearRows 0 / 4 / 12 / 16)
-#define MEMC_PROJ_NR(NR)                                                                                        \
-                hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW, true, NR>), dim3(walk_grid(ntx, nty, batch, sw)),  \
-                                   dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,    \
-                                   a.depth, a.count, a.out, flag, bounds, ws, sw, legacy_flags ? 1 : nonce)
-                if (variant == -40) MEMC_PROJ_NR(0);
-                else if (variant == -41) MEMC_PROJ_NR(4);
-                else if (variant == -42) MEMC_PROJ_NR(12);
-                else MEMC_PROJ_NR(16);
-#undef MEMC_PROJ_NR
-            } else if (variant == -32)         // A/B: without the motion bounds; flagged images take the general path
-                hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW, false>), dim3(walk_grid(ntx, nty, batch, sw)),
-                                   dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,
-                                   a.depth, a.count, a.out, flag, bounds, ws, sw, 1);
-            else
-#endif
             hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(16 * TH), 0,
                                stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
                                a.out, flag, bounds, ws, sw, legacy_flags ? 1 : nonce);
-            own4 = variant != -32;
+            own4 = true;
         }
         if (launch_status() != 0) return -1;
         if (own4 && !only_part) {
@@ -2342,18 +1652,6 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
             th = 16 << ((v - 130) / 10);
             sw = (v - 130) % 10;
             v = -30;
-        } else if (v >= 190 && v < 193) {      // proj_owner4 summary timing arms
-            th = 32;
-            sw = 4;
-            v = -50 - (v - 190);
-        } else if (v >= 180 && v < 184) {      // proj_owner4 with kNearRows = 0 / 4 / 12 / 16
-            th = 32;
-            sw = 4;
-            v = -40 - (v - 180);
-        } else if (v >= 170 && v < 180) {      // proj_owner4 without motion bounds + general path behind the flag
-            th = 32;
-            sw = v - 170;
-            v = -32;
         } else if (v >= 160 && v < 170) {      // proj_owner3 (persistent, TH = 32), stripe width v - 160
             th = 32;
             sw = v - 160;

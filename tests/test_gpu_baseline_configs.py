@@ -113,6 +113,33 @@ def test_config3_projection_scatter_1280x720_batch32(kind):
     close(g1, R.flow_projection_backward(f, cnt, gf), "config 3 FlowProjection backward (%s)" % kind)
 
 
+@pytest.mark.parametrize("kind", ["smooth", "iid"])
+def test_headline_config_batch32_against_reference_kernels(kind):
+    """The benchmark's own workload at its own size -- FilterInterpolation, C = 3, 32 x 720 x 1280 -- forward and
+    backward against the reference's kernels (2.8 GB of inputs; everything stays on the device), and shard independence
+    of the forward: the frames ranks 1 and 7 of an 8-GPU run would own (items 4-7 and 28-31) run alone give the very
+    bytes they have inside the full batch."""
+    import my_package._ext.my_lib as L
+    B, C, H, W = 32, 3, 720, 1280
+    t = synth.torch_inputs(dev(), B, C, H, W, flow_kind=kind, seed=1234, with_grad=True)
+    x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
+    del t
+    out = torch.full_like(x, float("nan"))
+    assert L.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+    close(out, R.filter_interpolation_forward(x, f, k), "headline forward, batch 32 (%s)" % kind)
+    for first in (4, 28):
+        sl = slice(first, first + 4)
+        o4 = torch.full_like(x[sl], float("nan"))
+        assert L.FilterInterpolationLayer_gpu_forward(x[sl].contiguous(), f[sl].contiguous(), k[sl].contiguous(), o4) == 0
+        assert torch.equal(o4, out[sl]), "shard %d..%d differs from the full batch" % (first, first + 3)
+    g1, g2, g3 = torch.zeros_like(x), torch.full_like(f, float("nan")), torch.full_like(k, float("nan"))
+    assert L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+    w1, w2, w3 = R.filter_interpolation_backward(x, f, k, g)
+    close(g1, w1, "headline backward gradinput1, batch 32 (%s)" % kind)
+    close(g2, w2, "headline backward gradinput2, batch 32 (%s)" % kind)
+    close(g3, w3, "headline backward gradinput3, batch 32 (%s)" % kind)
+
+
 def test_config5_adaptive_warp_4k_batch8():
     import my_package._ext.my_lib as L
     B, C, H, W = 8, 3, 2160, 3840

@@ -98,3 +98,40 @@ def test_fused_context_path_gives_the_same_network(net):
             net.fused_context = False
     for a, b in zip(base, fused):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_config4_shard_of_four_pairs_through_the_demo_padding(net, tmp_path):
+    """BASELINE config 4 as one GPU of eight sees it: 4 frame pairs of 1280 x 720 through networks/inference.py (replicate
+    padding to 1344 x 768 the way demo_HD720p.py:88-113 pads, crop back) on the HIP operators.  Shard independence:
+    pair k run alone gives what it gives inside the batch (the hot-path operators are per frame pair and deterministic
+    in the forward direction; the dense layers may pick another MIOpen solver for another batch size, hence a tolerance),
+    and the same frames through the YUV 4:2:0 demo loop (networks/yuv_io.py) give the same interpolated frames."""
+    import networks
+    torch.manual_seed(4)
+    f0, f2 = torch.rand(4, 3, 720, 1280, device="cuda"), torch.rand(4, 3, 720, 1280, device="cuda")
+    assert networks.pad_amounts(720, 1280) == (32, 32, 24, 24)
+    mid = networks.interpolate_pairs(net, f0, f2)
+    torch.cuda.synchronize()
+    assert mid.shape == (4, 3, 720, 1280) and torch.isfinite(mid).all()
+    scale = max(1.0, float(mid.abs().max()))
+    for k in (0, 3):
+        alone = networks.interpolate_pairs(net, f0[k:k + 1], f2[k:k + 1])
+        err = float((alone[0] - mid[k]).abs().max())
+        assert err <= 1e-4 * scale, "pair %d alone differs from the batch by %.3g" % (k, err)
+    # the demo loop on a small YUV file: frames 0 and 2 in, frame 1 interpolated, batched or not
+    h, w = 128, 192
+    rng = np.random.default_rng(3)
+    src = str(tmp_path / "clip.yuv")
+    wr = networks.Yuv420Writer(src)
+    for i in range(5):
+        wr.write(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+    wr.close()
+    outs = []
+    for pairs in (1, 2):
+        dst = str(tmp_path / ("out%d.yuv" % pairs))
+        scores = networks.interpolate_yuv_sequence(net, src, dst, h, w, torch.device("cuda"), first=0, last=3,
+                                                   pairs_per_step=pairs)
+        assert [s[0] for s in scores] == [1, 3]
+        outs.append(np.fromfile(dst, dtype=np.uint8))
+    assert outs[0].size == 4 * (h * w * 3 // 2)
+    assert np.abs(outs[0].astype(int) - outs[1].astype(int)).max() <= 1        # 8-bit rounding of a 1e-5 difference
