@@ -12,6 +12,7 @@
 #include "memc_common.hpp"
 #include "memc_internal.h"
 #include "memc_tile.hpp"
+#include "memc_pk.hpp"
 
 namespace memc {
 
@@ -226,30 +227,39 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
     }
 }
 
-// Backward, tiled, RGB: image gradient splatted into LDS accumulators and flushed with coalesced atomics
-// (memc_tile.hpp "LDS-privatised scatter"); the flow gradient needs the four corner values, gathered from a
-// staged LDS image of the same box.
-template <int CAP>
-__global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
+#ifdef MEMC_MEASURE
+#include "arms/bl_bwd_arms.hpp"           // bl_bwd_tiled_c3 (rounds 1-2): measurement build only
+#endif
+
+// --------------------------------------------------------------------------------------------------
+// Backward, RGB, round 3: packed fixed-point planes (memc_pk.hpp), image gradient FIRST -- the scheme of fi_bwd_c3.hip
+// with a 2 x 2 footprint.  The bilinear weights are <= 1, so the tile's block exponent comes from its largest
+// |gradoutput| alone.  48 KiB of LDS: the two planes, then -- the same bytes -- the staged image; pitch by the box's
+// width (96 x 32, 80 x 38 or 64 x 48 cells; the fp64 plane of rounds 1-2 had a fixed pitch).
+//   load (planes zeroed meanwhile) -> box -> request image rows -> adds -> flush -> rows to LDS -> flow gradient.
+// Sites whose corners fall outside the (clipped) box scatter with global atomics and gather from global memory, as
+// before; a tile with a non-finite gradoutput scatters everything with global atomics.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void bl_bwd_c3_pk(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
     float *__restrict__ gin1, float *__restrict__ gin2, int sw)
 {
-    constexpr int LX = 16;
+    constexpr int LX = 16, CAP = 3072;
     using G = TileGeom<LX, CAP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // phase 1 uses the LDS as the staged image (48 KiB of pixel quads), phase 2 re-uses the same bytes as ONE
-    // transposed fp64 accumulator plane (AccT, 32 KiB) that the colour channels take in turn: three workgroups
-    // per CU, and the 16-lane groups of a ds_add_f64 hit adjacent slots (see memc_tile.hpp)
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
-    double *acc = reinterpret_cast<double *>(smem);
-    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+    unsigned long long *const accA = reinterpret_cast<unsigned long long *>(smem);   // the planes alias the image
+    unsigned long long *const accB = accA + CAP;
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);            // 16 ints: boxes; 4 ints: maxima
+    int *mx = bb + 16;
 
     const TileCoord tc = tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, sw);
     if (tc.tx >= tiles_x) return;
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
-    const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
+    const unsigned tid = tid_now();
+    const int x = tile_x0 + 4 * (int)(tid % LX), y = tile_y0 + (int)(tid / LX);
     const bool inb = x < W && y < H;
     const int xs = min(x, W - 4), ys = min(y, H - 1);
     const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
@@ -258,6 +268,11 @@ __global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
     f32x4 go[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) go[c] = ld_stream4(gout_p + c * s1c);
+    {                                          // both planes, while the loads are in flight
+        f32x4 *pz = reinterpret_cast<f32x4 *>(smem);
+#pragma unroll
+        for (int i = 0; i < CAP * 16 / 16 / 256; i++) pz[tid + i * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     BlSite st[4];
     int cmin = INT_MAX, cmax = -1, rmin = INT_MAX, rmax = -1;
@@ -270,25 +285,79 @@ __global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
             rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
         }
     }
-    const Region r = tile_region<LX, false, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    {                                          // the tile's largest |gradoutput| (bit pattern), per wave; handed over
+        int mg = 0;                            // by the barrier inside tile_region
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) mg = max(mg, __float_as_int(go[c][j]) & 0x7FFFFFFF);
+        mg = wave_max_i32(inb ? mg : 0);
+        if ((tid & (kWave - 1)) == 0) mx[tid / kWave] = mg;
+    }
+    const Region r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    int mg = max(max(mx[0], mx[1]), max(mx[2], mx[3]));
+    mg = __builtin_amdgcn_readfirstlane(mg);
+    // 0: nothing to add; 2: Inf / NaN in gradoutput -- global atomics; 1: the packed planes
+    const int mode = mg == 0 ? 0 : (mg >= 0x7F800000 ? 2 : 1);
+    const PkScale ps = pk_scale(mode == 1 ? mg : 0x3F800000, 0x3F7FFFFF);       // weights <= 1: their exponent is 0
     const float *in_b = in1 + b * s1b;
     float *gin1_b = gin1 + b * s1b;
-    tile_stage<LX, 3>(r, in_b, s1c, s1h, tile);
+    const StageSlot sl = stage_slots(r);
+    StageRegs<3> sr;
+    tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);             // in flight during adds and flush
+
+    // ---- image gradient: 4 corners x 3 colours per site = 8 packed LDS adds
+    unsigned staged_mask = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!st[j].valid) continue;
+        const BlSite &s = st[j];
+        const bool staged = r.covers(s.L, s.R, s.T, s.Bm);
+        staged_mask |= (staged ? 1u : 0u) << j;
+        if (mode == 0) continue;
+        if (staged && mode == 1) {
+            const int aT = (s.T - r.y0) * r.pitch, aB = (s.Bm - r.y0) * r.pitch;
+            const int aL = pk_col(s.L - r.x0, r.pitch >> 2), aR = pk_col(s.R - r.x0, r.pitch >> 2);
+            const float g0 = ps.sa * go[0][j], g1 = ps.sa * go[1][j], g2 = ps.sa * go[2][j];
+            pk_add3(accA, accB, aT + aL, g0, g1, g2, ps.sb * ((1 - s.a) * (1 - s.b)));
+            pk_add3(accA, accB, aT + aR, g0, g1, g2, ps.sb * (s.a * (1 - s.b)));
+            pk_add3(accA, accB, aB + aL, g0, g1, g2, ps.sb * ((1 - s.a) * s.b));
+            pk_add3(accA, accB, aB + aR, g0, g1, g2, ps.sb * (s.a * s.b));
+        } else {
+#pragma unroll 1
+            for (int c = 0; c < 3; c++) {
+                const float gv = c == 0 ? go[0][j] : (c == 1 ? go[1][j] : go[2][j]);
+                float *q = gin1_b + c * s1c;
+                atomic_add_f32(q + s.T * s1h + s.L, gv * (1 - s.a) * (1 - s.b));
+                atomic_add_f32(q + s.T * s1h + s.R, gv * s.a * (1 - s.b));
+                atomic_add_f32(q + s.Bm * s1h + s.L, gv * (1 - s.a) * s.b);
+                atomic_add_f32(q + s.Bm * s1h + s.R, gv * s.a * s.b);
+            }
+        }
+    }
+    if (mode == 1) {                           // (workgroup-uniform)
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kStageIts; it++)                 // the staged rows have landed: take the wait here, not
+#pragma unroll                                                 // behind the flush's conditional atomics (vmcnt is in order)
+            for (int c = 0; c < 3; c++)
+                asm volatile("" : "+v"(sr.v[it][c][0]), "+v"(sr.v[it][c][1]), "+v"(sr.v[it][c][2]), "+v"(sr.v[it][c][3]));
+        pk_flush(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
+    }
+    __syncthreads();                           // the planes have been read (or never used): the LDS becomes the image
+    tile_stage_store<3>(r, sl, sr, tile);
     __syncthreads();
 
-    // ---- phase 1: flow gradient from the four corner values
+    // ---- flow gradient from the four corner values
     f32x4 gx4 = {0.f, 0.f, 0.f, 0.f}, gy4 = gx4;
-    unsigned staged_mask = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (!st[j].valid) continue;
         const BlSite &s = st[j];
         const float x2 = (float)(x + j) + fx4[j], y2 = (float)y + fy4[j];
         const float gam_x = (float)s.Bm - y2, gam_y = (float)s.R - x2;   // clamped corners, my_lib_kernel.cu:634,652
-        const bool staged = r.covers(s.L, s.R, s.T, s.Bm);
-        staged_mask |= (staged ? 1u : 0u) << j;
         f32x4 vTL, vTR, vBL, vBR;
-        if (staged) {
+        if ((staged_mask >> j) & 1) {
             const int rT = (s.T - r.y0) * r.pitch, rB = (s.Bm - r.y0) * r.pitch;
             const int cL = swz_col(s.L - r.x0), cR = swz_col(s.R - r.x0);
             vTL = tile[rT + cL];  vTR = tile[rT + cR];  vBL = tile[rB + cL];  vBR = tile[rB + cR];
@@ -322,36 +391,6 @@ __global__ __launch_bounds__(256, 3) void bl_bwd_tiled_c3(
         float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
         st_stream4(g2, gx4);
         st_stream4(g2 + s2c, gy4);
-    }
-    __syncthreads();                           // the image has been read: the LDS becomes the accumulators
-
-    // ---- phase 2: image gradient, 4 fp64 LDS adds per site and channel
-    acct_zero<1>(acc);
-    __syncthreads();
-#pragma unroll 1
-    for (int c = 0; c < 3; c++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (!st[j].valid) continue;
-            const BlSite &s = st[j];
-            const bool staged = (staged_mask >> j) & 1;
-            const float gv = c == 0 ? go[0][j] : (c == 1 ? go[1][j] : go[2][j]);
-            const float a00 = gv * (1 - s.a) * (1 - s.b), a01 = gv * s.a * (1 - s.b);
-            const float a10 = gv * (1 - s.a) * s.b, a11 = gv * s.a * s.b;
-            if (staged) {
-                const int aT = (s.T - r.y0) * AccT::kPitch, aB = (s.Bm - r.y0) * AccT::kPitch;
-                const int aL = acct_col(s.L - r.x0), aR = acct_col(s.R - r.x0);
-                lds_add_f64(acc + aT + aL, (double)a00);  lds_add_f64(acc + aT + aR, (double)a01);
-                lds_add_f64(acc + aB + aL, (double)a10);  lds_add_f64(acc + aB + aR, (double)a11);
-            } else {
-                float *q = gin1_b + c * s1c;
-                atomic_add_f32(q + s.T * s1h + s.L, a00);   atomic_add_f32(q + s.T * s1h + s.R, a01);
-                atomic_add_f32(q + s.Bm * s1h + s.L, a10);  atomic_add_f32(q + s.Bm * s1h + s.R, a11);
-            }
-        }
-        __syncthreads();
-        acct_flush_zero(r, acc, gin1_b + c * s1c, s1h);        // leaves the plane zeroed for the next channel
-        __syncthreads();
     }
 }
 
@@ -408,23 +447,25 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
     if (channel == 3 && plane_fits_u32(w, h, {s1h}) &&
         vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2})) {
         using G = TileGeom<16>;
-        static_assert(AccT::kPlane * 8 <= G::kCapPx * 16 && G::kPitch <= AccT::kMaxW && G::kRows <= AccT::kRows,
-                      "the accumulator plane aliases the staged image");
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
-        static_assert(AccT::kPlane * 8 <= 2496 * 16, "the smaller budget still holds the accumulator plane");
         MEMC_PATH("bl_bwd:tiled_c3");
+#ifdef MEMC_MEASURE
 #define MEMC_BL_BWD(CAP)                                                                                        \
         hipLaunchKernelGGL(bl_bwd_tiled_c3<CAP>, dim3(walk_grid(ntx, nty, batch, sw)), dim3(256),                  \
                            (tile_lds_bytes<16, CAP>()), stream, w, h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h,  \
                            (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, gradoutput, gradinput1, gradinput2, sw)
-        // the smaller budget LOSES here (522 -> 601 us): the fixed-pitch accumulator plane gets 26 rows instead of 32
-        // and the sites beyond them scatter with global atomics
+#endif
+        // Product: the packed-plane kernel.  The fp64-plane kernel of rounds 1-2 stays as a measurement arm (bl_cap 0: its
+        // 48 KiB budget; 1: 39 KiB, which LOSES, 522 -> 601 us: the fixed-pitch plane gets 26 rows instead of 32)
 #ifdef MEMC_MEASURE
         if (g_cap_sel == 1) MEMC_BL_BWD(2496);
+        else if (g_cap_sel == 0) MEMC_BL_BWD(3072);
         else
 #endif
-        MEMC_BL_BWD(3072);
+        hipLaunchKernelGGL(bl_bwd_c3_pk, dim3(walk_grid(ntx, nty, batch, sw)), dim3(256), (tile_lds_bytes<16, 3072>() + 64),
+                           stream, w, h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                           input1, input2, gradoutput, gradinput1, gradinput2, sw);
 #undef MEMC_BL_BWD
         return launch_status();
     }

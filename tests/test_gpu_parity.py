@@ -188,6 +188,42 @@ def test_filter_interpolation_backward_rgb_scaling_and_special_values(oracle, ar
         M.reset()
 
 
+def test_interpolation_backward_rgb_packed_planes_special_values(oracle):
+    """The RGB bilinear-warp backward (interpolation.hip: bl_bwd_c3_pk, packed fixed-point planes): signed and huge /
+    tiny gradients against the oracle, a zero gradient, NaN / Inf in gradoutput landing where the reference puts them,
+    large motion (sites outside the staged box scatter with global atomics)."""
+    import my_package._ext.my_lib as my_lib
+    for ci, case in enumerate(((2, 80, 192, "smooth", 6.0), (1, 64, 256, "iid", 20.0), (1, 37, 52, "smooth", 3.0))):
+        B, H, W, kind, sigma = case
+        rng = np.random.default_rng(500 + ci)
+        xn, fn = synth.np_image(rng, B, 3, H, W), synth.np_flow(rng, B, H, W, kind, sigma)
+        gn = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+
+        def run(g, fill=0.0):
+            h1, h2 = torch.full(xn.shape, fill, device=dev()), torch.full(fn.shape, 3.0, device=dev())
+            assert my_lib.InterpolationLayer_gpu_backward(T(xn), T(fn), T(g), h1, h2) == 0
+            return N(h1), N(h2)
+        w1, w2 = oracle.interpolation_backward(xn, fn, gn)
+        h1, h2 = run(gn, 0.5)
+        close(h1, w1 + 0.5, "gradinput1 += %s" % (case,), RTOL)
+        close(h2, w2, "gradinput2 %s" % (case,), RTOL)
+        for scale in (3.7e12, 1.3e-17):
+            g = gn * np.float32(scale)
+            want = oracle.interpolation_backward(xn, fn, g)[0].astype(np.float64)
+            got = run(g)[0].astype(np.float64)
+            assert float(np.abs(got - want).max()) <= 1e-5 * float(np.abs(want).max()), (case, scale)
+        z1 = run(np.zeros_like(gn), 0.25)[0]
+        assert np.array_equal(z1, np.full_like(z1, 0.25)), "zero gradoutput must add nothing"
+        if W % 4 == 0:
+            g_bad = gn.copy()
+            g_bad[0, 1, 10, 20] = np.nan
+            g_bad[0, 2, 30, 40] = -np.inf
+            w1 = oracle.interpolation_backward(xn, fn, g_bad)[0]
+            h1 = run(g_bad)[0]
+            assert np.array_equal(np.isnan(h1), np.isnan(w1)) and np.array_equal(np.isinf(h1), np.isinf(w1)), case
+            close(h1, w1, "gradinput1 with NaN / Inf in gradoutput %s" % (case,), RTOL)
+
+
 def _many_channel_flows(kind, rng, B, H, W):
     """Flow fields that take fi_bwd_cn.hip's paths one by one (FilterInterpolation backward, C % 4 == 0)."""
     yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
