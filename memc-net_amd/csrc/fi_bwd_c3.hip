@@ -157,26 +157,23 @@ __device__ __noinline__ void fi_bwd_site_image_atomics(int x, int y, int W, int 
 //   packed planes, image first, pitch by the band's width                1364 / 1985 /  71.5
 //   packed planes, image gradient first (this kernel)                    1312 / 1929 /  71.4
 //   planes beside the image (78 KiB; adds straight behind phase 1)       1743 / 3462 /  90.1   (two-band sweeps; no overlap won)
-// LX / NT: 16 lanes per tile row x 256 lanes = 64 x 16 tiles (every grid that fills the chip); 8 x 128 = 32 x 16 tiles, four
-// workgroups of two waves per CU, for grids so small that 64 x 16 tiles would not give every CU two rounds of work
-// (BASELINE config 2, 8 x 448 x 256: 896 tiles on 512 slots) -- there a tile's serial chain is what the launch takes.
-template <int NT>
 struct PkGeom {
-    static constexpr int kCap = 12 * NT;                               // pixel quads staged = slots per plane (3 float4 per lane)
+    static constexpr int kCap = 3072;                                  // pixel quads staged = slots per plane
     static constexpr int kImageBytes = kCap * 16;
     static constexpr int kLds = kImageBytes + 128;
 };
 
-template <bool TR, int LX = 16, int NT = 256>
-__global__ __launch_bounds__(NT, 2) void fi_bwd_c3_pk(
+template <bool TR>
+__global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
     int W, int H, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
     const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2,
     float *__restrict__ gin3)
 {
-    using PG = PkGeom<NT>;
-    using G = TileGeom<LX, PG::kCap, NT>;
+    constexpr int LX = 16;
+    using PG = PkGeom;
+    using G = TileGeom<LX, PG::kCap>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     unsigned long long *const accA = reinterpret_cast<unsigned long long *>(smem);   // the planes alias the image
@@ -203,7 +200,7 @@ __global__ __launch_bounds__(NT, 2) void fi_bwd_c3_pk(
     for (int k = 0; k < 16; k++) tp[k] = ld_stream4_u(filt_b + k * s3c, o3);
     auto zero_planes = [&](int cells) {        // the first `cells` slots of both planes (whole 16-byte units)
         f32x4 *pa = reinterpret_cast<f32x4 *>(accA), *pb = reinterpret_cast<f32x4 *>(accB);
-        for (int i = (int)tid_now(); i < (cells >> 1); i += NT) {
+        for (int i = (int)tid_now(); i < (cells >> 1); i += 256) {
             pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -241,14 +238,9 @@ __global__ __launch_bounds__(NT, 2) void fi_bwd_c3_pk(
             mx[(tid / kWave) * 2 + 1] = mt;
         }
     }
-    const BBox box = tile_bbox<LX, NT>(cmin, cmax, rmin, rmax, bb);
+    const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
     const Bands bands = make_bands<LX, true, PG::kCap>(box);
-    int mg = 0, mt = 0;
-#pragma unroll
-    for (int wv = 0; wv < NT / kWave; wv++) {
-        mg = max(mg, mx[2 * wv]);
-        mt = max(mt, mx[2 * wv + 1]);
-    }
+    int mg = max(max(mx[0], mx[2]), max(mx[4], mx[6])), mt = max(max(mx[1], mx[3]), max(mx[5], mx[7]));
     mg = __builtin_amdgcn_readfirstlane(mg);
     mt = __builtin_amdgcn_readfirstlane(mt);
     // 0: nothing to add (every contribution of this tile is zero); 2: Inf / NaN among the inputs -- per-site global
@@ -287,7 +279,7 @@ __global__ __launch_bounds__(NT, 2) void fi_bwd_c3_pk(
     // later bands run only if some site still needs them; the vote is also the barrier that frees the LDS
     if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
     done |= fast;
-    const StageSlot sl = stage_slots<NT>(r);
+    const StageSlot sl = stage_slots(r);
     StageRegs<3> sr;
     tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);         // in flight during adds and flush
     if (mode == 1) {
@@ -303,7 +295,7 @@ __global__ __launch_bounds__(NT, 2) void fi_bwd_c3_pk(
 #pragma unroll                                                 // here, not behind the flush's atomics
             for (int c = 0; c < 3; c++)
                 asm volatile("" : "+v"(sr.v[it][c][0]), "+v"(sr.v[it][c][1]), "+v"(sr.v[it][c][2]), "+v"(sr.v[it][c][3]));
-        pk_flush<NT>(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
+        pk_flush(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
         __syncthreads();                   // the planes have been read: the LDS becomes the image
         if (bi == 0) trace_mark<TR>(4);                    // flushed
     } else if (mode == 2) {
@@ -336,22 +328,18 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
                  {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3}))
         return 0;
     using G = TileGeom<16>;
-    int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
-    unsigned ntiles = (unsigned)ntx * nty * batch;
-#define MEMC_FI_BWD_PK_G(TR, LX, NT)                                                                               \
-    hipLaunchKernelGGL((fi_bwd_c3_pk<TR, LX, NT>), dim3(ntiles), dim3(NT), PkGeom<NT>::kLds, stream, w, h, ntx, nty, batch, \
+    const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+    const unsigned ntiles = (unsigned)ntx * nty * batch;
+#define MEMC_FI_BWD_PK(TR)                                                                                         \
+    hipLaunchKernelGGL(fi_bwd_c3_pk<TR>, dim3(ntiles), dim3(256), PkGeom::kLds, stream, w, h, ntx, nty, batch,     \
                        (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,             \
                        (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)
-#define MEMC_FI_BWD_PK(TR) MEMC_FI_BWD_PK_G(TR, 16, 256)
-    // small grids: 32 x 16 tiles on 128 lanes (see fi_bwd_c3_pk) when the 64 x 16 tiles are fewer than four rounds of
-    // two workgroups per CU
-    bool small = ntiles < 4u * persistent_grid(2);
 #ifdef MEMC_MEASURE
     if (variant == 28) {                                   // + timestamps
         MEMC_FI_BWD_PK(true);
         return launch_status() == 0 ? 1 : -1;
     }
-    if (variant >= 0 && variant != 24 && variant != 25) {  // arms/fi_bwd_c3_arms.hip
+    if (variant >= 0) {                                    // arms/fi_bwd_c3_arms.hip
         const int r = fi_bwd_c3_arm_launch(variant, stream, w, h, ntx, nty, batch, s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c,
                                            s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3);
         if (r != 0) return r;
@@ -359,19 +347,8 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
 #else
     (void)variant;
 #endif
-#ifdef MEMC_MEASURE
-    if (variant == 24) small = false;                      // A/B: 64 x 16 tiles whatever the grid
-    if (variant == 25) small = true;                       //      32 x 16 tiles whatever the grid
-#endif
-    if (small) {
-        ntx = (w + 31) / 32;
-        ntiles = (unsigned)ntx * nty * batch;
-        MEMC_FI_BWD_PK_G(false, 8, 128);
-    } else {
-        MEMC_FI_BWD_PK(false);
-    }
+    MEMC_FI_BWD_PK(false);
 #undef MEMC_FI_BWD_PK
-#undef MEMC_FI_BWD_PK_G
     return launch_status() == 0 ? 1 : -1;
 }
 

@@ -914,64 +914,9 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
             oc[j] = v0;  ox[j] = v1;  oy[j] = v2;
         }
     }
-    if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
-        const int lx = 4 * (tid % 16), ly = tid / 16;
-        const bool hole = summary_add(sm, inb, oc, lx, ly, cx, cy, tid);
-        const int any_hole = __syncthreads_or(hole);           // (and every lane has read its part of P)
-        int needs_neighbour = 0;
-        if (any_hole) {                        // (workgroup-uniform; 13 % of the tiles on the benchmark's smooth flow)
-            // Holes whose three walks (left, right, up: my_lib_kernel.cu:1776-1797; the downward search is dead, :1799)
-            // end INSIDE this tile -- at a non-zero count or at the image border -- are filled here, from the counts and
-            // normalised values every lane still holds: the tile goes to the LDS (the planes are done with), a lane walks
-            // for its own holes.  Only a tile with a walk that leaves it is flagged for proj_fillhole_carry, which then
-            // redoes all of that tile's holes from global memory and the neighbours' summaries (same values: a fill
-            // reads only cells with a non-zero count, which no fill writes).
-            static_assert(sizeof(P) >= 3 * TH * 64 * sizeof(float), "the tile's count / x / y fit the planes' bytes");
-            float *cntL = reinterpret_cast<float *>(P), *oxL = cntL + TH * 64, *oyL = oxL + TH * 64;
-            // (cells past the image edge are never read: the walks test the edge themselves)
-            *reinterpret_cast<f32x4 *>(cntL + ly * 64 + lx) = oc;
-            *reinterpret_cast<f32x4 *>(oxL + ly * 64 + lx) = ox;
-            *reinterpret_cast<f32x4 *>(oyL + ly * 64 + lx) = oy;
-            __syncthreads();
-            bool leaves = false;
-            if (inb && hole) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (!(oc[j] <= 0.0f)) continue;                // what pass 3 fills (:1757)
-                    const int hx = lx + j, hy = ly;
-                    int lo = -1, ro = -1, uo = -1;
-                    for (int c = hx - 1; c >= 0 && lo < 0; c--)
-                        if (cntL[hy * 64 + c] != 0.0f) lo = c;
-                    for (int c = hx + 1; c < 64 && tx0 + c < W && ro < 0; c++)
-                        if (cntL[hy * 64 + c] != 0.0f) ro = c;
-                    for (int r = hy - 1; r >= 0 && uo < 0; r--)
-                        if (cntL[r * 64 + hx] != 0.0f) uo = r;
-                    // a walk without a hit ended at the tile's edge: that is the image border only for the outer tiles
-                    if ((lo < 0 && tx0 > 0) || (ro < 0 && tx0 + 64 < W) || (uo < 0 && ty0 > 0)) {
-                        leaves = true;
-                        continue;
-                    }
-                    const float lt = lo >= 0 ? cntL[hy * 64 + lo] : 0.0f, rt = ro >= 0 ? cntL[hy * 64 + ro] : 0.0f;
-                    const float ut = uo >= 0 ? cntL[uo * 64 + hx] : 0.0f, dt = 0.0f;
-                    if (lt + rt + ut + dt <= 0.0f) continue;
-                    const float fl = lt > 0.0f ? 1.0f : 0.0f, fr = rt > 0.0f ? 1.0f : 0.0f;
-                    const float fu = ut > 0.0f ? 1.0f : 0.0f, fd = 0.0f;
-                    // (a walk that found nothing ends at the border cell -- column 0 / W-1, row 0 -- whose value the
-                    // reference still multiplies by the flag 0: same operands as proj_fillhole_carry)
-                    const int lc = lo >= 0 ? lo : 0, rc = ro >= 0 ? ro : W - 1 - tx0, ur = uo >= 0 ? uo : 0;
-                    ox[j] = (fl * oxL[hy * 64 + lc] + fr * oxL[hy * 64 + rc] + fu * oxL[ur * 64 + hx] + fd * ox[j]) /
-                            (fl + fr + fu + fd);
-                    oy[j] = (fl * oyL[hy * 64 + lc] + fr * oyL[hy * 64 + rc] + fu * oyL[ur * 64 + hx] + fd * oy[j]) /
-                            (fl + fr + fu + fd);
-                }
-            }
-            needs_neighbour = __syncthreads_or(leaves);
-        }
-        summary_store(sm, needs_neighbour, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, tid);
-    }
     if (inb) {
         float *o = out + b * s1b + (int64_t)cy * s1h + cx, *cn = count + b * scb + (int64_t)cy * sch + cx;
-        if (ws.up) {                           // plain stores: pass 3 (hole fill) may re-read them
+        if (ws.up) {                           // plain stores: pass 3 (hole fill) re-reads them
             *reinterpret_cast<f32x4 *>(o) = ox;
             *reinterpret_cast<f32x4 *>(o + s1c) = oy;
             *reinterpret_cast<f32x4 *>(cn) = oc;
@@ -980,6 +925,11 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
             st_stream4(o + s1c, oy);
             st_stream4(cn, oc);
         }
+    }
+    if (ws.up) {                               // the counts are in registers: the filler's per-tile summaries are free
+        const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy, tid);
+        const int any_hole = __syncthreads_or(hole);
+        summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, tid);
     }
 }
 

@@ -148,7 +148,7 @@ def test_product_library_has_no_measurement_arms(hip_lib_path):
     # the RGB backward: the packed-plane kernel without timestamps, and none of the round-1/2 kernels (arms/)
     assert not [k for k in kernels if "15fi_bwd_tiled_c3" in k]
     bwd = [k for k in kernels if "12fi_bwd_c3_pk" in k]
-    assert bwd and all("pkILb0E" in k for k in bwd), bwd        # (no timestamps; tile shapes 16 x 256 and 8 x 128 lanes)
+    assert bwd and all("ILb0EEE" in k for k in bwd), bwd
 
 
 def test_measurement_library_is_separate_and_says_so(hip_lib_path):

@@ -91,9 +91,8 @@ def test_filter_interpolation(oracle, case):
     close(N(k.grad), g3, "gradinput3", RTOL)
 
 
-C3_ARMS = [-1, 24, 25, 0]
-C3_ARM_IDS = ["product: packed planes, image gradient first (tile shape by grid size)", "64x16 tiles forced", "32x16 tiles forced",
-              "arm: fp64 plane per colour (rounds 1-2)"]
+C3_ARMS = [-1, 0]
+C3_ARM_IDS = ["product: packed planes, image gradient first", "arm: fp64 plane per colour (rounds 1-2)"]
 C3_FLOWS = [(2, 100, 132, "smooth", 8.0), (1, 96, 256, "smooth", 25.0), (1, 64, 192, "converge", None),
             (2, 64, 256, "iid", 20.0), (1, 48, 64, "zero", None), (1, 37, 52, "smooth", 3.0)]
 
