@@ -240,13 +240,14 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
 // Sites whose corners fall outside the (clipped) box scatter with global atomics and gather from global memory, as
 // before; a tile with a non-finite gradoutput scatters everything with global atomics.
 // --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void bl_bwd_c3_pk(
+template <int CAP>                             // staging budget in cells: 3072 (48 KiB, 3 workgroups per CU) or 2496 (39 KiB, 4)
+__global__ __launch_bounds__(256, CAP == 3072 ? 3 : 4) void bl_bwd_c3_pk(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
     float *__restrict__ gin1, float *__restrict__ gin2, int sw)
 {
-    constexpr int LX = 16, CAP = 3072;
+    constexpr int LX = 16;
     using G = TileGeom<LX, CAP>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(256, 3) void bl_bwd_c3_pk(
     {                                          // both planes, while the loads are in flight
         f32x4 *pz = reinterpret_cast<f32x4 *>(smem);
 #pragma unroll
-        for (int i = 0; i < CAP * 16 / 16 / 256; i++) pz[tid + i * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < (CAP + 255) / 256; i++)
+            if (CAP % 256 == 0 || (int)tid + i * 256 < CAP) pz[tid + i * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     BlSite st[4];
@@ -463,9 +465,16 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
         else if (g_cap_sel == 0) MEMC_BL_BWD(3072);
         else
 #endif
-        hipLaunchKernelGGL(bl_bwd_c3_pk, dim3(walk_grid(ntx, nty, batch, sw)), dim3(256), (tile_lds_bytes<16, 3072>() + 64),
-                           stream, w, h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
-                           input1, input2, gradoutput, gradinput1, gradinput2, sw);
+#define MEMC_BL_BWD_PK(CAP)                                                                                     \
+        hipLaunchKernelGGL(bl_bwd_c3_pk<CAP>, dim3(walk_grid(ntx, nty, batch, sw)), dim3(256),                    \
+                           (tile_lds_bytes<16, CAP>() + 64), stream, w, h, ntx, nty, (int64_t)s1b, (int64_t)s1c,  \
+                           s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, gradoutput, gradinput1, gradinput2, sw)
+#ifdef MEMC_MEASURE
+        if (g_cap_sel == 3) MEMC_BL_BWD_PK(2496);          // A/B: 39 KiB, four workgroups per CU
+        else
+#endif
+        MEMC_BL_BWD_PK(3072);
+#undef MEMC_BL_BWD_PK
 #undef MEMC_BL_BWD
         return launch_status();
     }

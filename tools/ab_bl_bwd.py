@@ -24,13 +24,13 @@ for B, H, W, tag in ((32, 720, 1280, "720p"), (8, 256, 448, "c2")):
         burst = 20 if B * H * W < 4e6 else 1
         row = []
         for rnd in range(2):
-            for cap, name in ((-1, "packed planes"), (0, "fp64 plane per colour")):
+            for cap, name in ((-1, "packed planes"), (3, "packed planes, 39 KiB"), (0, "fp64 plane per colour")):
                 M.set_variant("bl_cap", cap)
                 med, mn = time_launches(lambda: L.InterpolationLayer_gpu_backward(x, f, g, g1, g2), lambda: g1.zero_(), burst=burst)
                 row.append((name, med))
         M.set_variant("bl_cap", -1)
         sites = B * H * W
-        for name in ("packed planes", "fp64 plane per colour"):
+        for name in ("packed planes", "packed planes, 39 KiB", "fp64 plane per colour"):
             best = min(m for n, m in row if n == name)
             print("interpolation_bwd %s C=3 %dx%dx%d flow=%-6s %-22s %8.1f us  %5.1f%% of 8 TB/s" % (
                 tag, B, H, W, kind, name, best * 1e6, 100 * sites * 52 / best / 8e12), flush=True)
