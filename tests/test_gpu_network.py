@@ -116,15 +116,15 @@ def test_config4_shard_of_four_pairs_through_the_demo_padding(net, tmp_path):
     # solver per shape -- and with these untrained weights the flow is rough, so an fp32 rounding difference that moves a
     # projected source across a pixel boundary changes a few output pixels by O(0.01).  Hence a distribution check: the
     # typical pixel agrees to 1e-4, and only a small fraction moves at all.
-    again = networks.interpolate_pairs(net, f0, f2)
-    assert torch.equal(again, mid), "the same batch twice must give the same bytes"
+    def agree(a, b, what):
+        diff = (a - b).abs().flatten()
+        median, worst, moved = float(diff.median()), float(diff.max()), float((diff > 1e-3).float().mean())
+        print("%s: median %.3g, max %.3g, fraction beyond 1e-3: %.4f" % (what, median, worst, moved))
+        assert median <= 1e-4 and moved <= 0.02, (what, median, worst, moved)
+    # (not even the same batch twice is bit-identical: some of MIOpen's solvers accumulate with atomics)
+    agree(networks.interpolate_pairs(net, f0, f2), mid, "the same batch twice")
     for k in (0, 3):
-        alone = networks.interpolate_pairs(net, f0[k:k + 1], f2[k:k + 1])
-        diff = (alone[0] - mid[k]).abs().flatten()
-        median, worst = float(diff.median()), float(diff.max())
-        moved = float((diff > 1e-3).float().mean())
-        print("pair %d alone vs in the batch: median %.3g, max %.3g, fraction beyond 1e-3: %.4f" % (k, median, worst, moved))
-        assert median <= 1e-4 and moved <= 0.02, (k, median, worst, moved)
+        agree(networks.interpolate_pairs(net, f0[k:k + 1], f2[k:k + 1])[0], mid[k], "pair %d alone vs in the batch" % k)
     # the demo loop on a small YUV file: frames 0 and 2 in, frame 1 interpolated, batched or not
     h, w = 128, 192
     rng = np.random.default_rng(3)
