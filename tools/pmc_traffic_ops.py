@@ -18,7 +18,7 @@ from pmc_traffic import biggest, counter_rows, run_pmc     # noqa: E402
 SITES = 32 * 720 * 1280
 # kernel-name fragment -> (algorithmic bytes per site, sites per launch); every tensor touched once
 KERNELS = {
-    "fi_bwd_tiled_c3<0, 2>": (180, SITES),            # x 12 + flow 8 + taps 64 + gout 12 | gin1 12 + gin2 8 + gin3 64
+    "fi_bwd_c3_pk": (180, SITES),                     # x 12 + flow 8 + taps 64 + gout 12 | gin1 12 + gin2 8 + gin3 64
     "fi_fwd_tiled_c4n": (4 * (2 * 64 + 2 + 16), SITES // 4),
     "fi_fwd_blend_c3": (188, SITES),
     "proj_owner4<false": (20, SITES),                 # flow 8 | count 4 + out 8
@@ -27,7 +27,7 @@ KERNELS = {
     "proj_bwd_tiled<false": (28, SITES),              # flow 8 + count 4 + gout 8 | gin 8
     "proj_bwd_tiled<true": (48, SITES),
     "bl_fwd_tiled<3": (32, SITES),                    # x 12 + flow 8 | out 12
-    "bl_bwd_tiled_c3": (52, SITES),                   # x 12 + flow 8 + gout 12 | gin1 12 + gin2 8
+    "bl_bwd_c3_pk": (52, SITES),                      # x 12 + flow 8 + gout 12 | gin1 12 + gin2 8
     # FilterInterpolation backward, C = 64, batch 8 (fi_bwd_cn.hip): the operator's 912 B/site split over its kernels
     "fi_bwd_taps_c4n": (4 * (2 * 64 + 2 + 16 + 2 + 16), SITES // 4),     # x, gout, flow, taps | gin2, gin3
     "fi_bwd_image_owner": (4 * (64 + 64 + 2 + 16), SITES // 4),          # gout, flow, taps | gin1
