@@ -50,3 +50,22 @@ def test_two_ranks_over_rccl():
     assert d["backend"] == "nccl" and d["world_size_seen"] == 2
     assert d["per_rank_items"] == [16, 16] and len(d["per_rank_ms_per_step"]) == 2
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["global_batch"] == 32
+
+
+def test_two_ranks_sharing_one_gpu_plumbing():
+    """The N > 1 code path end to end on a one-GPU box: two ranks on the same device, gloo standing in for RCCL (which
+    refuses two ranks on one device).  Not a measurement -- the line says so in `data` -- but every collective, the shard
+    plan, the HIP-graph replay of the rotating input sets and the `dist` record run for real."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--share-gpu", "--batch", "8", "--steps", "12", "--warmup", "3", "--prewarm", "6"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = _line(r.stdout)
+    d = line["dist"]
+    assert d["backend"] == "gloo" and d["world_size_seen"] == 2 and d["per_rank_items"] == [4, 4]
+    assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
+    assert "PLUMBING TEST" in line["data"] and line["n_gpus"] == 2 and line["config"]["global_batch"] == 8
+    assert line["config"]["launch"] == "hip_graph" and line["config"]["input_sets"] >= 4
+    assert "cpu_baseline" not in line and "check" not in line          # rank 0 at N = 1 only
