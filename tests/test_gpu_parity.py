@@ -716,6 +716,65 @@ def test_many_channel_backward_random_shapes(oracle):
         close(N(h2), v2, "bilinear gradinput2 " + what, 3 * RTOL)
 
 
+def test_rgb_backward_random_shapes_and_strided_views(oracle):
+    """Sixteen seeded random shapes (ragged heights / widths, multiples of four and not, five flow kinds, signed taps and
+    gradients of random magnitude) through the RGB backward passes -- packed fixed-point planes, fi_bwd_c3.hip and
+    interpolation.hip -- against the oracle; then the same kernels on channel slices of wider tensors with padded rows
+    (every stride different)."""
+    import my_package._ext.my_lib as my_lib
+    rng = np.random.default_rng(20260928)
+    kinds = ["smooth", "pan", "far", "converge", "iid"]
+    for _ in range(16):
+        B = int(rng.integers(1, 4))
+        H, W = int(rng.integers(5, 120)), int(rng.integers(3, 80)) * 4 + (int(rng.integers(0, 4)) if rng.random() < 0.2 else 0)
+        kind = kinds[int(rng.integers(0, len(kinds)))]
+        mag_g, mag_k = float(10.0 ** rng.uniform(-3, 2)), float(10.0 ** rng.uniform(-2, 0.5))
+        xn = synth.np_image(rng, B, 3, H, W)
+        kn = (rng.standard_normal((B, 16, H, W)) * mag_k / 4).astype(np.float32)
+        gn = (rng.standard_normal((B, 3, H, W)) * mag_g).astype(np.float32)
+        fn = _many_channel_flows(kind, rng, B, H, W)
+        what = "%dx3x%dx%d %s |g|~%.3g |k|~%.3g" % (B, H, W, kind, mag_g, mag_k)
+        x, f, k, g = T(xn), T(fn), T(kn), T(gn)
+        g1, g2, g3 = torch.zeros_like(x), torch.full_like(f, -3.0), torch.full_like(k, -3.0)
+        assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+        w1, w2, w3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+        # the operator's own scale: errors are judged against the largest gradient of the case (inputs span 1e-3 .. 1e2)
+        for got, want, name in ((g1, w1, "gradinput1"), (g2, w2, "gradinput2"), (g3, w3, "gradinput3")):
+            sc = max(1.0, float(np.abs(want).max()))
+            close(N(got) / sc, want / sc, "%s (scaled by %.3g) %s" % (name, sc, what), 3 * RTOL)
+        h1, h2 = torch.zeros_like(x), torch.full_like(f, -3.0)
+        assert my_lib.InterpolationLayer_gpu_backward(x, f, g, h1, h2) == 0
+        v1, v2 = oracle.interpolation_backward(xn, fn, gn)
+        for got, want, name in ((h1, v1, "bilinear gradinput1"), (h2, v2, "bilinear gradinput2")):
+            sc = max(1.0, float(np.abs(want).max()))
+            close(N(got) / sc, want / sc, "%s (scaled by %.3g) %s" % (name, sc, what), 3 * RTOL)
+    # strided views: RGB = channels 2..4 of a 6-channel tensor whose rows are 8 columns wider
+    B, H, W = 2, 48, 128
+    xn, kn, gn = synth.np_image(rng, B, 3, H, W), synth.np_filter(rng, B, H, W), synth.np_image(rng, B, 3, H, W)
+    fn = synth.np_flow(rng, B, H, W, "smooth", 5.0)
+
+    def wide(a, cpad, wpad, fill=0.0):
+        big = torch.full((a.shape[0], a.shape[1] + cpad, a.shape[2], a.shape[3] + wpad), fill, device=dev())
+        v = big[:, cpad:, :, :a.shape[3]]
+        v.copy_(T(a))
+        return v
+    x, g = wide(xn, 2, 8), wide(gn, 2, 8)
+    f, k = wide(fn, 1, 4), wide(kn, 3, 12)
+    g1 = wide(np.zeros_like(xn), 2, 8)                     # same batch / channel strides as x (the layer checks that)
+    g2, g3 = wide(np.zeros_like(fn), 1, 4, fill=5.0), wide(np.zeros_like(kn), 3, 12, fill=5.0)
+    assert not x.is_contiguous() and not k.is_contiguous()
+    assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+    w1, w2, w3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+    close(N(g1), w1, "strided RGB gradinput1", RTOL)
+    close(N(g2), w2, "strided RGB gradinput2", RTOL)
+    close(N(g3), w3, "strided RGB gradinput3", RTOL)
+    h1, h2 = wide(np.zeros_like(xn), 2, 8), wide(np.zeros_like(fn), 1, 4, fill=5.0)
+    assert my_lib.InterpolationLayer_gpu_backward(x, f, g, h1, h2) == 0
+    v1, v2 = oracle.interpolation_backward(xn, fn, gn)
+    close(N(h1), v1, "strided RGB bilinear gradinput1", RTOL)
+    close(N(h2), v2, "strided RGB bilinear gradinput2", RTOL)
+
+
 def test_many_channel_backward_on_strided_views(oracle):
     """The owner kernels index every tensor through its own batch / channel / row strides: channel slices of wider
     tensors, rows of wider images (16-byte aligned, so still the vector path), all strides different."""
