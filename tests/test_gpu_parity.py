@@ -338,6 +338,26 @@ def test_filter_interpolation_backward_many_channels_measurement_arms(oracle, ar
         close(N(h3), g3, "gradinput3 %s" % (arm,), RTOL)
 
 
+@pytest.mark.parametrize("variant", [33, 34, 35, 36, 31], ids=["32x32 strips", "32x32 stripes of 4", "32x32 stripes of 2",
+                                                              "32x32 stripes of 8", "64x16 stripes of 4"])
+def test_context_warp_forward_tile_shape_arms(oracle, variant):
+    """The many-channel forward on 32 x 32 tiles (eight lanes per tile row, row-parity swizzle) and the stripe walks --
+    measurement arms of fi_fwd_tiled_c4n -- must give the oracle's results like the 64 x 16 product kernel."""
+    from tools import measure as M
+    my_lib = M.bound()
+    try:
+        M.set_variant("fi_fwd", variant)
+        for ci, (B, C, H, W, kind, sigma) in enumerate(((1, 8, 70, 200, "smooth", 6.0), (2, 16, 96, 132, "smooth", 14.0),
+                                                        (1, 64, 40, 256, "iid", 5.0), (1, 12, 33, 64, "smooth", 3.0))):
+            rng = np.random.default_rng(700 + ci)
+            xn, fn, kn = synth.np_image(rng, B, C, H, W), synth.np_flow(rng, B, H, W, kind, sigma), synth.np_filter(rng, B, H, W)
+            out = torch.full(xn.shape, float("nan"), device=dev())
+            assert my_lib.FilterInterpolationLayer_gpu_forward(T(xn), T(fn), T(kn), out) == 0
+            close(N(out), oracle.filter_interpolation_forward(xn, fn, kn), "forward %s variant %d" % ((B, C, H, W, kind), variant))
+    finally:
+        M.reset()
+
+
 def test_shapes_take_the_documented_kernel_paths():
     """DESIGN.md section 5 says which kernel family a shape takes; the measurement build records the launcher's choice
     (memc_debug_last_path), so the claim is checked instead of inferred from timings: aligned shapes must not
