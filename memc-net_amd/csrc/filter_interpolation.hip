@@ -68,19 +68,17 @@ __device__ __noinline__ void fi_site_scalar(int x, int y, int W, int H, int nch,
 // afterwards by fi_site_scalar (at the end of the kernel, once for all channels).
 // Gather + blend of the sites selected by `sel` (bit j) from the staged band; other sites keep their `res`.
 // Branch-free: unselected sites still issue their 16 LDS reads (at pixel 0, harmless).
-template <int LX, int NCH, bool ROWSWZ = false>
+template <int LX, int NCH>
 __device__ __forceinline__ void fi_gather(const Region &r, const FiSite4 &g, const f32x4 (&tp)[16], unsigned sel,
                                           int W, int H, const f32x4 *tile, f32x4 (&res)[4])
 {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const bool on = (sel >> j) & 1;
-        int ro[4], co[4], rs[4];
+        int ro[4], co[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int row = on ? clampi(g.iy[j] - 1 + k, H - 1) - r.y0 : 0;
-            ro[k] = row * r.pitch;
-            rs[k] = ROWSWZ ? swz_row(row) : 0;
+            ro[k] = on ? (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch : 0;
             co[k] = on ? swz_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0) : 0;
         }
         // quadrant sums, row-major inside each quadrant as in the reference (rows 0,1 top; 2,3 bottom)
@@ -89,7 +87,7 @@ __device__ __forceinline__ void fi_gather(const Region &r, const FiSite4 &g, con
         for (int k = 0; k < 4; k++) {
             f32x4 v[4];
 #pragma unroll
-            for (int m = 0; m < 4; m++) v[m] = tile[ro[k] + (ROWSWZ ? co[m] ^ rs[k] : co[m])];
+            for (int m = 0; m < 4; m++) v[m] = tile[ro[k] + co[m]];
             if (k < 2) {
                 TL += v[0] * tp[k * 4 + 0][j];  TL += v[1] * tp[k * 4 + 1][j];
                 TR += v[2] * tp[k * 4 + 2][j];  TR += v[3] * tp[k * 4 + 3][j];
@@ -258,7 +256,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
         stage_load(0);
 #pragma unroll 1
         for (int c0 = 0; c0 < C; c0 += 4) {
-            tile_stage_store<4, LX == 8>(r, sl, sr, tile);
+            tile_stage_store<4>(r, sl, sr, tile);
             __syncthreads();
             // next chunk's rows: in flight while this chunk is gathered (the last iteration re-reads its own
             // chunk -- harmless, keeps the loads unconditional)
@@ -273,7 +271,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
             f32x4 res[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) res[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            fi_gather<LX, 4, LX == 8>(r, g, tp, sel, W, H, tile, res);
+            fi_gather<LX, 4>(r, g, tp, sel, W, H, tile, res);
             const float *plane0 = in_b + c0 * s1c;
             float *o = out_p + c0 * s1c;
             if (wr & ~g.valid) {                           // out-of-range sites copy the input pixel
@@ -1187,10 +1185,6 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             MEMC_FI_C4N_LX(0, 256, false, 8);              // 32 x 32 tiles: the box of a square tile is the least dilated
         } else if (variant == 34 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N_LX(4, 256, false, 8);              // ... in stripes four tile columns wide
-        } else if (variant == 35 && channel % 4 == 0 && channel >= 8) {
-            MEMC_FI_C4N_LX(2, 256, false, 8);              // ... two
-        } else if (variant == 36 && channel % 4 == 0 && channel >= 8) {
-            MEMC_FI_C4N_LX(8, 256, false, 8);              // ... eight
         } else {
             handled = false;
         }

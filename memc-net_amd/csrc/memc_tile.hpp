@@ -85,10 +85,6 @@ __device__ __forceinline__ MEMC_GLOBAL float *at_u(float *ubase, unsigned byte_o
 }
 
 __device__ __forceinline__ int swz_col(int c) { return c ^ ((c >> 2) & 15); }
-// Tiles with EIGHT lanes per row (32 x 32 sites): a ds_read_b128 group is then 4 rows x 4 pixel quads, rows r / r + 3 and
-// r + 1 / r + 2 at the same columns -- under swz_col alone a 2-way conflict.  Odd staged rows take the other half of the
-// sixteen slots (bit 3): the group's sixteen addresses are distinct again for locally uniform flow.
-__device__ __forceinline__ int swz_row(int staged_row) { return (staged_row & 1) << 3; }
 
 // Kernels that address a plane as wave-uniform base + 32-bit byte offset (ld_stream4_u & co.) need every in-plane
 // byte offset (h - 1) * row_stride + w to fit 32 bits; a view with a gigantic row stride takes the 64-bit kernels.
@@ -360,7 +356,7 @@ __device__ __forceinline__ void tile_stage_load_planes(const Region &r, const St
     }
 }
 
-template <int NCH, bool ROWSWZ = false>
+template <int NCH>
 __device__ __forceinline__ void tile_stage_store(const Region &r, const StageSlot &sl, const StageRegs<NCH> &sr,
                                                  f32x4 *tile)
 {
@@ -368,13 +364,12 @@ __device__ __forceinline__ void tile_stage_store(const Region &r, const StageSlo
     for (int it = 0; it < kStageIts; it++) {
         if (sl.row[it] < r.h) {
             f32x4 *dst = tile + sl.row[it] * r.pitch;
-            const int rs = ROWSWZ ? swz_row(sl.row[it]) : 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 f32x4 px = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < NCH; c++) px[c] = sr.v[it][c][i];
-                dst[swz_col(4 * sl.q[it] + i) ^ rs] = px;
+                dst[swz_col(4 * sl.q[it] + i)] = px;
             }
         }
     }

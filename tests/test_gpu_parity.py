@@ -338,11 +338,10 @@ def test_filter_interpolation_backward_many_channels_measurement_arms(oracle, ar
         close(N(h3), g3, "gradinput3 %s" % (arm,), RTOL)
 
 
-@pytest.mark.parametrize("variant", [33, 34, 35, 36, 31], ids=["32x32 strips", "32x32 stripes of 4", "32x32 stripes of 2",
-                                                              "32x32 stripes of 8", "64x16 stripes of 4"])
+@pytest.mark.parametrize("variant", [33, 34, 31], ids=["32x32 strips", "32x32 stripes of 4", "64x16 stripes of 4"])
 def test_context_warp_forward_tile_shape_arms(oracle, variant):
-    """The many-channel forward on 32 x 32 tiles (eight lanes per tile row, row-parity swizzle) and the stripe walks --
-    measurement arms of fi_fwd_tiled_c4n -- must give the oracle's results like the 64 x 16 product kernel."""
+    """The many-channel forward on 32 x 32 tiles (eight lanes per tile row) and the stripe walks -- measurement arms of
+    fi_fwd_tiled_c4n -- must give the oracle's results like the 64 x 16 product kernel."""
     from tools import measure as M
     my_lib = M.bound()
     try:
