@@ -143,3 +143,23 @@ def test_config4_shard_of_four_pairs_through_the_demo_padding(net, tmp_path):
     assert outs[0].size == 4 * (h * w * 3 // 2)
     d = np.abs(outs[0].astype(int) - outs[1].astype(int))
     assert np.median(d) == 0 and float((d > 1).mean()) <= 0.02        # (same reasoning as above, in 8-bit steps)
+
+
+def test_hd_demo_command_line(tmp_path, capsys):
+    """tools/demo_hd720p.py (the reference's demo_HD720p.py loop as a command) on a small clip: output file and scores."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import importlib
+    demo = importlib.import_module("demo_hd720p")
+    import networks
+    h, w = 128, 192
+    rng = np.random.default_rng(8)
+    src, dst = str(tmp_path / "clip.yuv"), str(tmp_path / "out.yuv")
+    wr = networks.Yuv420Writer(src)
+    for _ in range(5):
+        wr.write(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+    wr.close()
+    demo.main(["--input", src, "--output", dst, "--height", str(h), "--width", str(w), "--model", "MEMC_Net",
+               "--last", "3", "--pairs-per-step", "2"])
+    out = capsys.readouterr().out
+    assert "frame    1" in out and "frame    3" in out and "average over 2 interpolated frames" in out
+    assert os.path.getsize(dst) == 4 * (h * w * 3 // 2)
