@@ -60,7 +60,7 @@ __device__ __forceinline__ void fi_bwd_phase1(const Region &r, unsigned fast, Fi
     f32x4 gx4 = {0.f, 0.f, 0.f, 0.f}, gy4 = gx4;
     // Loop order (tap row, tap column, site): one float4 of tap gradients is live at a time and four image reads
     // are in flight; cell addresses are recomputed per use (the asm keeps them from being CSE'd into a table) --
-    // the kernel lives or dies by fitting 168 registers without a spill.
+    // the kernel lives or dies by staying clear of spills (252 of 256 registers with the staged rows parked beside it).
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         int ro[4];
