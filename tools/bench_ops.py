@@ -292,6 +292,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="fi_fwd: only the 720p batch-32 smooth-flow row")
     ap.add_argument("--ctx-only", action="store_true", help="fi_fwd: only the C=64 context-warp row")
+    ap.add_argument("--ctx-flows", action="store_true", help="with --ctx-only: also the 4x smoother ('video') and the i.i.d. flow")
     ap.add_argument("--only", default="")
     ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "bench_ops.json"))
     ap.add_argument("--variants", default="-1", help="fi_fwd A/B arms, e.g. -1,1,0 (measurement build)")
@@ -312,6 +313,9 @@ def main():
         bench_copy(rows, dev)
     if want("fi_fwd") and args.ctx_only:
         bench_fi_fwd(rows, dev, 8, 64, 720, 1280, "smooth", variants, "ctx64")
+        if args.ctx_flows:                         # the same kernel on the two other flow statistics
+            bench_fi_fwd(rows, dev, 8, 64, 720, 1280, "video", variants[:1], "ctx64")
+            bench_fi_fwd(rows, dev, 8, 64, 720, 1280, "iid", variants[:1], "ctx64")
     elif want("fi_fwd"):
         bench_fi_fwd(rows, dev, 32, 3, 720, 1280, "smooth", variants, "c_headline")
         if not args.headline_only:
