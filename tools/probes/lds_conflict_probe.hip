@@ -1,0 +1,65 @@
+// tools/probes/lds_conflict_probe.hip -- what do SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE say for known LDS access patterns?
+// Every kernel: 256 lanes, 48 KiB of pixel quads, each lane issues 64 x 16 ds_read_b128 (or the write / atomic pattern) and
+// keeps the sum alive.  Patterns:
+//   0  linear: lane l reads slot (l + 64 it) & mask                    -- conflict-free by construction
+//   1  stride 4, no swizzle: slot 4 * (l % 16) + 96 * (l / 16)         -- 4-way conflicts
+//   2  the tiled kernels' gather for a UNIFORM flow: row l / 16 (+k), column 4 * (l % 16) + j + m, XOR-swizzled, pitch 96
+//   3  as 2 with pitch 80
+//   4  as 2, but the column of every lane perturbed by a pseudo-random 0..3 (a rough flow)
+//   5  ds_write_b128 in the staging pattern (lane q of a row writes pixel 4 q + i)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int swz_col(int c) { return c ^ ((c >> 2) & 15); }
+
+template <int P>
+__global__ __launch_bounds__(256) void lds_probe(float *out, int iters)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
+    const int l = threadIdx.x;
+    for (int i = l; i < 3072; i += 256) tile[i] = f32x4{(float)i, 1.f, 2.f, 3.f};
+    __syncthreads();
+    const int pitch = P == 3 ? 80 : 96;
+    const int row = l / 16, q = l % 16;
+    const int rnd = (l * 2654435761u >> 13) & 3;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                int idx;
+                if (P == 0) idx = (l + 64 * (k * 4 + m) + it) & 2047;
+                else if (P == 1) idx = (4 * q + 96 * row + k * 96 + m + it) & 2047;
+                else {
+                    const int c = 4 * q + 1 + m + (it & 3) + (P == 4 ? rnd : 0);
+                    idx = (row + k) * pitch + swz_col(c);
+                }
+                if (P == 5) {
+                    tile[(row + k) * pitch + swz_col(4 * q + m)] = acc + (float)it;
+                } else {
+                    acc += tile[idx];
+                }
+            }
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    }
+    if (P == 5) { __syncthreads(); acc = tile[l]; }
+    out[blockIdx.x * 256 + l] = acc[0] + acc[1] + acc[2] + acc[3];
+}
+
+extern "C" int lds_probe_run(void *stream, int pattern, float *out, int blocks, int iters)
+{
+    hipStream_t s = (hipStream_t)stream;
+#define RUN(P) hipLaunchKernelGGL(lds_probe<P>, dim3(blocks), dim3(256), 49152, s, out, iters)
+    switch (pattern) {
+    case 0: RUN(0); break;
+    case 1: RUN(1); break;
+    case 2: RUN(2); break;
+    case 3: RUN(3); break;
+    case 4: RUN(4); break;
+    case 5: RUN(5); break;
+    default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
