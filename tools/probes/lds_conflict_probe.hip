@@ -7,6 +7,11 @@
 //   3  as 2 with pitch 80
 //   4  as 2, but the column of every lane perturbed by a pseudo-random 0..3 (a rough flow)
 //   5  ds_write_b128 in the staging pattern (lane q of a row writes pixel 4 q + i)
+//   6  as 2 with a smooth drift: the column offset grows by one every five quads along the row, and differs by one between rows
+//   7  TRANSPOSED layout (column c of a row at (c & 3) * 32 + (c >> 2), row pitch 128 slots), uniform flow
+//   8  transposed, the random 0..3 perturbation of 4
+//   9  transposed, the smooth drift of 6
+//  10  transposed, ds_write_b128 staging pattern
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -23,6 +28,8 @@ __global__ __launch_bounds__(256) void lds_probe(float *out, int iters)
     const int pitch = P == 3 ? 80 : 96;
     const int row = l / 16, q = l % 16;
     const int rnd = (l * 2654435761u >> 13) & 3;
+    const int drift = q / 5 + (row & 1);
+    auto tr = [](int c) { return (c & 3) * 32 + (c >> 2); };
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -32,19 +39,24 @@ __global__ __launch_bounds__(256) void lds_probe(float *out, int iters)
                 int idx;
                 if (P == 0) idx = (l + 64 * (k * 4 + m) + it) & 2047;
                 else if (P == 1) idx = (4 * q + 96 * row + k * 96 + m + it) & 2047;
-                else {
-                    const int c = 4 * q + 1 + m + (it & 3) + (P == 4 ? rnd : 0);
+                else if (P >= 7) {
+                    const int c = 4 * q + 1 + m + (it & 3) + (P == 8 ? rnd : 0) + (P == 9 ? drift : 0);
+                    idx = ((row + k) * 128 + tr(c)) & 2047;        // (24 KiB of the 48: rows wrap, the banks do not care)
+                } else {
+                    const int c = 4 * q + 1 + m + (it & 3) + (P == 4 ? rnd : 0) + (P == 6 ? drift : 0);
                     idx = (row + k) * pitch + swz_col(c);
                 }
                 if (P == 5) {
                     tile[(row + k) * pitch + swz_col(4 * q + m)] = acc + (float)it;
+                } else if (P == 10) {
+                    tile[((row + k) * 128 + tr(4 * q + m)) & 2047] = acc + (float)it;
                 } else {
                     acc += tile[idx];
                 }
             }
         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
     }
-    if (P == 5) { __syncthreads(); acc = tile[l]; }
+    if (P == 5 || P == 10) { __syncthreads(); acc = tile[l]; }
     out[blockIdx.x * 256 + l] = acc[0] + acc[1] + acc[2] + acc[3];
 }
 
@@ -59,6 +71,11 @@ extern "C" int lds_probe_run(void *stream, int pattern, float *out, int blocks, 
     case 3: RUN(3); break;
     case 4: RUN(4); break;
     case 5: RUN(5); break;
+    case 6: RUN(6); break;
+    case 7: RUN(7); break;
+    case 8: RUN(8); break;
+    case 9: RUN(9); break;
+    case 10: RUN(10); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -15,7 +15,7 @@ lib = ctypes.CDLL(SO)
 lib.lds_probe_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 out = torch.zeros(2048 * 256, device="cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for p in range(6):
+for p in range(11):
     for _ in range(3):
         assert lib.lds_probe_run(st, p, ctypes.c_void_p(out.data_ptr()), 2048, 64) == 0
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
