@@ -68,7 +68,7 @@ __device__ __noinline__ void fi_site_scalar(int x, int y, int W, int H, int nch,
 // afterwards by fi_site_scalar (at the end of the kernel, once for all channels).
 // Gather + blend of the sites selected by `sel` (bit j) from the staged band; other sites keep their `res`.
 // Branch-free: unselected sites still issue their 16 LDS reads (at pixel 0, harmless).
-template <int LX, int NCH>
+template <int LX, int NCH, class LAY = LayXor>
 __device__ __forceinline__ void fi_gather(const Region &r, const FiSite4 &g, const f32x4 (&tp)[16], unsigned sel,
                                           int W, int H, const f32x4 *tile, f32x4 (&res)[4])
 {
@@ -79,7 +79,7 @@ __device__ __forceinline__ void fi_gather(const Region &r, const FiSite4 &g, con
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             ro[k] = on ? (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch : 0;
-            co[k] = on ? swz_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0) : 0;
+            co[k] = on ? LAY::col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0, r.pitch) : 0;
         }
         // quadrant sums, row-major inside each quadrant as in the reference (rows 0,1 top; 2,3 bottom)
         f32x4 TL = {0.f, 0.f, 0.f, 0.f}, TR = TL, BL = TL, BR = TL;
@@ -180,7 +180,10 @@ __device__ __forceinline__ void fi_fwd_chunk(
 // waves stalls the whole CU at every one of them -- the box traffic is not what binds this kernel.
 // RAGGED: any channel count >= 4 -- the last chunk re-reads the last plane for the channels it does not have and does not
 // store them (a separate instantiation: the C % 4 == 0 kernel, at 239 registers, is left exactly as it was).
-template <int SW, int NT = 256, bool RAGGED = false, int LX = 16>   // SW 0: one tile column per XCD strip; 2 / 4: stripes
+constexpr int kC4nTrLdsPx = 4864;              // LayTr: 38 rows at pitch 128 (76 rows at pitch 64) = 76 KiB
+// LAY: LayXor -- 48 KiB, rows at the band's own pitch -- or LayTr: the transposed rows of memc_tile.hpp, 76 KiB (this kernel
+// sits at two workgroups per CU by its registers anyway: the LDS is there).
+template <int SW, int NT = 256, bool RAGGED = false, int LX = 16, class LAY = LayXor>   // SW 0: one tile column per XCD strip; 2 / 4: stripes
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
@@ -188,10 +191,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
     float *__restrict__ out)
 {
     constexpr int CAP = NT == 256 ? 3072 : 3584;
+    constexpr int kLdsPx = LAY::kTransposed ? kC4nTrLdsPx : CAP;      // pixel quads of LDS behind `tile`
     using G = TileGeom<LX, CAP, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
-    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
+    int *bb = reinterpret_cast<int *>(smem + kLdsPx * 16);
 
     // With 64 channels the image is 88 % of the bytes read, and a tile stages its box dilated by the motion: what
     // the neighbouring tiles re-read must come out of THIS XCD's L2.  Stripes keep horizontal neighbours on one
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
         }
     }
     const BBox box = tile_bbox<LX, NT>(cmin, cmax, rmin, rmax, bb);
-    const Bands bands = make_bands<LX, true, CAP>(box);
+    const Bands bands = LAY::kTransposed ? make_bands_tr<LX, kC4nTrLdsPx, NT>(box) : make_bands<LX, true, CAP>(box);
     const float *in_b = in1 + b * s1b;
     float *out_p = out + b * s1b + (int64_t)y * s1h + x;
     unsigned done = 0;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
         stage_load(0);
 #pragma unroll 1
         for (int c0 = 0; c0 < C; c0 += 4) {
-            tile_stage_store<4>(r, sl, sr, tile);
+            tile_stage_store<4, LAY>(r, sl, sr, tile);
             __syncthreads();
             // next chunk's rows: in flight while this chunk is gathered (the last iteration re-reads its own
             // chunk -- harmless, keeps the loads unconditional)
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
             f32x4 res[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) res[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            fi_gather<LX, 4>(r, g, tp, sel, W, H, tile, res);
+            fi_gather<LX, 4, LAY>(r, g, tp, sel, W, H, tile, res);
             const float *plane0 = in_b + c0 * s1c;
             float *o = out_p + c0 * s1c;
             if (wr & ~g.valid) {                           // out-of-range sites copy the input pixel
@@ -1103,14 +1107,15 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
     } while (0)
 #define MEMC_FI_C4N(SW) MEMC_FI_C4N_NT(SW, 256, false)
 #define MEMC_FI_C4N_NT(SW, NT, RAG) MEMC_FI_C4N_LX(SW, NT, RAG, 16)
-#define MEMC_FI_C4N_LX(SW, NT, RAG, LX)                                                                         \
+#define MEMC_FI_C4N_LX(SW, NT, RAG, LX) MEMC_FI_C4N_LAY(SW, NT, RAG, LX, LayXor)
+#define MEMC_FI_C4N_LAY(SW, NT, RAG, LX, LAY)                                                                   \
     do {                                                                                                   \
         using G = TileGeom<LX, (NT == 256 ? 3072 : 3584), NT>;                                             \
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                        \
-        const int lds = G::kCapPx * 16 + 4 * 4 * (NT / 64);                                                \
-        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG, LX>, lds), true);                 \
+        const int lds = (LAY::kTransposed ? kC4nTrLdsPx : G::kCapPx) * 16 + 4 * 4 * (NT / 64);             \
+        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG, LX, LAY>, lds), true);            \
         (void)once;                                                                                        \
-        hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT, RAG, LX>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
+        hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT, RAG, LX, LAY>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
                                                                     (SW ? SW : 1)) * nty * batch),          \
                            dim3(NT), lds, stream, w, h, channel, ntx, nty, (int64_t)s1b,                   \
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c,    \
@@ -1185,6 +1190,10 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             MEMC_FI_C4N_LX(0, 256, false, 8);              // 32 x 32 tiles: the box of a square tile is the least dilated
         } else if (variant == 34 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N_LX(4, 256, false, 8);              // ... in stripes four tile columns wide
+        } else if (variant == 37 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N_LAY(0, 256, false, 16, LayTr);     // transposed LDS rows (76 KiB)
+        } else if (variant == 38 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N_LAY(4, 256, false, 16, LayTr);     // ... in stripes four tile columns wide
         } else {
             handled = false;
         }
@@ -1225,6 +1234,7 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
 #undef MEMC_FI_C4N
 #undef MEMC_FI_C4N_NT
 #undef MEMC_FI_C4N_LX
+#undef MEMC_FI_C4N_LAY
 #undef MEMC_FI_TILED
 #undef MEMC_FI_TILED_A
     return launch_status();
