@@ -1105,14 +1105,16 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, \
                            s3h, input1, input2, input3, output);                                           \
     } while (0)
+    int c4n_lds_pad = 0;                                   // (measurement arm 39: the product kernel with 76 KiB requested)
 #define MEMC_FI_C4N(SW) MEMC_FI_C4N_NT(SW, 256, false)
 #define MEMC_FI_C4N_NT(SW, NT, RAG) MEMC_FI_C4N_LX(SW, NT, RAG, 16)
 #define MEMC_FI_C4N_LX(SW, NT, RAG, LX) MEMC_FI_C4N_LAY(SW, NT, RAG, LX, LayXor)
 #define MEMC_FI_C4N_LAY(SW, NT, RAG, LX, LAY)                                                                   \
     do {                                                                                                   \
+        const int lds_pad = c4n_lds_pad;                                                                   \
         using G = TileGeom<LX, (NT == 256 ? 3072 : 3584), NT>;                                             \
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                        \
-        const int lds = (LAY::kTransposed ? kC4nTrLdsPx : G::kCapPx) * 16 + 4 * 4 * (NT / 64);             \
+        const int lds = (LAY::kTransposed ? kC4nTrLdsPx : G::kCapPx) * 16 + 4 * 4 * (NT / 64) + lds_pad;   \
         static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG, LX, LAY>, lds), true);            \
         (void)once;                                                                                        \
         hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT, RAG, LX, LAY>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
@@ -1190,6 +1192,10 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             MEMC_FI_C4N_LX(0, 256, false, 8);              // 32 x 32 tiles: the box of a square tile is the least dilated
         } else if (variant == 34 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N_LX(4, 256, false, 8);              // ... in stripes four tile columns wide
+        } else if (variant == 39 && channel % 4 == 0 && channel >= 8) {
+            c4n_lds_pad = (kC4nTrLdsPx - 3072) * 16;       // LayXor as shipped, LDS request as LayTr: occupancy check
+            MEMC_FI_C4N(0);
+            c4n_lds_pad = 0;
         } else if (variant == 37 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N_LAY(0, 256, false, 16, LayTr);     // transposed LDS rows (76 KiB)
         } else if (variant == 38 && channel % 4 == 0 && channel >= 8) {
