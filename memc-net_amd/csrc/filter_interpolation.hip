@@ -68,7 +68,7 @@ __device__ __noinline__ void fi_site_scalar(int x, int y, int W, int H, int nch,
 // afterwards by fi_site_scalar (at the end of the kernel, once for all channels).
 // Gather + blend of the sites selected by `sel` (bit j) from the staged band; other sites keep their `res`.
 // Branch-free: unselected sites still issue their 16 LDS reads (at pixel 0, harmless).
-template <int LX, int NCH, class LAY = LayXor>
+template <int LX, int NCH>
 __device__ __forceinline__ void fi_gather(const Region &r, const FiSite4 &g, const f32x4 (&tp)[16], unsigned sel,
                                           int W, int H, const f32x4 *tile, f32x4 (&res)[4])
 {
@@ -79,7 +79,7 @@ __device__ __forceinline__ void fi_gather(const Region &r, const FiSite4 &g, con
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             ro[k] = on ? (clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch : 0;
-            co[k] = on ? LAY::col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0, r.pitch) : 0;
+            co[k] = on ? swz_col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0) : 0;
         }
         // quadrant sums, row-major inside each quadrant as in the reference (rows 0,1 top; 2,3 bottom)
         f32x4 TL = {0.f, 0.f, 0.f, 0.f}, TR = TL, BL = TL, BR = TL;
@@ -88,63 +88,6 @@ __device__ __forceinline__ void fi_gather(const Region &r, const FiSite4 &g, con
             f32x4 v[4];
 #pragma unroll
             for (int m = 0; m < 4; m++) v[m] = tile[ro[k] + co[m]];
-            if (k < 2) {
-                TL += v[0] * tp[k * 4 + 0][j];  TL += v[1] * tp[k * 4 + 1][j];
-                TR += v[2] * tp[k * 4 + 2][j];  TR += v[3] * tp[k * 4 + 3][j];
-            } else {
-                BL += v[0] * tp[k * 4 + 0][j];  BL += v[1] * tp[k * 4 + 1][j];
-                BR += v[2] * tp[k * 4 + 2][j];  BR += v[3] * tp[k * 4 + 3][j];
-            }
-        }
-        const float a = g.a[j], bt = g.b[j];
-        const f32x4 val = ((1 - a) * (1 - bt)) * TL + (a * (1 - bt)) * TR + ((1 - a) * bt) * BL + (a * bt) * BR;
-        res[j] = on ? val : res[j];
-    }
-}
-
-// The same gather from PACKED cell addresses: a site's four row offsets (16 bits each, two words) and four column slots
-// (8 bits each, one word) are worked out ONCE per band and unpacked per use -- the chunk loop of the many-channel kernel
-// otherwise recomputes clamp / subtract / swizzle / multiply for its 32 offsets in every one of its C / 4 iterations
-// (hoisted as plain integers they would cost 32 registers the kernel does not have; measured on the C = 64 forward:
-// VALU issue is what binds it, a layout with half the LDS conflict cycles but two more integer operations per address ran
-// 8 % SLOWER, profiles/r03_ctx64_tile_shapes.txt).
-struct FiPackedAddr {
-    unsigned co[4], r01[4], r23[4];            // per site: columns 0..3 (bytes), rows 0 / 1 and 2 / 3 (halves)
-};
-template <class LAY>
-__device__ __forceinline__ FiPackedAddr fi_pack_addresses(const Region &r, const FiSite4 &g, unsigned sel, int W, int H)
-{
-    FiPackedAddr p;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const bool on = (sel >> j) & 1;
-        unsigned ro[4], co[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            ro[k] = on ? (unsigned)((clampi(g.iy[j] - 1 + k, H - 1) - r.y0) * r.pitch) : 0u;
-            co[k] = on ? (unsigned)LAY::col(clampi(g.ix[j] - 1 + k, W - 1) - r.x0, r.pitch) : 0u;
-        }
-        p.co[j] = co[0] | (co[1] << 8) | (co[2] << 16) | (co[3] << 24);
-        p.r01[j] = ro[0] | (ro[1] << 16);
-        p.r23[j] = ro[2] | (ro[3] << 16);
-    }
-    return p;
-}
-__device__ __forceinline__ void fi_gather_packed(const FiPackedAddr &p, const FiSite4 &g, const f32x4 (&tp)[16],
-                                                 unsigned sel, const f32x4 *tile, f32x4 (&res)[4])
-{
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const bool on = (sel >> j) & 1;
-        // quadrant sums, row-major inside each quadrant as in the reference (rows 0,1 top; 2,3 bottom)
-        f32x4 TL = {0.f, 0.f, 0.f, 0.f}, TR = TL, BL = TL, BR = TL;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const unsigned rw = k < 2 ? p.r01[j] : p.r23[j];
-            const unsigned ro = (k & 1) ? rw >> 16 : rw & 0xFFFFu;
-            f32x4 v[4];
-#pragma unroll
-            for (int m = 0; m < 4; m++) v[m] = tile[ro + ((p.co[j] >> (8 * m)) & 0xFFu)];
             if (k < 2) {
                 TL += v[0] * tp[k * 4 + 0][j];  TL += v[1] * tp[k * 4 + 1][j];
                 TR += v[2] * tp[k * 4 + 2][j];  TR += v[3] * tp[k * 4 + 3][j];
@@ -237,11 +180,7 @@ __device__ __forceinline__ void fi_fwd_chunk(
 // waves stalls the whole CU at every one of them -- the box traffic is not what binds this kernel.
 // RAGGED: any channel count >= 4 -- the last chunk re-reads the last plane for the channels it does not have and does not
 // store them (a separate instantiation: the C % 4 == 0 kernel, at 239 registers, is left exactly as it was).
-constexpr int kC4nTrLdsPx = 4864;              // LayTr: 38 rows at pitch 128 (76 rows at pitch 64) = 76 KiB
-// LAY: LayXor -- 48 KiB, rows at the band's own pitch -- or LayTr: the transposed rows of memc_tile.hpp, 76 KiB (this kernel
-// sits at two workgroups per CU by its registers anyway: the LDS is there).
-// PK: cell addresses packed once per band (fi_gather_packed) instead of recomputed per chunk.
-template <int SW, int NT = 256, bool RAGGED = false, int LX = 16, class LAY = LayXor, bool PK = false>   // SW 0: one tile column per XCD strip; 2 / 4: stripes
+template <int SW, int NT = 256, bool RAGGED = false, int LX = 16>   // SW 0: one tile column per XCD strip; 2 / 4: stripes
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
@@ -249,11 +188,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
     float *__restrict__ out)
 {
     constexpr int CAP = NT == 256 ? 3072 : 3584;
-    constexpr int kLdsPx = LAY::kTransposed ? kC4nTrLdsPx : CAP;      // pixel quads of LDS behind `tile`
     using G = TileGeom<LX, CAP, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
-    int *bb = reinterpret_cast<int *>(smem + kLdsPx * 16);
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
 
     // With 64 channels the image is 88 % of the bytes read, and a tile stages its box dilated by the motion: what
     // the neighbouring tiles re-read must come out of THIS XCD's L2.  Stripes keep horizontal neighbours on one
@@ -286,26 +224,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
         }
     }
     const BBox box = tile_bbox<LX, NT>(cmin, cmax, rmin, rmax, bb);
-    const Bands bands = LAY::kTransposed ? make_bands_tr<LX, kC4nTrLdsPx, NT>(box) : make_bands<LX, true, CAP>(box);
+    const Bands bands = make_bands<LX, true, CAP>(box);
     const float *in_b = in1 + b * s1b;
     float *out_p = out + b * s1b + (int64_t)y * s1h + x;
     unsigned done = 0;
-    // PK: (ix, iy) of a site travel as one word between the bands -- the chunk loop needs neither, only the packed cell
-    // addresses and the blend weights -- so that the twelve address words cost four registers net, not twelve
-    unsigned gxy[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) gxy[j] = PK ? (unsigned)g.ix[j] | ((unsigned)g.iy[j] << 16) : 0u;
 #pragma unroll 1
     for (int bi = 0; bi < bands.n; bi++) {
         const Region r = band_region(box, bands, bi);
-        if (PK) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                asm volatile("" : "+v"(gxy[j]));
-                g.ix[j] = (int)(gxy[j] & 0xFFFFu);
-                g.iy[j] = (int)(gxy[j] >> 16);
-            }
-        }
         const unsigned sel = inb ? fi_covered(r, g, W, H) & ~done : 0u;
         // later bands only run when somebody still needs them; the vote is also the barrier that frees the LDS
         if (bi > 0 && !__syncthreads_or(sel != 0)) continue;
@@ -329,11 +254,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
             }
         };
         stage_load(0);
-        FiPackedAddr pa;
-        if (PK) pa = fi_pack_addresses<LAY>(r, g, sel, W, H);
 #pragma unroll 1
         for (int c0 = 0; c0 < C; c0 += 4) {
-            tile_stage_store<4, LAY>(r, sl, sr, tile);
+            tile_stage_store<4>(r, sl, sr, tile);
             __syncthreads();
             // next chunk's rows: in flight while this chunk is gathered (the last iteration re-reads its own
             // chunk -- harmless, keeps the loads unconditional)
@@ -344,15 +267,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
             for (int k = 0; k < 16; k++)
                 asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (PK) asm volatile("" : "+v"(pa.co[j]), "+v"(pa.r01[j]), "+v"(pa.r23[j]), "+v"(g.a[j]), "+v"(g.b[j]), "+v"(gxy[j]));
-                else asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
-            }
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
             f32x4 res[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) res[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (PK) fi_gather_packed(pa, g, tp, sel, tile, res);
-            else fi_gather<LX, 4, LAY>(r, g, tp, sel, W, H, tile, res);
+            fi_gather<LX, 4>(r, g, tp, sel, W, H, tile, res);
             const float *plane0 = in_b + c0 * s1c;
             float *o = out_p + c0 * s1c;
             if (wr & ~g.valid) {                           // out-of-range sites copy the input pixel
@@ -1182,20 +1101,16 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, \
                            s3h, input1, input2, input3, output);                                           \
     } while (0)
-    int c4n_lds_pad = 0;                                   // (measurement arm 39: the product kernel with 76 KiB requested)
 #define MEMC_FI_C4N(SW) MEMC_FI_C4N_NT(SW, 256, false)
 #define MEMC_FI_C4N_NT(SW, NT, RAG) MEMC_FI_C4N_LX(SW, NT, RAG, 16)
-#define MEMC_FI_C4N_LX(SW, NT, RAG, LX) MEMC_FI_C4N_LAY(SW, NT, RAG, LX, LayXor)
-#define MEMC_FI_C4N_LAY(SW, NT, RAG, LX, LAY) MEMC_FI_C4N_PK(SW, NT, RAG, LX, LAY, false)
-#define MEMC_FI_C4N_PK(SW, NT, RAG, LX, LAY, PK)                                                                \
+#define MEMC_FI_C4N_LX(SW, NT, RAG, LX)                                                                         \
     do {                                                                                                   \
-        const int lds_pad = c4n_lds_pad;                                                                   \
         using G = TileGeom<LX, (NT == 256 ? 3072 : 3584), NT>;                                             \
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                        \
-        const int lds = (LAY::kTransposed ? kC4nTrLdsPx : G::kCapPx) * 16 + 4 * 4 * (NT / 64) + lds_pad;   \
-        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG, LX, LAY, PK>, lds), true);        \
+        const int lds = G::kCapPx * 16 + 4 * 4 * (NT / 64);                                                \
+        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG, LX>, lds), true);                 \
         (void)once;                                                                                        \
-        hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT, RAG, LX, LAY, PK>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
+        hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT, RAG, LX>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
                                                                     (SW ? SW : 1)) * nty * batch),          \
                            dim3(NT), lds, stream, w, h, channel, ntx, nty, (int64_t)s1b,                   \
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c,    \
@@ -1270,18 +1185,6 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             MEMC_FI_C4N_LX(0, 256, false, 8);              // 32 x 32 tiles: the box of a square tile is the least dilated
         } else if (variant == 34 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N_LX(4, 256, false, 8);              // ... in stripes four tile columns wide
-        } else if (variant == 40 && channel % 4 == 0 && channel >= 8) {
-            MEMC_FI_C4N_PK(0, 256, false, 16, LayXor, true);     // packed cell addresses
-        } else if (variant == 41 && channel % 4 == 0 && channel >= 8) {
-            MEMC_FI_C4N_PK(0, 256, false, 16, LayTr, true);      // packed cell addresses + transposed LDS rows
-        } else if (variant == 39 && channel % 4 == 0 && channel >= 8) {
-            c4n_lds_pad = (kC4nTrLdsPx - 3072) * 16;       // LayXor as shipped, LDS request as LayTr: occupancy check
-            MEMC_FI_C4N(0);
-            c4n_lds_pad = 0;
-        } else if (variant == 37 && channel % 4 == 0 && channel >= 8) {
-            MEMC_FI_C4N_LAY(0, 256, false, 16, LayTr);     // transposed LDS rows (76 KiB)
-        } else if (variant == 38 && channel % 4 == 0 && channel >= 8) {
-            MEMC_FI_C4N_LAY(4, 256, false, 16, LayTr);     // ... in stripes four tile columns wide
         } else {
             handled = false;
         }
@@ -1322,8 +1225,6 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
 #undef MEMC_FI_C4N
 #undef MEMC_FI_C4N_NT
 #undef MEMC_FI_C4N_LX
-#undef MEMC_FI_C4N_LAY
-#undef MEMC_FI_C4N_PK
 #undef MEMC_FI_TILED
 #undef MEMC_FI_TILED_A
     return launch_status();

@@ -86,21 +86,6 @@ __device__ __forceinline__ MEMC_GLOBAL float *at_u(float *ubase, unsigned byte_o
 
 __device__ __forceinline__ int swz_col(int c) { return c ^ ((c >> 2) & 15); }
 
-// Where column c of a staged row lives.  LayXor: the swizzle above -- conflict-free for a locally UNIFORM flow only: one
-// pixel of drift along a tile row puts lanes with different low column bits on the same slots (measured: 11.5 LDS
-// cycles per ds_read_b128 instead of 4, profiles/r03_lds_conflict_probe.txt).  LayTr: the row is stored TRANSPOSED in
-// quads of columns -- column c at (c & 3) * (pitch / 4) + (c >> 2), pitch 64 or 128 -- so the slot of a pixel is its
-// column / 4 (mod 16) whatever its low bits: lanes 4 px apart collide only where the flow compresses across a multiple
-// of four (7.0 - 7.5 cycles under the same perturbations).  Costs LDS: a row is padded to 64 or 128 pixel quads.
-struct LayXor {
-    static constexpr bool kTransposed = false;
-    __device__ static __forceinline__ int col(int c, int /*pitch*/) { return swz_col(c); }
-};
-struct LayTr {
-    static constexpr bool kTransposed = true;
-    __device__ static __forceinline__ int col(int c, int pitch) { return (c & 3) * (pitch >> 2) + (c >> 2); }
-};
-
 // Kernels that address a plane as wave-uniform base + 32-bit byte offset (ld_stream4_u & co.) need every in-plane
 // byte offset (h - 1) * row_stride + w to fit 32 bits; a view with a gigantic row stride takes the 64-bit kernels.
 inline bool plane_fits_u32(int w, int h, std::initializer_list<long> row_strides)
@@ -237,8 +222,6 @@ __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int 
 // at least one band.  At most kMaxBands rounds; what is still uncovered after that (pathological motion) goes
 // to the scalar path.  Ordinary tiles have exactly one band and pay nothing for this.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kStageIts = 3;                    // float4 slots per lane of the staging pass (see stage_slots below)
-
 struct BBox {
     int x0, w, y0, h;          // unclipped box, x0 % 4 == 0, w % 4 == 0; w == 0: no valid site
 };
@@ -311,25 +294,6 @@ __device__ __forceinline__ Bands make_bands(const BBox &b)
     return d;
 }
 
-// Transposed layout (LayTr): pitch 64 or 128 pixel quads by the band's width; rows = what the LDS holds at that pitch (LDSPX
-// pixel quads in all) and what the staging registers hold (three float4 slots per lane).
-template <int LX, int LDSPX, int NT = 256>
-__device__ __forceinline__ Bands make_bands_tr(const BBox &b)
-{
-    using G = TileGeom<LX>;
-    Bands d;
-    d.bw = min(b.w, G::kPitch);
-    d.pitch = d.bw <= 64 ? 64 : 128;
-    const int rows = min(LDSPX / d.pitch, kStageIts * NT / max(d.bw >> 2, 1));
-    d.bh = min(b.h, rows);
-    d.sx = (G::kPitch - 4) & ~3;
-    d.sy = rows - 3;
-    d.nbx = b.w > d.bw ? (b.w - d.bw + d.sx - 1) / d.sx + 1 : 1;
-    d.nby = b.h > d.bh ? (b.h - d.bh + d.sy - 1) / d.sy + 1 : 1;
-    d.n = b.w == 0 ? 1 : min(d.nbx * d.nby, kMaxBands);
-    return d;
-}
-
 __device__ __forceinline__ Region band_region(const BBox &b, const Bands &d, int i)
 {
     Region r;
@@ -346,6 +310,7 @@ __device__ __forceinline__ Region band_region(const BBox &b, const Bands &d, int
 // round-robin in row-major order, kStageIts = 3 slots each (3 * 256 * 4 px = the whole 3072-pixel budget).
 // All loads are issued before the first LDS write and are unconditional -- slots past the end of the box read
 // the plane's first element -- so that no load result becomes a phi (see fi_fwd_tiled_fs4).
+constexpr int kStageIts = 3;
 
 struct StageSlot {
     int row[kStageIts], q[kStageIts];      // q = float4 column; row >= r.h marks an empty slot
@@ -391,7 +356,7 @@ __device__ __forceinline__ void tile_stage_load_planes(const Region &r, const St
     }
 }
 
-template <int NCH, class LAY = LayXor>
+template <int NCH>
 __device__ __forceinline__ void tile_stage_store(const Region &r, const StageSlot &sl, const StageRegs<NCH> &sr,
                                                  f32x4 *tile)
 {
@@ -404,7 +369,7 @@ __device__ __forceinline__ void tile_stage_store(const Region &r, const StageSlo
                 f32x4 px = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < NCH; c++) px[c] = sr.v[it][c][i];
-                dst[LAY::col(4 * sl.q[it] + i, r.pitch)] = px;
+                dst[swz_col(4 * sl.q[it] + i)] = px;
             }
         }
     }
