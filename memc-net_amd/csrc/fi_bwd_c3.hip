@@ -169,15 +169,10 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
     const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2,
-    float *__restrict__ gin3, int stagger)
+    float *__restrict__ gin3)
 {
     constexpr int LX = 16;
     using PG = PkGeom;
-    // Small grids (fewer than four rounds of workgroups): everything starts at once and stays in lockstep -- all workgroups
-    // load together, then all of them work on their LDS together.  The second workgroup of every CU (the chip's first 256
-    // workgroups take one CU each) starts `stagger` x 4 us late, so that its memory phase meets the first one's LDS phases.
-    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-        for (int i = 0; i < stagger; i++) __builtin_amdgcn_s_sleep(127);
     using G = TileGeom<LX, PG::kCap>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
@@ -338,17 +333,13 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
 #define MEMC_FI_BWD_PK(TR)                                                                                         \
     hipLaunchKernelGGL(fi_bwd_c3_pk<TR>, dim3(ntiles), dim3(256), PkGeom::kLds, stream, w, h, ntx, nty, batch,     \
                        (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,             \
-                       (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3, stagger)
-    int stagger = 0;
+                       (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)
 #ifdef MEMC_MEASURE
-    if (variant == 26) stagger = 2;                        // A/B: second workgroup of every CU 8 us late
-    if (variant == 27) stagger = 1;                        //      4 us
-    if (variant == 25) stagger = 4;                        //      16 us
     if (variant == 28) {                                   // + timestamps
         MEMC_FI_BWD_PK(true);
         return launch_status() == 0 ? 1 : -1;
     }
-    if (variant >= 0 && (variant < 25 || variant > 27)) {  // arms/fi_bwd_c3_arms.hip
+    if (variant >= 0) {                                    // arms/fi_bwd_c3_arms.hip
         const int r = fi_bwd_c3_arm_launch(variant, stream, w, h, ntx, nty, batch, s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c,
                                            s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3);
         if (r != 0) return r;
