@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
 #pragma unroll                                                 // here, not behind the flush's atomics
             for (int c = 0; c < 3; c++)
                 asm volatile("" : "+v"(sr.v[it][c][0]), "+v"(sr.v[it][c][1]), "+v"(sr.v[it][c][2]), "+v"(sr.v[it][c][3]));
-        pk_flush(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
+        pk_flush<256>(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
         __syncthreads();                   // the planes have been read: the LDS becomes the image
         if (bi == 0) trace_mark<TR>(4);                    // flushed
     } else if (mode == 2) {

@@ -240,21 +240,23 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
 // Sites whose corners fall outside the (clipped) box scatter with global atomics and gather from global memory, as
 // before; a tile with a non-finite gradoutput scatters everything with global atomics.
 // --------------------------------------------------------------------------------------------------
-template <int CAP>                             // staging budget in cells: 3072 (48 KiB, 3 workgroups per CU) or 2496 (39 KiB, 4)
-__global__ __launch_bounds__(256, CAP == 3072 ? 3 : 4) void bl_bwd_c3_pk(
+// NT lanes take a tile of 64 x NT/16 sites; CAP is the staging budget in cells.  Product: 512 lanes, 64 x 32 tiles, 4096 cells
+// (64 KiB, two workgroups of eight waves per CU).  Measurement arms: 256 lanes with 3072 (48 KiB, 3 per CU) or 2496 (39 KiB, 4).
+template <int CAP, int NT = 256>
+__global__ __launch_bounds__(NT, NT == 256 && CAP == 3072 ? 3 : 4) void bl_bwd_c3_pk(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
     float *__restrict__ gin1, float *__restrict__ gin2, int sw)
 {
     constexpr int LX = 16;
-    using G = TileGeom<LX, CAP>;
+    using G = TileGeom<LX, CAP, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     unsigned long long *const accA = reinterpret_cast<unsigned long long *>(smem);   // the planes alias the image
     unsigned long long *const accB = accA + CAP;
-    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);            // 16 ints: boxes; 4 ints: maxima
-    int *mx = bb + 16;
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);            // 4 ints per wave: boxes; then one per wave: maxima
+    int *mx = bb + 4 * (NT / kWave);
 
     const TileCoord tc = tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, sw);
     if (tc.tx >= tiles_x) return;
@@ -272,8 +274,8 @@ __global__ __launch_bounds__(256, CAP == 3072 ? 3 : 4) void bl_bwd_c3_pk(
     {                                          // both planes, while the loads are in flight
         f32x4 *pz = reinterpret_cast<f32x4 *>(smem);
 #pragma unroll
-        for (int i = 0; i < (CAP + 255) / 256; i++)
-            if (CAP % 256 == 0 || (int)tid + i * 256 < CAP) pz[tid + i * 256] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < (CAP + NT - 1) / NT; i++)
+            if (CAP % NT == 0 || (int)tid + i * NT < CAP) pz[tid + i * NT] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
     BlSite st[4];
@@ -296,15 +298,37 @@ __global__ __launch_bounds__(256, CAP == 3072 ? 3 : 4) void bl_bwd_c3_pk(
         mg = wave_max_i32(inb ? mg : 0);
         if ((tid & (kWave - 1)) == 0) mx[tid / kWave] = mg;
     }
-    const Region r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
-    int mg = max(max(mx[0], mx[1]), max(mx[2], mx[3]));
+    Region r;
+    if (NT == 256) {
+        r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    } else {                                   // tile_region for any workgroup size: the box, clipped around the tile's centre
+        const BBox bx = tile_bbox<LX, NT>(cmin, cmax, rmin, rmax, bb);
+        r.x0 = bx.x0;  r.y0 = bx.y0;  r.w = bx.w;  r.h = bx.h;  r.pitch = G::kPitch;
+        if (bx.w > 0) {
+            if (r.w > G::kPitch) {
+                const int lo = r.x0, hi = r.x0 + r.w - G::kPitch;
+                r.x0 = min(max((tile_x0 + G::kTW / 2 - G::kPitch / 2) & ~3, lo), hi);
+                r.w = G::kPitch;
+            }
+            r.pitch = (r.w + 15) & ~15;
+            const int rows = min(CAP / r.pitch, kStageIts * NT / (r.w >> 2));
+            if (r.h > rows) {
+                const int lo = r.y0, hi = r.y0 + r.h - rows;
+                r.y0 = min(max(tile_y0 + G::kTH / 2 - rows / 2, lo), hi);
+                r.h = rows;
+            }
+        }
+    }
+    int mg = 0;
+#pragma unroll
+    for (int wv = 0; wv < NT / kWave; wv++) mg = max(mg, mx[wv]);
     mg = __builtin_amdgcn_readfirstlane(mg);
     // 0: nothing to add; 2: Inf / NaN in gradoutput -- global atomics; 1: the packed planes
     const int mode = mg == 0 ? 0 : (mg >= 0x7F800000 ? 2 : 1);
     const PkScale ps = pk_scale(mode == 1 ? mg : 0x3F800000, 0x3F7FFFFF);       // weights <= 1: their exponent is 0
     const float *in_b = in1 + b * s1b;
     float *gin1_b = gin1 + b * s1b;
-    const StageSlot sl = stage_slots(r);
+    const StageSlot sl = stage_slots<NT>(r);
     StageRegs<3> sr;
     tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);             // in flight during adds and flush
 
@@ -344,7 +368,7 @@ __global__ __launch_bounds__(256, CAP == 3072 ? 3 : 4) void bl_bwd_c3_pk(
 #pragma unroll                                                 // behind the flush's conditional atomics (vmcnt is in order)
             for (int c = 0; c < 3; c++)
                 asm volatile("" : "+v"(sr.v[it][c][0]), "+v"(sr.v[it][c][1]), "+v"(sr.v[it][c][2]), "+v"(sr.v[it][c][3]));
-        pk_flush(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
+        pk_flush<NT>(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
     }
     __syncthreads();                           // the planes have been read (or never used): the LDS becomes the image
     tile_stage_store<3>(r, sl, sr, tile);
@@ -449,7 +473,8 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
     if (channel == 3 && plane_fits_u32(w, h, {s1h}) &&
         vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2})) {
         using G = TileGeom<16>;
-        const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+        const int ntx = (w + G::kTW - 1) / G::kTW;
+        [[maybe_unused]] const int nty = (h + G::kTH - 1) / G::kTH;
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         MEMC_PATH("bl_bwd:tiled_c3");
 #ifdef MEMC_MEASURE
@@ -465,15 +490,26 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
         else if (g_cap_sel == 0) MEMC_BL_BWD(3072);
         else
 #endif
-#define MEMC_BL_BWD_PK(CAP)                                                                                     \
-        hipLaunchKernelGGL(bl_bwd_c3_pk<CAP>, dim3(walk_grid(ntx, nty, batch, sw)), dim3(256),                    \
-                           (tile_lds_bytes<16, CAP>() + 64), stream, w, h, ntx, nty, (int64_t)s1b, (int64_t)s1c,  \
-                           s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, gradoutput, gradinput1, gradinput2, sw)
+#define MEMC_BL_BWD_PK(CAP, NT)                                                                                 \
+        do {                                                                                                       \
+            constexpr size_t lds = CAP * 16 + 32 * (NT / kWave);    /* image or planes; 20 bytes per wave: box, maximum */ \
+            static const bool once = (allow_big_lds(bl_bwd_c3_pk<CAP, NT>, lds), true);                            \
+            (void)once;                                                                                            \
+            const int ntyk = (h + NT / 16 - 1) / (NT / 16);                                                        \
+            hipLaunchKernelGGL((bl_bwd_c3_pk<CAP, NT>), dim3(walk_grid(ntx, ntyk, batch, sw)), dim3(NT), lds,      \
+                               stream, w, h, ntx, ntyk, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, \
+                               s2h, input1, input2, gradoutput, gradinput1, gradinput2, sw);                       \
+        } while (0)
+        // 64 x 32 tiles on 512 lanes, 64 KiB, two workgroups per CU.  The flush's global atomics bound this kernel, and a
+        // bigger tile's box holds fewer cells per site: against 64 x 16 tiles on 256 lanes (bl_cap 4; 3: the same in
+        // 39 KiB) 526 -> 484 us smooth, 759 -> 640 i.i.d., 478 -> 459 video; 64 x 64 tiles on 1024 lanes, one workgroup per CU
+        // and nothing to overlap its phases with, lose: 548 / 885 / 512 (profiles/r03_bl_bwd_ab.txt).
 #ifdef MEMC_MEASURE
-        if (g_cap_sel == 3) MEMC_BL_BWD_PK(2496);          // A/B: 39 KiB, four workgroups per CU
+        if (g_cap_sel == 3) MEMC_BL_BWD_PK(2496, 256);
+        else if (g_cap_sel == 4) MEMC_BL_BWD_PK(3072, 256);
         else
 #endif
-        MEMC_BL_BWD_PK(3072);
+        MEMC_BL_BWD_PK(4096, 512);
 #undef MEMC_BL_BWD_PK
 #undef MEMC_BL_BWD
         return launch_status();

@@ -73,6 +73,7 @@ __device__ __forceinline__ void pk_add3(unsigned long long *accA, unsigned long 
 // neighbouring tiles overlap).  The 256 lanes walk the box's cells in row-major order, so a wave's 64 cells are one
 // run of a row (256 contiguous bytes per colour) and, in the planes, 4 x 8 consecutive slots: conflict-free.
 // inv = 2^(e_g + e_t - 22) as a double (the float may not exist).
+template <int NT = 256>
 __device__ __forceinline__ void pk_flush(const Region &r, const unsigned long long *accA,
                                                 const unsigned long long *accB, double inv, float *gin1_b,
                                                 int64_t s1c, int s1h)
@@ -80,11 +81,11 @@ __device__ __forceinline__ void pk_flush(const Region &r, const unsigned long lo
     const unsigned tid = tid_now();
     const int w = max(r.w, 1), total = r.w * r.h;
     int row = tid / w, col = tid % w;                      // one run-time division per band
-    const int drow = 256 / w, dcol = 256 % w;
+    const int drow = NT / w, dcol = NT % w;
     const uintptr_t b0 = pin_sgpr(gin1_b), b1 = pin_sgpr(gin1_b + s1c), b2 = pin_sgpr(gin1_b + 2 * s1c);
     constexpr int kBatch = 4;
 #pragma unroll 1
-    for (int base = 0; base < total; base += 256 * kBatch) {
+    for (int base = 0; base < total; base += NT * kBatch) {
         long long A[kBatch], B[kBatch];
         unsigned off[kBatch];
         bool on[kBatch];

@@ -626,7 +626,7 @@ def test_tile_walks_and_staging_budgets(oracle, case):
     dout, dcnt = oracle.depth_flow_projection_forward(d["flow"], d["depth"], 0)
     want_q1, want_q2 = oracle.depth_flow_projection_backward(d["flow"], d["depth"], dcnt, dout, d["gflow"])
     try:
-        for walk, cap in ((0, 0), (2, 1), (4, 2), (3, -1), (-1, 1)):
+        for walk, cap in ((0, 0), (2, 1), (4, 2), (3, -1), (-1, 1), (-1, 3), (1, 4)):
             M.set_variant("walk", walk)
             M.set_variant("bl_cap", cap)
             tag = "walk %d budget %d" % (walk, cap)
