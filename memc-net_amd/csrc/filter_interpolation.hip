@@ -173,21 +173,22 @@ __device__ __forceinline__ void fi_fwd_chunk(
 // on their way to registers while the current chunk is gathered from LDS, so the round trip hides behind
 // ~1 us of FMA work per chunk (at C = 64 the operator is about as VALU-bound as it is HBM-bound).
 // --------------------------------------------------------------------------------------------------
-// NT = 512 (measurement arm 32): 64 x 32 tiles, one workgroup of 512 lanes per CU instead of two of 256 -- the same waves
-// per CU, and the staged box covers 1.5x its sites instead of 1.8x (PMC: the 64 x 16 tiles read the image 2.0 times,
+// NT = 512 (measurement arms 32 / 35): 64 x 32 tiles, one workgroup of 512 lanes per CU instead of two of 256 -- the same
+// waves per CU, and the staged box covers 1.5x its sites instead of 1.8x (PMC: the 64 x 16 tiles read the image 2.0 times,
 // nothing is shared between neighbouring tiles through the L2s: they drift apart in their chunk loops).  Measured
-// 1698 us against 1132 us (8 x 64 x 720 x 1280): two independent workgroups cover each other's barriers, one of eight
-// waves stalls the whole CU at every one of them -- the box traffic is not what binds this kernel.
+// 1288 us (in stripes of four: 1243) against 1133 us (8 x 64 x 720 x 1280) with a 6144-cell budget (round 2 gave this arm
+// 3584 cells, most tiles swept their box in two bands: 1698 us).  Two LDS buffers and ONE barrier per chunk change nothing
+// (1289 us; round 3, removed): it is not the barriers of the eight-wave workgroup, and not the box traffic, that bind.
 // RAGGED: any channel count >= 4 -- the last chunk re-reads the last plane for the channels it does not have and does not
 // store them (a separate instantiation: the C % 4 == 0 kernel, at 239 registers, is left exactly as it was).
-template <int SW, int NT = 256, bool RAGGED = false, int LX = 16>   // SW 0: one tile column per XCD strip; 2 / 4: stripes
+template <int SW, int NT = 256, bool RAGGED = false, int LX = 16, int ABL = 0>   // SW 0: one tile column per XCD strip; 2 / 4: stripes
 __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
     float *__restrict__ out)
 {
-    constexpr int CAP = NT == 256 ? 3072 : 3584;
+    constexpr int CAP = NT == 256 ? 3072 : 6144;
     using G = TileGeom<LX, CAP, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
             // next chunk's rows: in flight while this chunk is gathered (the last iteration re-reads its own
             // chunk -- harmless, keeps the loads unconditional)
             const int cn = c0 + 4 < C ? c0 + 4 : c0;
-            stage_load(cn);
+            if (ABL != 2) stage_load(cn);
             // keep the loop-invariant tap splats / LDS addresses inside the loop (see fi_fwd_tiled_fs4)
 #pragma unroll
             for (int k = 0; k < 16; k++)
@@ -271,6 +272,15 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
             f32x4 res[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) res[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ABL == 1) {                                // timing arm: one LDS read per site instead of sixteen
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) t += tp[k][j];
+                    res[j] = tile[(threadIdx.x * 4 + j) & 2047] * t;
+                }
+            } else
             fi_gather<LX, 4>(r, g, tp, sel, W, H, tile, res);
             const float *plane0 = in_b + c0 * s1c;
             float *o = out_p + c0 * s1c;
@@ -1103,14 +1113,15 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
     } while (0)
 #define MEMC_FI_C4N(SW) MEMC_FI_C4N_NT(SW, 256, false)
 #define MEMC_FI_C4N_NT(SW, NT, RAG) MEMC_FI_C4N_LX(SW, NT, RAG, 16)
-#define MEMC_FI_C4N_LX(SW, NT, RAG, LX)                                                                         \
+#define MEMC_FI_C4N_LX(SW, NT, RAG, LX) MEMC_FI_C4N_ABL(SW, NT, RAG, LX, 0)
+#define MEMC_FI_C4N_ABL(SW, NT, RAG, LX, ABL)                                                                   \
     do {                                                                                                   \
-        using G = TileGeom<LX, (NT == 256 ? 3072 : 3584), NT>;                                             \
+        using G = TileGeom<LX, (NT == 256 ? 3072 : 6144), NT>;                                             \
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                        \
         const int lds = G::kCapPx * 16 + 4 * 4 * (NT / 64);                                                \
-        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG, LX>, lds), true);                 \
+        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG, LX, ABL>, lds), true);            \
         (void)once;                                                                                        \
-        hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT, RAG, LX>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
+        hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT, RAG, LX, ABL>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
                                                                     (SW ? SW : 1)) * nty * batch),          \
                            dim3(NT), lds, stream, w, h, channel, ntx, nty, (int64_t)s1b,                   \
                            (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c,    \
@@ -1181,6 +1192,16 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             MEMC_FI_C4N(4);
         } else if (variant == 32 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N_NT(0, 512, false);                 // 64 x 32 tiles, 512 lanes
+        } else if (variant == 35 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N_NT(4, 512, false);                 // ... in stripes four tile columns wide
+        } else if (variant == 36 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N_ABL(0, 256, false, 16, 1);         // timing: no gathers
+        } else if (variant == 37 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N_ABL(0, 256, false, 16, 2);         // timing: no image loads after the first chunk
+        } else if (variant == 38 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N_ABL(0, 512, false, 16, 1);
+        } else if (variant == 39 && channel % 4 == 0 && channel >= 8) {
+            MEMC_FI_C4N_ABL(0, 512, false, 16, 2);
         } else if (variant == 33 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N_LX(0, 256, false, 8);              // 32 x 32 tiles: the box of a square tile is the least dilated
         } else if (variant == 34 && channel % 4 == 0 && channel >= 8) {

@@ -338,7 +338,9 @@ def test_filter_interpolation_backward_many_channels_measurement_arms(oracle, ar
         close(N(h3), g3, "gradinput3 %s" % (arm,), RTOL)
 
 
-@pytest.mark.parametrize("variant", [33, 34, 31], ids=["32x32 strips", "32x32 stripes of 4", "64x16 stripes of 4"])
+@pytest.mark.parametrize("variant", [33, 34, 31, 32, 35],
+                         ids=["32x32 strips", "32x32 stripes of 4", "64x16 stripes of 4", "64x32 on 512 lanes",
+                              "64x32 on 512 lanes, stripes of 4"])
 def test_context_warp_forward_tile_shape_arms(oracle, variant):
     """The many-channel forward on 32 x 32 tiles (eight lanes per tile row) and the stripe walks -- measurement arms of
     fi_fwd_tiled_c4n -- must give the oracle's results like the 64 x 16 product kernel."""
