@@ -349,7 +349,8 @@ def test_context_warp_forward_tile_shape_arms(oracle, variant):
     try:
         M.set_variant("fi_fwd", variant)
         for ci, (B, C, H, W, kind, sigma) in enumerate(((1, 8, 70, 200, "smooth", 6.0), (2, 16, 96, 132, "smooth", 14.0),
-                                                        (1, 64, 40, 256, "iid", 5.0), (1, 12, 33, 64, "smooth", 3.0))):
+                                                        (1, 64, 40, 256, "iid", 5.0), (1, 12, 33, 64, "smooth", 3.0),
+                                                        (2, 6, 45, 72, "smooth", 4.0), (1, 7, 18, 300, "iid", 2.0))):
             rng = np.random.default_rng(700 + ci)
             xn, fn, kn = synth.np_image(rng, B, C, H, W), synth.np_flow(rng, B, H, W, kind, sigma), synth.np_filter(rng, B, H, W)
             out = torch.full(xn.shape, float("nan"), device=dev())

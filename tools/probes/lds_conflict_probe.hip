@@ -12,6 +12,10 @@
 //   8  transposed, the random 0..3 perturbation of 4
 //   9  transposed, the smooth drift of 6
 //  10  transposed, ds_write_b128 staging pattern
+//  11-13  PLANAR layout (one float per pixel and channel, row pitch 76 floats; what an LDS-DMA staging would leave): a lane reads
+//         the four consecutive floats of a window row, 4-byte aligned -- two ds_read2_b32; uniform flow / random 0..3 / drift
+//  14-16  the same three as ONE ds_read_b128 at that 4-byte alignment (inline asm; does the hardware take it, and at what rate?)
+//  17-19  the same three with a row pitch of 80 floats, two ds_read2_b32
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -31,6 +35,30 @@ __global__ __launch_bounds__(256) void lds_probe(float *out, int iters)
     const int drift = q / 5 + (row & 1);
     auto tr = [](int c) { return (c & 3) * 32 + (c >> 2); };
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (P >= 11) {
+        const float *pl = reinterpret_cast<const float *>(smem);
+        const int pf = P >= 17 ? 80 : 76;
+        const int mode = (P - 11) % 3;                             // 0 uniform, 1 random, 2 drift
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int ch = 0; ch < 4; ch++) {                   // four "channels": planes 3040 floats apart
+                    const int c = 4 * q + 1 + (it & 3) + (mode == 1 ? rnd : 0) + (mode == 2 ? drift : 0);
+                    const int fi = ch * 3040 + (row + k) * pf + c;
+                    if (P >= 14 && P <= 16) {
+                        f32x4 v;
+                        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(fi * 4)));
+                        acc += v;
+                    } else {
+                        acc[0] += pl[fi];  acc[1] += pl[fi + 1];  acc[2] += pl[fi + 2];  acc[3] += pl[fi + 3];
+                    }
+                }
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        }
+        out[blockIdx.x * 256 + l] = acc[0] + acc[1] + acc[2] + acc[3];
+        return;
+    }
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -76,6 +104,15 @@ extern "C" int lds_probe_run(void *stream, int pattern, float *out, int blocks, 
     case 8: RUN(8); break;
     case 9: RUN(9); break;
     case 10: RUN(10); break;
+    case 11: RUN(11); break;
+    case 12: RUN(12); break;
+    case 13: RUN(13); break;
+    case 14: RUN(14); break;
+    case 15: RUN(15); break;
+    case 16: RUN(16); break;
+    case 17: RUN(17); break;
+    case 18: RUN(18); break;
+    case 19: RUN(19); break;
     default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -15,9 +15,13 @@ lib = ctypes.CDLL(SO)
 lib.lds_probe_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 out = torch.zeros(2048 * 256, device="cuda")
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for p in range(11):
+sums = {}
+for p in range(20):
     for _ in range(3):
         assert lib.lds_probe_run(st, p, ctypes.c_void_p(out.data_ptr()), 2048, 64) == 0
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); lib.lds_probe_run(st, p, ctypes.c_void_p(out.data_ptr()), 2048, 64); b.record(); b.synchronize()
-    print("pattern %d: %.1f us" % (p, a.elapsed_time(b) * 1e3), flush=True)
+    sums[p] = float(out.double().sum())
+    print("pattern %d: %.1f us  (sum of results %.6g)" % (p, a.elapsed_time(b) * 1e3, sums[p]), flush=True)
+for p in (14, 15, 16):
+    print("unaligned ds_read_b128, pattern %d against %d: %s" % (p, p - 3, "same values" if sums[p] == sums[p - 3] else "DIFFERENT"))
