@@ -152,6 +152,8 @@ __device__ __forceinline__ void bl_fwd_chunk(const Region &r, const BlSite4 &g, 
         st_stream4(out_p + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
 }
 
+// (64 x 32 tiles on 512 lanes, which pay for the RGB backward, lose here: 234 against 201 us -- this kernel is bound by the
+// number of independent tile chains per CU, see the launcher -- profiles/r03_bl_bwd_ab.txt.)
 template <int CT, int CAP>
 __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
     int W, int H, int C, int tiles_x, int tiles_y,
@@ -298,27 +300,7 @@ __global__ __launch_bounds__(NT, NT == 256 && CAP == 3072 ? 3 : 4) void bl_bwd_c
         mg = wave_max_i32(inb ? mg : 0);
         if ((tid & (kWave - 1)) == 0) mx[tid / kWave] = mg;
     }
-    Region r;
-    if (NT == 256) {
-        r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
-    } else {                                   // tile_region for any workgroup size: the box, clipped around the tile's centre
-        const BBox bx = tile_bbox<LX, NT>(cmin, cmax, rmin, rmax, bb);
-        r.x0 = bx.x0;  r.y0 = bx.y0;  r.w = bx.w;  r.h = bx.h;  r.pitch = G::kPitch;
-        if (bx.w > 0) {
-            if (r.w > G::kPitch) {
-                const int lo = r.x0, hi = r.x0 + r.w - G::kPitch;
-                r.x0 = min(max((tile_x0 + G::kTW / 2 - G::kPitch / 2) & ~3, lo), hi);
-                r.w = G::kPitch;
-            }
-            r.pitch = (r.w + 15) & ~15;
-            const int rows = min(CAP / r.pitch, kStageIts * NT / (r.w >> 2));
-            if (r.h > rows) {
-                const int lo = r.y0, hi = r.y0 + r.h - rows;
-                r.y0 = min(max(tile_y0 + G::kTH / 2 - rows / 2, lo), hi);
-                r.h = rows;
-            }
-        }
-    }
+    const Region r = tile_region<LX, true, CAP, NT>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
     int mg = 0;
 #pragma unroll
     for (int wv = 0; wv < NT / kWave; wv++) mg = max(mg, mx[wv]);
@@ -428,12 +410,11 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
         using G = TileGeom<16>;
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
-        const unsigned nwg_t = walk_grid(ntx, nty, batch, sw);
         MEMC_PATH(channel == 3 ? "bl_fwd:tiled_c3" : "bl_fwd:tiled_chunks");
 #define MEMC_BL_FWD(CT, CAP)                                                                                    \
-            hipLaunchKernelGGL((bl_fwd_tiled<CT, CAP>), dim3(nwg_t), dim3(256), (tile_lds_bytes<16, CAP>() + g_extra_lds), \
-                               stream, w, h, channel, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,          \
-                               (int64_t)s2c, s2h, input1, input2, output, sw)
+            hipLaunchKernelGGL((bl_fwd_tiled<CT, CAP>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(256),            \
+                               (tile_lds_bytes<16, CAP>() + g_extra_lds), stream, w, h, channel, ntx, nty, (int64_t)s1b, \
+                               (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, output, sw)
         if (channel == 3) {
             // 39 KiB instead of 48: 4 workgroups per CU.  The kernel is bound by the latency of a tile's serial chain
             // (1 / 2 / 3 per CU: 483 / 280 / 215 us), its 2x2 footprint rarely needs the rows given up: 218 -> 190 us

@@ -106,6 +106,8 @@ inline bool vec4_ok(int w, std::initializer_list<long> strides, std::initializer
     return true;
 }
 
+constexpr int kStageItsMax = 3;                 // float4 staging slots per lane (see stage_slots)
+
 // Tile geometry: 256 threads, LX lanes per tile row, 4 sites per lane.
 // CAP: the LDS budget in pixel quads.  3072 px * 16 B = 48 KiB -> 3 workgroups per CU (the 4x4-window kernels, whose
 // boxes need it); the 2x2-footprint kernels stage smaller boxes and trade budget for workgroups per CU.
@@ -154,11 +156,12 @@ struct Region {
 // (cmin > cmax).  One __syncthreads.
 // DYN: the pixel-quad image uses the narrowest pitch (multiple of 16) that holds the box, which buys rows:
 // 96 -> 32 rows, 80 -> 38, 64 -> 48.  Kernels that also keep fixed-shape accumulator planes pass DYN = false.
-template <int LX, bool DYN = false, int CAP = 3072>
+template <int LX, bool DYN = false, int CAP = 3072, int NT = 256>
 __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int rmax, int tile_x0, int tile_y0,
-                                              int *bb /* 16 ints in LDS */)
+                                              int *bb /* 4 ints per wave in LDS */)
 {
-    using G = TileGeom<LX, CAP>;
+    using G = TileGeom<LX, CAP, NT>;
+    static_assert(CAP <= kStageItsMax * NT * 4, "the staging slots cover the budget");
     // wave-level reduction on the VALU/SALU only (DPP row shifts, then the four row leaders through readlane);
     // ds_bpermute-based shuffles would put ~700 clocks of LDS round trips on the tile's critical chain
     cmin = wave_min_i32(cmin);
@@ -310,7 +313,7 @@ __device__ __forceinline__ Region band_region(const BBox &b, const Bands &d, int
 // round-robin in row-major order, kStageIts = 3 slots each (3 * 256 * 4 px = the whole 3072-pixel budget).
 // All loads are issued before the first LDS write and are unconditional -- slots past the end of the box read
 // the plane's first element -- so that no load result becomes a phi (see fi_fwd_tiled_fs4).
-constexpr int kStageIts = 3;
+constexpr int kStageIts = kStageItsMax;
 
 struct StageSlot {
     int row[kStageIts], q[kStageIts];      // q = float4 column; row >= r.h marks an empty slot
@@ -389,19 +392,19 @@ __device__ __forceinline__ void tile_stage_load(const Region &r, const StageSlot
     tile_stage_load_planes<NCH>(r, sl, plane, hs, sr);
 }
 
-template <int LX, int NCH>
+template <int LX, int NCH, int NT = 256>
 __device__ __forceinline__ void tile_stage_planes(const Region &r, const float *const (&plane)[NCH],
                                                   const int (&hstride)[NCH], f32x4 *tile)
 {
     static_assert(TileGeom<LX>::kCapPx <= kStageIts * 256 * 4, "three float4 slots per lane cover the budget");
-    const StageSlot sl = stage_slots(r);
+    const StageSlot sl = stage_slots<NT>(r);
     StageRegs<NCH> sr;
     tile_stage_load_planes<NCH>(r, sl, plane, hstride, sr);
     tile_stage_store<NCH>(r, sl, sr, tile);
 }
 
 // channel planes of ONE tensor: plane c = plane0 + c * cstride, common row stride
-template <int LX, int NCH>
+template <int LX, int NCH, int NT = 256>
 __device__ __forceinline__ void tile_stage(const Region &r, const float *plane0, int64_t cstride, int hstride,
                                            f32x4 *tile)
 {
@@ -412,7 +415,7 @@ __device__ __forceinline__ void tile_stage(const Region &r, const float *plane0,
         plane[c] = plane0 + c * cstride;
         hs[c] = hstride;
     }
-    tile_stage_planes<LX, NCH>(r, plane, hs, tile);
+    tile_stage_planes<LX, NCH, NT>(r, plane, hs, tile);
 }
 
 // ---------------------------------------------------------------------------------------------------------
