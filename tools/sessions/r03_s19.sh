@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 3, GPU session 19: the context warp with two LDS buffers and one barrier per chunk (arms 36-38).
+# (The two-buffer arms 36-38 were removed after this session; the numbers 36-39 now name the timing arms of session 20.)
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/r03_s19

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 3, GPU session 22: the context warp on a planar LDS image, one lane per tile column (arm 40): parity, then time.
+# (Arm 40 was removed after sessions 22-24: the script is the record of what ran, it no longer selects that kernel.)
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/r03_s22

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 3, GPU session 23: SQ counters of the column-mapped arm (40) against the product.
+# (Arm 40 was removed after sessions 22-24: the script is the record of what ran, it no longer selects that kernel.)
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/r03_s23

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 3, GPU session 25: RGB bilinear warp FORWARD on 64 x 32 tiles / 512 lanes (bl_cap 4 / 5); the backward after the refactoring.
+# (The forward arms bl_cap 4 / 5 were removed after this session; bl_cap 4 now only selects the 64 x 16 / 256-lane backward.)
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/r03_s25
