@@ -9,7 +9,8 @@ from .MEMC_Net import MEMC_Net
 from .MEMC_Net_star import MEMC_Net_star
 from .inference import interpolate_pairs, pad_amounts
 from .replicate import broadcast_module_state, shard_pairs
+from .png_io import interpolate_png_tree, read_png, write_png
 from .yuv_io import Yuv420Reader, Yuv420Writer, interpolate_yuv_sequence
 
 __all__ = ("MEMC_Net", "MEMC_Net_star", "broadcast_module_state", "shard_pairs", "interpolate_pairs", "pad_amounts",
-           "Yuv420Reader", "Yuv420Writer", "interpolate_yuv_sequence")
+           "Yuv420Reader", "Yuv420Writer", "interpolate_yuv_sequence", "read_png", "write_png", "interpolate_png_tree")

@@ -163,3 +163,36 @@ def test_hd_demo_command_line(tmp_path, capsys):
     out = capsys.readouterr().out
     assert "frame    1" in out and "frame    3" in out and "average over 2 interpolated frames" in out
     assert os.path.getsize(dst) == 4 * (h * w * 3 // 2)
+
+
+def test_still_image_demo_command_line(tmp_path, capsys):
+    """tools/demo_middlebury.py (the reference's demo_MiddleBury.py loop as a command) on a small scene tree: PNG files in,
+    the interpolated frame and the difference picture out, scores printed; a grey scene is skipped as the reference skips it."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import importlib
+    demo = importlib.import_module("demo_middlebury")
+    import networks
+    rng = np.random.default_rng(9)
+    data, gt, out = tmp_path / "data", tmp_path / "gt", tmp_path / "out"
+    for scene, (h, w) in (("Alpha", (128, 192)), ("Beta", (128, 192))):     # the HD demo test's size: no new MIOpen searches
+        os.makedirs(str(data / scene))
+        os.makedirs(str(gt / scene))
+        base = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        networks.write_png(str(data / scene / "frame10.png"), base)
+        networks.write_png(str(data / scene / "frame11.png"), np.roll(base, 2, axis=1))
+        if scene == "Alpha":
+            networks.write_png(str(gt / scene / "frame10i11.png"), np.roll(base, 1, axis=1))
+    os.makedirs(str(data / "Grey"))
+    for name in ("frame10.png", "frame11.png"):
+        networks.write_png(str(data / "Grey" / name), rng.integers(0, 256, (64, 64), dtype=np.uint8))
+    demo.main(["--data", str(data), "--gt", str(gt), "--output", str(out), "--model", "MEMC_Net"])
+    text = capsys.readouterr().out
+    assert "Alpha" in text and "interpolation error / PSNR" in text and "Beta" in text and "no ground truth" in text
+    assert "for all 1 images" in text and "Grey" not in text
+    rec = networks.read_png(str(out / "Alpha" / "frame10i11.png"))
+    assert rec.shape == (128, 192, 3) and rec.dtype == np.uint8
+    assert networks.read_png(str(out / "Beta" / "frame10i11.png")).shape == (128, 192, 3)
+    diffs = [f for f in os.listdir(str(out / "Alpha")) if f.startswith("frame10i11_diff")]
+    assert len(diffs) == 1 and networks.read_png(str(out / "Alpha" / diffs[0])).shape == (128, 192, 3)
+    assert not os.path.exists(str(out / "Grey"))
+
