@@ -36,6 +36,10 @@ BYTES_PER_SITE = {               # ALGORITHMIC bytes per output site, every tens
     "fi_bwd": lambda C, fs: 4 * (3 * C + 2 * (2 + fs * fs)),
     "proj_fwd": lambda C, fs: 20,
     "depth_proj_fwd": lambda C, fs: 24,
+    "proj_bwd": lambda C, fs: 28,
+    "depth_proj_bwd": lambda C, fs: 48,
+    "interp_fwd": lambda C, fs: 4 * (2 * C + 2),
+    "interp_bwd": lambda C, fs: 4 * (3 * C + 4),
 }
 CHECK_TOLERANCE = 1e-4           # BASELINE.json: "outputs within 1e-4 of reference"
 
@@ -245,7 +249,27 @@ def secondary_rows(my_lib, synth, torch, device, seed):
             lambda: my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, fill), torch, device, burst=4), "bursts of 4")
     row("config3_depth_flow_projection_fwd_fillhole1_32x720x1280", "depth_proj_fwd", 0, sites, _avg_launch_s(
         lambda: my_lib.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, po, 1), torch, device, burst=4), "bursts of 4")
-    del f, dep, cnt, po
+    # ... and their backward passes (the count / output planes of a forward without hole filling, as in training)
+    gout, gin, gd = torch.rand_like(f), torch.zeros_like(f), torch.zeros_like(dep)
+    cnt.zero_(); po.zero_()
+    my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, 0)
+    row("config3_flow_projection_bwd_32x720x1280", "proj_bwd", 0, sites, _avg_launch_s(
+        lambda: my_lib.FlowProjectionLayer_gpu_backward(f, cnt, gout, gin), torch, device, burst=4), "bursts of 4")
+    cnt.zero_(); po.zero_()
+    my_lib.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, po, 0)
+    row("config3_depth_flow_projection_bwd_32x720x1280", "depth_proj_bwd", 0, sites, _avg_launch_s(
+        lambda: my_lib.DepthFlowProjectionLayer_gpu_backward(f, dep, cnt, po, gout, gin, gd), torch, device, burst=4),
+        "bursts of 4")
+    del dep, cnt, po, gin, gd
+    # the bilinear warp (Interpolation) at the headline size, forward and backward
+    x = torch.rand((32, 3, 720, 1280), device=device)
+    out, g1, g2 = torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(f)
+    gx = torch.rand_like(x)
+    row("interpolation_fwd_32x3x720x1280", "interp_fwd", 3, sites, _avg_launch_s(
+        lambda: my_lib.InterpolationLayer_gpu_forward(x, f, out), torch, device, burst=4), "bursts of 4")
+    row("interpolation_bwd_32x3x720x1280", "interp_bwd", 3, sites, _avg_launch_s(
+        lambda: my_lib.InterpolationLayer_gpu_backward(x, f, gx, g1, g2), torch, device, burst=4), "bursts of 4")
+    del f, gout, x, out, g1, g2, gx
     # config 5: 4K adaptive warp forward, batch 8
     t = synth.torch_inputs(device, 8, 3, 2160, 3840, flow_kind="smooth", seed=seed + 5)
     out = torch.zeros_like(t["x"])
