@@ -580,6 +580,37 @@ def test_streams_and_repeatability(oracle):
     assert torch.equal(a, b)                                       # the forward gather is deterministic
 
 
+def test_headline_size_image_gradients_are_the_adjoints_of_the_warps():
+    """BASELINE's headline size (32 x 3 x 720 x 1280), a size-independent property of the two scattering backward passes:
+    for a fixed flow (and taps) the warp is linear in the image, and gradinput1 is its transpose applied to gradoutput --
+    <warp(x), g> == <x, gradinput1(g)> (float64 sums; FilterInterpolation copies the input pixel at out-of-range sites and
+    back-propagates nothing there, so its g is masked to the valid sites)."""
+    import my_package._ext.my_lib as my_lib
+    B, C, H, W = 32, 3, 720, 1280
+    t = synth.torch_inputs(dev(), B, C, H, W, flow_kind="smooth", seed=77, with_grad=True)
+    x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
+    xs = torch.arange(W, device=dev(), dtype=torch.float32).view(1, 1, W)
+    ys = torch.arange(H, device=dev(), dtype=torch.float32).view(1, H, 1)
+    x2, y2 = xs + f[:, 0], ys + f[:, 1]
+    valid = (x2 >= 0) & (y2 >= 0) & (x2 <= W - 1) & (y2 <= H - 1) & (f[:, 0].abs() < W / 2.0) & (f[:, 1].abs() < H / 2.0)
+    gm = g * valid.unsqueeze(1)
+
+    def dot(a, b):
+        return float((a.double() * b.double()).sum())
+    out = torch.empty_like(x)
+    g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
+    assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+    assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, gm, g1, g2, g3) == 0
+    lhs, rhs = dot(out, gm), dot(x, g1)
+    assert abs(lhs - rhs) <= 2e-6 * abs(lhs), ("FilterInterpolation", lhs, rhs)
+    del g3
+    out.zero_(); g1.zero_()
+    assert my_lib.InterpolationLayer_gpu_forward(x, f, out) == 0
+    assert my_lib.InterpolationLayer_gpu_backward(x, f, g, g1, g2) == 0
+    lhs, rhs = dot(out, g), dot(x, g1)
+    assert abs(lhs - rhs) <= 2e-6 * abs(lhs), ("Interpolation", lhs, rhs)
+
+
 def test_full_size_properties():
     """BASELINE sizes (720p, batch 8 here to bound host time) through size-independent properties:
       * zero flow + one-hot tap 5 is the identity (SURVEY A.7);
