@@ -299,6 +299,18 @@ int FlowUpsample4_gpu_forward_kernel(
     const int output_b_stride, const int output_c_stride, const int output_h_stride,
     const float mul, const float div, const int align_corners, const float *input, float *output);
 
+/* ------------------------------------------------------------------------------------------------------
+ * MEASUREMENT AID -- no reference counterpart.  What this device's HBM gives the access pattern of the library's tiled
+ * kernels (16 bytes per lane, non-temporal, workgroups dealt to the XCDs in contiguous runs):
+ *
+ *     dst[i] = src[i] + src[n + i] + ... + src[(reads_per_write - 1) n + i]     i in [0, n_float4), 16-byte elements
+ *
+ * reads_per_write 1 .. 8 (1: a copy; 7: the read : write mix of the RGB adaptive warp).  src holds reads_per_write *
+ * n_float4 elements, dst n_float4; both 16-byte aligned device pointers.  bench.py reports the rate as
+ * `roofline.achievable_peak`.  Returns 0 / -1 like the operators.
+ * ------------------------------------------------------------------------------------------------------ */
+int memc_calibration_stream(memc_stream_t stream, const float *src, float *dst, int64_t n_float4, int reads_per_write);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

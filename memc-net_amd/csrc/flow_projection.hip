@@ -403,88 +403,7 @@ __device__ __forceinline__ void trace_mark_proj(int slot)
     if (ON && threadIdx.x == 0) g_trace_buf_proj[(size_t)blockIdx.x * 16 + slot] = __builtin_readcyclecounter();
 }
 
-// ---- carry-based hole filling (pass 3), shared pieces; the scheme is described at proj_fillhole_carry ----------
-struct FillWs {
-    int *up, *left, *right;       // per-tile summaries: last non-zero row per column, last / first non-zero column per row
-    int *hole;                    // hole[tile] != 0: the tile (id (b * tiles_y + ty) * tiles_x + tx) contains a hole.
-};                                // Every tile writes its own entry with a plain store -- round 1 appended such tiles
-                                  // to a list with a RETURNING global atomic, i.e. a workgroup that was otherwise done
-                                  // sat on its CU for another memory round trip (~10 us of the kernel)
-
-template <int TH>
-struct TileSummary {              // LDS
-    int col_last[64], row_first[TH], row_last[TH];
-};
-
-// (the summary helpers take the thread index as an argument: a kernel that rebuilds it late -- proj_owner4 -- must not
-// keep threadIdx.x alive in a register just for them)
-template <int TH>
-__device__ __forceinline__ void summary_init(TileSummary<TH> &t, int tid = threadIdx.x)
-{
-    if (tid < 64) t.col_last[tid] = -1;
-    if (tid < TH) {
-        t.row_first[tid] = INT_MAX;
-        t.row_last[tid] = -1;
-    }
-}
-
-// the lane's four counts at (x .. x+3, y), local coordinates (lx .. lx+3, ly); returns "one of them is a hole".
-// A barrier must separate summary_init from this, and this from summary_store.
-// min over each group of 16 consecutive lanes (one DPP row), valid in the group's LAST lane
-__device__ __forceinline__ int row16_min_i32(int v)
-{
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));      // row_shr:1,2,4,8
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
-    return v;
-}
-
-// The lane's four counts at (x .. x+3, y), local coordinates (lx .. lx+3, ly); returns "one of them is a hole".
-// Lane layout: the 16 lanes of a tile row are 16 CONSECUTIVE lanes (lx = 4 * (lane % 16)) -- a row's first / last
-// non-zero column is then a DPP reduction and one plain LDS store by the row's last lane (sixteen lanes bumping
-// one LDS word with atomics serialise); the columns' last non-zero rows span waves and stay LDS atomics.
-// Converged code only.  A barrier must separate summary_init from this, and this from summary_store.
-template <int TH>
-__device__ __forceinline__ bool summary_add(TileSummary<TH> &t, bool inb, const f32x4 &c4, int lx, int ly, int x, int y,
-                                            int tid = threadIdx.x)
-{
-    bool hole = false;
-    int first = INT_MAX, last = -1;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (!inb) continue;
-        hole = hole || c4[j] <= 0.0f;                      // what pass 3 fills (my_lib_kernel.cu:1757)
-        if (c4[j] != 0.0f) {                               // what stops a walk (:1778-1797)
-            atomicMax(&t.col_last[lx + j], y);
-            first = min(first, x + j);
-            last = max(last, x + j);
-        }
-    }
-    first = row16_min_i32(first);
-    last = -row16_min_i32(-last);
-    if ((tid & 15) == 15) {                                // one writer per row
-        t.row_first[ly] = first;
-        t.row_last[ly] = last;
-    }
-    return hole;
-}
-
-template <int TH>
-__device__ __forceinline__ void summary_store(const TileSummary<TH> &t, int any_hole, const FillWs &ws, int b, int tx,
-                                              int ty, int W, int H, int ntx, int nty, int tid = threadIdx.x)
-{
-    const int tx0 = tx * 64, ty0 = ty * TH;
-    if (tid < 64 && tx0 + (int)tid < W)
-        ws.up[((int64_t)b * nty + ty) * W + tx0 + tid] = t.col_last[tid];
-    if (tid < TH && ty0 + (int)tid < H) {
-        // [b][tx][y]: a tile's rows are one contiguous run (row-major [b][y][tx] made these TH scattered 4-byte stores)
-        const int64_t i = ((int64_t)b * ntx + tx) * H + ty0 + tid;
-        ws.right[i] = t.row_first[tid] == INT_MAX ? -1 : t.row_first[tid];
-        ws.left[i] = t.row_last[tid];
-    }
-    if (tid == 0) ws.hole[((int64_t)b * nty + ty) * ntx + tx] = any_hole;
-}
+#include "proj_fill.hpp"                  // pass 3: masks, the owner kernels' fill epilogue, proj_fill_pending
 
 #ifdef MEMC_MEASURE
 #define MEMC_PROJ_ARMS_PART_A
@@ -662,297 +581,10 @@ struct OwnerTile {
         }
     }
 };
-
-// stores, and the hole filler's per-tile summaries (the counts are in registers: they are free)
-template <int TH>
-__device__ __forceinline__ void owner_store(TileSummary<TH> &sm, const FillWs &ws, int tid, int b, int tx, int ty, int W,
-                                            int H, int tiles_x, int tiles_y, int64_t s1b, int64_t s1c, int s1h,
-                                            int64_t scb, int sch, float *count, float *out, const f32x4 &ox,
-                                            const f32x4 &oy, const f32x4 &oc)
-{
-    const int cx = tx * 64 + 4 * (tid % 16), cy = ty * TH + tid / 16;
-    const bool inb = cx < W && cy < H;            // (no early exit: the summary below has a barrier)
-    if (inb) {
-        float *o = out + b * s1b + (int64_t)cy * s1h + cx;
-        *reinterpret_cast<f32x4 *>(o) = ox;    // plain stores: pass 3 (hole fill) re-reads them
-        *reinterpret_cast<f32x4 *>(o + s1c) = oy;
-        *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
-    }
-    if (ws.up) {
-        const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy);
-        const int any_hole = __syncthreads_or(hole);
-        summary_store(sm, any_hole, ws, b, tx, ty, W, H, tiles_x, tiles_y);
-    }
-}
-
-// (Written out rather than built from OwnerTile's methods: at 64 VGPRs -- eight waves per SIMD, which is what lets
-// four workgroups share a CU -- the allocator is at its limit, and the method form of the very same code spilled five
-// registers and ran 25 % slower.)
-// (Round 2 measured three knobs of this kernel that are no longer built: rows whose fx / depth loads are deferred --
-// 0 / 4 / 12 / 16 instead of 8: equal / equal / 245 us / 245 us; no motion bounds, flagged images through the general path:
-// four more normally idle launches; timing arms of the summaries: ~20 us of the call with hole filling.)
-template <bool DEPTH, int TH, int kReach, int MINW>
-__global__ __launch_bounds__(16 * TH, MINW) void proj_owner4(
-    int W, int H, int tiles_x, int tiles_y,
-    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
-    const float *__restrict__ flow, const float *__restrict__ depth,
-    float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, int *__restrict__ bounds,
-    FillWs ws, int sw, int nonce)
-{
-    constexpr int NT = 16 * TH;                   // one lane per four owned cells
-    constexpr int NP = DEPTH ? 3 : 2;             // planes: (count, vx, vy) or (count * 2^20 + vx, vy)
-    constexpr int kPtH = TH + 1, kPlane = kPtH * kPtW4;
-    constexpr int kScanPadX = kReach + 4;         // dilated tile: columns, kept 4-aligned
-    constexpr int kScanW = 64 + 2 * kScanPadX;    // source columns
-    constexpr int kScanH = TH + 2 * kReach + 1;   // source rows: [ty0 - kReach - 1, ty0 + TH + kReach)
-    constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + NT - 1) / NT;
-    static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
-    static_assert((2 * kReach + 1) * (2 * kReach + 1) < 4096 && kReach <= 128, "count * 2^20 + sum(vx) must split exactly");
-    __shared__ __attribute__((aligned(16))) double P[NP * kPlane];
-    __shared__ TileSummary<TH> sm;                // for the hole filler, when one follows (ws.up != nullptr)
-    __shared__ int tile_max[2];                   // bit patterns of max |fx|, max |fy| over the tile's own FAR sources (0: none)
-
-    const TileCoord tc = tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, sw);
-    if (tc.tx >= tiles_x) return;                 // virtual column of the last stripe
-    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * TH;
-    const int tid0 = threadIdx.x;                 // (thread index of the first half of the kernel, see below)
-    const int wave_index = __builtin_amdgcn_readfirstlane(tid0 / kWave);
-    summary_init(sm, tid0);
-    if (tid0 < 2) tile_max[tid0] = 0;
-    {
-        f32x4 *pz = reinterpret_cast<f32x4 *>(P);
-        for (int i = tid0; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    // scan loads: see proj_owner2 (slots, far rows, unconditional addresses)
-    constexpr int kNearRows = 8;
-    auto far_it = [](int it) {
-        const int first = NT * it / kCols4, last = (NT * it + NT - 1) / kCols4;
-        return last <= kReach + 1 - kNearRows || first >= kReach + 1 + TH + kNearRows;
-    };
-    const float *flow_b = flow + b * s1b;
-    const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
-    f32x4 fx[kIts], fy[kIts], dd[kIts];
-    int sx[kIts], sy[kIts];
-    bool live[kIts];
-    int row = tid0 / kCols4, c4 = tid0 % kCols4;
-#pragma unroll
-    for (int it = 0; it < kIts; it++) {
-        sx[it] = tx0 - kScanPadX + 4 * c4;
-        sy[it] = ty0 - kReach - 1 + row;
-        live[it] = row < kScanH && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
-        const unsigned off = live[it] ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;         // dead slots read pixel 0
-        fy[it] = ld_cached4_u(flow_b + s1c, off);
-        if (!far_it(it)) {
-            fx[it] = ld_cached4_u(flow_b, off);
-            if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
-        }
-        row += NT / kCols4;
-        c4 += NT % kCols4;
-        if (c4 >= kCols4) {
-            c4 -= kCols4;
-            row++;
-        }
-    }
-    __syncthreads();                           // P is zero
-
-    // wave-uniform window bounds (see proj_owner2: the upper bounds are compared as bit patterns)
-    const float xlo = (float)max(tx0 - 1, 0), ylo = (float)max(ty0 - 1, 0);
-    const int xhi_bits = min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1);
-    const int yhi_bits = min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1);
-    const unsigned lane = tid0 & (kWave - 1);
-    // the wave's batch of waiting hits: entry i sits in lane i; `fill` of them are valid (wave-uniform)
-    int p_cell = 0;
-    float p_vx = 0.0f, p_vy = 0.0f, p_vc = 0.0f;
-    unsigned fill = 0;
-    bool far = false;
-
-    // (cell, vx, vy as compacted above: cell without its wave-uniform offset, +f instead of v = -f)
-    const int cell0 = (ty0 - 1) * kPtW4 + (tx0 - 1);
-    auto splat = [&](int cell, float vx, float vy, float vc) {
-        double *q = P + (cell - cell0);
-        if (DEPTH) {
-            lds_add_f64(q, (double)vc);
-            lds_add_f64(q + kPlane, -(double)vx);
-            lds_add_f64(q + 2 * kPlane, -(double)vy);
-        } else {
-            lds_add_f64(q, kCountUnit - (double)vx);           // one source: count += 1, sum(vx) += -fx
-            lds_add_f64(q + kPlane, -(double)vy);
-        }
-    };
-
-#pragma unroll
-    for (int it = 0; it < kIts; it++) {
-        const bool lv = live[it];
-        const float syf = (float)sy[it], sxf = (float)sx[it];
-        // The quad lies inside the tile itself (tx0, the pad and sx are multiples of 4: all four sites or none) -- only
-        // slots that can hold rows of the tile evaluate this (and the far-source test below) at all.
-        const bool kHomeIt = NT * it / kCols4 < kReach + 1 + TH && (NT * it + NT - 1) / kCols4 >= kReach + 1;   // folds: `it` is unrolled
-        const bool homeq = kHomeIt && lv && (unsigned)(sy[it] - ty0) < (unsigned)TH && (unsigned)(sx[it] - tx0) < 64u;
-        float y2[4];
-        bool wy[4], rowany = false;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            y2[j] = syf + fy[it][j];
-            wy[j] = lv && y2[j] >= ylo && __float_as_int(y2[j]) < yhi_bits;
-            rowany = rowany || wy[j];
-        }
-        // rows farther from the tile than the local motion: the whole wave leaves after the four y tests
-        if (__builtin_amdgcn_ballot_w64(rowany || homeq) == 0) continue;
-        f32x4 fxq = fx[it], ddq = dd[it];
-        if (far_it(it)) {                      // rare: requested only now (and consumed inside this branch)
-            const unsigned off = lv ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
-            fxq = ld_cached4_u(flow_b, off);
-            if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const float fxv = fxq[j], fyv = fy[it][j];
-            const float x2 = (sxf + (float)j) + fxv;           // (float)x + fx, as the reference rounds it
-            // A far source (|f| >= kReach) whose home is this tile: the image is redone by proj_owner_far.  The hit
-            // test below does NOT ask for |f| < kReach: an image without a valid far source has only near hits, which
-            // every owner of their point sees (they lie inside its scan region); in an image WITH one the owners may
-            // disagree -- and every tile of that image is recomputed anyway.  Two compares less per scanned source.
-            if (kHomeIt && homeq && !(fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach)) {
-                const bool valid = x2 >= 0.0f && y2[j] >= 0.0f && x2 <= (float)(W - 1) && y2[j] <= (float)(H - 1);
-                far = far || valid;
-                if (valid) {                   // (cold) the tile's bound on its far sources' motion, for proj_owner_far:
-                    atomicMax(&tile_max[0], __float_as_int(fabsf(fxv)));      // non-negative floats order like their bits
-                    atomicMax(&tile_max[1], __float_as_int(fabsf(fyv)));
-                }
-            }
-            const bool hit = wy[j] && x2 >= xlo && __float_as_int(x2) < xhi_bits;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-            if (m == 0) continue;              // wave-uniform
-            const unsigned n = (unsigned)__builtin_popcountll(m);
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            // Push the hits to the consecutive lanes fill, fill + 1, ... (cyclically) of the batch.  Lanes without a
-            // hit aim at the LAST slot of the cycle, which a hit only takes when all 64 lanes hit (no such lane then).
-            const int dst = (int)((fill + (hit ? rank : 63u)) & 63u) << 2;
-            // cell = ((int)y2 - (ty0 - 1)) * pitch + (int)x2 - (tx0 - 1); the wave-uniform part is added at the splat
-            const int cell = (int)y2[j] * kPtW4 + (int)x2;                                   // (garbage without a hit)
-            // what travels is +f (or d * f): the sign of v = -f is applied where it is converted to double
-            float vx = fxv, vy = fyv, vc = 1.0f;
-            if (DEPTH) {                       // my_lib_kernel.cu:2102-2114: v = -d * f, count += d
-                vx = ddq[j] * fxv;
-                vy = ddq[j] * fyv;
-                vc = ddq[j] * 1.0f;
-            }
-            const int r_cell = __builtin_amdgcn_ds_permute(dst, cell);
-            const float r_vx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vx)));
-            const float r_vy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vy)));
-            float r_vc = 1.0f;
-            if (DEPTH) r_vc = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vc)));
-            if (fill + n < (unsigned)kWave) {  // (wave-uniform) the batch is not full yet: lanes [fill, fill + n) take theirs
-                const bool recv = ((lane - fill) & 63u) < n;
-                p_cell = recv ? r_cell : p_cell;
-                p_vx = recv ? r_vx : p_vx;
-                p_vy = recv ? r_vy : p_vy;
-                if (DEPTH) p_vc = recv ? r_vc : p_vc;
-                fill += n;
-            } else {                           // full: lanes [fill, 64) hold new entries, lanes [0, fill) waiting ones
-                const bool fresh = lane >= fill;
-                splat(fresh ? r_cell : p_cell, fresh ? r_vx : p_vx, fresh ? r_vy : p_vy, fresh ? r_vc : p_vc);
-                fill = fill + n - (unsigned)kWave;            // the entries that wrapped around: lanes [0, fill)
-                p_cell = r_cell;  p_vx = r_vx;  p_vy = r_vy;  p_vc = r_vc;
-            }
-        }
-    }
-    if (lane < fill) splat(p_cell, p_vx, p_vy, p_vc);          // what is still waiting
-    if (far) {                                 // this image is redone by proj_owner_far.  The flag words are NOT cleared
-        far_flag[b % kFlagWords] = nonce;      // before the call: "raised" = "holds this call's nonce" (launcher), so stale
-        far_flag[kFlagWords] = nonce;          // or uninitialised words can at worst cause a needless redo, never a missed one
-    }
-    __syncthreads();                           // every wave's points are in P (and the tile's motion bound in tile_max)
-    // (from here on the thread index is REBUILT from the wave's index, a scalar, and the lane's rank in the wave:
-    // kept in a VGPR across the scan it was the one value the allocator spilled at 64 registers)
-    const int tid = wave_index * kWave + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if (tid < 2) bounds[2 * (((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx) + tid] = tile_max[tid];
-
-    // Every lane owns four cells of a row: 2x2 box sums of the points of columns c-1 .. c+3, rows cy-1 and cy (border
-    // duplicates as weights 2, see proj_scatter_tiled), summed in DOUBLE -- exact, also for the packed plane:
-    // sum_i w_i (count_i 2^20 + S_i) = (sum w count) 2^20 + sum w S with |sum w S| < 2^19 (at most 2500 sources reach a
-    // 2x2 block, weights <= 4, |v| < kReach) -- then split and rounded to fp32 ONCE per cell (four splits per lane
-    // instead of ten; the reference's fp32 atomics add in arbitrary order anyway).
-    const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
-    const bool inb = cx < W && cy < H;            // (no early exit: the summary below has a barrier)
-    const double wy0 = (cy == H - 1) ? 2.0 : 1.0;
-    f32x4 ox, oy, oc;
-    {
-        typedef double f64x2 __attribute__((ext_vector_type(2)));
-        const double *r0 = P + (cy - ty0) * kPtW4 + (cx - tx0);   // column offset a multiple of 4: 16-byte pairs
-        double box[NP][4];
-#pragma unroll
-        for (int pl = 0; pl < NP; pl++) {
-            const double *a = r0 + pl * kPlane, *c = a + kPtW4;
-            const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
-            const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
-            const double top[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
-            const double bot[5] = {c01[0], c01[1], c23[0], c23[1], c[4]};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const double wx0 = (cx + j == W - 1) ? 2.0 : 1.0;
-                box[pl][j] = __builtin_fma(wy0, __builtin_fma(wx0, bot[j + 1], bot[j]), __builtin_fma(wx0, top[j + 1], top[j]));
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float v0, v1, v2;
-            if (DEPTH) {
-                v0 = (float)box[0][j];  v1 = (float)box[1][j];  v2 = (float)box[NP - 1][j];
-            } else {                           // A = count * 2^20 + sum(vx): split exactly
-                const double cnt = __builtin_rint(box[0][j] * (1.0 / kCountUnit));
-                v0 = (float)cnt;
-                v1 = (float)__builtin_fma(cnt, -kCountUnit, box[0][j]);
-                v2 = (float)box[1][j];
-            }
-            if (v0 > 0.0f) {                   // my_lib_kernel.cu:1730-1735; one reciprocal for both components
-                const float inv = 1.0f / v0;   // (<= 1 ulp from the two divisions)
-                v1 = v1 * inv;
-                v2 = v2 * inv;
-            }
-            oc[j] = v0;  ox[j] = v1;  oy[j] = v2;
-        }
-    }
-    if (inb) {
-        float *o = out + b * s1b + (int64_t)cy * s1h + cx, *cn = count + b * scb + (int64_t)cy * sch + cx;
-        if (ws.up) {                           // plain stores: pass 3 (hole fill) re-reads them
-            *reinterpret_cast<f32x4 *>(o) = ox;
-            *reinterpret_cast<f32x4 *>(o + s1c) = oy;
-            *reinterpret_cast<f32x4 *>(cn) = oc;
-        } else {                               // single-use streams otherwise
-            st_stream4(o, ox);
-            st_stream4(o + s1c, oy);
-            st_stream4(cn, oc);
-        }
-    }
-    if (ws.up) {                               // the filler's per-tile summaries, from the counts in registers
-        // A tile whose every cell has a positive count (82 % of the tiles under the benchmark's smooth flow) has the
-        // trivial summary -- every walk that enters it stops at its first cell -- and no hole: one vote instead of the
-        // LDS atomics, the row reductions and their barrier.
-        const bool full = !inb || (oc[0] > 0.0f && oc[1] > 0.0f && oc[2] > 0.0f && oc[3] > 0.0f);
-        if (__syncthreads_and(full)) {
-            const int tx0 = tc.tx * 64, ty0 = tc.ty * TH;
-            if (tid < 64 && tx0 + (int)tid < W)
-                ws.up[((int64_t)b * tiles_y + tc.ty) * W + tx0 + tid] = min(ty0 + TH - 1, H - 1);
-            if (tid < TH && ty0 + (int)tid < H) {
-                const int64_t i = ((int64_t)b * tiles_x + tc.tx) * H + ty0 + tid;
-                ws.right[i] = tx0;
-                ws.left[i] = min(tx0 + 63, W - 1);
-            }
-            if (tid == 0) ws.hole[((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx] = 0;
-            return;
-        }
-        const bool hole = summary_add(sm, inb, oc, 4 * (tid % 16), tid / 16, cx, cy, tid);
-        const int any_hole = __syncthreads_or(hole);
-        summary_store(sm, any_hole, ws, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, tid);
-    }
-}
-
-// The images flagged by proj_owner4, redone exactly: every tile of such an image scans whole source tiles -- those
-// whose motion bound (kReach, or what proj_owner4 recorded in bounds[] for the tile's far sources: max |fx|, max |fy|)
-// lets one of their sources land in the window -- with no limit on |flow|.  Queued behind proj_owner4 as a short grid that strides over the tiles; returns
-// at once when no flag was raised.
+// The images flagged by the owner kernel, redone exactly: every tile of such an image scans whole source tiles -- those
+// whose motion bound (kReach, or what the owner kernel recorded in bounds[] for the tile's far sources: max |fx|,
+// max |fy|) lets one of their sources land in the window -- with no limit on |flow|.  Queued behind the owner kernel as a
+// short grid that strides over the tiles; returns at once when no flag was raised.
 template <bool DEPTH, int TH, int kReach>
 __global__ __launch_bounds__(16 * TH) void proj_owner_far(
     int W, int H, int tiles_x, int tiles_y, int batch,
@@ -964,7 +596,7 @@ __global__ __launch_bounds__(16 * TH) void proj_owner_far(
     using OT = OwnerTile<DEPTH, TH>;
     constexpr int NT = 16 * TH;
     __shared__ __attribute__((aligned(16))) double P[OT::NP * OT::kPlane];
-    __shared__ TileSummary<TH> sm;
+    __shared__ FillLds<TH> fl;
     if (far_flag[kFlagWords] != nonce) return;
     const unsigned per_image = (unsigned)tiles_x * tiles_y, ntiles = per_image * batch;
 #pragma unroll 1
@@ -975,7 +607,7 @@ __global__ __launch_bounds__(16 * TH) void proj_owner_far(
         const int tx0 = tx * 64, ty0 = ty * TH;
         OT t;
         t.begin(P, tx0, ty0, W, H, tid & (kWave - 1));
-        summary_init(sm);
+        fill_lds_init(fl, tid);
         t.template zero<NT>(tid);
         __syncthreads();
         const float *flow_b = flow + b * s1b;
@@ -1007,141 +639,30 @@ __global__ __launch_bounds__(16 * TH) void proj_owner_far(
         }
         t.finish();
         __syncthreads();                       // every wave's points are in P
+        const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
+        const bool inb = cx < W && cy < H;     // (no early exit: barriers below)
         f32x4 ox, oy, oc;
-        t.readout(tx0 + 4 * (tid % 16), ty0 + tid / 16, W, H, ox, oy, oc);
-        owner_store(sm, ws, tid, b, tx, ty, W, H, tiles_x, tiles_y, s1b, s1c, s1h, scb, sch, count, out, ox, oy, oc);
-        __syncthreads();                       // P and the summary are rebuilt by the next tile
+        t.readout(cx, cy, W, H, ox, oy, oc);
+        if (ws.up)                             // pass 3 follows: fill what the tile can, summaries, masks (proj_fill.hpp)
+            owner_fill_epilogue<TH, NT>(fl, reinterpret_cast<float *>(P), ws, tid, b, tx, ty, W, H, tiles_x, tiles_y, inb, ox,
+                                        oy, oc);
+        if (inb) {
+            float *o = out + b * s1b + (int64_t)cy * s1h + cx;
+            *reinterpret_cast<f32x4 *>(o) = ox;
+            *reinterpret_cast<f32x4 *>(o + s1c) = oy;
+            *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
+        }
+        __syncthreads();                       // P and the masks are rebuilt by the next tile
     }
 }
 
-// --------------------------------------------------------------------------------------------------
-// Pass 3 with carries: the hole filler whose walks never leave a tile.
-// The reference walks from every hole to the nearest cell with a non-zero count to its left, to its right and above
-// (my_lib_kernel.cu:1776-1800).  Walked literally, a camera pan -- an uncovered strip along one image border --
-// makes every hole of a vertical strip climb the whole strip (measured: projection + fill 765 .. 1320 us against
-// 244 .. 266 us without, 720p batch 32).  Here a walk covers its own 64 x TH tile only; what lies beyond comes from
-// three small carry tables built by two tiny scans over per-tile summaries:
-//   up   [b][ty][x]   last row of band ty whose cell in column x has a non-zero count            (-1: none)
-//   left [b][tx][y]   last column of tile column tx with a non-zero count in row y               (-1: none)
-//   right[b][tx][y]   first such column
-// (round 1 turned these into "nearest beyond the tile" tables with a scan kernel; now the filler walks the
-// neighbouring tiles' entries itself, nearest first -- one launch and 13 us less, usually one step)
-// plus the list of the tiles that contain a hole (the filler is launched over that list only).
-// Same cells, same flags, same arithmetic as the walks -- identical results.  The tables (0.4 B per pixel) live in
-// a stream-ordered allocation made and released by the launcher.
-// --------------------------------------------------------------------------------------------------
-// Summaries from the count plane, for the paths on which the owner kernel did not write them: the general path on
-// its own (far_flag == nullptr: every tile) or behind the far flag (only the images it redid; returns at once when
-// no image was flagged).  Grid-stride over tiles.
-template <int TH>
-__global__ __launch_bounds__(256) void proj_fill_summary(
-    int W, int H, int tiles_x, int tiles_y, int batch, int64_t scb, int sch, const float *__restrict__ count,
-    FillWs ws, const int *__restrict__ far_flag)
-{
-    __shared__ TileSummary<TH> sm;
-    if (far_flag && far_flag[kFlagWords] == 0) return;
-    const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((unsigned)tiles_x * tiles_y);
-        if (far_flag && far_flag[b % kFlagWords] == 0) continue;          // wave-uniform
-        summary_init(sm);
-        __syncthreads();
-        bool hole = false;
-#pragma unroll
-        for (int r = 0; r < TH / 16; r++) {
-            const int lx = 4 * (threadIdx.x % 16), ly = threadIdx.x / 16 + 16 * r;
-            const int x = tx * 64 + lx, y = ty * TH + ly;
-            const bool inb = x < W && y < H;
-            const f32x4 own = ld_cached4(count + b * scb + (int64_t)min(y, H - 1) * sch + min(x, W - 4));
-            hole = summary_add(sm, inb, own, lx, ly, x, y) || hole;
-        }
-        const int any_hole = __syncthreads_or(hole);       // (also orders the LDS atomics before the reads below)
-        summary_store(sm, any_hole, ws, b, tx, ty, W, H, tiles_x, tiles_y);
-        __syncthreads();                                   // before the next tile re-initialises the summary
-    }
-}
+#include "proj_owner5.hpp"               // the production owner kernel
 
-// (One WAVE per flagged tile instead of a 256-thread workgroup -- no workgroup barriers, four times the tiles in
-// flight -- was measured and LOST: 61 us against 29; a tile's holes come in clusters of more than 64.)
-template <int TH>
-__global__ __launch_bounds__(256) void proj_fillhole_carry(
-    int W, int H, int tiles_x, int tiles_y, int batch, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch,
-    const float *__restrict__ count, float *out, FillWs ws)
-{
-    __shared__ __attribute__((aligned(16))) float cnt[TH * 64];
-    __shared__ int n_holes;
-    __shared__ unsigned short hole_list[TH * 64];
-    // workgroup i looks after the tiles i, i + grid, ...: their flags are fetched by one load (lane k: tile i + k grid),
-    // then the flagged ones are taken in turn
-    const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
-    const unsigned mine = blockIdx.x + (threadIdx.x & 63u) * gridDim.x;
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(mine < ntiles && ws.hole[mine < ntiles ? mine : 0] != 0);
-    for (; todo; todo &= todo - 1) {
-    const unsigned tile = blockIdx.x + (unsigned)__builtin_ctzll(todo) * gridDim.x;
-    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((unsigned)tiles_x * tiles_y);
-    const int tx0 = tx * 64, ty0 = ty * TH;
-    const float *cn = count + b * scb;
-    if (threadIdx.x == 0) n_holes = 0;
-    f32x4 own[TH / 16];
-#pragma unroll
-    for (int r = 0; r < TH / 16; r++) {
-        const int lx = 4 * (threadIdx.x % 16), ly = threadIdx.x / 16 + 16 * r;
-        const int x = tx0 + lx, y = ty0 + ly;
-        const bool inb = x < W && y < H;
-        own[r] = ld_cached4(cn + (int64_t)min(y, H - 1) * sch + min(x, W - 4));
-        // cells past the image edge are staged as "non-zero": the walks below test the edge themselves
-        *reinterpret_cast<f32x4 *>(cnt + ly * 64 + lx) = inb ? own[r] : f32x4{1.f, 1.f, 1.f, 1.f};
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < TH / 16; r++) {
-        const int lx = 4 * (threadIdx.x % 16), ly = threadIdx.x / 16 + 16 * r;
-        if (tx0 + lx < W && ty0 + ly < H) {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (own[r][j] <= 0.0f) hole_list[atomicAdd(&n_holes, 1)] = (unsigned short)((ly << 6) | (lx + j));
-        }
-    }
-    __syncthreads();
-    const int n = n_holes;
-    float *o = out + b * s1b;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int cell = hole_list[i], hx = cell & 63, hy = cell >> 6;
-        const int gx = tx0 + hx, gy = ty0 + hy;
-        // inside the tile: LDS; beyond it: the carry tables (position only -- the count there is read back)
-        int lo = -1, ro = -1, uo = -1;
-        for (int c = hx - 1; c >= 0 && lo < 0; c--)
-            if (cnt[hy * 64 + c] != 0.0f) lo = tx0 + c;
-        // (tile summaries of this row, nearest first: the last non-zero column of each tile to the left)
-        for (int t = tx - 1; t >= 0 && lo < 0; t--) lo = ws.left[((int64_t)b * tiles_x + t) * H + gy];
-        for (int c = hx + 1; c < 64 && tx0 + c < W && ro < 0; c++)
-            if (cnt[hy * 64 + c] != 0.0f) ro = tx0 + c;
-        for (int t = tx + 1; t < tiles_x && ro < 0; t++) ro = ws.right[((int64_t)b * tiles_x + t) * H + gy];
-        for (int r = hy - 1; r >= 0 && uo < 0; r--)
-            if (cnt[r * 64 + hx] != 0.0f) uo = ty0 + r;
-        for (int t = ty - 1; t >= 0 && uo < 0; t--) uo = ws.up[((int64_t)b * tiles_y + t) * W + gx];
-        // the counts the walks stopped at (0 when they ran into the image border)
-        const float lt = lo >= 0 ? cn[(int64_t)gy * sch + lo] : 0.0f;
-        const float rt = ro >= 0 ? cn[(int64_t)gy * sch + ro] : 0.0f;
-        const float ut = uo >= 0 ? cn[(int64_t)uo * sch + gx] : 0.0f;
-        const float dt = 0.0f;                              // dead downward search (my_lib_kernel.cu:1799)
-        if (lt + rt + ut + dt <= 0.0f) continue;
-        const float fl = lt > 0.0f ? 1.0f : 0.0f, fr = rt > 0.0f ? 1.0f : 0.0f;
-        const float fu = ut > 0.0f ? 1.0f : 0.0f, fd = 0.0f;
-        // a walk that found nothing ends at the border cell (column 0 / W-1, row 0): its flag is 0, but the
-        // reference still multiplies that cell's value by it -- keep the operand finite and identical
-        const int lc = lo >= 0 ? lo : 0, rc = ro >= 0 ? ro : W - 1, ur = uo >= 0 ? uo : 0;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            float *pl = o + k * s1c;
-            float *self = pl + (int64_t)gy * s1h + gx;
-            *self = (fl * pl[(int64_t)gy * s1h + lc] + fr * pl[(int64_t)gy * s1h + rc] +
-                     fu * pl[(int64_t)ur * s1h + gx] + fd * *self) / (fl + fr + fu + fd);
-        }
-    }
-    __syncthreads();                                        // the LDS tile and list are reused by the next tile
-    }   // listed tiles
-}
+#ifdef MEMC_MEASURE
+#define MEMC_PROJ_ARMS_PART_C
+#include "arms/proj_owner_arms.hpp"      // proj_owner4 and the carry filler (round 3's production set): measurement build only
+#undef MEMC_PROJ_ARMS_PART_C
+#endif  // MEMC_MEASURE
 
 #ifdef MEMC_MEASURE
 #define MEMC_PROJ_ARMS_PART_B
@@ -1465,8 +986,10 @@ struct ProjArgs {
 // counters, and two calls handed the same scratch block could carry the same nonce: a needless whole-image redo).
 static std::atomic<unsigned> g_proj_call_counter{0};
 
-// vectorised forward: owner-computes fast path + the general path behind its far flag (+ hole filling), with the
-// tile height TH of the owner kernel and the filler.  variant: measurement build only (-1 otherwise).
+// vectorised forward: owner-computes fast path (proj_owner5; images with a far source redone by proj_owner_far behind a
+// device flag), hole filling from masks (proj_fill.hpp), with the tile height TH of the owner kernel and the filler;
+// without scratch the general path (zero, scatter with atomics, average) and the literal hole walker.
+// variant: measurement build only (-1 otherwise).
 template <bool DEPTH, int TH>
 static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
 {
@@ -1478,23 +1001,38 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     const int snty = (h + 15) / 16;                          // the general path scatters from 64x16 SOURCE tiles
     const unsigned sntiles = (unsigned)ntx * snty * batch;
     const unsigned gs = 256 * 8;                             // grid-stride: 8 workgroups per CU
-    const unsigned gq = 256 * 2;                             // ... of the kernels queued behind the far flag (normally idle)
     const int64_t s1b = a.s1b, s1c = a.s1c, sdb = a.sdb, scb = a.scb;
     const int s1h = a.s1h, sdh = a.sdh, sch = a.sch;
+
+    // which set of kernels (measurement build: the rounds 1-3 arms keep their own summaries and filler)
+    bool r3_set = false;                                     // proj_owner4 / proj_owner_far_r3 / proj_fillhole_carry
+    bool legacy_owner = false;                               // proj_owner, proj_owner2, proj_owner3 (+ general path behind the flag)
+#ifdef MEMC_MEASURE
+    r3_set = variant == -40 || variant == -20;
+    legacy_owner = variant == -10 || variant == -7 || variant == -6 || variant == -30 || variant == -31 ||
+                   (variant <= -21 && variant >= -29);
+#endif
+    constexpr bool kNewOk = TH <= 32;                        // a column mask of proj_fill.hpp is one 32-bit word
+    if (!kNewOk && !legacy_owner) return -1;
+    const bool old_fill = r3_set || legacy_owner;
 
     // (the owner kernel addresses the flow / depth planes with 32-bit offsets)
     const bool want_fast = variant != 1 && variant < 2 && plane_fits_u32(w, h, {s1h, sdh});
     const bool want_carry = a.fillhole && variant != -8 && variant != -9;
-    // scratch layout (ints): [0, 320) far flags (image b -> word b % 256, word 256 = "any"), the tiles' motion bounds
-    // (2 per tile), then -- with hole filling -- the three tables of per-tile summaries and the per-tile hole flags
+    // scratch layout: [0, 320) ints of far flags (image b -> word b % 256, word 256 = "any"), the tiles' motion bounds
+    // (2 ints per tile), then -- with hole filling -- the three tables of per-tile summaries, the per-tile hole flags and
+    // (8-byte aligned) the tiles' masks
     constexpr size_t kHead = 320;
     const size_t n_bnd = want_fast ? 2 * (size_t)ntiles : 0;
     const size_t n_up = (size_t)batch * nty * w, n_row = (size_t)batch * h * ntx;
-    const size_t ints = kHead + n_bnd + (want_carry ? n_up + 2 * n_row + (size_t)ntiles : 0);
+    size_t ints = kHead + n_bnd + (want_carry ? n_up + 2 * n_row + (size_t)ntiles : 0);
+    ints = (ints + 1) / 2 * 2;
+    size_t mask_words = 0;
+    if constexpr (kNewOk) mask_words = want_carry && !old_fill ? (size_t)ntiles * tile_mask_words<TH>() : 0;
     CallScratch scratch;
     int *flag = nullptr, *bounds = nullptr;
-    FillWs ws = {nullptr, nullptr, nullptr, nullptr};
-    // The production pair (proj_owner4 / proj_owner_far) needs no cleared flag words: a flag is "raised" when it holds
+    FillWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // The production pair (proj_owner5 / proj_owner_far) needs no cleared flag words: a flag is "raised" when it holds
     // this call's nonce -- a process-wide counter, never 0, so consecutive calls (which the pool hands the same block)
     // never see each other's flags; a stale or uninitialised word equal to the nonce (2^-32) would only cause a
     // needless redo.  That saves a 5 us memset launch per call.  The measurement build's older kernels keep 0 / 1
@@ -1502,14 +1040,9 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     unsigned nonce_u = g_proj_call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
     if (nonce_u == 0) nonce_u = g_proj_call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
     const int nonce = (int)nonce_u;
-    bool legacy_flags = false;
-#ifdef MEMC_MEASURE
-    legacy_flags = variant == -10 || variant == -7 || variant == -6 || variant == -30 || variant == -31 ||
-                   (variant <= -21 && variant >= -29);
-#endif
-    if ((want_fast || want_carry) && scratch.alloc(ints * sizeof(int), stream)) {
+    if ((want_fast || want_carry) && scratch.alloc(ints * sizeof(int) + mask_words * 8, stream)) {
         int *base = static_cast<int *>(scratch.p);
-        if (legacy_flags && hipMemsetAsync(base, 0, kHead * sizeof(int), stream) != hipSuccess) return -1;
+        if (legacy_owner && hipMemsetAsync(base, 0, kHead * sizeof(int), stream) != hipSuccess) return -1;
         if (want_fast) {
             flag = base;
             bounds = base + kHead;
@@ -1519,6 +1052,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             ws.left = ws.up + n_up;
             ws.right = ws.left + n_row;
             ws.hole = ws.right + n_row;
+            ws.masks = reinterpret_cast<unsigned long long *>(base + ints);
         }
     }
     // Without scratch (inside a stream capture, or the allocation failed): the general path on its own and the
@@ -1530,12 +1064,50 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                        scb, sch, a.flow, a.depth, a.count, a.out, FLAG)
     bool only_part = false;                                  // measurement arms that time one piece
     MEMC_PATH(flag ? (DEPTH ? "dproj_fwd:owner" : "proj_fwd:owner") : (DEPTH ? "dproj_fwd:general" : "proj_fwd:general"));
-    if (flag) {
-        // fast path: owner-computes (no atomics, fused averaging, hole-filler summaries for free); images with a
-        // far source are redone by proj_owner_far behind a device flag (round-1 / ring kernels of the measurement
-        // build: by the general path behind the same flag)
-        bool launched = false, own4 = false;
+    // waves per SIMD the register allocator must leave room for = what the LDS admits: FlowProjection 4 workgroups per
+    // CU at TH = 32 (2 planes, 35 KiB), the depth operator 3 (53 KiB)
+    constexpr int kWgCu = TH == 16 ? (DEPTH ? 4 : 6) : (TH == 32 ? (DEPTH ? 3 : 4) : 1);
+    constexpr int kMinW = (kWgCu * (16 * TH / 64) + 3) / 4 > 8 ? 8 : (kWgCu * (16 * TH / 64) + 3) / 4;
+    if (flag && !legacy_owner) {
+        if constexpr (kNewOk) {
+            const WalkPlan plan = make_walk_plan(ntx, nty, batch, sw);
 #ifdef MEMC_MEASURE
+            only_part = variant == -5 || variant == -20 || variant == -41;
+            if (r3_set) {
+                hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(16 * TH),
+                                   0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
+                                   a.out, flag, bounds, ws, sw, nonce);
+            } else if (variant == -41) {       // timestamps (tools/trace_kernel.py proj5)
+                hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinW, true>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w, h,
+                                   ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,
+                                   bounds, ws, plan, nonce);
+            } else
+#endif
+            hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinW>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w, h, ntx, nty,
+                               s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag, bounds, ws, plan,
+                               nonce);
+            if (launch_status() != 0) return -1;
+            if (!only_part) {
+                const unsigned pg = persistent_grid(1);
+#ifdef MEMC_MEASURE
+                if (r3_set)
+                    hipLaunchKernelGGL((proj_owner_far_r3<DEPTH, TH, 24>), dim3(ntiles < pg ? ntiles : pg), dim3(16 * TH), 0,
+                                       stream, w, h, ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth,
+                                       a.count, a.out, flag, bounds, ws, nonce);
+                else
+#endif
+                hipLaunchKernelGGL((proj_owner_far<DEPTH, TH, 24>), dim3(ntiles < pg ? ntiles : pg), dim3(16 * TH), 0, stream,
+                                   w, h, ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
+                                   a.out, flag, bounds, ws, nonce);
+                if (launch_status() != 0) return -1;
+            }
+        }
+    }
+#ifdef MEMC_MEASURE
+    else if (flag) {
+        // rounds 1-2 owner kernels: 0 / 1 flags, flagged images redone by the general path queued behind the flag
+        const unsigned gq = 256 * 2;
+        bool launched = false;
         if (variant == -10 || variant == -7 || variant == -6) {       // round-1 owner kernel (64x16, strips)
             const unsigned nwg = ntiles;
 #define MEMC_PROJ_OWNER(REACH, TRACE)                                                                              \
@@ -1549,14 +1121,12 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             }
 #undef MEMC_PROJ_OWNER
         }
-        only_part = variant == -5 || variant == -7;
-#endif
-#ifdef MEMC_MEASURE
+        only_part = variant == -7;
 #define MEMC_PROJ_OWNER2(ABL, TRACE)                                                                              \
             hipLaunchKernelGGL((proj_owner2<DEPTH, TH, 24, ABL, TRACE>), dim3(walk_grid(ntx, nty, batch, sw)),          \
                                dim3(16 * TH), 0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow,       \
                                a.depth, a.count, a.out, flag, ws, sw)
-        if (!launched && variant <= -20 && variant > -30) {   // -21 .. -26: timing arms of proj_owner2 (wrong results); -29: timestamps
+        if (!launched && variant <= -21 && variant > -30) {   // -21 .. -26: timing arms of proj_owner2 (wrong results); -29: timestamps
             only_part = true;
             launched = true;
             if (variant == -21) MEMC_PROJ_OWNER2(1, false);
@@ -1566,7 +1136,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             else if (variant == -25) MEMC_PROJ_OWNER2(5, false);
             else if (variant == -26) MEMC_PROJ_OWNER2(6, false);
             else if (variant == -29) MEMC_PROJ_OWNER2(0, true);
-            else launched = false;                         // -20: the production kernel alone
+            else launched = false;
         }
         if (!launched && variant == -30) {     // proj_owner2: LDS rings, three planes
             MEMC_PROJ_OWNER2(0, false);
@@ -1582,25 +1152,9 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             }
         }
 #undef MEMC_PROJ_OWNER2
-#endif
-        if (!launched) {
-            // waves per SIMD the register allocator must leave room for = what the LDS admits: FlowProjection 4
-            // workgroups per CU at TH = 32 (2 planes, 35 KiB), the depth operator 3 (53 KiB)
-            constexpr int kWgCu = TH == 16 ? (DEPTH ? 4 : 6) : (TH == 32 ? (DEPTH ? 3 : 4) : 1);
-            constexpr int kMinW = (kWgCu * (16 * TH / 64) + 3) / 4 > 8 ? 8 : (kWgCu * (16 * TH / 64) + 3) / 4;
-            hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(16 * TH), 0,
-                               stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
-                               a.out, flag, bounds, ws, sw, legacy_flags ? 1 : nonce);
-            own4 = true;
-        }
+        if (!launched) return -1;
         if (launch_status() != 0) return -1;
-        if (own4 && !only_part) {
-            const unsigned pg = persistent_grid(1);
-            hipLaunchKernelGGL((proj_owner_far<DEPTH, TH, 24>), dim3(ntiles < pg ? ntiles : pg), dim3(16 * TH), 0, stream, w, h,
-                               ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,
-                               bounds, ws, nonce);
-            if (launch_status() != 0) return -1;
-        } else if (!only_part) {
+        if (!only_part) {
             hipLaunchKernelGGL(proj_redo_zero, dim3(gq), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
                                a.count, a.out, flag);
             MEMC_PROJ_SCATTER(0, flag);
@@ -1611,9 +1165,13 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                                    sch, a.count, ws, flag);
             if (launch_status() != 0) return -1;
         }
-    } else {
+    }
+#endif
+    else {
         // the general path on its own: it DEFINES count and output (zero, scatter, average), it does not rely on
         // the caller's zero fill
+        const unsigned gq = 0;                 // (unused: no flag)
+        (void)gq;
 #ifdef MEMC_MEASURE
         only_part = variant >= 2;               // (the ablation arms 2 / 3 time the scatter pass alone)
         if (variant == 2) MEMC_PROJ_SCATTER(2, (const int *)nullptr);
@@ -1625,9 +1183,17 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             MEMC_PROJ_SCATTER(0, (const int *)nullptr);
             hipLaunchKernelGGL(proj_average_v4, dim3(gs), dim3(256), 0, stream, w, h, s1b, s1c, s1h, scb, sch, batch,
                                a.count, a.out, (const int *)nullptr);
-            if (ws.up)
-                hipLaunchKernelGGL(proj_fill_summary<TH>, dim3(gs), dim3(256), 0, stream, w, h, ntx, nty, batch, scb,
-                                   sch, a.count, ws, (const int *)nullptr);
+            if (ws.up) {
+#ifdef MEMC_MEASURE
+                if (old_fill)
+                    hipLaunchKernelGGL(proj_fill_summary<TH>, dim3(gs), dim3(256), 0, stream, w, h, ntx, nty, batch, scb,
+                                       sch, a.count, ws, (const int *)nullptr);
+                else
+#endif
+                if constexpr (kNewOk)
+                    hipLaunchKernelGGL(proj_fill_masks<TH>, dim3(ntiles < gs ? ntiles : gs), dim3(16 * TH), 0, stream, w, h,
+                                       ntx, nty, batch, scb, sch, a.count, ws);
+            }
         }
         if (launch_status() != 0) return -1;
     }
@@ -1635,11 +1201,17 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     if (a.fillhole && !only_part) {
         if (ws.up) {
             // workgroup i looks after the tiles i, i + grid, ... (at most 64 of them: one flag per lane of a wave); most
-            // tiles have no hole (13 % on the benchmark's smooth flow) and cost their workgroup one flag load
-            // (round 3 measured a grid of one workgroup per tile, and of min(tiles, 16384): 219.8 / 218.0 us against 212.8)
+            // tiles have no hole (18 % on the benchmark's smooth flow) and cost their workgroup one flag load
             const unsigned fg = ntiles < 4096u ? ntiles : (ntiles + 63u) / 64u > 4096u ? (ntiles + 63u) / 64u : 4096u;
-            hipLaunchKernelGGL(proj_fillhole_carry<TH>, dim3(fg), dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c, s1h,
-                               scb, sch, a.count, a.out, ws);
+#ifdef MEMC_MEASURE
+            if (old_fill)
+                hipLaunchKernelGGL(proj_fillhole_carry<TH>, dim3(fg), dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c,
+                                   s1h, scb, sch, a.count, a.out, ws);
+            else
+#endif
+            if constexpr (kNewOk)
+                hipLaunchKernelGGL(proj_fill_pending<TH>, dim3(fg), dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c, s1h,
+                                   scb, sch, a.count, a.out, ws);
         } else {
             hipLaunchKernelGGL(proj_fillhole_v4, dim3(sntiles), dim3(256), 0, stream, w, h, ntx, snty, s1b, s1c, s1h,
                                scb, sch, a.count, a.out, variant == -8 ? 1 : 0);
@@ -1661,10 +1233,14 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
 #ifdef MEMC_MEASURE
         // 100 + 10 * log2(TH / 16) + stripe width: owner geometry under test; -10 / -7 / -6: the round-1 owner
         int v = g_proj_variant, th = kOwnerTH, sw = kOwnerSW;
-        if (v >= 100 && v < 130) {             // the production kernel (proj_owner4) in another geometry
+        if (v >= 100 && v < 120) {             // the production kernel (proj_owner5) in another geometry (TH 16 / 32)
             th = 16 << ((v - 100) / 10);
             sw = (v - 100) % 10;
             v = -1;
+        } else if (v >= 400 && v < 420) {      // round 3's production set (proj_owner4 + carry filler), same geometry code + 300
+            th = 16 << ((v - 400) / 10);
+            sw = (v - 400) % 10;
+            v = -40;
         } else if (v >= 130 && v < 160) {      // proj_owner2 (LDS rings, three planes), same geometry code + 30
             th = 16 << ((v - 130) / 10);
             sw = (v - 130) % 10;

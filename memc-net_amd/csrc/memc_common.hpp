@@ -147,6 +147,74 @@ inline unsigned walk_grid(int tiles_x, int tiles_y, int batch, int sw)
     return (unsigned)cols * tiles_y * batch;
 }
 
+// tile_walk with its launch constants -- and the reciprocals of its divisors -- precomputed on the host: the walk's
+// eight integer divisions are ~25 scalar instructions each when the divisor is a kernel argument, and every wave of
+// every workgroup executes them; for a kernel whose scalar pipe is as busy as its vector pipe (the projection's owner
+// kernel) that was a third of its scalar instructions.  n / d == mulhi(n, ceil(2^32 / d)) exactly while n * d < 2^32
+// (make_walk_plan checks; `fast` == 0 -> the kernel calls tile_walk).
+struct WalkPlan {
+    unsigned nwg, q, r;                  // grid; nwg / 8, nwg % 8
+    unsigned per, Q, R, big, sml;        // tiles per stripe; stripes / 8, stripes % 8; tiles of a big / small XCD class
+    unsigned stripes_x, sw;              // stripes per image, tile columns per stripe (strips: tiles_x, 1)
+    unsigned m_big, m_sml, m_per, m_sx, m_sw;
+    int tiles_x, tiles_y, fast;
+};
+
+inline unsigned walk_recip(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+
+inline WalkPlan make_walk_plan(int tiles_x, int tiles_y, int batch, int sw)
+{
+    WalkPlan p;
+    p.tiles_x = tiles_x;
+    p.tiles_y = tiles_y;
+    p.sw = sw > 0 ? (unsigned)sw : 1u;
+    p.stripes_x = sw > 0 ? (unsigned)((tiles_x + sw - 1) / sw) : (unsigned)tiles_x;
+    p.nwg = walk_grid(tiles_x, tiles_y, batch, sw);
+    p.q = p.nwg / kXcds;
+    p.r = p.nwg % kXcds;
+    p.per = p.sw * (unsigned)tiles_y;
+    const unsigned S = p.nwg / p.per;                      // stripes in the launch
+    p.Q = S / kXcds;
+    p.R = S % kXcds;
+    p.big = (p.Q + 1) * p.per;
+    p.sml = p.Q * p.per;
+    p.m_big = walk_recip(p.big);
+    p.m_sml = walk_recip(p.sml);
+    p.m_per = walk_recip(p.per);
+    p.m_sx = walk_recip(p.stripes_x);
+    p.m_sw = walk_recip(p.sw);
+    const unsigned long long dmax = p.big > p.stripes_x ? p.big : p.stripes_x;
+    p.fast = (unsigned long long)p.nwg * dmax < 0x100000000ull ? 1 : 0;
+    return p;
+}
+
+__device__ __forceinline__ unsigned walk_div(unsigned n, unsigned d, unsigned m) { return d <= 1 ? n : __umulhi(n, m); }
+
+// == tile_walk(bid, p.nwg, p.tiles_x, p.tiles_y, sw) for p.fast != 0
+__device__ __forceinline__ TileCoord tile_walk_plan(unsigned bid, const WalkPlan &p)
+{
+    const unsigned xcd = bid % kXcds, idx = bid / kXcds;
+    const unsigned pos = (xcd < p.r ? xcd * (p.q + 1) : p.r * (p.q + 1) + (xcd - p.r) * p.q) + idx;
+    unsigned k, rem;
+    if (pos < p.R * p.big) {
+        k = walk_div(pos, p.big, p.m_big);
+        rem = pos - k * p.big;
+    } else {
+        const unsigned pp = pos - p.R * p.big, kk = walk_div(pp, p.sml, p.m_sml);
+        k = p.R + kk;
+        rem = pp - kk * p.sml;
+    }
+    const unsigned st = walk_div(rem, p.per, p.m_per), in_stripe = rem - st * p.per;
+    const unsigned s = k + kXcds * st;
+    const unsigned b = walk_div(s, p.stripes_x, p.m_sx), sx = s - b * p.stripes_x;
+    const unsigned ty = walk_div(in_stripe, p.sw, p.m_sw);
+    TileCoord c;
+    c.b = (int)b;
+    c.tx = (int)(sx * p.sw + (in_stripe - ty * p.sw));
+    c.ty = (int)ty;
+    return c;
+}
+
 // Measurement knobs.  They exist only in the MEASUREMENT build (-DMEMC_MEASURE -> lib/libmemc_hip_measure.so, used by
 // tools/ and by the tests that force a particular kernel).  In the product build (libmemc_hip.so) every knob is a
 // compile-time constant at its default: the ablation arms -- some of which return wrong results by construction --

@@ -1,0 +1,296 @@
+// proj_fill.hpp -- pass 3 of (Depth)FlowProjection, round 4: hole filling from BIT MASKS.  Textually included by
+// flow_projection.hip (namespace memc).
+//
+// Replaces my_package/src/my_lib_kernel.cu:1742-1836 (and the identical :2169-2264) of the reference.  The reference
+// walks from every hole (count <= 0) to the nearest cell with a non-zero count to its left, to its right and above (the
+// downward search is dead code, :1799) and writes the mean of the output at those of them whose count is positive.
+//
+// Rounds 1-3 detected holes, wrote per-tile summaries with LDS atomics and row reductions, stored the planes through the
+// cache and ran a second kernel that re-read the count cells of every tile holding a hole (8.4x its algorithmic bytes)
+// and walked them cell by cell: +46 us on a 160 us projection (720p, batch 32).  Now:
+//   * the owner kernel, which has every count of its 64 x TH tile in registers at its store epilogue, builds the tile's
+//     NON-ZERO MASKS -- one 64-bit word per row (an OR over the 16 lanes of a row: DPP), one TH-bit word per column
+//     (ds_or_b32) -- only when the tile holds a hole (one vote; 82 % of the tiles of the benchmark's flow do not);
+//   * a walk inside the tile is then a mask, a count-leading-zeros and nothing else: the owner fills, from the staged
+//     planes in LDS and BEFORE its one store of the cell, every hole whose three walks end inside the tile or at the
+//     image border (round 3 tried this with cell-by-cell walks and lost 59 us);
+//   * the holes that need a neighbouring tile are left as bits of a PENDING mask; tiles with a hole write their masks
+//     (TH + TH 64-bit words + 64 32-bit words) and all tiles their three summaries (last non-zero row per column,
+//     first / last non-zero column per row: a ctz / clz of the masks) to the call's scratch;
+//   * proj_fill_pending visits the flagged tiles, reads the masks (768 B instead of 8 KiB of counts) and finishes the
+//     pending holes: in-tile part from the masks, beyond the tile through the neighbours' summaries, nearest first.
+// Same cells, same flags, same arithmetic as the reference's walks.
+#pragma once
+
+struct FillWs {
+    int *up, *left, *right;       // per-tile summaries: last non-zero row per column, last / first non-zero column per row
+    int *hole;                    // hole[tile] != 0: tile (id (b * tiles_y + ty) * tiles_x + tx) holds a hole and wrote masks
+    unsigned long long *masks;    // per tile TileMasks<TH>, valid where hole[tile] != 0 (round 4; unused by the round 1-3 arms)
+};
+
+template <int TH>
+struct TileMasks {                // global scratch, per tile
+    unsigned long long row[TH];   // bit c: cell (row, c) of the tile has a non-zero count (stops a walk, :1778-1797)
+    unsigned long long pend[TH];  // bit c: the cell is a hole (count <= 0, :1757) that is still to be filled
+    unsigned col[64];             // bit r of word c: the same as row[r] bit c
+};
+template <int TH>
+constexpr size_t tile_mask_words() { return sizeof(TileMasks<TH>) / 8; }
+
+template <int TH>
+struct FillLds {                  // LDS of the owner kernels
+    unsigned long long row[TH];
+    unsigned col[64];
+};
+
+template <int TH>
+__device__ __forceinline__ void fill_lds_init(FillLds<TH> &f, int tid)
+{
+    static_assert(TH <= 32, "a column mask is one 32-bit word");
+    if (tid < 64) f.col[tid] = 0u;
+}
+
+// OR over each group of 16 consecutive lanes (one DPP row), result in ALL 16 lanes (row rotates)
+__device__ __forceinline__ unsigned row16_or_u32(unsigned v)
+{
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);      // row_ror:1
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);      // row_ror:2
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);      // row_ror:4
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);      // row_ror:8
+    return v;
+}
+
+__device__ __forceinline__ int last_bit64(unsigned long long m) { return 63 - __builtin_clzll(m); }   // m != 0
+
+// The three walks of the hole at (r, c) of a tile, as far as the tile's masks can tell.
+// Returns per direction: >= 0 the LOCAL position found; -1 "ran into the image border, nothing found" (count 0 there,
+// my_lib_kernel.cu:1778-1797 with the loop's bound); -2 unresolved: the walk leaves the tile.
+struct TileWalk {
+    int l, r, u;
+};
+__device__ __forceinline__ TileWalk tile_walk_masks(unsigned long long rowm, unsigned colm, int r, int c, bool first_tx,
+                                                    bool last_tx, bool first_ty)
+{
+    const unsigned long long below = (1ull << c) - 1ull;            // columns < c
+    const unsigned long long lm = rowm & below, rm = rowm & ~(below | (1ull << c));
+    const unsigned um = colm & ((1u << r) - 1u);
+    TileWalk w;
+    w.l = lm ? last_bit64(lm) : (first_tx ? -1 : -2);
+    w.r = rm ? (int)__builtin_ctzll(rm) : (last_tx ? -1 : -2);     // (cells past the image edge carry no bit)
+    w.u = um ? 31 - (int)__builtin_clz(um) : (first_ty ? -1 : -2);
+    return w;
+}
+
+// my_lib_kernel.cu:1801-1832: the fill value of one component from the three stops (counts lt / rt / ut: 0 where the walk
+// found nothing; values vl / vr / vu there; `self` the cell's own value: the dead downward search contributes 0 * self)
+__device__ __forceinline__ float fill_value(float lt, float rt, float ut, float vl, float vr, float vu, float self)
+{
+    const float fl = lt > 0.0f ? 1.0f : 0.0f, fr = rt > 0.0f ? 1.0f : 0.0f;
+    const float fu = ut > 0.0f ? 1.0f : 0.0f, fd = 0.0f;
+    return (fl * vl + fr * vr + fu * vu + fd * self) / (fl + fr + fu + fd);
+}
+
+// Store epilogue of an owner tile when pass 3 follows.  Lane `tid` owns the cells (4 q .. 4 q + 3, r) of the tile, r = tid / 16,
+// q = tid % 16, with count / output in oc / ox / oy (updated in place for the holes filled here).  `stage`: LDS the point
+// planes occupied (>= 3 TH 64 floats), free once every wave is past its read-out -- which the vote below establishes.
+// Converged code only (barriers).
+template <int TH, int NT>
+__device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stage, const FillWs &ws, int tid, int b, int tx,
+                                                    int ty, int W, int H, int tiles_x, int tiles_y, bool inb, f32x4 &ox,
+                                                    f32x4 &oy, const f32x4 &oc)
+{
+    static_assert(NT == 16 * TH, "one lane per four cells");
+    const int r = tid / 16, q = tid % 16;
+    const int tx0 = tx * 64, ty0 = ty * TH;
+    const int64_t tile_id = ((int64_t)b * tiles_y + ty) * tiles_x + tx;
+    unsigned nz = 0, hole = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (inb && oc[j] != 0.0f) nz |= 1u << j;               // what stops a walk (my_lib_kernel.cu:1778-1797)
+        if (inb && oc[j] <= 0.0f) hole |= 1u << j;             // what pass 3 fills (:1757)
+    }
+    if (!__syncthreads_or(hole != 0)) {
+        // No hole: every cell of the tile inside the image has a positive count -- every walk that enters the tile stops at
+        // its first cell.  The trivial summaries, no masks.
+        if (tid < 64 && tx0 + tid < W) ws.up[((int64_t)b * tiles_y + ty) * W + tx0 + tid] = min(ty0 + TH - 1, H - 1);
+        if (tid < TH && ty0 + tid < H) {
+            const int64_t i = ((int64_t)b * tiles_x + tx) * H + ty0 + tid;      // [b][tx][y]: a tile's rows are one run
+            ws.right[i] = tx0;
+            ws.left[i] = min(tx0 + 63, W - 1);
+        }
+        if (tid == 0) ws.hole[tile_id] = 0;
+        return;
+    }
+    // masks: the row's 64 bits in every lane of the row; the columns' TH bits in LDS
+    unsigned lo = row16_or_u32(q < 8 ? nz << (4 * q) : 0u), hi = row16_or_u32(q >= 8 ? nz << (4 * (q - 8)) : 0u);
+    const unsigned long long rowm = ((unsigned long long)hi << 32) | lo;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if ((nz >> j) & 1u) atomicOr(&fl.col[4 * q + j], 1u << r);
+    // planes staged for the gathers below: [count, x, y][r][64]
+    *reinterpret_cast<f32x4 *>(stage + r * 64 + 4 * q) = oc;
+    *reinterpret_cast<f32x4 *>(stage + TH * 64 + r * 64 + 4 * q) = ox;
+    *reinterpret_cast<f32x4 *>(stage + 2 * TH * 64 + r * 64 + 4 * q) = oy;
+    __syncthreads();
+    unsigned pend = 0;
+    if (hole) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!((hole >> j) & 1u)) continue;
+            const int c = 4 * q + j;
+            const TileWalk w = tile_walk_masks(rowm, fl.col[c], r, c, tx == 0, tx == tiles_x - 1, ty == 0);
+            if (w.l == -2 || w.r == -2 || w.u == -2) {         // a walk leaves the tile: proj_fill_pending finishes it
+                pend |= 1u << j;
+                continue;
+            }
+            // a walk that found nothing stops at the border cell, whose count is 0: its flag is 0 and the reference
+            // multiplies that cell's value by it -- 0 here
+            const int il = r * 64 + max(w.l, 0), ir = r * 64 + max(w.r, 0), iu = max(w.u, 0) * 64 + c;
+            const float lt = w.l >= 0 ? stage[il] : 0.0f, rt = w.r >= 0 ? stage[ir] : 0.0f, ut = w.u >= 0 ? stage[iu] : 0.0f;
+            if (lt + rt + ut + 0.0f <= 0.0f) continue;         // my_lib_kernel.cu:1801: the cell keeps its value
+            const float *sx = stage + TH * 64, *sy = stage + 2 * TH * 64;
+            ox[j] = fill_value(lt, rt, ut, w.l >= 0 ? sx[il] : 0.0f, w.r >= 0 ? sx[ir] : 0.0f, w.u >= 0 ? sx[iu] : 0.0f, ox[j]);
+            oy[j] = fill_value(lt, rt, ut, w.l >= 0 ? sy[il] : 0.0f, w.r >= 0 ? sy[ir] : 0.0f, w.u >= 0 ? sy[iu] : 0.0f, oy[j]);
+        }
+    }
+    // summaries (what a walk from ANOTHER tile needs) and, for proj_fill_pending, the masks
+    const unsigned plo = row16_or_u32(q < 8 ? pend << (4 * q) : 0u), phi = row16_or_u32(q >= 8 ? pend << (4 * (q - 8)) : 0u);
+    TileMasks<TH> *tm = reinterpret_cast<TileMasks<TH> *>(ws.masks) + tile_id;
+    if (q == 15 && ty0 + r < H) {
+        const int64_t i = ((int64_t)b * tiles_x + tx) * H + ty0 + r;
+        ws.right[i] = rowm ? tx0 + (int)__builtin_ctzll(rowm) : -1;
+        ws.left[i] = rowm ? tx0 + last_bit64(rowm) : -1;
+    }
+    if (q == 15) {
+        tm->row[r] = rowm;
+        tm->pend[r] = ((unsigned long long)phi << 32) | plo;
+    }
+    if (tid < 64) {
+        const unsigned cm = fl.col[tid];
+        tm->col[tid] = cm;
+        if (tx0 + tid < W) ws.up[((int64_t)b * tiles_y + ty) * W + tx0 + tid] = cm ? ty0 + 31 - (int)__builtin_clz(cm) : -1;
+    }
+    if (tid == 0) ws.hole[tile_id] = 1;
+}
+
+// Summaries and masks from the count plane, for the paths on which no owner kernel wrote them: the general path on its own
+// (far_flag == nullptr: every tile) -- every hole is pending there.  Grid-stride over tiles, 16 TH lanes.
+template <int TH>
+__global__ __launch_bounds__(16 * TH) void proj_fill_masks(
+    int W, int H, int tiles_x, int tiles_y, int batch, int64_t scb, int sch, const float *__restrict__ count, FillWs ws)
+{
+    __shared__ FillLds<TH> fl;
+    const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((unsigned)tiles_x * tiles_y);
+        const int tid = tid_now(), r = tid / 16, q = tid % 16;
+        const int tx0 = tx * 64, ty0 = ty * TH, x = tx0 + 4 * q, y = ty0 + r;
+        const bool inb = x < W && y < H;
+        fill_lds_init(fl, tid);
+        const f32x4 oc = ld_cached4(count + b * scb + (int64_t)min(y, H - 1) * sch + min(x, W - 4));
+        unsigned nz = 0, hole = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (inb && oc[j] != 0.0f) nz |= 1u << j;
+            if (inb && oc[j] <= 0.0f) hole |= 1u << j;
+        }
+        const int any_hole = __syncthreads_or(hole != 0);      // (also: fl.col is zero)
+        const unsigned lo = row16_or_u32(q < 8 ? nz << (4 * q) : 0u), hi = row16_or_u32(q >= 8 ? nz << (4 * (q - 8)) : 0u);
+        const unsigned long long rowm = ((unsigned long long)hi << 32) | lo;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if ((nz >> j) & 1u) atomicOr(&fl.col[4 * q + j], 1u << r);
+        __syncthreads();
+        const unsigned plo = row16_or_u32(q < 8 ? hole << (4 * q) : 0u), phi = row16_or_u32(q >= 8 ? hole << (4 * (q - 8)) : 0u);
+        TileMasks<TH> *tm = reinterpret_cast<TileMasks<TH> *>(ws.masks) + tile;
+        if (q == 15 && y < H) {
+            const int64_t i = ((int64_t)b * tiles_x + tx) * H + y;
+            ws.right[i] = rowm ? tx0 + (int)__builtin_ctzll(rowm) : -1;
+            ws.left[i] = rowm ? tx0 + last_bit64(rowm) : -1;
+        }
+        if (q == 15 && any_hole) {
+            tm->row[r] = rowm;
+            tm->pend[r] = ((unsigned long long)phi << 32) | plo;
+        }
+        if (tid < 64) {
+            const unsigned cm = fl.col[tid];
+            if (any_hole) tm->col[tid] = cm;
+            if (tx0 + tid < W) ws.up[((int64_t)b * tiles_y + ty) * W + tx0 + tid] = cm ? ty0 + 31 - (int)__builtin_clz(cm) : -1;
+        }
+        if (tid == 0) ws.hole[tile] = any_hole;
+        __syncthreads();                                       // fl is re-initialised by the next tile
+    }
+}
+
+// The pending holes of the flagged tiles.  Workgroup i looks after the tiles i, i + grid, ... (at most 64 of them: one
+// flag per lane of a wave).  A tile's masks go to LDS, its pending cells are listed and dealt out one per lane; a walk
+// that leaves the tile steps through the neighbouring tiles' summaries, nearest first (usually one step).
+template <int TH>
+__global__ __launch_bounds__(256) void proj_fill_pending(
+    int W, int H, int tiles_x, int tiles_y, int batch, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch,
+    const float *__restrict__ count, float *out, FillWs ws)
+{
+    __shared__ TileMasks<TH> tm;
+    __shared__ int n_holes;
+    __shared__ unsigned short hole_list[TH * 64];
+    const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
+    const unsigned mine = blockIdx.x + (threadIdx.x & 63u) * gridDim.x;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(mine < ntiles && ws.hole[mine < ntiles ? mine : 0] != 0);
+    for (; todo; todo &= todo - 1) {
+        const unsigned tile = blockIdx.x + (unsigned)__builtin_ctzll(todo) * gridDim.x;
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((unsigned)tiles_x * tiles_y);
+        const int tx0 = tx * 64, ty0 = ty * TH;
+        const TileMasks<TH> *g = reinterpret_cast<const TileMasks<TH> *>(ws.masks) + tile;
+        const int tid = threadIdx.x;
+        unsigned long long pd = 0;
+        if (tid < TH) {
+            pd = g->pend[tid];
+            tm.pend[tid] = pd;
+            tm.row[tid] = g->row[tid];
+        }
+        if (tid < 64) tm.col[tid] = g->col[tid];
+        if (tid == 0) n_holes = 0;
+        if (!__syncthreads_or(pd != 0)) continue;              // (the owner kernel filled all of this tile's holes)
+        {
+            // lane t lists the pending cells of row t / 8, columns 8 (t % 8) .. + 7
+            const int rr = tid / 8, c0 = 8 * (tid % 8);
+            unsigned bits = rr < TH ? (unsigned)(tm.pend[rr] >> c0) & 0xffu : 0u;
+            for (; bits; bits &= bits - 1)
+                hole_list[atomicAdd(&n_holes, 1)] = (unsigned short)((rr << 6) | (c0 + __builtin_ctz(bits)));
+        }
+        __syncthreads();
+        const int n = n_holes;
+        const float *cn = count + b * scb;
+        float *o = out + b * s1b;
+        for (int i = tid; i < n; i += 256) {
+            const int cell = hole_list[i], hx = cell & 63, hy = cell >> 6;
+            const int gx = tx0 + hx, gy = ty0 + hy;
+            const TileWalk w = tile_walk_masks(tm.row[hy], tm.col[hx], hy, hx, tx == 0, tx == tiles_x - 1, ty == 0);
+            int lo = w.l >= 0 ? tx0 + w.l : -1, ro = w.r >= 0 ? tx0 + w.r : -1, uo = w.u >= 0 ? ty0 + w.u : -1;
+            // beyond the tile: the last / first non-zero column of each tile to the left / right in this row, the last
+            // non-zero row of each band above in this column, nearest first
+            if (w.l == -2)
+                for (int t = tx - 1; t >= 0 && lo < 0; t--) lo = ws.left[((int64_t)b * tiles_x + t) * H + gy];
+            if (w.r == -2)
+                for (int t = tx + 1; t < tiles_x && ro < 0; t++) ro = ws.right[((int64_t)b * tiles_x + t) * H + gy];
+            if (w.u == -2)
+                for (int t = ty - 1; t >= 0 && uo < 0; t--) uo = ws.up[((int64_t)b * tiles_y + t) * W + gx];
+            // the counts the walks stopped at (0 when they ran into the image border)
+            const float lt = lo >= 0 ? cn[(int64_t)gy * sch + lo] : 0.0f;
+            const float rt = ro >= 0 ? cn[(int64_t)gy * sch + ro] : 0.0f;
+            const float ut = uo >= 0 ? cn[(int64_t)uo * sch + gx] : 0.0f;
+            if (lt + rt + ut + 0.0f <= 0.0f) continue;
+            // a walk that found nothing ends at the border cell (column 0 / W-1, row 0): its flag is 0, but the reference
+            // still multiplies that cell's value by it -- keep the operand identical
+            const int lc = lo >= 0 ? lo : 0, rc = ro >= 0 ? ro : W - 1, ur = uo >= 0 ? uo : 0;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                float *pl = o + k * s1c;
+                float *self = pl + (int64_t)gy * s1h + gx;
+                *self = fill_value(lt, rt, ut, pl[(int64_t)gy * s1h + lc], pl[(int64_t)gy * s1h + rc],
+                                   pl[(int64_t)ur * s1h + gx], *self);
+            }
+        }
+        __syncthreads();                                       // the masks and the list are reused by the next tile
+    }
+}

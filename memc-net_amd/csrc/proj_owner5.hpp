@@ -1,0 +1,239 @@
+// proj_owner5.hpp -- the owner-computes (Depth)FlowProjection forward, round 4.  Textually included by
+// flow_projection.hip (namespace memc, behind FillWs / kPtW4 / kCountUnit / trace_mark_proj).
+//
+// Replaces my_package/src/my_lib_kernel.cu:1630-1735 (scatter + averaging) and :2053-2167 (depth) of the reference.
+//
+// What round 3's proj_owner4 was bound by (ISA of the product build): 1450 vector and 1900
+// SCALAR instructions per wave, both pipes near their issue rate.  Two thirds of them were the per-wave register
+// compaction of the hits (ballot, mbcnt, three ds_permute, cyclic batch bookkeeping -- executed by all 64 lanes for
+// every one of the 20 sources a lane scans) and the mask algebra of four float compares per source.  Here:
+//   * a window test is ONE subtract and ONE unsigned compare per axis: for x2 >= 0 the float order is the order of the
+//     bit patterns, so  bits(x2) - bits(xlo) < bits(xhi) - bits(xlo)  (unsigned) is  xlo <= x2 < xhi; negative values,
+//     NaNs and values below xlo wrap to huge unsigned numbers and fail;
+//   * a hit goes STRAIGHT to the fp64 point planes under its exec mask -- ds_add_f64 costs the same 8.8 clocks per
+//     wave-instruction whatever the number of active lanes (tools/probes, round 1), so the ~90 masked splat
+//     instructions per plane and tile cost ~1.6 k LDS clocks, against the ~6 k issue clocks the compaction cost the
+//     vector and scalar pipes;
+//   * far-source detection of the home quads is a max3 chain and one compare per quad.
+// Everything else is proj_owner4's: 64 x TH cell tiles, 16 TH lanes, the scan region dilated by kReach, deferred fx loads
+// for rows far from the tile, two planes (count * 2^20 + sum vx, sum vy) for FlowProjection and three for the depth
+// operator, box sums in double, one reciprocal per cell, far flags by nonce, per-tile motion bounds.
+#pragma once
+
+template <bool DEPTH, int TH, int kReach, int MINW, bool TRACE = false>
+__global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
+    int W, int H, int tiles_x, int tiles_y,
+    int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
+    const float *__restrict__ flow, const float *__restrict__ depth,
+    float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, int *__restrict__ bounds,
+    FillWs ws, WalkPlan plan, int nonce)
+{
+    constexpr int NT = 16 * TH;                   // one lane per four owned cells
+    constexpr int NP = DEPTH ? 3 : 2;             // planes: (count, vx, vy) or (count * 2^20 + vx, vy)
+    constexpr int kPtH = TH + 1, kPlane = kPtH * kPtW4;
+    constexpr int kScanPadX = kReach + 4;         // dilated tile: columns, kept 4-aligned
+    constexpr int kScanW = 64 + 2 * kScanPadX;    // source columns
+    constexpr int kScanH = TH + 2 * kReach + 1;   // source rows: [ty0 - kReach - 1, ty0 + TH + kReach)
+    constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + NT - 1) / NT;
+    static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
+    static_assert((2 * kReach + 1) * (2 * kReach + 1) < 4096 && kReach <= 128, "count * 2^20 + sum(vx) must split exactly");
+    __shared__ __attribute__((aligned(16))) double P[NP * kPlane];
+    __shared__ FillLds<TH> fl;                    // the hole filler's masks (fill epilogue only)
+    __shared__ int tile_max[2];                   // bit patterns of max |fx|, max |fy| over the tile's own FAR sources (0: none)
+
+    const TileCoord tc = plan.fast ? tile_walk_plan(blockIdx.x, plan)
+                                   : tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, plan.sw > 1 || plan.stripes_x != (unsigned)tiles_x ? (int)plan.sw : 0);
+    if (tc.tx >= tiles_x) return;                 // virtual column of the last stripe
+    const int b = tc.b, tx0 = tc.tx * 64, ty0 = tc.ty * TH;
+    const int tid0 = threadIdx.x;                 // (thread index of the first half of the kernel, see below)
+    const int wave_index = __builtin_amdgcn_readfirstlane(tid0 / kWave);
+    trace_mark_proj<TRACE>(0);
+    fill_lds_init(fl, tid0);
+    if (tid0 < 2) tile_max[tid0] = 0;
+    {
+        f32x4 *pz = reinterpret_cast<f32x4 *>(P);
+        for (int i = tid0; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // scan loads: slot -> (row, column) by one division and increments; fy of every slot now, fx / depth now only for
+    // the slots whose rows lie within kNearRows of the tile (the others almost never pass the row test and fetch theirs
+    // inside the branch); unconditional addresses (dead slots read pixel 0)
+    constexpr int kNearRows = 8;
+    auto far_it = [](int it) {
+        const int first = NT * it / kCols4, last = (NT * it + NT - 1) / kCols4;
+        return last <= kReach + 1 - kNearRows || first >= kReach + 1 + TH + kNearRows;
+    };
+    const float *flow_b = flow + b * s1b;
+    const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
+    f32x4 fx[kIts], fy[kIts], dd[kIts];
+    int sx[kIts], sy[kIts];
+    bool live[kIts];
+    int row = tid0 / kCols4, c4 = tid0 % kCols4;
+#pragma unroll
+    for (int it = 0; it < kIts; it++) {
+        sx[it] = tx0 - kScanPadX + 4 * c4;
+        sy[it] = ty0 - kReach - 1 + row;
+        live[it] = row < kScanH && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
+        const unsigned off = live[it] ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
+        fy[it] = ld_cached4_u(flow_b + s1c, off);
+        if (!far_it(it)) {
+            fx[it] = ld_cached4_u(flow_b, off);
+            if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+        }
+        row += NT / kCols4;
+        c4 += NT % kCols4;
+        if (c4 >= kCols4) {
+            c4 -= kCols4;
+            row++;
+        }
+    }
+    trace_mark_proj<TRACE>(1);                 // loads issued, P zeroed
+    __syncthreads();                           // P is zero
+    if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    trace_mark_proj<TRACE>(2);                 // loads arrived
+
+    // Window [ty0 - 1, ty0 + TH - 1] x [tx0 - 1, tx0 + 63] of the points (T, L) = ((int)y2, (int)x2), and validity
+    // (0 <= x2 <= W - 1, my_lib_kernel.cu:1670), as ONE range test per axis on the bit patterns.
+    const int xlo_b = __float_as_int((float)max(tx0 - 1, 0)), ylo_b = __float_as_int((float)max(ty0 - 1, 0));
+    const unsigned xrange = (unsigned)(min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1) - xlo_b);
+    const unsigned yrange = (unsigned)(min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1) - ylo_b);
+    // point (py, px) -> byte offset 8 (py * pitch + px - cell0) into a plane (the constants pinned in SGPRs: rematerialised at every use
+    // they cost the scalar pipe, which is as busy as the vector one here, two or three moves per source)
+    unsigned pitch8 = 8 * kPtW4, ucell8 = (unsigned)-(8 * ((ty0 - 1) * kPtW4 + (tx0 - 1)));
+    double kunit = kCountUnit;
+    asm volatile("" : "+s"(pitch8), "+s"(ucell8), "+s"(kunit));
+    bool far = false;
+
+#pragma unroll
+    for (int it = 0; it < kIts; it++) {
+        const bool lv = live[it];
+        // dead slots (outside the image / the scan region) fail every window test: their row is NaN
+        const float syf = lv ? (float)sy[it] : __int_as_float(0x7fc00000), sxf = (float)sx[it];
+        // The quad lies inside the tile itself (tx0, the pad and sx are multiples of 4: all four sites or none) -- only
+        // slots that can hold rows of the tile evaluate this (and the far-source test below) at all.
+        const bool kHomeIt = NT * it / kCols4 < kReach + 1 + TH && (NT * it + NT - 1) / kCols4 >= kReach + 1;   // folds: `it` is unrolled
+        if (kHomeIt) {
+            // A far source (|f| >= kReach) whose home is this tile: the image is redone by proj_owner_far.  The hit test
+            // below does NOT ask for |f| < kReach: an image without a valid far source has only near hits, which every
+            // owner of their point sees (they lie inside its scan region); in an image WITH one the owners may disagree
+            // -- and every tile of that image is recomputed anyway.  One max chain and one compare per quad; NaN motion
+            // takes the branch too and is found not valid.
+            const bool homeq = lv && (unsigned)(sy[it] - ty0) < (unsigned)TH && (unsigned)(sx[it] - tx0) < 64u;
+            const f32x4 &a = fx[it], &c = fy[it];
+            const float m = fmaxf(fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))),
+                                  fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3]))));
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(homeq && !(m < (float)kReach)) != 0, 0)) {   // wave-uniform, cold
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float fxv = a[j], fyv = c[j], x2 = (sxf + (float)j) + fxv, y2 = syf + fyv;
+                    const bool valid = homeq && !(fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach) && x2 >= 0.0f &&
+                                       y2 >= 0.0f && x2 <= (float)(W - 1) && y2 <= (float)(H - 1);
+                    far = far || valid;
+                    if (valid) {               // the tile's bound on its far sources' motion, for proj_owner_far:
+                        atomicMax(&tile_max[0], __float_as_int(fabsf(fxv)));      // non-negative floats order like their bits
+                        atomicMax(&tile_max[1], __float_as_int(fabsf(fyv)));
+                    }
+                }
+            }
+        }
+        float y2[4];
+        bool wy[4], rowany = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            y2[j] = syf + fy[it][j];
+            wy[j] = (unsigned)(__float_as_int(y2[j]) - ylo_b) < yrange;
+            rowany = rowany || wy[j];
+        }
+        // rows farther from the tile than the local motion: the whole wave leaves after the four y tests
+        if (__builtin_amdgcn_ballot_w64(rowany) == 0) continue;
+        f32x4 fxq = fx[it], ddq = dd[it];
+        if (far_it(it)) {                      // rare: requested only now (and consumed inside this branch)
+            const unsigned off = lv ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
+            fxq = ld_cached4_u(flow_b, off);
+            if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float fxv = fxq[j], fyv = fy[it][j];
+            const float x2 = (sxf + (float)j) + fxv;           // (float)x + fx, as the reference rounds it
+            if (wy[j] && (unsigned)(__float_as_int(x2) - xlo_b) < xrange) {
+                const unsigned a = __umul24((unsigned)(int)y2[j], pitch8) + ((((unsigned)(int)x2) << 3) + ucell8);
+                double *q = reinterpret_cast<double *>(reinterpret_cast<char *>(P) + a);
+                if (DEPTH) {                   // my_lib_kernel.cu:2102-2114: v = -d * f, count += d
+                    const float d = ddq[j];
+                    lds_add_f64(q, (double)(d * 1.0f));
+                    lds_add_f64(q + kPlane, -(double)(d * fxv));
+                    lds_add_f64(q + 2 * kPlane, -(double)(d * fyv));
+                } else {                       // one source: count += 1, sum(vx) += -fx
+                    lds_add_f64(q, kunit - (double)fxv);
+                    lds_add_f64(q + kPlane, -(double)fyv);
+                }
+            }
+        }
+    }
+    if (far) {                                 // this image is redone by proj_owner_far.  The flag words are NOT cleared
+        far_flag[b % kFlagWords] = nonce;      // before the call: "raised" = "holds this call's nonce" (launcher), so stale
+        far_flag[kFlagWords] = nonce;          // or uninitialised words can at worst cause a needless redo, never a missed one
+    }
+    trace_mark_proj<TRACE>(3);                 // scan + splat done (wave 0)
+    __syncthreads();                           // every wave's points are in P (and the tile's motion bound in tile_max)
+    trace_mark_proj<TRACE>(4);
+    // (from here on the thread index is REBUILT from the wave's index, a scalar, and the lane's rank in the wave:
+    // it need not live through the scan)
+    const int tid = wave_index * kWave + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (tid < 2) bounds[2 * (((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx) + tid] = tile_max[tid];
+
+    // Every lane owns four cells of a row: 2x2 box sums of the points of columns c-1 .. c+3, rows cy-1 and cy (border
+    // duplicates as weights 2, see proj_scatter_tiled), summed in DOUBLE -- exact, also for the packed plane:
+    // sum_i w_i (count_i 2^20 + S_i) = (sum w count) 2^20 + sum w S with |sum w S| < 2^19 (at most 2500 sources reach a
+    // 2x2 block, weights <= 4, |v| < kReach) -- then split and rounded to fp32 ONCE per cell.
+    const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
+    const bool inb = cx < W && cy < H;            // (no early exit: the epilogue below has barriers)
+    const double wy0 = (cy == H - 1) ? 2.0 : 1.0;
+    f32x4 ox, oy, oc;
+    {
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const double *r0 = P + (cy - ty0) * kPtW4 + (cx - tx0);   // column offset a multiple of 4: 16-byte pairs
+        double box[NP][4];
+#pragma unroll
+        for (int pl = 0; pl < NP; pl++) {
+            const double *a = r0 + pl * kPlane, *c = a + kPtW4;
+            const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
+            const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
+            const double top[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
+            const double bot[5] = {c01[0], c01[1], c23[0], c23[1], c[4]};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const double wx0 = (cx + j == W - 1) ? 2.0 : 1.0;
+                box[pl][j] = __builtin_fma(wy0, __builtin_fma(wx0, bot[j + 1], bot[j]), __builtin_fma(wx0, top[j + 1], top[j]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v0, v1, v2;
+            if (DEPTH) {
+                v0 = (float)box[0][j];  v1 = (float)box[1][j];  v2 = (float)box[NP - 1][j];
+            } else {                           // A = count * 2^20 + sum(vx): split exactly
+                const double cnt = __builtin_rint(box[0][j] * (1.0 / kCountUnit));
+                v0 = (float)cnt;
+                v1 = (float)__builtin_fma(cnt, -kCountUnit, box[0][j]);
+                v2 = (float)box[1][j];
+            }
+            if (v0 > 0.0f) {                   // my_lib_kernel.cu:1730-1735; one reciprocal for both components
+                const float inv = 1.0f / v0;   // (<= 1 ulp from the two divisions)
+                v1 = v1 * inv;
+                v2 = v2 * inv;
+            }
+            oc[j] = v0;  ox[j] = v1;  oy[j] = v2;
+        }
+    }
+    if (ws.up)                                 // pass 3 (hole filling) follows: fill what the tile can, summaries, masks
+        owner_fill_epilogue<TH, NT>(fl, reinterpret_cast<float *>(P), ws, tid, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, inb,
+                                    ox, oy, oc);
+    if (inb) {                                 // single-use streams: nothing of this launch reads them back from cache
+        st_stream4(out + b * s1b + (int64_t)cy * s1h + cx, ox);
+        st_stream4(out + b * s1b + s1c + (int64_t)cy * s1h + cx, oy);
+        st_stream4(count + b * scb + (int64_t)cy * sch + cx, oc);
+    }
+    trace_mark_proj<TRACE>(5);
+}

@@ -161,3 +161,23 @@ for _name in list(_SYMBOLS):
     _cpu = _name.replace("_gpu_", "_cpu_")
     globals()[_cpu] = _cpu_unavailable(_cpu)
     __all__.append(_cpu)
+
+
+def calibration_stream(src, dst, reads_per_write):
+    """memc_calibration_stream (include/memc_warp.h, measurement aid): dst[i] = sum of `reads_per_write` streams of src,
+    16 bytes per lane, non-temporal, the tiled kernels' XCD walk.  src: flat float32 CUDA tensor of reads_per_write *
+    dst.numel() elements; dst.numel() a multiple of 4.  Returns the C function's int."""
+    if not (src.is_cuda and dst.is_cuda and src.dtype == torch.float32 and dst.dtype == torch.float32):
+        raise TypeError("calibration_stream: float32 CUDA tensors")
+    if dst.numel() % 4 or src.numel() != int(reads_per_write) * dst.numel() or not (src.is_contiguous() and dst.is_contiguous()):
+        raise TypeError("calibration_stream: src must hold reads_per_write * dst.numel() contiguous elements")
+    cfunc = _lib.memc_calibration_stream
+    cfunc.restype = ctypes.c_int
+    cfunc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
+    with torch.cuda.device(src.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)
+        return int(cfunc(stream, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), dst.numel() // 4,
+                         int(reads_per_write)))
+
+
+__all__.append("calibration_stream")

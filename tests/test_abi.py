@@ -15,7 +15,7 @@ def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"^\s*(?:const\s+char\s*\*\s*|int\s+)(\w+)\s*\(", text, flags=re.M)
-    assert len(names) == 28, names      # 10 layer entry points + 10 kernel launchers + memc_hip_version + memc_gradinput1_is_stored + 3 x 2 of the three extensions
+    assert len(names) == 29, names      # 10 layer entry points + 10 kernel launchers + memc_hip_version + memc_gradinput1_is_stored + 3 x 2 of the three extensions + memc_calibration_stream
     return names
 
 

@@ -1124,9 +1124,10 @@ def test_projection_forward_needs_no_zero_fill(oracle, case):
     dwant = oracle.depth_flow_projection_forward(d["flow"], d["depth"], 1)
     try:
         # automatic (fast path where it applies), general, scalar; then the owner kernel's geometries (tile height
-        # 16 / 32 / 64 x walk in strips / stripes 2 / 4 tile columns wide: 10x-12x the production kernel, 13x-15x the
-        # LDS-ring kernel, 16x the persistent one) and the round-1 owner kernel
-        for variant in (-1, 1, 0, 100, 104, 110, 112, 120, 124, 130, 142, 154, 160, 164, -10):
+        # 16 / 32 x walk in strips / stripes 2 / 4 tile columns wide: 10x-11x the production kernel, 40x-41x round 3's
+        # production set -- proj_owner4 and the carry filler --, 13x-15x the LDS-ring kernel (tile height up to 64), 16x the
+        # persistent one) and the round-1 owner kernel
+        for variant in (-1, 1, 0, 100, 104, 110, 112, -40, 400, 404, 412, 130, 142, 154, 160, 164, -10):
             M.set_variant("projection", variant)
             for fh in (0, 1):
                 cnt = torch.full((f.shape[0], 1, f.shape[2], f.shape[3]), float("nan"), device=dev())
@@ -1159,8 +1160,9 @@ def test_hole_filling_on_camera_pans(oracle, shift):
     assert (want_cnt == 0).mean() > 0.02                         # the strip is there
     f = T(flow)
     try:
-        # carry filler, literal walker, general path + carries; carry filler over 16 / 32 / 64-row bands
-        for variant in (-1, -9, 1, 100, 114, 124, 134, 140, 164, -10):
+        # mask filler (in the owner's epilogue + proj_fill_pending), literal walker, general path + masks; 16-row bands;
+        # round 3's carry filler over 16 / 32 / 64-row bands
+        for variant in (-1, -9, 1, 100, 114, -40, 400, 414, 134, 140, 154, 164, -10):
             M.set_variant("projection", variant)
             cnt, out = torch.full((B, 1, H, W), float("nan"), device=dev()), torch.full_like(f, float("nan"))
             assert my_lib.FlowProjectionLayer_gpu_forward(f, cnt, out, 1) == 0

@@ -246,7 +246,8 @@ def bench_projection(rows, dev, B, H, W, flow_kind, tag, proj_variants=()):
     def pre2():
         gin.zero_(); gd.zero_()
     med, mn = time_launches(lambda: L.DepthFlowProjectionLayer_gpu_backward(f, d, cnt, out, gout, gin, gd), pre2)
-    report(rows, "depth_flow_projection_bwd %s %dx%dx%d flow=%s" % (tag, B, H, W, flow_kind), B * H * W, 48, med, mn)
+    # flow 8 + depth 4 + count 4 + forward output 8 + gradoutput 8 | gradinput1 8 + gradinput2 4 (rounds 1-3 booked 48)
+    report(rows, "depth_flow_projection_bwd %s %dx%dx%d flow=%s" % (tag, B, H, W, flow_kind), B * H * W, 44, med, mn)
 
 
 def bench_interp(rows, dev, B, C, H, W, flow_kind, tag):

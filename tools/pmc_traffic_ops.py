@@ -21,11 +21,11 @@ KERNELS = {
     "fi_bwd_c3_pk": (180, SITES),                     # x 12 + flow 8 + taps 64 + gout 12 | gin1 12 + gin2 8 + gin3 64
     "fi_fwd_tiled_c4n": (4 * (2 * 64 + 2 + 16), SITES // 4),
     "fi_fwd_blend_c3": (188, SITES),
-    "proj_owner4<false": (20, SITES),                 # flow 8 | count 4 + out 8
-    "proj_owner4<true": (24, SITES),
-    "proj_fillhole_carry": (0.5, SITES),              # (a small fraction of the cells: holes and what their walks read)
+    "proj_owner5<false": (20, SITES),                 # flow 8 | count 4 + out 8
+    "proj_owner5<true": (24, SITES),
+    "proj_fill_pending": (0.05, SITES),               # (the holes the owner left pending and what their walks read)
     "proj_bwd_tiled<false": (28, SITES),              # flow 8 + count 4 + gout 8 | gin 8
-    "proj_bwd_tiled<true": (48, SITES),
+    "proj_bwd_tiled<true": (44, SITES),               # flow 8 + depth 4 + count 4 + out 8 + gout 8 | gin1 8 + gin2 4
     "bl_fwd_tiled<3": (32, SITES),                    # x 12 + flow 8 | out 12
     "bl_bwd_c3_pk": (52, SITES),                      # x 12 + flow 8 + gout 12 | gin1 12 + gin2 8
     # FilterInterpolation backward, C = 64, batch 8 (fi_bwd_cn.hip): the operator's 912 B/site split over its kernels

@@ -12,7 +12,7 @@ M.use()                             # the measurement build: ablation / A-B arms
 
 dev = torch.device("cuda:0")
 # automatic, general path, owner geometries (tile height 16 / 32 / 64, strips / stripes), the round-1 owner kernel
-OTHERS = (-1, 1, 100, 104, 110, 112, 120, 122, 130, 144, 150, 164, -10)
+OTHERS = (-1, 1, 100, 104, 110, 112, -40, 402, 414, 130, 144, 150, 164, -10)
 bad = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     g = torch.Generator(device=dev); g.manual_seed(it)

@@ -40,6 +40,11 @@ KERNELS = {
 _PROJ2_MARKS = [(1, "issue scan loads + zero P + barrier"), (2, "wait for the loads"),
                 (3, "scan: window test + compaction + dense fp64 splat (wave 0)"), (4, "barrier (slowest wave)"),
                 (5, "box sum + normalise + store")]
+# round 4: the production owner kernel (direct masked splats) with timestamps
+KERNELS["proj5"] = dict(setter="memc_debug_set_trace_buffer_proj", op="projection", variant=-41, last=5, th=32,
+                        marks=[(1, "issue scan loads + zero P"), (2, "barrier + wait for the loads"),
+                               (3, "scan: window tests + masked fp64 splats (wave 0)"), (4, "barrier (slowest wave)"),
+                               (5, "box sum + normalise + store")])
 for _code, _th in ((0, 16), (1, 32), (2, 64)):      # proj_owner2 (round 2), tile height 16 / 32 / 64
     KERNELS["proj2_%d" % _th] = dict(setter="memc_debug_set_trace_buffer_proj", op="projection", variant=290 + _code,
                                      last=5, th=_th, marks=_PROJ2_MARKS)
