@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     unsigned long long *const accA = reinterpret_cast<unsigned long long *>(smem);   // the planes alias the image
     unsigned long long *const accB = accA + PG::kCap;
-    int *bb = reinterpret_cast<int *>(smem + PG::kImageBytes);           // 16 ints: boxes; 8 ints: maxima
+    int *bb = reinterpret_cast<int *>(smem + PG::kImageBytes);           // 16 ints: boxes; 16 ints: the waves' bound statistics
     int *mx = bb + 16;
 
     trace_mark<TR>(0);
@@ -222,37 +222,36 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
             rmin = min(rmin, max(s.iy - 1, 0));  rmax = max(rmax, min(s.iy + 2, H - 1));
         }
     }
-    {                                          // the tile's largest |gradoutput| and |tap| (bit patterns), per wave;
-        int mg = 0, mt = 0;                    // handed over by the barrier inside tile_bbox
+    // per-site bounds of the packed planes (memc_pk.hpp): s = (the site's largest |gradoutput|) x (its largest |tap|),
+    // published per wave and handed over by the barrier inside tile_bbox
+    int sbits[4], gbits[4], tmax = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < 4; j++) {
+        int mg = 0, mt = 0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) mg = max(mg, __float_as_int(go[c][j]) & 0x7FFFFFFF);
+        for (int c = 0; c < 3; c++) mg = max(mg, __float_as_int(go[c][j]) & 0x7FFFFFFF);
 #pragma unroll
-            for (int k = 0; k < 16; k++) mt = max(mt, __float_as_int(tp[k][j]) & 0x7FFFFFFF);
-        }
-        mg = wave_max_i32(inb ? mg : 0);
-        mt = wave_max_i32(inb ? mt : 0);
-        if ((tid & (kWave - 1)) == 0) {
-            mx[(tid / kWave) * 2] = mg;
-            mx[(tid / kWave) * 2 + 1] = mt;
-        }
+        for (int k = 0; k < 16; k++) mt = max(mt, __float_as_int(tp[k][j]) & 0x7FFFFFFF);
+        const float sv = __int_as_float(mg) * __int_as_float(mt);
+        gbits[j] = mg;
+        tmax = max(tmax, ((g.valid >> j) & 1u) ? mt : 0);
+        // (Inf x 0 = NaN: not finite, per-site atomics put it where the reference does; a zero bound adds nothing)
+        sbits[j] = (mg >= 0x7F800000 || mt >= 0x7F800000) ? 0x7FC00000 : __float_as_int(sv);
     }
+    pk_tile_publish(mx, tid, sbits, gbits, g.valid, tmax);
     const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
     const Bands bands = make_bands<LX, true, PG::kCap>(box);
-    int mg = max(max(mx[0], mx[2]), max(mx[4], mx[6])), mt = max(max(mx[1], mx[3]), max(mx[5], mx[7]));
-    mg = __builtin_amdgcn_readfirstlane(mg);
-    mt = __builtin_amdgcn_readfirstlane(mt);
-    // 0: nothing to add (every contribution of this tile is zero); 2: Inf / NaN among the inputs -- per-site global
-    // atomics; 1: the packed planes
-    const int mode = (mg == 0 || mt == 0) ? 0 : ((mg >= 0x7F800000 || mt >= 0x7F800000) ? 2 : 1);
-    const PkScale ps = pk_scale(mode == 1 ? mg : 0x3F800000, mode == 1 ? mt : 0x3F800000);     // memc_pk.hpp
+    const PkTile ps = pk_tile_resolve<4>(mx);
+    // packed: the site's image gradient goes through the planes; outl: per-site global atomics (a bound beyond the tile's
+    // block exponent, or an Inf / NaN among the site's inputs -- which then land exactly where the reference puts them)
+    const unsigned packed = pk_packed_sites(ps, sbits, g.valid), outl = pk_outlier_sites(ps, sbits, g.valid);
+    const int mode = ps.any;                   // 0: no packed site has anything to add (workgroup-uniform)
     const float *in_b = in1 + b * s1b;
     float *gin1_b = gin1 + b * s1b;
     unsigned done = 0;
     trace_mark<TR>(2);                                         // bounding box known
     fi_bwd_zero_invalid(inb, g.valid, gin2_b, s2c, o2, gin3_b, s3c, o3);
-    auto image_atomics = [&](unsigned todo) {  // mode 2
+    auto image_atomics = [&](unsigned todo) {  // outlier sites
         while (todo) {
             const int j = __ffs(todo) - 1;
             todo &= todo - 1;
@@ -287,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
             zero_planes(r.h * r.pitch);
             __syncthreads();
         }
-        fi_bwd_adds_pk(r, fast, g, tp, go, ps.sa, ps.sb, accA, accB, W, H);
+        fi_bwd_adds_pk(r, fast & packed, g, tp, go, ps.sa, ps.sb, accA, accB, W, H);
         __syncthreads();
         if (bi == 0) trace_mark<TR>(3);                    // accumulated
 #pragma unroll
@@ -298,9 +297,8 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
         pk_flush<256>(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
         __syncthreads();                   // the planes have been read: the LDS becomes the image
         if (bi == 0) trace_mark<TR>(4);                    // flushed
-    } else if (mode == 2) {
-        image_atomics(fast);
     }
+    if (fast & outl) image_atomics(fast & outl);
     tile_stage_store<3>(r, sl, sr, tile);
     __syncthreads();
     if (bi == 0) trace_mark<TR>(5);                        // image staged

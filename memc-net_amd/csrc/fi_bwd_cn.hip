@@ -1220,8 +1220,7 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
 #define MEMC_OWNER(TH, TR, TRACE)                                                                                  \
     do {                                                                                                           \
         using Gm_ = OwnGeom<FpFilter, TH>;                                                                         \
-        static const bool once = (allow_big_lds(fi_bwd_image_owner<FpFilter, TH, TR>, Gm_::kBytes), true);         \
-        (void)once;                                                                                                \
+        allow_big_lds(fi_bwd_image_owner<FpFilter, TH, TR>, Gm_::kBytes);   /* per launch: a per-DEVICE attribute */ \
         const int cty = (h + TH - 1) / TH;                                                                         \
         hipLaunchKernelGGL((fi_bwd_image_owner<FpFilter, TH, TR>), dim3((unsigned)ntx * cty * batch),              \
                            dim3(Gm_::kThreads), Gm_::kBytes, stream, w, h, channel, ntx, cty, nty,                 \
@@ -1264,8 +1263,7 @@ int bl_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                        w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                        input1, input2, gradoutput, gradinput2, tbox);
     using Gm = OwnGeom<FpBilinear, 16>;
-    static const bool once = (allow_big_lds(fi_bwd_image_owner<FpBilinear, 16, false>, Gm::kBytes), true);
-    (void)once;
+    allow_big_lds(fi_bwd_image_owner<FpBilinear, 16, false>, Gm::kBytes);   // per launch: the attribute belongs to the current device
     hipLaunchKernelGGL((fi_bwd_image_owner<FpBilinear, 16, false>), dim3(ntiles), dim3(Gm::kThreads), Gm::kBytes, stream,
                        w, h, channel, ntx, nty, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c,
                        s2h, (int64_t)0, (int64_t)0, 0, input2, static_cast<const float *>(nullptr), gradoutput,

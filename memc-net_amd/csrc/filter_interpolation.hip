@@ -1119,8 +1119,7 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
         using G = TileGeom<LX, (NT == 256 ? 3072 : 6144), NT>;                                             \
         const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                        \
         const int lds = G::kCapPx * 16 + 4 * 4 * (NT / 64);                                                \
-        static const bool once = (allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG, LX, ABL>, lds), true);            \
-        (void)once;                                                                                        \
+        allow_big_lds(fi_fwd_tiled_c4n<SW, NT, RAG, LX, ABL>, lds);   /* per launch: a per-DEVICE attribute */ \
         hipLaunchKernelGGL((fi_fwd_tiled_c4n<SW, NT, RAG, LX, ABL>), dim3((unsigned)((ntx + (SW ? SW : 1) - 1) / (SW ? SW : 1) * \
                                                                     (SW ? SW : 1)) * nty * batch),          \
                            dim3(NT), lds, stream, w, h, channel, ntx, nty, (int64_t)s1b,                   \

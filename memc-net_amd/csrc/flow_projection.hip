@@ -1062,7 +1062,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3((FLAG) != nullptr && sntiles > gq ? gq : sntiles), \
                        dim3(256), 4 * A::kPlane * 4 + 64, stream, w, h, ntx, snty, sntiles, s1b, s1c, s1h, sdb, sdh,  \
                        scb, sch, a.flow, a.depth, a.count, a.out, FLAG)
-    bool only_part = false;                                  // measurement arms that time one piece
+    bool only_part = false, skip_pending = false;            // measurement arms that time one piece
     MEMC_PATH(flag ? (DEPTH ? "dproj_fwd:owner" : "proj_fwd:owner") : (DEPTH ? "dproj_fwd:general" : "proj_fwd:general"));
     // waves per SIMD the register allocator must leave room for = what the LDS admits: FlowProjection 4 workgroups per
     // CU at TH = 32 (2 planes, 35 KiB), the depth operator 3 (53 KiB)
@@ -1073,6 +1073,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             const WalkPlan plan = make_walk_plan(ntx, nty, batch, sw);
 #ifdef MEMC_MEASURE
             only_part = variant == -5 || variant == -20 || variant == -41;
+            skip_pending = variant == -42;          // timing arm: everything but proj_fill_pending (pending holes stay unfilled)
             if (r3_set) {
                 hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(16 * TH),
                                    0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
@@ -1198,7 +1199,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
         if (launch_status() != 0) return -1;
     }
 #undef MEMC_PROJ_SCATTER
-    if (a.fillhole && !only_part) {
+    if (a.fillhole && !only_part && !skip_pending) {
         if (ws.up) {
             // workgroup i looks after the tiles i, i + grid, ... (at most 64 of them: one flag per lane of a wave); most
             // tiles have no hole (18 % on the benchmark's smooth flow) and cost their workgroup one flag load

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NT, NT == 256 && CAP == 3072 ? 3 : 4) void bl_bwd_c
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     unsigned long long *const accA = reinterpret_cast<unsigned long long *>(smem);   // the planes alias the image
     unsigned long long *const accB = accA + CAP;
-    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);            // 4 ints per wave: boxes; then one per wave: maxima
+    int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);            // 4 ints per wave: boxes; then 4 per wave: bound statistics
     int *mx = bb + 4 * (NT / kWave);
 
     const TileCoord tc = tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, sw);
@@ -291,23 +291,25 @@ __global__ __launch_bounds__(NT, NT == 256 && CAP == 3072 ? 3 : 4) void bl_bwd_c
             rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
         }
     }
-    {                                          // the tile's largest |gradoutput| (bit pattern), per wave; handed over
-        int mg = 0;                            // by the barrier inside tile_region
+    // per-site bounds of the packed planes (memc_pk.hpp): the bilinear weights are <= 1, so a site's bound is its largest
+    // |gradoutput|; published per wave and handed over by the barrier inside tile_region
+    int sbits[4];
+    unsigned vmask = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+    for (int j = 0; j < 4; j++) {
+        int mg = 0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) mg = max(mg, __float_as_int(go[c][j]) & 0x7FFFFFFF);
-        mg = wave_max_i32(inb ? mg : 0);
-        if ((tid & (kWave - 1)) == 0) mx[tid / kWave] = mg;
+        for (int c = 0; c < 3; c++) mg = max(mg, __float_as_int(go[c][j]) & 0x7FFFFFFF);
+        sbits[j] = mg;                         // (>= 0x7F800000: Inf / NaN -- per-site global atomics)
+        vmask |= (st[j].valid ? 1u : 0u) << j;
     }
+    pk_tile_publish(mx, tid, sbits, sbits, vmask, 0x3F800000);
     const Region r = tile_region<LX, true, CAP, NT>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
-    int mg = 0;
-#pragma unroll
-    for (int wv = 0; wv < NT / kWave; wv++) mg = max(mg, mx[wv]);
-    mg = __builtin_amdgcn_readfirstlane(mg);
-    // 0: nothing to add; 2: Inf / NaN in gradoutput -- global atomics; 1: the packed planes
-    const int mode = mg == 0 ? 0 : (mg >= 0x7F800000 ? 2 : 1);
-    const PkScale ps = pk_scale(mode == 1 ? mg : 0x3F800000, 0x3F7FFFFF);       // weights <= 1: their exponent is 0
+    const PkTile ps = pk_tile_resolve<NT / kWave>(mx);
+    // packed: through the planes; everything else with a non-zero bound (beyond the tile's block exponent, or not finite)
+    // scatters with global atomics, exactly as the reference does
+    const unsigned packed = pk_packed_sites(ps, sbits, vmask);
+    const int mode = ps.any;                   // 0: no packed site has anything to add (workgroup-uniform)
     const float *in_b = in1 + b * s1b;
     float *gin1_b = gin1 + b * s1b;
     const StageSlot sl = stage_slots<NT>(r);
@@ -322,8 +324,8 @@ __global__ __launch_bounds__(NT, NT == 256 && CAP == 3072 ? 3 : 4) void bl_bwd_c
         const BlSite &s = st[j];
         const bool staged = r.covers(s.L, s.R, s.T, s.Bm);
         staged_mask |= (staged ? 1u : 0u) << j;
-        if (mode == 0) continue;
-        if (staged && mode == 1) {
+        if (sbits[j] == 0) continue;           // a zero gradient adds nothing
+        if (staged && ((packed >> j) & 1u)) {
             const int aT = (s.T - r.y0) * r.pitch, aB = (s.Bm - r.y0) * r.pitch;
             const int aL = pk_col(s.L - r.x0, r.pitch >> 2), aR = pk_col(s.R - r.x0, r.pitch >> 2);
             const float g0 = ps.sa * go[0][j], g1 = ps.sa * go[1][j], g2 = ps.sa * go[2][j];
@@ -473,9 +475,8 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
 #endif
 #define MEMC_BL_BWD_PK(CAP, NT)                                                                                 \
         do {                                                                                                       \
-            constexpr size_t lds = CAP * 16 + 32 * (NT / kWave);    /* image or planes; 20 bytes per wave: box, maximum */ \
-            static const bool once = (allow_big_lds(bl_bwd_c3_pk<CAP, NT>, lds), true);                            \
-            (void)once;                                                                                            \
+            constexpr size_t lds = CAP * 16 + 32 * (NT / kWave);    /* image or planes; 32 bytes per wave: box, bounds */ \
+            allow_big_lds(bl_bwd_c3_pk<CAP, NT>, lds);    /* per launch: the attribute belongs to the CURRENT device */ \
             const int ntyk = (h + NT / 16 - 1) / (NT / 16);                                                        \
             hipLaunchKernelGGL((bl_bwd_c3_pk<CAP, NT>), dim3(walk_grid(ntx, ntyk, batch, sw)), dim3(NT), lds,      \
                                stream, w, h, ntx, ntyk, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, \

@@ -302,7 +302,9 @@ inline int launch_status()
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// Kernels that carve more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU) must opt in once.
+// Kernels that carve more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU) must opt in -- per DEVICE
+// (hipFuncSetAttribute applies to the current device): the launchers call this before every such launch, it is cheap,
+// and a process that drives several GPUs stays correct (a once-per-process flag would leave device 1 without it).
 template <typename K>
 inline void allow_big_lds(K kernel, int bytes)
 {

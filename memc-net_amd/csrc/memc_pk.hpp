@@ -119,26 +119,123 @@ __device__ __forceinline__ void pk_flush(const Region &r, const unsigned long lo
 // largest value of a non-negative int over the wave (float bit patterns of |x| order like ints; NaN sorts last)
 __device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
 
-// Block exponents from the tile's largest |a| and |b| (bit patterns, both finite and non-zero): 2^(ea + eb) > max|a| x
-// max|b|, off by less than a factor two -- the mantissas' product tells whether the sum of the two exponents is one too
-// many.  sa = 2^(11 - ea), sb = 2^(11 - eb) pre-scale the factors, inv = 2^(ea + eb - 22) (a double: the float may not
-// exist) restores the sums.
-struct PkScale {
-    float sa, sb;
-    double inv;
-};
-__device__ __forceinline__ PkScale pk_scale(int abits, int bbits)
+// sum over the 64 lanes of a wave, returned in every lane
+__device__ __forceinline__ float wave_sum_f32(float v)
 {
-    const int ea = pk_exponent(abits);
-    int eb = pk_exponent(bbits);
-    int e0, e1;
-    const float mm = frexpf(__int_as_float(abits), &e0) * frexpf(__int_as_float(bbits), &e1);
-    if (mm < 0.4999f && eb > -100) eb -= 1;
-    PkScale s;
-    s.sa = ldexpf(1.0f, 11 - ea);
-    s.sb = ldexpf(1.0f, 11 - eb);
-    s.inv = ldexp(1.0, ea + eb - 22);
-    return s;
+    // row_shr:1,2,4,8 inside each row of 16 lanes (bound_ctrl: lanes without a source add 0)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));
+    const int a = __builtin_amdgcn_readlane(__float_as_int(v), 15), b = __builtin_amdgcn_readlane(__float_as_int(v), 31);
+    const int c = __builtin_amdgcn_readlane(__float_as_int(v), 47), d = __builtin_amdgcn_readlane(__float_as_int(v), 63);
+    return (__int_as_float(a) + __int_as_float(b)) + (__int_as_float(c) + __int_as_float(d));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The tile's block exponent, round 4: from PER-SITE bounds, with outlier sites set aside.
+//
+// Rounds 3's exponent came from (the tile's largest |gradoutput|) x (its largest |tap|): one site with a gradient or a tap
+// of 1e4 coarsened the fixed-point grid of the whole tile, and cells whose own gradient is O(0.01) lost their 1e-4 -- a
+// coupling between sites that the reference's fp32 atomics do not have (my_lib_kernel.cu:1276-1288).  Now every site
+// has its own bound s = (its largest |gradoutput|) x (its largest |tap|) >= each of its contributions, and the tile takes
+//     B = min(max s, kPkOutlier x mean s)          over its valid sites with a finite, non-zero bound
+// as the bound of the PACKED sites: 2^e > B by less than a factor two, contributions are rounded once to a multiple of
+// 2^(e - 22), a cell's error is at most (its contributions) x 2^(e - 23) <= n x 1.9e-6 x (the tile's MEAN site bound).
+// Sites beyond B -- and sites with an Inf / NaN input -- add their image gradient with per-site global atomics, exactly as
+// the reference does.  (By Markov fewer than 1 / 16 of a tile's sites can exceed 16 x the mean.)
+// ---------------------------------------------------------------------------------------------------------
+constexpr float kPkOutlier = 16.0f;
+struct PkTile {
+    float sa, sb;      // pre-scales of gradoutput and of the weights: |g sa| |w sb| <= 2^22 for every packed site
+    double inv;        // 2^(e - 22): restores the sums
+    float limit;       // B: a site is packed iff its bound is <= limit (never true for NaN; -1: no site is)
+    int any;           // some packed site has something to add
+};
+
+// Before the workgroup's next barrier: the wave's share of (max s, max |g|, sum s, count) -> mx[4 wave .. 4 wave + 3].
+// sbits[j] / gbits[j]: bit patterns of site j's bound and of its largest |gradoutput| (non-negative floats);
+// valid: the lane's sites that take part at all; tbits: bit pattern of the lane's largest |weight factor| (the taps; 1.0
+// where the weights are the bilinear ones alone) -- only its exponent travels, for the overflow guard of pk_tile_resolve.
+__device__ __forceinline__ void pk_tile_publish(int *mx, unsigned tid, const int (&sbits)[4], const int (&gbits)[4], unsigned valid,
+                                                int tbits)
+{
+    int M = 0, G = 0, cnt = 0;
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bool use = ((valid >> j) & 1u) && sbits[j] != 0 && sbits[j] < 0x7F800000;
+        M = max(M, use ? sbits[j] : 0);
+        G = max(G, use ? gbits[j] : 0);
+        sum += use ? __int_as_float(sbits[j]) : 0.0f;
+        cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(use));
+    }
+    M = wave_max_i32(M);
+    G = wave_max_i32(G);
+    sum = wave_sum_f32(sum);
+    const int T = wave_max_i32(tbits < 0x7F800000 ? tbits : 0);
+    if ((tid & (kWave - 1)) == 0) {
+        int *m = mx + 4 * (tid / kWave);
+        m[0] = M;  m[1] = G;  m[2] = __float_as_int(sum);  m[3] = cnt | (T & ~0xFFFF);   // (cnt <= 256 per wave)
+    }
+}
+
+// After that barrier (NW waves published).  Workgroup-uniform.
+template <int NW>
+__device__ __forceinline__ PkTile pk_tile_resolve(const int *mx)
+{
+    int M = 0, G = 0, T = 0, cnt = 0;
+    float sum = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        M = max(M, mx[4 * w]);
+        G = max(G, mx[4 * w + 1]);
+        sum += __int_as_float(mx[4 * w + 2]);
+        cnt += mx[4 * w + 3] & 0xFFFF;
+        T = max(T, mx[4 * w + 3] & ~0xFFFF);
+    }
+    M = __builtin_amdgcn_readfirstlane(M);
+    G = __builtin_amdgcn_readfirstlane(G);
+    T = __builtin_amdgcn_readfirstlane(T);
+    cnt = __builtin_amdgcn_readfirstlane(cnt);
+    sum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sum)));
+    PkTile t;
+    t.sa = t.sb = 1.0f;  t.inv = 1.0;  t.limit = -1.0f;  t.any = 0;
+    if (cnt == 0) return t;                                // nothing finite and non-zero: whatever is left is an outlier
+    const float B = fminf(__int_as_float(M), kPkOutlier * (sum / (float)cnt));
+    if (!(B > 0.0f) || !(B < 3.0e38f)) return t;           // (a mean that overflowed)
+    int e, eg, et;
+    (void)frexpf(B, &e);                                   // B < 2^e
+    (void)frexpf(__int_as_float(G), &eg);
+    (void)frexpf(__int_as_float(T), &et);
+    // The factors are scaled separately -- |g sa| < 2^11 by construction, |w sb| <= 2^(11 + eg + et - e) -- and every one
+    // of sa, sb and w sb must stay a normal float: magnitudes beyond that (a tile whose largest |gradoutput| x largest
+    // |tap| exceeds its packed bound by 2^100, gradients below 2^-100) take per-site atomics for everything.
+    if (eg < -100 || 11 - e + eg < -100 || 11 - e + eg > 100 || eg + et - e > 100) return t;
+    t.sa = ldexpf(1.0f, 11 - eg);
+    t.sb = ldexpf(1.0f, 11 - e + eg);
+    t.inv = ldexp(1.0, e - 22);
+    t.limit = B;
+    t.any = 1;
+    return t;
+}
+
+// the lane's sites that are packed / that take per-site atomics instead
+__device__ __forceinline__ unsigned pk_packed_sites(const PkTile &t, const int (&sbits)[4], unsigned valid)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (((valid >> j) & 1u) && sbits[j] != 0 && __int_as_float(sbits[j]) <= t.limit) m |= 1u << j;
+    return m;
+}
+__device__ __forceinline__ unsigned pk_outlier_sites(const PkTile &t, const int (&sbits)[4], unsigned valid)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (((valid >> j) & 1u) && sbits[j] != 0 && !(__int_as_float(sbits[j]) <= t.limit)) m |= 1u << j;
+    return m;
 }
 
 }  // namespace memc

@@ -41,7 +41,7 @@ def N(t):
 
 def close(got, want, what, rtol=RTOL):
     """tests/_parity.py: 1e-4 abs where |want| <= 10, max(1e-4, rtol * |want|) beyond; the observed error is recorded."""
-    return P.close(np.asarray(got), np.asarray(want), what, rtol if rtol else RTOL)
+    return P.close(np.asarray(got), np.asarray(want), what, rtol)          # (rtol = 0.0: 1e-4 absolute everywhere)
 
 
 CASES = [
@@ -186,6 +186,55 @@ def test_filter_interpolation_backward_rgb_scaling_and_special_values(oracle, ar
                 sg, st, float(np.abs(got - want).max()) / scale)
     finally:
         M.reset()
+
+
+def _heavy_tail_variants(rng, kn, gn):
+    """(name, taps, gradoutput): a few values four to five orders of magnitude above their O(0.05) neighbours."""
+    out = []
+    k1 = kn.copy(); k1[0, 5, 20, 70] = 1.0e4                       # one tap of one site
+    out.append(("one tap of 1e4", k1, gn))
+    g1 = gn.copy(); g1[0, 1, 21, 33] = 1.0e4; g1[0, 2, 40, 100] = -3.0e3
+    out.append(("gradoutput of 1e4 and -3e3 at two sites", kn, g1))
+    g2 = gn.copy()                                                  # a heavy tail: 3 % of the sites a hundred times larger
+    m = rng.random(g2.shape[0:1] + g2.shape[2:]) < 0.03
+    g2 *= np.where(m, 100.0, 1.0).astype(np.float32)[:, None]
+    out.append(("3 % of the sites with 100 x the gradient", kn, g2))
+    g3 = gn.copy(); g3[:, :, :, 64:] *= np.float32(2.0 ** 12)      # half of a tile row 4096 x the other half
+    out.append(("a step of 2^12 across the tiles", kn, g3))
+    return out
+
+
+def test_rgb_backward_packed_planes_heavy_tailed_tile(oracle):
+    """The packed fixed-point planes of the RGB backward passes round every contribution to the TILE's grid (memc_pk.hpp).
+    The reference's fp32 atomics (my_lib_kernel.cu:1276-1288) have no coupling between sites: a tap or a gradient of 1e4
+    beside O(0.05) values must not cost the small cells their 1e-4.  Round 4: per-site bounds, block exponent from
+    min(max, 16 x mean), sites beyond it by per-site atomics -- gradinput1 against the oracle under the ordinary rule
+    (1e-4 absolute up to |want| = 10, 1e-5 relative beyond)."""
+    import my_package._ext.my_lib as my_lib
+    rng = np.random.default_rng(77)
+    B, H, W = 1, 48, 128
+    xn, fn = synth.np_image(rng, B, 3, H, W), synth.np_flow(rng, B, H, W, "smooth", 2.0)
+    kn = (rng.random((B, 16, H, W)) * 0.05).astype(np.float32)
+    gn = (rng.standard_normal((B, 3, H, W)) * 0.05).astype(np.float32)
+    for name, kk, gg in _heavy_tail_variants(rng, kn, gn):
+        w1, w2, w3 = oracle.filter_interpolation_backward(xn, fn, kk, gg)
+        h1, h2, h3 = _c3_backward(my_lib, xn, fn, kk, gg)
+        small = np.abs(w1) <= 1.0                                   # the cells the outliers do not reach
+        assert small.mean() > 0.5
+        err_small = float(np.abs(h1[small].astype(np.float64) - w1[small]).max())
+        assert err_small <= 2e-5, "FilterInterpolation gradinput1, %s: small cells off by %.3g" % (name, err_small)
+        close(h1, w1, "FilterInterpolation gradinput1, " + name, RTOL)
+        close(h2, w2, "FilterInterpolation gradinput2, " + name, 3 * RTOL)
+        close(h3, w3, "FilterInterpolation gradinput3, " + name, RTOL)
+        # the bilinear warp's backward: the same planes, bound = the site's largest |gradoutput|
+        v1, v2 = oracle.interpolation_backward(xn, fn, gg)
+        i1, i2 = torch.zeros(xn.shape, device=dev()), torch.full(fn.shape, 3.0, device=dev())
+        assert my_lib.InterpolationLayer_gpu_backward(T(xn), T(fn), T(gg), i1, i2) == 0
+        small = np.abs(v1) <= 1.0
+        err_small = float(np.abs(N(i1)[small].astype(np.float64) - v1[small]).max())
+        assert err_small <= 2e-5, "Interpolation gradinput1, %s: small cells off by %.3g" % (name, err_small)
+        close(N(i1), v1, "Interpolation gradinput1, " + name, RTOL)
+        close(N(i2), v2, "Interpolation gradinput2, " + name, 3 * RTOL)
 
 
 def test_interpolation_backward_rgb_packed_planes_special_values(oracle):
