@@ -37,13 +37,23 @@
  *   - work is enqueued asynchronously on `stream`; no host synchronisation, no state carried from one call to
  *     the next (one process-wide call COUNTER excepted: it only makes every call's "far source" flag value unique),
  *     nothing shared between concurrent calls (any number of streams / host threads), nothing read from the
- *     environment.  One exception to "never allocates": a (Depth)FlowProjection FORWARD call takes a
- *     stream-ordered scratch allocation for the duration of the call (1.3 KiB of per-image "far source" flags for
- *     its fast path; with hole filling also the filler's carry tables, about 0.4 bytes per pixel), released in
- *     stream order before the call returns (hipMallocFromPoolAsync / hipFreeAsync).  It comes from a PRIVATE memory
- *     pool of the stream's device, created on the first such call and kept for the life of the process; the
- *     device's default pool and its attributes are not touched.  Inside a stream capture, or if the allocation
- *     fails, the call uses its general path and a hole filler that need no scratch (slower, same results);
+ *     environment.  One exception to "never allocates": a (Depth)FlowProjection FORWARD call uses a scratch block on the
+ *     device (1.3 KiB of per-image "far source" flags and 8 bytes per tile for its fast path; with hole filling also the
+ *     filler's per-tile summaries and masks, about 0.8 bytes per pixel).  The block comes from a PRIVATE memory pool of
+ *     the stream's device (created on the first such call; the device's default pool and its attributes are not
+ *     touched) and is kept for the NEXT call on the same stream -- calls on one stream run in order, and a stream-ordered
+ *     allocation per call cost the host ~30 us (round 4) -- for the life of the process, one block per stream that ever
+ *     ran such a call.  Two host threads enqueueing on the same stream at the same time do not share it (the second
+ *     takes a stream-ordered allocation of its own, released in stream order before the call returns).  Inside a
+ *     stream capture, or if the allocation fails, the call uses its general path and a hole filler that need no scratch
+ *     (slower, same results);
+ *   - precision of the two scattered-into image gradients at three channels (FilterInterpolation / Interpolation
+ *     gradinput1): every contribution g * weight is rounded ONCE to a multiple of 2^(e - 22), where 2^e bounds the
+ *     contributions of the PACKED sites of its 64 x 16 (64 x 32) tile: 2^e < 2 * min(largest site bound, 16 x a robust
+ *     mean of the tile's site bounds), a site's bound being (its largest |gradoutput|) x (its largest |tap|).  A cell's
+ *     error is at most (its number of contributions) x 2^(e - 23) -- ~2e-6 x the tile's typical contribution at the 16
+ *     contributions of an ordinary cell.  Sites beyond that bound, and sites with an Inf / NaN input, add with fp32
+ *     atomics exactly as the reference does (my_lib_kernel.cu:1276-1288); four and more channels never round;
  *   - return 0 on success, -1 on a failed shape/stride check or a launch error (my_lib_cuda.c:611-646,
  *     my_lib_kernel.cu:1559-1566).
  *

@@ -1203,7 +1203,8 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
         if (ws.up) {
             // workgroup i looks after the tiles i, i + grid, ... (at most 64 of them: one flag per lane of a wave); most
             // tiles have no hole (18 % on the benchmark's smooth flow) and cost their workgroup one flag load
-            const unsigned fg = ntiles < 4096u ? ntiles : (ntiles + 63u) / 64u > 4096u ? (ntiles + 63u) / 64u : 4096u;
+            // (2048: what the chip holds at once -- eight 256-lane workgroups on each of 256 CUs)
+            const unsigned fg = ntiles < 2048u ? ntiles : (ntiles + 63u) / 64u > 2048u ? (ntiles + 63u) / 64u : 2048u;
 #ifdef MEMC_MEASURE
             if (old_fill)
                 hipLaunchKernelGGL(proj_fillhole_carry<TH>, dim3(fg), dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c,

@@ -139,7 +139,8 @@ __device__ __forceinline__ float wave_sum_f32(float v)
 // of 1e4 coarsened the fixed-point grid of the whole tile, and cells whose own gradient is O(0.01) lost their 1e-4 -- a
 // coupling between sites that the reference's fp32 atomics do not have (my_lib_kernel.cu:1276-1288).  Now every site
 // has its own bound s = (its largest |gradoutput|) x (its largest |tap|) >= each of its contributions, and the tile takes
-//     B = min(max s, kPkOutlier x mean s)          over its valid sites with a finite, non-zero bound
+//     B = min(max s, kPkOutlier x mean s)          over its valid sites with a finite, non-zero bound (a ROBUST mean:
+//                                                  the median of the waves' means, each without its wave's largest s)
 // as the bound of the PACKED sites: 2^e > B by less than a factor two, contributions are rounded once to a multiple of
 // 2^(e - 22), a cell's error is at most (its contributions) x 2^(e - 23) <= n x 1.9e-6 x (the tile's MEAN site bound).
 // Sites beyond B -- and sites with an Inf / NaN input -- add their image gradient with per-site global atomics, exactly as
@@ -181,29 +182,43 @@ __device__ __forceinline__ void pk_tile_publish(int *mx, unsigned tid, const int
 }
 
 // After that barrier (NW waves published).  Workgroup-uniform.
+// The "mean" is robust against the very outliers it is there to find: every wave's mean leaves out the wave's largest
+// bound, and the tile takes the (lower) MEDIAN of its waves' means -- one site of 1e4 among a thousand of 0.1 would lift
+// the plain mean a hundredfold, and with it the grid of everything packed.
 template <int NW>
 __device__ __forceinline__ PkTile pk_tile_resolve(const int *mx)
 {
-    int M = 0, G = 0, T = 0, cnt = 0;
-    float sum = 0.0f;
+    int M = 0, G = 0, T = 0, nmean = 0;
+    int mean_bits[NW];                                     // bit patterns of the waves' trimmed means (non-negative floats)
 #pragma unroll
     for (int w = 0; w < NW; w++) {
-        M = max(M, mx[4 * w]);
-        G = max(G, mx[4 * w + 1]);
-        sum += __int_as_float(mx[4 * w + 2]);
-        cnt += mx[4 * w + 3] & 0xFFFF;
-        T = max(T, mx[4 * w + 3] & ~0xFFFF);
+        const int Mw = __builtin_amdgcn_readfirstlane(mx[4 * w]);
+        const int cw = __builtin_amdgcn_readfirstlane(mx[4 * w + 3]);
+        const float sw = __int_as_float(__builtin_amdgcn_readfirstlane(mx[4 * w + 2]));
+        M = max(M, Mw);
+        G = max(G, __builtin_amdgcn_readfirstlane(mx[4 * w + 1]));
+        T = max(T, cw & ~0xFFFF);
+        const int cnt = cw & 0xFFFF;
+        // (sum - max can come out a rounding error below zero when the wave's largest bound IS the sum)
+        const float mean = cnt > 1 ? fmaxf(sw - __int_as_float(Mw), 0.0f) / (float)(cnt - 1) : __int_as_float(Mw);
+        mean_bits[w] = cnt > 0 ? __builtin_amdgcn_readfirstlane(__float_as_int(mean)) : -1;
+        nmean += cnt > 0 ? 1 : 0;
     }
-    M = __builtin_amdgcn_readfirstlane(M);
-    G = __builtin_amdgcn_readfirstlane(G);
-    T = __builtin_amdgcn_readfirstlane(T);
-    cnt = __builtin_amdgcn_readfirstlane(cnt);
-    sum = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sum)));
     PkTile t;
     t.sa = t.sb = 1.0f;  t.inv = 1.0;  t.limit = -1.0f;  t.any = 0;
-    if (cnt == 0) return t;                                // nothing finite and non-zero: whatever is left is an outlier
-    const float B = fminf(__int_as_float(M), kPkOutlier * (sum / (float)cnt));
-    if (!(B > 0.0f) || !(B < 3.0e38f)) return t;           // (a mean that overflowed)
+    if (nmean == 0) return t;                              // nothing finite and non-zero: whatever is left is an outlier
+    // lower median of the nmean valid means: the one with exactly (nmean - 1) / 2 valid means before it (ties by index)
+    int med = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        int before = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++)
+            before += (mean_bits[k] >= 0 && (mean_bits[k] < mean_bits[i] || (mean_bits[k] == mean_bits[i] && k < i))) ? 1 : 0;
+        if (mean_bits[i] >= 0 && before == (nmean - 1) / 2) med = mean_bits[i];
+    }
+    const float B = fminf(__int_as_float(M), kPkOutlier * fmaxf(__int_as_float(med), 1.0e-37f));
+    if (!(B > 0.0f) || !(B < 3.0e38f)) return t;
     int e, eg, et;
     (void)frexpf(B, &e);                                   // B < 2^e
     (void)frexpf(__int_as_float(G), &eg);

@@ -39,8 +39,10 @@ constexpr size_t tile_mask_words() { return sizeof(TileMasks<TH>) / 8; }
 
 template <int TH>
 struct FillLds {                  // LDS of the owner kernels
-    unsigned long long row[TH];
-    unsigned col[64];
+    unsigned long long row[TH];   // non-zero mask of every row
+    unsigned long long pend[TH];  // pending holes of every row
+    unsigned col[64];             // non-zero mask of every column
+    int n_holes;                  // (the holes' list itself lives behind the staged planes, in the point planes' bytes)
 };
 
 template <int TH>
@@ -48,6 +50,8 @@ __device__ __forceinline__ void fill_lds_init(FillLds<TH> &f, int tid)
 {
     static_assert(TH <= 32, "a column mask is one 32-bit word");
     if (tid < 64) f.col[tid] = 0u;
+    if (tid < TH) f.pend[tid] = 0ull;
+    if (tid == 0) f.n_holes = 0;
 }
 
 // OR over each group of 16 consecutive lanes (one DPP row), result in ALL 16 lanes (row rotates)
@@ -92,8 +96,12 @@ __device__ __forceinline__ float fill_value(float lt, float rt, float ut, float 
 
 // Store epilogue of an owner tile when pass 3 follows.  Lane `tid` owns the cells (4 q .. 4 q + 3, r) of the tile, r = tid / 16,
 // q = tid % 16, with count / output in oc / ox / oy (updated in place for the holes filled here).  `stage`: LDS the point
-// planes occupied (>= 3 TH 64 floats), free once every wave is past its read-out -- which the vote below establishes.
-// Converged code only (barriers).
+// planes occupied (>= 3 TH 64 floats + TH 64 shorts), free once every wave is past its read-out -- which the vote below
+// establishes.
+// Holes are a per cent of the cells: handled by the lanes that own them, a wave would run the walk four times (once per
+// cell of a lane) with a lane or two active.  They are LISTED in LDS and dealt out one per lane instead -- with the
+// benchmark's flows the whole list is one pass of the first wave -- and the owners read their cells back from the stage.
+// Converged code only (barriers).  ws.hole[tile]: 0 no hole, 1 holes, all filled here, 2 holes pending.
 template <int TH, int NT>
 __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stage, const FillWs &ws, int tid, int b, int tx,
                                                     int ty, int W, int H, int tiles_x, int tiles_y, bool inb, f32x4 &ox,
@@ -121,56 +129,70 @@ __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stag
         if (tid == 0) ws.hole[tile_id] = 0;
         return;
     }
-    // masks: the row's 64 bits in every lane of the row; the columns' TH bits in LDS
-    unsigned lo = row16_or_u32(q < 8 ? nz << (4 * q) : 0u), hi = row16_or_u32(q >= 8 ? nz << (4 * (q - 8)) : 0u);
-    const unsigned long long rowm = ((unsigned long long)hi << 32) | lo;
+    // masks: the row's 64 bits (an OR over the 16 lanes of a row), the columns' TH bits (LDS); the holes' list
+    {
+        const unsigned lo = row16_or_u32(q < 8 ? nz << (4 * q) : 0u), hi = row16_or_u32(q >= 8 ? nz << (4 * (q - 8)) : 0u);
+        if (q == 15) fl.row[r] = ((unsigned long long)hi << 32) | lo;
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if ((nz >> j) & 1u) atomicOr(&fl.col[4 * q + j], 1u << r);
+    unsigned short *const hole_list = reinterpret_cast<unsigned short *>(stage + 3 * TH * 64);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if ((hole >> j) & 1u) hole_list[atomicAdd(&fl.n_holes, 1)] = (unsigned short)((r << 6) | (4 * q + j));
     // planes staged for the gathers below: [count, x, y][r][64]
     *reinterpret_cast<f32x4 *>(stage + r * 64 + 4 * q) = oc;
     *reinterpret_cast<f32x4 *>(stage + TH * 64 + r * 64 + 4 * q) = ox;
     *reinterpret_cast<f32x4 *>(stage + 2 * TH * 64 + r * 64 + 4 * q) = oy;
     __syncthreads();
-    unsigned pend = 0;
-    if (hole) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (!((hole >> j) & 1u)) continue;
-            const int c = 4 * q + j;
-            const TileWalk w = tile_walk_masks(rowm, fl.col[c], r, c, tx == 0, tx == tiles_x - 1, ty == 0);
-            if (w.l == -2 || w.r == -2 || w.u == -2) {         // a walk leaves the tile: proj_fill_pending finishes it
-                pend |= 1u << j;
-                continue;
-            }
-            // a walk that found nothing stops at the border cell, whose count is 0: its flag is 0 and the reference
-            // multiplies that cell's value by it -- 0 here
-            const int il = r * 64 + max(w.l, 0), ir = r * 64 + max(w.r, 0), iu = max(w.u, 0) * 64 + c;
-            const float lt = w.l >= 0 ? stage[il] : 0.0f, rt = w.r >= 0 ? stage[ir] : 0.0f, ut = w.u >= 0 ? stage[iu] : 0.0f;
-            if (lt + rt + ut + 0.0f <= 0.0f) continue;         // my_lib_kernel.cu:1801: the cell keeps its value
-            const float *sx = stage + TH * 64, *sy = stage + 2 * TH * 64;
-            ox[j] = fill_value(lt, rt, ut, w.l >= 0 ? sx[il] : 0.0f, w.r >= 0 ? sx[ir] : 0.0f, w.u >= 0 ? sx[iu] : 0.0f, ox[j]);
-            oy[j] = fill_value(lt, rt, ut, w.l >= 0 ? sy[il] : 0.0f, w.r >= 0 ? sy[ir] : 0.0f, w.u >= 0 ? sy[iu] : 0.0f, oy[j]);
+    const int n = fl.n_holes;
+    float *const sx = stage + TH * 64, *const sy = stage + 2 * TH * 64;
+    for (int i = tid; i < n; i += NT) {
+        const int cell = hole_list[i], hr = cell >> 6, hc = cell & 63;
+        const TileWalk w = tile_walk_masks(fl.row[hr], fl.col[hc], hr, hc, tx == 0, tx == tiles_x - 1, ty == 0);
+        if (w.l == -2 || w.r == -2 || w.u == -2) {             // a walk leaves the tile: proj_fill_pending finishes it
+            atomicOr(&fl.pend[hr], 1ull << hc);
+            continue;
         }
+        // a walk that found nothing stops at the border cell, whose count is 0: its flag is 0 and the reference
+        // multiplies that cell's value by it -- 0 here
+        const int il = hr * 64 + max(w.l, 0), ir = hr * 64 + max(w.r, 0), iu = max(w.u, 0) * 64 + hc;
+        const float lt = w.l >= 0 ? stage[il] : 0.0f, rt = w.r >= 0 ? stage[ir] : 0.0f, ut = w.u >= 0 ? stage[iu] : 0.0f;
+        if (lt + rt + ut + 0.0f <= 0.0f) continue;             // my_lib_kernel.cu:1801: the cell keeps its value
+        // (reads touch cells with a non-zero count -- or times 0 --, writes cells with count <= 0: no ordering needed)
+        const float vx = fill_value(lt, rt, ut, w.l >= 0 ? sx[il] : 0.0f, w.r >= 0 ? sx[ir] : 0.0f, w.u >= 0 ? sx[iu] : 0.0f, sx[cell]);
+        const float vy = fill_value(lt, rt, ut, w.l >= 0 ? sy[il] : 0.0f, w.r >= 0 ? sy[ir] : 0.0f, w.u >= 0 ? sy[iu] : 0.0f, sy[cell]);
+        sx[cell] = vx;
+        sy[cell] = vy;
     }
-    // summaries (what a walk from ANOTHER tile needs) and, for proj_fill_pending, the masks
-    const unsigned plo = row16_or_u32(q < 8 ? pend << (4 * q) : 0u), phi = row16_or_u32(q >= 8 ? pend << (4 * (q - 8)) : 0u);
-    TileMasks<TH> *tm = reinterpret_cast<TileMasks<TH> *>(ws.masks) + tile_id;
-    if (q == 15 && ty0 + r < H) {
-        const int64_t i = ((int64_t)b * tiles_x + tx) * H + ty0 + r;
+    __syncthreads();
+    ox = *reinterpret_cast<const f32x4 *>(sx + r * 64 + 4 * q);     // the owners take their cells back
+    oy = *reinterpret_cast<const f32x4 *>(sy + r * 64 + 4 * q);
+    // summaries (what a walk from ANOTHER tile needs) and, for proj_fill_pending, the masks of a tile with pending holes
+    int pending = 0;
+#pragma unroll
+    for (int i = 0; i < TH; i += 16) pending |= (fl.pend[i + q] != 0) ? 1 : 0;      // (every lane: 2 broadcast-free reads)
+    pending = __builtin_amdgcn_ballot_w64(pending != 0) != 0;
+    if (tid < TH && ty0 + tid < H) {
+        const unsigned long long rowm = fl.row[tid];
+        const int64_t i = ((int64_t)b * tiles_x + tx) * H + ty0 + tid;
         ws.right[i] = rowm ? tx0 + (int)__builtin_ctzll(rowm) : -1;
         ws.left[i] = rowm ? tx0 + last_bit64(rowm) : -1;
     }
-    if (q == 15) {
-        tm->row[r] = rowm;
-        tm->pend[r] = ((unsigned long long)phi << 32) | plo;
-    }
-    if (tid < 64) {
+    if (tid < 64 && tx0 + tid < W) {
         const unsigned cm = fl.col[tid];
-        tm->col[tid] = cm;
-        if (tx0 + tid < W) ws.up[((int64_t)b * tiles_y + ty) * W + tx0 + tid] = cm ? ty0 + 31 - (int)__builtin_clz(cm) : -1;
+        ws.up[((int64_t)b * tiles_y + ty) * W + tx0 + tid] = cm ? ty0 + 31 - (int)__builtin_clz(cm) : -1;
     }
-    if (tid == 0) ws.hole[tile_id] = 1;
+    if (pending) {                                             // (wave-uniform; the same in every wave)
+        TileMasks<TH> *tm = reinterpret_cast<TileMasks<TH> *>(ws.masks) + tile_id;
+        if (tid < TH) {
+            tm->row[tid] = fl.row[tid];
+            tm->pend[tid] = fl.pend[tid];
+        }
+        if (tid < 64) tm->col[tid] = fl.col[tid];
+    }
+    if (tid == 0) ws.hole[tile_id] = pending ? 2 : 1;
 }
 
 // Summaries and masks from the count plane, for the paths on which no owner kernel wrote them: the general path on its own
@@ -217,9 +239,27 @@ __global__ __launch_bounds__(16 * TH) void proj_fill_masks(
             if (any_hole) tm->col[tid] = cm;
             if (tx0 + tid < W) ws.up[((int64_t)b * tiles_y + ty) * W + tx0 + tid] = cm ? ty0 + 31 - (int)__builtin_clz(cm) : -1;
         }
-        if (tid == 0) ws.hole[tile] = any_hole;
+        if (tid == 0) ws.hole[tile] = any_hole ? 2 : 0;        // (2: pending holes -- here every hole is)
         __syncthreads();                                       // fl is re-initialised by the next tile
     }
+}
+
+// first entry >= 0 of table[t * stride] for t = t0, t0 + dir, ... (t != tend), -1 if none: independent loads, eight at a time
+__device__ __forceinline__ int nearest_summary(const int *table, int64_t stride, int t0, int dir, int tend)
+{
+    constexpr int CH = 8;
+    int res = -1;
+    for (int t = t0; res < 0 && (dir > 0 ? t < tend : t > tend); t += CH * dir) {
+        int v[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const int tt = t + k * dir;
+            v[k] = (dir > 0 ? tt < tend : tt > tend) ? table[(int64_t)tt * stride] : -1;
+        }
+#pragma unroll
+        for (int k = CH - 1; k >= 0; k--) res = v[k] >= 0 ? v[k] : res;     // (the nearest valid one wins)
+    }
+    return res;
 }
 
 // The pending holes of the flagged tiles.  Workgroup i looks after the tiles i, i + grid, ... (at most 64 of them: one
@@ -235,7 +275,7 @@ __global__ __launch_bounds__(256) void proj_fill_pending(
     __shared__ unsigned short hole_list[TH * 64];
     const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
     const unsigned mine = blockIdx.x + (threadIdx.x & 63u) * gridDim.x;
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(mine < ntiles && ws.hole[mine < ntiles ? mine : 0] != 0);
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(mine < ntiles && ws.hole[mine < ntiles ? mine : 0] == 2);
     for (; todo; todo &= todo - 1) {
         const unsigned tile = blockIdx.x + (unsigned)__builtin_ctzll(todo) * gridDim.x;
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((unsigned)tiles_x * tiles_y);
@@ -250,7 +290,7 @@ __global__ __launch_bounds__(256) void proj_fill_pending(
         }
         if (tid < 64) tm.col[tid] = g->col[tid];
         if (tid == 0) n_holes = 0;
-        if (!__syncthreads_or(pd != 0)) continue;              // (the owner kernel filled all of this tile's holes)
+        __syncthreads();
         {
             // lane t lists the pending cells of row t / 8, columns 8 (t % 8) .. + 7
             const int rr = tid / 8, c0 = 8 * (tid % 8);
@@ -268,13 +308,12 @@ __global__ __launch_bounds__(256) void proj_fill_pending(
             const TileWalk w = tile_walk_masks(tm.row[hy], tm.col[hx], hy, hx, tx == 0, tx == tiles_x - 1, ty == 0);
             int lo = w.l >= 0 ? tx0 + w.l : -1, ro = w.r >= 0 ? tx0 + w.r : -1, uo = w.u >= 0 ? ty0 + w.u : -1;
             // beyond the tile: the last / first non-zero column of each tile to the left / right in this row, the last
-            // non-zero row of each band above in this column, nearest first
-            if (w.l == -2)
-                for (int t = tx - 1; t >= 0 && lo < 0; t--) lo = ws.left[((int64_t)b * tiles_x + t) * H + gy];
-            if (w.r == -2)
-                for (int t = tx + 1; t < tiles_x && ro < 0; t++) ro = ws.right[((int64_t)b * tiles_x + t) * H + gy];
-            if (w.u == -2)
-                for (int t = ty - 1; t >= 0 && uo < 0; t--) uo = ws.up[((int64_t)b * tiles_y + t) * W + gx];
+            // non-zero row of each band above in this column, nearest first -- eight neighbours per round trip (an uncovered
+            // strip along an image border makes every hole of the strip look at ALL tiles of its row or column: walked
+            // one dependent load at a time that chain was the whole kernel)
+            if (w.l == -2) lo = nearest_summary(ws.left + (int64_t)b * tiles_x * H + gy, H, tx - 1, -1, -1);
+            if (w.r == -2) ro = nearest_summary(ws.right + (int64_t)b * tiles_x * H + gy, H, tx + 1, +1, tiles_x);
+            if (w.u == -2) uo = nearest_summary(ws.up + (int64_t)b * tiles_y * W + gx, W, ty - 1, -1, -1);
             // the counts the walks stopped at (0 when they ran into the image border)
             const float lt = lo >= 0 ? cn[(int64_t)gy * sch + lo] : 0.0f;
             const float rt = ro >= 0 ? cn[(int64_t)gy * sch + ro] : 0.0f;

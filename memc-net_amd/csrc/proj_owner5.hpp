@@ -36,6 +36,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     constexpr int kScanH = TH + 2 * kReach + 1;   // source rows: [ty0 - kReach - 1, ty0 + TH + kReach)
     constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + NT - 1) / NT;
     static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
+    static_assert(NP * kPlane * 8 >= 3 * TH * 64 * 4 + TH * 64 * 2, "the fill epilogue stages three planes and the holes' list in P");
     static_assert((2 * kReach + 1) * (2 * kReach + 1) < 4096 && kReach <= 128, "count * 2^20 + sum(vx) must split exactly");
     __shared__ __attribute__((aligned(16))) double P[NP * kPlane];
     __shared__ FillLds<TH> fl;                    // the hole filler's masks (fill epilogue only)
@@ -220,7 +221,10 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
                 v2 = (float)box[1][j];
             }
             if (v0 > 0.0f) {                   // my_lib_kernel.cu:1730-1735; one reciprocal for both components
-                const float inv = 1.0f / v0;   // (<= 1 ulp from the two divisions)
+                // FlowProjection's count is a whole number >= 1: v_rcp_f32 (1 ulp, one instruction; the IEEE division is
+                // ten, and this kernel is bound by its vector instruction count) -- within 2 ulp of the two divisions.
+                // The depth operator's count is a sum of arbitrary depths (it may be denormal): the full division.
+                const float inv = DEPTH ? 1.0f / v0 : __builtin_amdgcn_rcpf(v0);
                 v1 = v1 * inv;
                 v2 = v2 * inv;
             }
