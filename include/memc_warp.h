@@ -86,6 +86,18 @@ typedef struct memc_tensor4 {
 /* Library / build identification: returns a static string such as "memc_hip 0.1 gfx950". */
 const char *memc_hip_version(void);
 
+/* Which kernel family did the most recent operator call made BY THE CALLING THREAD take?  A static string
+ * "<operator>:<family>", e.g. "fi_fwd:tiled_c3", "proj_fwd:owner", "bl_bwd:direct"; "" before the first call.
+ * The production kernels need 16-byte aligned geometry (width, strides and base pointers multiples of four elements) and,
+ * for FilterInterpolation, filter_size 4; anything else is served by scalar kernels -- same results, 2-3x slower
+ * (profiles/r04_slow_paths.txt) -- whose family names are
+ *     "direct"  (FilterInterpolation / Interpolation: one lane per site, global gathers and atomics),
+ *     "generic" (FilterInterpolation, filter_size != 4),
+ *     "scalar"  ((Depth)FlowProjection forward / backward),
+ *     "general" ((Depth)FlowProjection forward without scratch: inside a stream capture, or a plane beyond 4 GiB).
+ * The reference has no counterpart (it has one kernel per operator). */
+const char *memc_last_kernel_path(void);
+
 /* Does the backward of this operator STORE gradinput1 (1) or ACCUMULATE into it like the reference's atomicAdd (0)?
  * filter_size: FilterInterpolation's fs (e.g. 4); 0 for Interpolation / InterpolationCh.
  * The reference accumulates for every channel count (my_lib_kernel.cu:1276, :690) and its callers hand over a

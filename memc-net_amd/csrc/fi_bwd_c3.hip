@@ -157,14 +157,23 @@ __device__ __noinline__ void fi_bwd_site_image_atomics(int x, int y, int W, int 
 //   packed planes, image first, pitch by the band's width                1364 / 1985 /  71.5
 //   packed planes, image gradient first (this kernel)                    1312 / 1929 /  71.4
 //   planes beside the image (78 KiB; adds straight behind phase 1)       1743 / 3462 /  90.1   (two-band sweeps; no overlap won)
-struct PkGeom {
-    static constexpr int kCap = 3072;                                  // pixel quads staged = slots per plane
+// NT lanes take a tile of 64 x NT / 16 sites.  256 (64 x 16, 48 KiB, two workgroups per CU) is the product.
+// 128 (64 x 8, 24 KiB, four workgroups of two waves per CU) was built in round 4 for SMALL grids -- BASELINE config 2
+// (8 x 448 x 256) is 896 tiles of 64 x 16 on 512 workgroup slots, 1.75 rounds of one tile's serial chain; as 1792 tiles of
+// 64 x 8 on 1024 slots the chain per tile should have been shorter and the tail round half as long -- and LOST in one
+// process (profiles/r04_fi_bwd_tile_height_ab.txt): config 2 72.9 -> 102.8 us, 720p 1436 -> 2134 us, i.i.d. flow 2.7x
+// slower.  A box of 8 + 3 + motion rows holds 2.3x its tile's cells (64 x 16: 1.7x): the flush's atomics, the staged rows
+// and the barriers per site all grow, and nothing in the chain got shorter.  Measurement arm 61 only.
+template <int NT>
+struct PkGeomT {
+    static constexpr int kCap = 12 * NT;                               // pixel quads staged = slots per plane: 3 float4 per lane
     static constexpr int kImageBytes = kCap * 16;
     static constexpr int kLds = kImageBytes + 128;
 };
+using PkGeom = PkGeomT<256>;
 
-template <bool TR>
-__global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
+template <bool TR, int NT = 256>
+__global__ __launch_bounds__(NT, 2) void fi_bwd_c3_pk(
     int W, int H, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
@@ -172,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
     float *__restrict__ gin3)
 {
     constexpr int LX = 16;
-    using PG = PkGeom;
-    using G = TileGeom<LX, PG::kCap>;
+    using PG = PkGeomT<NT>;
+    using G = TileGeom<LX, PG::kCap, NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     unsigned long long *const accA = reinterpret_cast<unsigned long long *>(smem);   // the planes alias the image
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
     for (int k = 0; k < 16; k++) tp[k] = ld_stream4_u(filt_b + k * s3c, o3);
     auto zero_planes = [&](int cells) {        // the first `cells` slots of both planes (whole 16-byte units)
         f32x4 *pa = reinterpret_cast<f32x4 *>(accA), *pb = reinterpret_cast<f32x4 *>(accB);
-        for (int i = (int)tid_now(); i < (cells >> 1); i += 256) {
+        for (int i = (int)tid_now(); i < (cells >> 1); i += NT) {
             pa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -239,9 +248,9 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
         sbits[j] = (mg >= 0x7F800000 || mt >= 0x7F800000) ? 0x7FC00000 : __float_as_int(sv);
     }
     pk_tile_publish(mx, tid, sbits, gbits, g.valid, tmax);
-    const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
+    const BBox box = tile_bbox<LX, NT>(cmin, cmax, rmin, rmax, bb);
     const Bands bands = make_bands<LX, true, PG::kCap>(box);
-    const PkTile ps = pk_tile_resolve<4>(mx);
+    const PkTile ps = pk_tile_resolve<NT / kWave>(mx);
     // packed: the site's image gradient goes through the planes; outl: per-site global atomics (a bound beyond the tile's
     // block exponent, or an Inf / NaN among the site's inputs -- which then land exactly where the reference puts them)
     const unsigned packed = pk_packed_sites(ps, sbits, g.valid), outl = pk_outlier_sites(ps, sbits, g.valid);
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
     // later bands run only if some site still needs them; the vote is also the barrier that frees the LDS
     if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
     done |= fast;
-    const StageSlot sl = stage_slots(r);
+    const StageSlot sl = stage_slots<NT>(r);
     StageRegs<3> sr;
     tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);         // in flight during adds and flush
     if (mode == 1) {
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_c3_pk(
 #pragma unroll                                                 // here, not behind the flush's atomics
             for (int c = 0; c < 3; c++)
                 asm volatile("" : "+v"(sr.v[it][c][0]), "+v"(sr.v[it][c][1]), "+v"(sr.v[it][c][2]), "+v"(sr.v[it][c][3]));
-        pk_flush<256>(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
+        pk_flush<NT>(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
         __syncthreads();                   // the planes have been read: the LDS becomes the image
         if (bi == 0) trace_mark<TR>(4);                    // flushed
     }
@@ -328,16 +337,21 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
     using G = TileGeom<16>;
     const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
     const unsigned ntiles = (unsigned)ntx * nty * batch;
-#define MEMC_FI_BWD_PK(TR)                                                                                         \
-    hipLaunchKernelGGL(fi_bwd_c3_pk<TR>, dim3(ntiles), dim3(256), PkGeom::kLds, stream, w, h, ntx, nty, batch,     \
+#define MEMC_FI_BWD_PK(TR, NT_, NTY, NTILES)                                                                       \
+    hipLaunchKernelGGL((fi_bwd_c3_pk<TR, NT_>), dim3(NTILES), dim3(NT_), PkGeomT<NT_>::kLds, stream, w, h, ntx, NTY, batch, \
                        (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,             \
                        (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)
 #ifdef MEMC_MEASURE
     if (variant == 28) {                                   // + timestamps
-        MEMC_FI_BWD_PK(true);
+        MEMC_FI_BWD_PK(true, 256, nty, ntiles);
         return launch_status() == 0 ? 1 : -1;
     }
-    if (variant >= 0) {                                    // arms/fi_bwd_c3_arms.hip
+    if (variant == 61) {                                   // A/B arm: 64 x 8 tiles on 128 lanes (LOST, see PkGeomT)
+        const int nty8 = (h + 7) / 8;
+        MEMC_FI_BWD_PK(false, 128, nty8, (unsigned)ntx * nty8 * batch);
+        return launch_status() == 0 ? 1 : -1;
+    }
+    if (variant >= 0 && variant != 60) {                   // arms/fi_bwd_c3_arms.hip (60: this kernel, named)
         const int r = fi_bwd_c3_arm_launch(variant, stream, w, h, ntx, nty, batch, s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c,
                                            s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3);
         if (r != 0) return r;
@@ -345,7 +359,7 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
 #else
     (void)variant;
 #endif
-    MEMC_FI_BWD_PK(false);
+    MEMC_FI_BWD_PK(false, 256, nty, ntiles);
 #undef MEMC_FI_BWD_PK
     return launch_status() == 0 ? 1 : -1;
 }

@@ -88,11 +88,12 @@ int bilinear_backward(bool require_c3, memc_stream_t stream, const memc_tensor4 
 
 }  // namespace
 
-#ifdef MEMC_MEASURE
-extern "C" {
-__attribute__((visibility("default"))) const char *g_memc_last_path = "";
-const char *memc_debug_last_path(void) { return g_memc_last_path; }
+namespace memc {
+thread_local const char *t_last_path = "";
 }
+extern "C" const char *memc_last_kernel_path(void) { return memc::t_last_path; }
+#ifdef MEMC_MEASURE
+extern "C" const char *memc_debug_last_path(void) { return memc::t_last_path; }
 #endif
 
 extern "C" {

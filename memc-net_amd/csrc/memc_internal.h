@@ -44,19 +44,13 @@ int bl_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
 }  // namespace memc
 #endif
 
-// Which kernel family a launcher chose: recorded in the measurement build only (tests assert that a shape took the
-// path it is documented to take), compiled away in the product.
-#ifdef MEMC_MEASURE
+// Which kernel family a launcher chose: recorded per host thread, in both builds; memc_last_kernel_path()
+// (include/memc_warp.h) hands it to the caller, so that a C-ABI user sees when a shape fell to the scalar / direct kernels.
 #ifdef __cplusplus
-extern "C" {
-#endif
-extern const char *g_memc_last_path;
-#ifdef __cplusplus
+namespace memc {
+extern thread_local const char *t_last_path;
 }
-#endif
-#define MEMC_PATH(name) (g_memc_last_path = (name))
-#else
-#define MEMC_PATH(name) ((void)0)
+#define MEMC_PATH(name) (memc::t_last_path = (name))
 #endif
 
 #ifdef MEMC_MEASURE
@@ -76,7 +70,7 @@ int memc_debug_set_trace_buffer(void *device_u64_buffer);        // gridDim.x * 
 int memc_debug_set_trace_buffer_proj(void *device_u64_buffer);   // the same for the projection's trace arm
 void memc_debug_set_bl_bwd_direct(int on);       // bilinear backward: 1 = the direct kernel for any channel count
 int memc_debug_set_trace_buffer_cn(void *device_u64_buffer);
-const char *memc_debug_last_path(void);          // the kernel family the last launcher call chose, e.g. "fi_fwd:tiled_c3"     // fi_bwd_image_owner's phase clocks; NULL switches them off
+const char *memc_debug_last_path(void);          // == memc_last_kernel_path() (kept for the round-2/3 tools)
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

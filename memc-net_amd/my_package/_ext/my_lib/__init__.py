@@ -42,6 +42,15 @@ def version():
     return _lib.memc_hip_version().decode()
 
 
+_lib.memc_last_kernel_path.restype = ctypes.c_char_p
+
+
+def last_kernel_path():
+    """The kernel family the most recent operator call of THIS thread took (include/memc_warp.h), e.g. "fi_fwd:tiled_c3";
+    families "direct", "generic", "scalar" and "general" are the slow fallbacks (unaligned geometry, fs != 4, no scratch)."""
+    return _lib.memc_last_kernel_path().decode()
+
+
 _lib.memc_gradinput1_is_stored.restype = ctypes.c_int
 _lib.memc_gradinput1_is_stored.argtypes = [ctypes.c_int, ctypes.c_int]
 
@@ -119,7 +128,7 @@ _EXTENSIONS = {
 }
 _OPTIONAL = {"FilterInterpolationCtxLayer_gpu_forward": (4, 5, 6)}
 
-__all__ = ["version", "LIB_PATH"]
+__all__ = ["version", "last_kernel_path", "LIB_PATH"]
 for _name, (_n, _flag) in list(_SYMBOLS.items()) + list(_EXTENSIONS.items()):
     globals()[_name] = _bind(_name, _n, _flag, optional=_OPTIONAL.get(_name, ()))
     __all__.append(_name)

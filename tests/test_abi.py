@@ -15,7 +15,7 @@ def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"^\s*(?:const\s+char\s*\*\s*|int\s+)(\w+)\s*\(", text, flags=re.M)
-    assert len(names) == 29, names      # 10 layer entry points + 10 kernel launchers + memc_hip_version + memc_gradinput1_is_stored + 3 x 2 of the three extensions + memc_calibration_stream
+    assert len(names) == 30, names      # 10 layer entry points + 10 kernel launchers + memc_hip_version + memc_last_kernel_path + memc_gradinput1_is_stored + 3 x 2 of the three extensions + memc_calibration_stream
     return names
 
 
@@ -140,7 +140,7 @@ def test_product_library_has_no_measurement_arms(hip_lib_path):
     kernels = [n for n in syms if n.startswith("_ZN4memc")]
     assert kernels, "kernel handles expected"
     for k in kernels:
-        for arm in ("fi_fwd_refshape", "persistent", "10proj_ownerI"):
+        for arm in ("fi_fwd_refshape", "persistent", "10proj_ownerI", "11proj_owner4", "19proj_fillhole_carry"):
             assert arm not in k, k
     # the tiled FI forward exists in exactly its production instantiations (ABL == 0 is the last template argument)
     fwd = [k for k in kernels if "16fi_fwd_tiled_fs4" in k]
@@ -148,7 +148,7 @@ def test_product_library_has_no_measurement_arms(hip_lib_path):
     # the RGB backward: the packed-plane kernel without timestamps, and none of the round-1/2 kernels (arms/)
     assert not [k for k in kernels if "15fi_bwd_tiled_c3" in k]
     bwd = [k for k in kernels if "12fi_bwd_c3_pk" in k]
-    assert bwd and all("ILb0EEE" in k for k in bwd), bwd
+    assert bwd and all("ILb0ELi256EEE" in k for k in bwd), bwd     # no timestamps, 64 x 16 tiles only
 
 
 def test_measurement_library_is_separate_and_says_so(hip_lib_path):
