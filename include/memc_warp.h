@@ -131,7 +131,11 @@ int InterpolationChLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *
 int FilterInterpolationLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *input1,
                                          const memc_tensor4 *input2, const memc_tensor4 *input3,
                                          const memc_tensor4 *output);
-/* my_lib_cuda.h:77-85 / my_lib_cuda.c:669-749 */
+/* my_lib_cuda.h:77-85 / my_lib_cuda.c:669-749.
+ * EXTENSION: gradinput1 may be NULL -- "the image gradient is not wanted" (the reference's networks never use it: the frames
+ * they warp are data, networks/MEMC_Net_star.py:266-277): three channels, filter_size 4 and 16-byte aligned geometry
+ * then skip its accumulation and its zero fill; any other shape returns -1 with nothing written and the caller
+ * passes a buffer.  The launcher below takes a NULL gradinput1 pointer the same way. */
 int FilterInterpolationLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
                                           const memc_tensor4 *input2, const memc_tensor4 *input3,
                                           const memc_tensor4 *gradoutput,

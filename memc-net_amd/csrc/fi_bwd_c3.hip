@@ -172,8 +172,23 @@ struct PkGeomT {
 };
 using PkGeom = PkGeomT<256>;
 
-template <bool TR, int NT = 256>
-__global__ __launch_bounds__(NT, 2) void fi_bwd_c3_pk(
+// PART: 0 the whole backward; 1 the image gradient alone (planes, adds, flush); 2 the tap and flow gradients alone (staged
+// image, phase 1).
+//   * PART 2 is what a caller gets who passes gradinput1 == NULL: it does not want the image gradient (the reference's
+//     networks never do: the frames they warp are data, MEMC_Net_star.py:266-277).  720p batch 32: 1037 us against 1432 us
+//     for the whole backward on the same box (+ the 70 us zero fill of gradinput1 that the caller no longer needs);
+//     BASELINE config 2 (8 x 448 x 256): 46.8 us against 72.9 (profiles/r04_fi_bwd_halves_ab.txt).
+//   * PART 1 + PART 2 as two launches were round 4's second attempt at SMALL grids (config 2 is 896 tiles on 512 workgroup
+//     slots: 1.75 rounds of a four-barrier chain; two shorter chains, and at 2/3 of the registers three workgroups per CU,
+//     were to beat that).  They need 189 / 207 VGPRs: at three per CU (168) both spill inside their hot loops; at two per
+//     CU the split reads the inputs twice and LOSES -- config 2 72.9 -> 83.1 us, 720p 1432 -> 1792 us.  Measurement arm 62.
+#ifdef MEMC_PART_THREE
+constexpr bool kPartThree = true;              // (experiment: the halves at three workgroups per CU -- 168 VGPRs, and they SPILL:
+#else                                          //  96 / 160 B per lane, reloaded inside the add loop and phase 1)
+constexpr bool kPartThree = false;
+#endif
+template <bool TR, int NT = 256, int PART = 0>
+__global__ __launch_bounds__(NT, PART == 0 || !kPartThree ? 2 : 3) void fi_bwd_c3_pk(
     int W, int H, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(NT, 2) void fi_bwd_c3_pk(
             pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    zero_planes(PG::kCap);                     // while the loads are in flight
+    if (PART != 2) zero_planes(PG::kCap);      // while the loads are in flight
     if (TR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     trace_mark<TR>(1);                                         // inputs have arrived
 
@@ -233,33 +248,38 @@ __global__ __launch_bounds__(NT, 2) void fi_bwd_c3_pk(
     }
     // per-site bounds of the packed planes (memc_pk.hpp): s = (the site's largest |gradoutput|) x (its largest |tap|),
     // published per wave and handed over by the barrier inside tile_bbox
-    int sbits[4], gbits[4], tmax = 0;
+    int sbits[4] = {0, 0, 0, 0}, gbits[4] = {0, 0, 0, 0}, tmax = 0;
+    if (PART != 2) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int mg = 0, mt = 0;
+        for (int j = 0; j < 4; j++) {
+            int mg = 0, mt = 0;
 #pragma unroll
-        for (int c = 0; c < 3; c++) mg = max(mg, __float_as_int(go[c][j]) & 0x7FFFFFFF);
+            for (int c = 0; c < 3; c++) mg = max(mg, __float_as_int(go[c][j]) & 0x7FFFFFFF);
 #pragma unroll
-        for (int k = 0; k < 16; k++) mt = max(mt, __float_as_int(tp[k][j]) & 0x7FFFFFFF);
-        const float sv = __int_as_float(mg) * __int_as_float(mt);
-        gbits[j] = mg;
-        tmax = max(tmax, ((g.valid >> j) & 1u) ? mt : 0);
-        // (Inf x 0 = NaN: not finite, per-site atomics put it where the reference does; a zero bound adds nothing)
-        sbits[j] = (mg >= 0x7F800000 || mt >= 0x7F800000) ? 0x7FC00000 : __float_as_int(sv);
+            for (int k = 0; k < 16; k++) mt = max(mt, __float_as_int(tp[k][j]) & 0x7FFFFFFF);
+            const float sv = __int_as_float(mg) * __int_as_float(mt);
+            gbits[j] = mg;
+            tmax = max(tmax, ((g.valid >> j) & 1u) ? mt : 0);
+            // (Inf x 0 = NaN: not finite, per-site atomics put it where the reference does; a zero bound adds nothing)
+            sbits[j] = (mg >= 0x7F800000 || mt >= 0x7F800000) ? 0x7FC00000 : __float_as_int(sv);
+        }
+        pk_tile_publish(mx, tid, sbits, gbits, g.valid, tmax);
     }
-    pk_tile_publish(mx, tid, sbits, gbits, g.valid, tmax);
     const BBox box = tile_bbox<LX, NT>(cmin, cmax, rmin, rmax, bb);
     const Bands bands = make_bands<LX, true, PG::kCap>(box);
-    const PkTile ps = pk_tile_resolve<NT / kWave>(mx);
+    PkTile ps;
+    ps.sa = ps.sb = 1.0f;  ps.inv = 1.0;  ps.limit = -1.0f;  ps.any = 0;
+    if (PART != 2) ps = pk_tile_resolve<NT / kWave>(mx);
     // packed: the site's image gradient goes through the planes; outl: per-site global atomics (a bound beyond the tile's
     // block exponent, or an Inf / NaN among the site's inputs -- which then land exactly where the reference puts them)
-    const unsigned packed = pk_packed_sites(ps, sbits, g.valid), outl = pk_outlier_sites(ps, sbits, g.valid);
+    const unsigned packed = PART != 2 ? pk_packed_sites(ps, sbits, g.valid) : 0u;
+    const unsigned outl = PART != 2 ? pk_outlier_sites(ps, sbits, g.valid) : 0u;
     const int mode = ps.any;                   // 0: no packed site has anything to add (workgroup-uniform)
     const float *in_b = in1 + b * s1b;
     float *gin1_b = gin1 + b * s1b;
     unsigned done = 0;
     trace_mark<TR>(2);                                         // bounding box known
-    fi_bwd_zero_invalid(inb, g.valid, gin2_b, s2c, o2, gin3_b, s3c, o3);
+    if (PART != 1) fi_bwd_zero_invalid(inb, g.valid, gin2_b, s2c, o2, gin3_b, s3c, o3);
     auto image_atomics = [&](unsigned todo) {  // outlier sites
         while (todo) {
             const int j = __ffs(todo) - 1;
@@ -289,8 +309,8 @@ __global__ __launch_bounds__(NT, 2) void fi_bwd_c3_pk(
     done |= fast;
     const StageSlot sl = stage_slots<NT>(r);
     StageRegs<3> sr;
-    tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);         // in flight during adds and flush
-    if (mode == 1) {
+    if (PART != 1) tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);     // in flight during adds and flush
+    if (PART != 2 && mode == 1) {
         if (bi > 0) {                      // (band 0: zeroed at the top, ordered by the barrier of tile_bbox)
             zero_planes(r.h * r.pitch);
             __syncthreads();
@@ -298,29 +318,40 @@ __global__ __launch_bounds__(NT, 2) void fi_bwd_c3_pk(
         fi_bwd_adds_pk(r, fast & packed, g, tp, go, ps.sa, ps.sb, accA, accB, W, H);
         __syncthreads();
         if (bi == 0) trace_mark<TR>(3);                    // accumulated
+        if (PART != 1) {
 #pragma unroll
-        for (int it = 0; it < kStageIts; it++)             // the staged rows have landed long ago: take the wait
-#pragma unroll                                                 // here, not behind the flush's atomics
-            for (int c = 0; c < 3; c++)
-                asm volatile("" : "+v"(sr.v[it][c][0]), "+v"(sr.v[it][c][1]), "+v"(sr.v[it][c][2]), "+v"(sr.v[it][c][3]));
+            for (int it = 0; it < kStageIts; it++)         // the staged rows have landed long ago: take the wait
+#pragma unroll                                             // here, not behind the flush's atomics
+                for (int c = 0; c < 3; c++)
+                    asm volatile("" : "+v"(sr.v[it][c][0]), "+v"(sr.v[it][c][1]), "+v"(sr.v[it][c][2]), "+v"(sr.v[it][c][3]));
+        }
         pk_flush<NT>(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
-        __syncthreads();                   // the planes have been read: the LDS becomes the image
+        if (PART != 1) __syncthreads();    // the planes have been read: the LDS becomes the image
         if (bi == 0) trace_mark<TR>(4);                    // flushed
     }
-    if (fast & outl) image_atomics(fast & outl);
-    tile_stage_store<3>(r, sl, sr, tile);
-    __syncthreads();
-    if (bi == 0) trace_mark<TR>(5);                        // image staged
-    phase1(r, fast);
-    if (bi == 0) trace_mark<TR>(6);                        // phase 1 done (this wave)
+    if (PART != 2 && (fast & outl)) image_atomics(fast & outl);
+    if (PART != 1) {
+        tile_stage_store<3>(r, sl, sr, tile);
+        __syncthreads();
+        if (bi == 0) trace_mark<TR>(5);                    // image staged
+        phase1(r, fast);
+        if (bi == 0) trace_mark<TR>(6);                    // phase 1 done (this wave)
+    }
     }   // bands
     trace_mark<TR>(12);
     unsigned slow = inb ? g.valid & ~done : 0u;            // not coverable within kMaxBands bands
     while (slow) {                            // rare: redone from global memory with global atomics
         const int j = __ffs(slow) - 1;
         slow &= slow - 1;
-        fi_bwd_site_scalar(x + j, y, W, H, 3, 4, in_b, gin1_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j,
-                           s2c, filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
+        if (PART == 0)
+            fi_bwd_site_scalar(x + j, y, W, H, 3, 4, in_b, gin1_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j,
+                               s2c, filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
+        else if (PART == 1)
+            fi_bwd_site_image_atomics(x + j, y, W, H, gin1_b, s1c, s1h, flow_b + o2 / 4 + j, s2c, filt_b + o3 / 4 + j, s3c,
+                                      gout_b + o1 / 4 + j);
+        else
+            fi_bwd_site_taps(x + j, y, W, H, in_b, s1c, s1h, flow_b + o2 / 4 + j, gin2_b + o2 / 4 + j, s2c,
+                             filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
     }
 }
 // 1: taken, 0: geometry not 16-byte aligned (the caller takes the direct kernel), -1: launch error.  `variant` >= 0
@@ -332,16 +363,18 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
 {
     if (!plane_fits_u32(w, h, {s1h, s2h, s3h}) ||
         !vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
-                 {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3}))
+                 {input1, input2, input3, gradoutput, gradinput1 /* may be NULL: aligned */, gradinput2, gradinput3}))
         return 0;
     using G = TileGeom<16>;
     const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
     const unsigned ntiles = (unsigned)ntx * nty * batch;
-#define MEMC_FI_BWD_PK(TR, NT_, NTY, NTILES)                                                                       \
-    hipLaunchKernelGGL((fi_bwd_c3_pk<TR, NT_>), dim3(NTILES), dim3(NT_), PkGeomT<NT_>::kLds, stream, w, h, ntx, NTY, batch, \
+#define MEMC_FI_BWD_PK(TR, NT_, NTY, NTILES) MEMC_FI_BWD_PK_PART(TR, NT_, NTY, NTILES, 0)
+#define MEMC_FI_BWD_PK_PART(TR, NT_, NTY, NTILES, PART_)                                                           \
+    hipLaunchKernelGGL((fi_bwd_c3_pk<TR, NT_, PART_>), dim3(NTILES), dim3(NT_), PkGeomT<NT_>::kLds, stream, w, h, ntx, NTY, batch, \
                        (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,             \
                        (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)
 #ifdef MEMC_MEASURE
+    bool split = false;                                    // arm 62: the two halves as two launches (LOST, see the kernel)
     if (variant == 28) {                                   // + timestamps
         MEMC_FI_BWD_PK(true, 256, nty, ntiles);
         return launch_status() == 0 ? 1 : -1;
@@ -356,10 +389,23 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
                                            s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3);
         if (r != 0) return r;
     }
+    if (variant == 62) split = true;                       // (60: the product kernel, named)
 #else
     (void)variant;
 #endif
-    MEMC_FI_BWD_PK(false, 256, nty, ntiles);
+    if (gradinput1 == nullptr) {                           // the caller does not want the image gradient
+        MEMC_FI_BWD_PK_PART(false, 256, nty, ntiles, 2);
+    }
+#ifdef MEMC_MEASURE
+    else if (split) {
+        MEMC_FI_BWD_PK_PART(false, 256, nty, ntiles, 1);
+        MEMC_FI_BWD_PK_PART(false, 256, nty, ntiles, 2);
+    }
+#endif
+    else {
+        MEMC_FI_BWD_PK(false, 256, nty, ntiles);
+    }
+#undef MEMC_FI_BWD_PK_PART
 #undef MEMC_FI_BWD_PK
     return launch_status() == 0 ? 1 : -1;
 }

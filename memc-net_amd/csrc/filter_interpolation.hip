@@ -1266,6 +1266,9 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
     const int tiles_y = (h + 3) / 4;
     const unsigned nwg = (unsigned)tiles_x * tiles_y * batch;
     int taken = 0;
+    // EXTENSION: gradinput1 == NULL ("the image gradient is not wanted", include/memc_warp.h) is served by the RGB tiled
+    // kernel only; every other shape returns -1 and the caller passes a buffer
+    if (gradinput1 == nullptr && (filter_size != 4 || channel != 3)) return -1;
 #ifdef MEMC_MEASURE
     const bool direct_only = g_fi_bwd_variant == 40;       // A/B: the direct kernel (global atomics) for any channel count
 #else
@@ -1295,6 +1298,7 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
         MEMC_PATH("fi_bwd:owner");
         return taken > 0 ? 0 : -1;                         // many channels: fi_bwd_cn.hip
     } else if (channel == 3) {
+        if (gradinput1 == nullptr) return -1;              // (unaligned geometry: the direct kernel needs the buffer)
         MEMC_PATH("fi_bwd:direct");
         hipLaunchKernelGGL((fi_bwd_direct_fs4<3, 4>), dim3(nwg), dim3(256), 0, stream, w, h, channel,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,

@@ -151,7 +151,8 @@ int FilterInterpolationLayer_gpu_backward(memc_stream_t stream, const memc_tenso
                                           const memc_tensor4 *gradoutput, const memc_tensor4 *gradinput1,
                                           const memc_tensor4 *gradinput2, const memc_tensor4 *gradinput3)
 {
-    if (!ok(input1) || !ok(input2) || !ok(input3) || !ok(gradoutput) || !ok(gradinput1) ||
+    // EXTENSION: gradinput1 == NULL -- the caller does not want the image gradient (include/memc_warp.h)
+    if (!ok(input1) || !ok(input2) || !ok(input3) || !ok(gradoutput) || (gradinput1 && !ok(gradinput1)) ||
         !ok(gradinput2) || !ok(gradinput3))
         return kErr;                                                                // :716-718
     if (!flow_matches(input1, input2)) return kErr;                                 // :685-691
@@ -160,14 +161,14 @@ int FilterInterpolationLayer_gpu_backward(memc_stream_t stream, const memc_tenso
         return kErr;
     const int filter_size = (int)sqrt((float)input3->size[1]);                      // :693-694
     if (filter_size < 1) return kErr;
-    if (!same_layout(input1, gradinput1) || !same_layout(input2, gradinput2) ||
+    if ((gradinput1 && !same_layout(input1, gradinput1)) || !same_layout(input2, gradinput2) ||
         !same_layout(input3, gradinput3))
         return kErr;                                                                // :719-723
     if (!same_layout(input1, gradoutput)) return kErr;
     return FilterInterpolationLayer_gpu_backward_kernel(
         stream, nelem(gradoutput), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
         (int)input1->size[0], filter_size, S4(input1), S4(input2), S4(input3), input1->data, input2->data,
-        input3->data, gradoutput->data, gradinput1->data, gradinput2->data, gradinput3->data);
+        input3->data, gradoutput->data, gradinput1 ? gradinput1->data : nullptr, gradinput2->data, gradinput3->data);
 }
 
 // EXTENSION (memc_warp.h): fused dual warp + occlusion blend.  Same checks as two FilterInterpolation forwards,

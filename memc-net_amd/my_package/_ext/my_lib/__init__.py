@@ -126,7 +126,8 @@ _EXTENSIONS = {
     "FilterInterpolationBlendLayer_gpu_forward": (9, False),
     "FilterInterpolationCtxLayer_gpu_forward": (9, False),
 }
-_OPTIONAL = {"FilterInterpolationCtxLayer_gpu_forward": (4, 5, 6)}
+_OPTIONAL = {"FilterInterpolationCtxLayer_gpu_forward": (4, 5, 6),
+             "FilterInterpolationLayer_gpu_backward": (4,)}        # gradinput1 = None: the image gradient is not wanted
 
 __all__ = ["version", "last_kernel_path", "LIB_PATH"]
 for _name, (_n, _flag) in list(_SYMBOLS.items()) + list(_EXTENSIONS.items()):

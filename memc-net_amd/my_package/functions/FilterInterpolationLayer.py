@@ -43,7 +43,11 @@ class _FilterInterpolationFunction(Function):
         # every path (four and more channels with the 4x4 filter; include/memc_warp.h: memc_gradinput1_is_stored):
         # the memset would be a fifth of the call's traffic
         stored = my_lib.gradinput1_is_stored(int(input3.size(1) ** 0.5 + 1e-6), input1.size(1))     # fs as my_lib.c:925
-        gradinput1 = torch.empty_like(input1) if stored else torch.zeros_like(input1)
+        # the warped frames are data in the reference's networks (MEMC_Net_star.py:266-277): when autograd does not ask
+        # for gradinput1, the RGB kernel skips its accumulation and this layer its zero fill (a NULL gradinput1,
+        # include/memc_warp.h; shapes the extension does not serve return -1 and are redone with a buffer)
+        want1 = ctx.needs_input_grad[0]
+        gradinput1 = None if not want1 else (torch.empty_like(input1) if stored else torch.zeros_like(input1))
         # the reference zero-fills these two as well (:47-48); the backward kernels DEFINE every element of them
         # (invalid sites store zero; tests/test_gpu_parity.py::test_backward_defines_flow_and_tap_gradients), so
         # 72 B/site of memsets -- a seventh of the call at 720p -- are skipped
@@ -51,6 +55,10 @@ class _FilterInterpolationFunction(Function):
         gradinput3 = torch.empty_like(input3)
         err = my_lib.FilterInterpolationLayer_gpu_backward(
             input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)
+        if err != 0 and gradinput1 is None:
+            scratch1 = torch.empty_like(input1) if stored else torch.zeros_like(input1)
+            err = my_lib.FilterInterpolationLayer_gpu_backward(
+                input1, input2, input3, gradoutput, scratch1, gradinput2, gradinput3)
         check(err, "FilterInterpolationLayer_gpu_backward")
         return gradinput1, gradinput2, gradinput3
 

@@ -189,6 +189,36 @@ def test_filter_interpolation_backward_rgb_scaling_and_special_values(oracle, ar
         M.reset()
 
 
+def test_filter_interpolation_backward_without_image_gradient(oracle):
+    """EXTENSION (include/memc_warp.h): gradinput1 == NULL -- the caller does not want the image gradient (the reference's
+    networks warp frames that are data, MEMC_Net_star.py:266-277): the RGB kernel then computes the flow and tap gradients
+    alone.  Same gradinput2 / gradinput3 as the full call, for every flow kind; shapes the extension does not serve return
+    -1 and write nothing; the Python layer asks for it exactly when autograd does not need input1's gradient."""
+    import my_package._ext.my_lib as my_lib
+    from my_package.modules.FilterInterpolationModule import FilterInterpolationModule
+    for ci, case in enumerate(C3_FLOWS):
+        xn, fn, kn, gn = _c3_inputs(case, 40 + ci, signed=True)
+        w1, w2, w3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+        h2, h3 = torch.full(fn.shape, 3.0, device=dev()), torch.full(kn.shape, 3.0, device=dev())
+        rc = my_lib.FilterInterpolationLayer_gpu_backward(T(xn), T(fn), T(kn), T(gn), None, h2, h3)
+        if xn.shape[3] % 4:
+            assert rc == -1 and float(h2.min()) == 3.0 and float(h3.min()) == 3.0       # not served, nothing written
+            continue
+        assert rc == 0 and my_lib.last_kernel_path() == "fi_bwd:tiled_c3"
+        close(N(h2), w2, "gradinput2 without gradinput1 %s" % (case,), 3 * RTOL)
+        close(N(h3), w3, "gradinput3 without gradinput1 %s" % (case,), RTOL)
+        # the module: frames without requires_grad
+        x, f, k = T(xn), T(fn, True), T(kn, True)
+        FilterInterpolationModule()(x, f, k).backward(T(gn))
+        assert x.grad is None
+        close(N(f.grad), w2, "module gradinput2, frames are data %s" % (case,), 3 * RTOL)
+        close(N(k.grad), w3, "module gradinput3, frames are data %s" % (case,), RTOL)
+    # more than three channels: not served
+    xn, fn, kn, gn = synth.np_image(np.random.default_rng(1), 1, 8, 16, 64), np.zeros((1, 2, 16, 64), np.float32), \
+        synth.np_filter(np.random.default_rng(2), 1, 16, 64), synth.np_image(np.random.default_rng(3), 1, 8, 16, 64)
+    assert my_lib.FilterInterpolationLayer_gpu_backward(T(xn), T(fn), T(kn), T(gn), None, T(fn), T(kn)) == -1
+
+
 def _heavy_tail_variants(rng, kn, gn):
     """(name, taps, gradoutput): a few values four to five orders of magnitude above their O(0.05) neighbours."""
     out = []

@@ -49,6 +49,8 @@ def main():
             "depth_fill": (lambda: L.DepthFlowProjectionLayer_gpu_forward(f, d, cnt, out, 1), None, 1),
             "fi_bwd": (lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), g1, 1),
             "fi_bwd_c2": (lambda: L.FilterInterpolationLayer_gpu_backward(t2["x"], t2["flow"], t2["filt"], t2["gout"], h1, h2, h3), h1, 20),
+            "fi_bwd_nog1": (lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, None, g2, g3), None, 1),
+            "fi_bwd_c2_nog1": (lambda: L.FilterInterpolationLayer_gpu_backward(t2["x"], t2["flow"], t2["filt"], t2["gout"], None, h2, h3), None, 20),
             "bl_bwd": (lambda: L.InterpolationLayer_gpu_backward(x, f, g, g1, g2), g1, 1),
         }
         for _ in range(150):
