@@ -1191,7 +1191,12 @@ __global__ __launch_bounds__(256) void fi_bwd_zero_rows(float *__restrict__ p, i
 // RGB has its own kernels, one or two channels are few atomics).  For them gradinput1 is STORED on every path: when the owner kernels cannot run
 // (odd geometry, no scratch inside a stream capture) the buffer is cleared here before the caller falls back to the
 // accumulating direct kernel.
-bool fi_bwd_cn_class(int channel, int filter_size) { return filter_size == 4 && channel >= 4; }
+#ifdef MEMC_MEASURE
+bool g_bwd_cn_allow_c3 = false;               // arm: the bilinear warp's RGB backward through the owner kernels (bl_cap 5)
+#else
+constexpr bool g_bwd_cn_allow_c3 = false;
+#endif
+bool fi_bwd_cn_class(int channel, int filter_size) { return filter_size == 4 && (channel >= 4 || (g_bwd_cn_allow_c3 && channel == 3)); }
 
 int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                      int s1b, int s1c, int s1h, int s2b, int s2c, int s2h, int s3b, int s3c, int s3h,

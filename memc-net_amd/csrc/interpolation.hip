@@ -453,7 +453,7 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
                          const float *gradoutput, float *gradinput1, float *gradinput2)
 {
     if (w <= 0 || h <= 0 || channel <= 0 || batch <= 0) return 0;
-    if (channel == 3 && plane_fits_u32(w, h, {s1h}) &&
+    if (channel == 3 && g_cap_sel != 5 && plane_fits_u32(w, h, {s1h}) &&
         vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2})) {
         using G = TileGeom<16>;
         const int ntx = (w + G::kTW - 1) / G::kTW;
@@ -496,7 +496,12 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
 #undef MEMC_BL_BWD
         return launch_status();
     }
+#ifdef MEMC_MEASURE
+    g_bwd_cn_allow_c3 = g_cap_sel == 5;                    // arm: RGB through the owner kernels (one chunk, a padded plane)
+    if (channel != 3 || g_cap_sel == 5) {
+#else
     if (channel != 3) {                                    // many channels: fi_bwd_cn.hip (owner-computes)
+#endif
 #ifdef MEMC_MEASURE
         const bool direct_only = g_bl_bwd_direct != 0;
 #else

@@ -22,6 +22,9 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                      float *gradinput1, float *gradinput2, float *gradinput3, bool force_direct);
 // the class of channel counts fi_bwd_cn.hip takes -- and for which gradinput1 is stored on every path
 bool fi_bwd_cn_class(int channel, int filter_size);
+#ifdef MEMC_MEASURE
+extern bool g_bwd_cn_allow_c3;               // arm (bl_cap 5): the bilinear warp's RGB backward through the owner kernels
+#endif
 // fi_bwd_c3.hip: the same operator for RGB (C == 3), fs == 4, LDS-tiled.  1: taken, 0: geometry not 16-byte aligned
 // (the caller takes the direct kernel), -1: launch error.  variant: measurement arm (-1 in the product).
 int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,

@@ -29,7 +29,10 @@ def main():
     ap.add_argument("--flows", default="smooth")
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--lib", default="", help="another measurement build to bind (default: lib/libmemc_hip_measure.so)")
     a = ap.parse_args()
+    if a.lib:
+        M.MEASURE_LIB = os.path.abspath(a.lib)
     M.use()
     L = M.bound()
     dev = torch.device("cuda:0")
