@@ -1,8 +1,10 @@
 """Frame-pair inference the way the reference demos run it (the part with a bearing on the
 hot path): replicate-pad both frames so that H and W are multiples of 128 -- or by 32 on each side when they
 already are -- run the network, crop the padding off (demo_HD720p.py:88-113,138-146; demo_MiddleBury.py:74-110).
-The HD demo's YUV 4:2:0 reader / writer and its per-pair loop are in yuv_io.py (numpy only); the PNG readers of the
-MiddleBury demo (scipy.misc.imread) are not reproduced.
+The HD demo's YUV 4:2:0 reader / writer and its per-pair loop are in yuv_io.py (numpy only); the still-image demo's
+files are read and written by png_io.py (zlib + numpy): 8-bit grey, grey + alpha, RGB, RGBA and palette PNGs, all five
+scanline filters, CRC-checked -- no tRNS chunk (palette transparency is ignored), no 16-bit samples, no interlacing
+(both rejected with an error).
 """
 import torch
 import torch.nn.functional as F

@@ -130,7 +130,8 @@ def rgb_scores(rec_rgb, gt_rgb):
     diff = 128.0 + np.asarray(rec_rgb, dtype=np.float64) - np.asarray(gt_rgb, dtype=np.float64)
     err = float(np.mean(np.abs(diff - 128.0)))
     mse = float(np.mean((diff - 128.0) ** 2))
-    psnr = float("inf") if mse == 0 else float(20.0 * np.log10(255.0 / np.sqrt(mse)))
+    psnr = 100.0 if mse == 0 else min(100.0, float(20.0 * np.log10(255.0 / np.sqrt(mse))))    # (capped like the luma scores:
+                                                                                              #  an exact match must not make the scene average inf)
     return err, psnr, (diff.astype(np.int64) & 0xFF).astype(np.uint8)
 
 

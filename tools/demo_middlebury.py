@@ -40,8 +40,18 @@ def main(argv=None):
     dev = torch.device("cuda", 0)
     net = getattr(networks, a.model)(channel=3, filter_size=4, training=False, align_corners=a.align_corners)
     if a.weights:
+        # as the reference demo does (demo_MiddleBury.py:48-60): keep the checkpoint's entries that exist in the model, load
+        # those, leave the rest of the model as constructed -- and say what was left out on either side
         state = torch.load(a.weights, map_location="cpu")
-        net.load_state_dict(state.get("state_dict", state), strict=True)
+        state = state.get("state_dict", state)
+        own = net.state_dict()
+        kept = {k: v for k, v in state.items() if k in own}
+        skipped, missing = sorted(set(state) - set(own)), sorted(set(own) - set(state))
+        own.update(kept)
+        net.load_state_dict(own, strict=True)
+        if skipped or missing:
+            print("checkpoint: %d entries loaded, %d not in the model (%s...), %d of the model not in the checkpoint (%s...)" % (
+                len(kept), len(skipped), ", ".join(skipped[:3]), len(missing), ", ".join(missing[:3])))
     net = net.to(dev).eval()
     os.makedirs(a.output, exist_ok=True)
     results = networks.interpolate_png_tree(net, a.data, a.output, dev, gt_dir=a.gt or None, which=a.save_which)
