@@ -34,6 +34,7 @@ HBM_PEAK_BPS = 8.0e12           # MI355X HBM3E spec peak (guides/MI355X_MICROARC
 BYTES_PER_SITE = {               # ALGORITHMIC bytes per output site, every tensor touched once
     "fi_fwd": lambda C, fs: 4 * (2 * C + 2 + fs * fs),
     "fi_bwd": lambda C, fs: 4 * (3 * C + 2 * (2 + fs * fs)),
+    "fi_bwd_nog1": lambda C, fs: 4 * (2 * C + 2 * (2 + fs * fs)),     # gradinput1 not wanted (NULL): no image gradient written
     "proj_fwd": lambda C, fs: 20,
     "depth_proj_fwd": lambda C, fs: 24,
     "proj_bwd": lambda C, fs: 28,
@@ -237,6 +238,11 @@ def secondary_rows(my_lib, synth, torch, device, seed):
     row("config2_fi_bwd_8x3x256x448", "fi_bwd", 3, sites, _avg_launch_s(
         lambda: my_lib.FilterInterpolationLayer_gpu_backward(t["x"], t["flow"], t["filt"], t["gout"], g1, g2, g3),
         torch, device, burst=20), "bursts of 20")
+    # ... and as the reference's networks run it: the warped frames are data, autograd does not ask for gradinput1
+    # (MEMC_Net_star.py:266-277) -- the extension of include/memc_warp.h (gradinput1 NULL)
+    row("config2_fi_bwd_without_image_gradient_8x3x256x448", "fi_bwd_nog1", 3, sites, _avg_launch_s(
+        lambda: my_lib.FilterInterpolationLayer_gpu_backward(t["x"], t["flow"], t["filt"], t["gout"], None, g2, g3),
+        torch, device, burst=20), "bursts of 20; gradinput1 = NULL (extension): flow and tap gradients only")
     del t, out, g1, g2, g3
     # the backward at the headline size (the only channel count the reference back-propagates through)
     t = synth.torch_inputs(device, 32, 3, 720, 1280, flow_kind="smooth", seed=seed + 6, with_grad=True)
@@ -251,6 +257,9 @@ def secondary_rows(my_lib, synth, torch, device, seed):
     rows["fi_bwd_32x3x720x1280"]["with_memset_us"] = round(_avg_launch_s(bwd_with_memset, torch, device) * 1e6, 2)
     rows["fi_bwd_32x3x720x1280"]["note"] = ("with_memset_us: the same call preceded by the zero fill of gradinput1 it relies on "
                                             "(C = 3 accumulates; memc_gradinput1_is_stored)")
+    row("fi_bwd_without_image_gradient_32x3x720x1280", "fi_bwd_nog1", 3, 32 * 720 * 1280, _avg_launch_s(
+        lambda: my_lib.FilterInterpolationLayer_gpu_backward(t["x"], t["flow"], t["filt"], t["gout"], None, g2, g3),
+        torch, device), "gradinput1 = NULL (extension): what a training step of the reference's networks needs")
     del g1, g2, g3
     # config 3: FlowProjection / DepthFlowProjection scatter, 1280 x 720, batch 32 (same flow; + depth)
     f = t["flow"]

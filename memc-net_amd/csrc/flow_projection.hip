@@ -1201,10 +1201,11 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
 #undef MEMC_PROJ_SCATTER
     if (a.fillhole && !only_part && !skip_pending) {
         if (ws.up) {
-            // workgroup i looks after the tiles i, i + grid, ... (at most 64 of them: one flag per lane of a wave); most
-            // tiles have no hole (18 % on the benchmark's smooth flow) and cost their workgroup one flag load
-            // (2048: what the chip holds at once -- eight 256-lane workgroups on each of 256 CUs)
-            const unsigned fg = ntiles < 2048u ? ntiles : (ntiles + 63u) / 64u > 2048u ? (ntiles + 63u) / 64u : 2048u;
+            // round 3's filler: workgroup i looks after the tiles i, i + grid, ... (one flag per lane of a wave)
+            [[maybe_unused]] const unsigned fg = ntiles < 4096u ? ntiles : (ntiles + 63u) / 64u > 4096u ? (ntiles + 63u) / 64u : 4096u;
+            // proj_fill_pending: one WAVE per tile, four to a workgroup; 8192 waves are what the chip holds at once
+            const unsigned pw = ntiles < 8192u ? ntiles : ((ntiles + 63u) / 64u > 8192u ? (ntiles + 63u) / 64u : 8192u);
+            const unsigned pg = (pw + 3u) / 4u;
 #ifdef MEMC_MEASURE
             if (old_fill)
                 hipLaunchKernelGGL(proj_fillhole_carry<TH>, dim3(fg), dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c,
@@ -1212,7 +1213,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             else
 #endif
             if constexpr (kNewOk)
-                hipLaunchKernelGGL(proj_fill_pending<TH>, dim3(fg), dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c, s1h,
+                hipLaunchKernelGGL(proj_fill_pending<TH>, dim3(pg), dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c, s1h,
                                    scb, sch, a.count, a.out, ws);
         } else {
             hipLaunchKernelGGL(proj_fillhole_v4, dim3(sntiles), dim3(256), 0, stream, w, h, ntx, snty, s1b, s1c, s1h,

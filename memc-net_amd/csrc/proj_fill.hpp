@@ -244,92 +244,127 @@ __global__ __launch_bounds__(16 * TH) void proj_fill_masks(
     }
 }
 
-// first entry >= 0 of table[t * stride] for t = t0, t0 + dir, ... (t != tend), -1 if none: independent loads, eight at a time
-__device__ __forceinline__ int nearest_summary(const int *table, int64_t stride, int t0, int dir, int tend)
+// One direction of a walk beyond the tile: table[t * stride] for t = t0, t0 + dir, ... (t != tend) holds, per neighbouring
+// tile, the position of its nearest non-zero cell in this row / column (-1: none).
+struct TableWalk {
+    const int *table;
+    int64_t stride;
+    int t, dir, tend, res;
+    bool open;                                 // still looking
+};
+__device__ __forceinline__ TableWalk table_walk(bool wanted, const int *table, int64_t stride, int t0, int dir, int tend)
+{
+    TableWalk w = {table, stride, t0, dir, tend, -1, wanted};
+    w.open = wanted && (dir > 0 ? t0 < tend : t0 > tend);
+    return w;
+}
+// The three directions advance TOGETHER, eight neighbours each per round trip: an uncovered strip along an image border
+// makes every hole of the strip look at all tiles of its row or column, and walked one dependent load at a time that
+// chain was the whole kernel.
+__device__ __forceinline__ void table_walks(TableWalk (&w)[3])
 {
     constexpr int CH = 8;
-    int res = -1;
-    for (int t = t0; res < 0 && (dir > 0 ? t < tend : t > tend); t += CH * dir) {
-        int v[CH];
+    while (w[0].open || w[1].open || w[2].open) {
+        int v[3][CH];
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-            const int tt = t + k * dir;
-            v[k] = (dir > 0 ? tt < tend : tt > tend) ? table[(int64_t)tt * stride] : -1;
+        for (int d = 0; d < 3; d++)
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const int tt = w[d].t + k * w[d].dir;
+                v[d][k] = (w[d].open && (w[d].dir > 0 ? tt < w[d].tend : tt > w[d].tend)) ? w[d].table[(int64_t)tt * w[d].stride] : -1;
+            }
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            if (!w[d].open) continue;
+#pragma unroll
+            for (int k = CH - 1; k >= 0; k--) w[d].res = v[d][k] >= 0 ? v[d][k] : w[d].res;     // (the nearest valid one wins)
+            w[d].t += CH * w[d].dir;
+            w[d].open = w[d].res < 0 && (w[d].dir > 0 ? w[d].t < w[d].tend : w[d].t > w[d].tend);
         }
-#pragma unroll
-        for (int k = CH - 1; k >= 0; k--) res = v[k] >= 0 ? v[k] : res;     // (the nearest valid one wins)
     }
-    return res;
 }
 
-// The pending holes of the flagged tiles.  Workgroup i looks after the tiles i, i + grid, ... (at most 64 of them: one
-// flag per lane of a wave).  A tile's masks go to LDS, its pending cells are listed and dealt out one per lane; a walk
-// that leaves the tile steps through the neighbouring tiles' summaries, nearest first (usually one step).
+// The pending holes of the flagged tiles (flag 2).  One WAVE per tile -- the pending lists are short (the owner kernel filled
+// what it could), a tile's masks are 768 bytes, and nothing in a tile's chain of round trips (flag -> masks -> neighbours'
+// summaries -> counts and values -> store) has work for more than a few lanes: what matters is how many tiles are in
+// flight.  Wave g of the launch looks after the tiles g, g + waves, ... (one flag per lane).  Wave-synchronous: the LDS of a
+// wave is touched by that wave only.
 template <int TH>
 __global__ __launch_bounds__(256) void proj_fill_pending(
     int W, int H, int tiles_x, int tiles_y, int batch, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch,
     const float *__restrict__ count, float *out, FillWs ws)
 {
-    __shared__ TileMasks<TH> tm;
-    __shared__ int n_holes;
-    __shared__ unsigned short hole_list[TH * 64];
+    __shared__ TileMasks<TH> tms[4];
+    __shared__ unsigned short lists[4][TH * 64];
+    const int wv = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    TileMasks<TH> &tm = tms[wv];
+    unsigned short *hole_list = lists[wv];
     const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
-    const unsigned mine = blockIdx.x + (threadIdx.x & 63u) * gridDim.x;
+    const unsigned nwaves = gridDim.x * 4u, gw = blockIdx.x * 4u + wv;
+    const unsigned mine = gw + (unsigned)lane * nwaves;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(mine < ntiles && ws.hole[mine < ntiles ? mine : 0] == 2);
     for (; todo; todo &= todo - 1) {
-        const unsigned tile = blockIdx.x + (unsigned)__builtin_ctzll(todo) * gridDim.x;
+        const unsigned tile = gw + (unsigned)__builtin_ctzll(todo) * nwaves;
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((unsigned)tiles_x * tiles_y);
         const int tx0 = tx * 64, ty0 = ty * TH;
         const TileMasks<TH> *g = reinterpret_cast<const TileMasks<TH> *>(ws.masks) + tile;
-        const int tid = threadIdx.x;
         unsigned long long pd = 0;
-        if (tid < TH) {
-            pd = g->pend[tid];
-            tm.pend[tid] = pd;
-            tm.row[tid] = g->row[tid];
+        if (lane < TH) {
+            pd = g->pend[lane];
+            tm.row[lane] = g->row[lane];
         }
-        if (tid < 64) tm.col[tid] = g->col[tid];
-        if (tid == 0) n_holes = 0;
-        __syncthreads();
+        tm.col[lane] = g->col[lane];
+        // the list: lane r holds row r's pending bits; every lane appends its row's cells behind the rows before it
+        const int mycount = __builtin_popcountll(pd);
+        int before = 0;                                        // exclusive prefix sum over the lanes (6 DPP-free steps: shuffles)
         {
-            // lane t lists the pending cells of row t / 8, columns 8 (t % 8) .. + 7
-            const int rr = tid / 8, c0 = 8 * (tid % 8);
-            unsigned bits = rr < TH ? (unsigned)(tm.pend[rr] >> c0) & 0xffu : 0u;
-            for (; bits; bits &= bits - 1)
-                hole_list[atomicAdd(&n_holes, 1)] = (unsigned short)((rr << 6) | (c0 + __builtin_ctz(bits)));
+            int acc = mycount;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const int up = __shfl_up(acc, off, kWave);
+                acc += lane >= off ? up : 0;
+            }
+            before = acc - mycount;
         }
-        __syncthreads();
-        const int n = n_holes;
+        const int n = __shfl(before + mycount, kWave - 1, kWave);
+        for (int k = before; pd; pd &= pd - 1, k++) hole_list[k] = (unsigned short)((lane << 6) | __builtin_ctzll(pd));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const float *cn = count + b * scb;
         float *o = out + b * s1b;
-        for (int i = tid; i < n; i += 256) {
+        for (int i = lane; i < n; i += kWave) {
             const int cell = hole_list[i], hx = cell & 63, hy = cell >> 6;
             const int gx = tx0 + hx, gy = ty0 + hy;
             const TileWalk w = tile_walk_masks(tm.row[hy], tm.col[hx], hy, hx, tx == 0, tx == tiles_x - 1, ty == 0);
-            int lo = w.l >= 0 ? tx0 + w.l : -1, ro = w.r >= 0 ? tx0 + w.r : -1, uo = w.u >= 0 ? ty0 + w.u : -1;
             // beyond the tile: the last / first non-zero column of each tile to the left / right in this row, the last
-            // non-zero row of each band above in this column, nearest first -- eight neighbours per round trip (an uncovered
-            // strip along an image border makes every hole of the strip look at ALL tiles of its row or column: walked
-            // one dependent load at a time that chain was the whole kernel)
-            if (w.l == -2) lo = nearest_summary(ws.left + (int64_t)b * tiles_x * H + gy, H, tx - 1, -1, -1);
-            if (w.r == -2) ro = nearest_summary(ws.right + (int64_t)b * tiles_x * H + gy, H, tx + 1, +1, tiles_x);
-            if (w.u == -2) uo = nearest_summary(ws.up + (int64_t)b * tiles_y * W + gx, W, ty - 1, -1, -1);
-            // the counts the walks stopped at (0 when they ran into the image border)
-            const float lt = lo >= 0 ? cn[(int64_t)gy * sch + lo] : 0.0f;
-            const float rt = ro >= 0 ? cn[(int64_t)gy * sch + ro] : 0.0f;
-            const float ut = uo >= 0 ? cn[(int64_t)uo * sch + gx] : 0.0f;
-            if (lt + rt + ut + 0.0f <= 0.0f) continue;
+            // non-zero row of each band above in this column, nearest first
+            TableWalk tw[3] = {table_walk(w.l == -2, ws.left + (int64_t)b * tiles_x * H + gy, H, tx - 1, -1, -1),
+                               table_walk(w.r == -2, ws.right + (int64_t)b * tiles_x * H + gy, H, tx + 1, +1, tiles_x),
+                               table_walk(w.u == -2, ws.up + (int64_t)b * tiles_y * W + gx, W, ty - 1, -1, -1)};
+            table_walks(tw);
+            const int lo = w.l >= 0 ? tx0 + w.l : tw[0].res, ro = w.r >= 0 ? tx0 + w.r : tw[1].res;
+            const int uo = w.u >= 0 ? ty0 + w.u : tw[2].res;
             // a walk that found nothing ends at the border cell (column 0 / W-1, row 0): its flag is 0, but the reference
-            // still multiplies that cell's value by it -- keep the operand identical
+            // still multiplies that cell's value by it -- keep the operand identical.  Counts and values are requested
+            // together (the values do not depend on the counts).
             const int lc = lo >= 0 ? lo : 0, rc = ro >= 0 ? ro : W - 1, ur = uo >= 0 ? uo : 0;
+            const float cl = cn[(int64_t)gy * sch + lc], cr = cn[(int64_t)gy * sch + rc], cu = cn[(int64_t)ur * sch + gx];
+            float vl[2], vr[2], vu[2], self[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                float *pl = o + k * s1c;
-                float *self = pl + (int64_t)gy * s1h + gx;
-                *self = fill_value(lt, rt, ut, pl[(int64_t)gy * s1h + lc], pl[(int64_t)gy * s1h + rc],
-                                   pl[(int64_t)ur * s1h + gx], *self);
+                const float *pl = o + k * s1c;
+                vl[k] = pl[(int64_t)gy * s1h + lc];
+                vr[k] = pl[(int64_t)gy * s1h + rc];
+                vu[k] = pl[(int64_t)ur * s1h + gx];
+                self[k] = pl[(int64_t)gy * s1h + gx];
             }
+            // the counts the walks stopped at (0 when they ran into the image border)
+            const float lt = lo >= 0 ? cl : 0.0f, rt = ro >= 0 ? cr : 0.0f, ut = uo >= 0 ? cu : 0.0f;
+            if (lt + rt + ut + 0.0f <= 0.0f) continue;
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                o[k * s1c + (int64_t)gy * s1h + gx] = fill_value(lt, rt, ut, vl[k], vr[k], vu[k], self[k]);
         }
-        __syncthreads();                                       // the masks and the list are reused by the next tile
+        __builtin_amdgcn_wave_barrier();                       // the masks and the list are reused by the wave's next tile
     }
 }

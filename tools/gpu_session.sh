@@ -4,7 +4,7 @@
 # 4 slots, they cost 3 + 2).
 # Usage (from the repo root, via gpurun):  bash tools/gpu_session.sh <tag> [quick]
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 QUICK=${2:-}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
@@ -20,11 +20,20 @@ echo "== bench";   timeout 900 python bench.py 2>&1 | tail -3 | tee "$OUT/bench.
 echo "== bench, strong-scaling shard sizes on one GPU (what rank 0 of an N-GPU run executes: batch 32 / N, HIP graph, rotating input sets)"
 for b in 16 8 4; do timeout 300 python bench.py --batch $b --no-cpu-baseline --no-secondary 2>&1 | tail -1 | tee -a "$OUT/bench_shards.log"; done
 echo "== model"; timeout 600 python tools/bench_model.py --json "$OUT/bench_model.json" 2>&1 | tail -2 | tee "$OUT/bench_model.log"
-echo "== RGB backward: phase clocks of the product kernel and of the rounds 1-2 kernel (measurement build)"
-for k in fi_bwd_pk2 fi_bwd; do timeout 300 python tools/trace_kernel.py $k 2>&1 | grep -v amdgpu.ids | tee -a "$OUT/fi_bwd_traces.txt"; done
-echo "== RGB backward A/B in one process: product against the rounds 1-2 kernel (arm 0)"
-timeout 600 python tools/bench_ops.py --only fi_bwd --bwd-variants 0 --json "$OUT/bench_fi_bwd_ab.json" 2>&1 | grep -v amdgpu.ids | tee "$OUT/bench_fi_bwd_ab.log"
+echo "== projection: phase clocks of the owner kernel (measurement build), A/B against round 3's set in one process"
+timeout 300 python tools/trace_kernel.py proj5 2>&1 | grep -v amdgpu.ids | tee "$OUT/proj_owner5_phases.txt"
+timeout 600 python tools/ab_variants.py --op projection --variants=-1,-40 --cases proj,proj_fill,depth,depth_fill --flows smooth,iid 2>&1 | grep -v amdgpu.ids | tee "$OUT/proj_ab.txt"
+timeout 300 python tools/probes/proj_burst.py 2>&1 | grep -v amdgpu.ids | tee "$OUT/proj_burst.txt"
+echo "== RGB backward: without the image gradient (gradinput1 NULL) next to the whole backward, one process"
+timeout 600 python tools/ab_variants.py --op fi_bwd --variants=-1 --cases fi_bwd_c2,fi_bwd_c2_nog1,fi_bwd,fi_bwd_nog1 --flows smooth 2>&1 | grep -v amdgpu.ids | tee "$OUT/fi_bwd_nog1.txt"
 echo "== race screen"; timeout 600 python tools/stress_projection.py 60 2>&1 | tail -3 | tee "$OUT/stress.log"
+echo "== projection kernels of a call (kernel trace)"
+( cd /tmp && export TMPDIR=/tmp && for kind in smooth iid; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof_proj_$kind" -o proj -- python "$REPO/tools/probes/proj_calls.py" $kind 60 2>&1 | grep "flow=" | tee -a "$OUT/proj_calls.txt"
+  python "$REPO/tools/probes/proj_calls_summary.py" "$OUT/prof_proj_$kind/proj_results.db" 150 | tee -a "$OUT/proj_calls.txt"
+  rm -rf "$OUT/prof_proj_$kind"; done )
+echo "== SQ counters of the owner kernel"
+bash tools/pmc_sq.sh $TAG/sq proj "proj_owner5<false" 2>&1 | tail -45 | tee "$OUT/proj_owner5_sq.txt"
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprof kernel trace of bench.py (the same command as the bench line above, minus the CPU baseline and the secondary rows)"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_trace" -o bench -- python "$REPO/bench.py" --no-cpu-baseline --no-secondary > "$OUT/prof_trace.log" 2>&1
