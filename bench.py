@@ -201,9 +201,18 @@ def copy_calibration(my_lib, device, nbytes, iters=20):
     return rates
 
 
-def _avg_launch_s(fn, torch, device, warm=15, iters=40, burst=1):
+def _avg_launch_s(fn, torch, device, warm=15, iters=40, burst=1, warm_seconds=0.08):
+    # warm-up by TIME as well as by count: after host-side work (allocations, random fills) the device needs ~60 ms of
+    # launches to be back at its steady clocks (tools/timeline.py) -- 15 launches of a 120 us kernel are 2 ms, and the
+    # first secondary row measured behind such a pause read 10 % slow (round 4, config 3 without hole filling)
     for _ in range(warm):
         fn()
+    torch.cuda.synchronize(device)
+    t_end = time.perf_counter() + warm_seconds
+    while time.perf_counter() < t_end:
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize(device)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for a0, a1 in ev:
         a0.record()

@@ -23,7 +23,7 @@ KERNELS = {
     "fi_fwd_blend_c3": (188, SITES),
     "proj_owner5<false": (20, SITES),                 # flow 8 | count 4 + out 8
     "proj_owner5<true": (24, SITES),
-    "proj_fill_pending": (0.05, SITES),               # (the holes the owner left pending and what their walks read)
+    "proj_fill_pending": (0.5, SITES),                # (booked like round 3's proj_fillhole_carry: the holes and what their walks read)
     "proj_bwd_tiled<false": (28, SITES),              # flow 8 + count 4 + gout 8 | gin 8
     "proj_bwd_tiled<true": (44, SITES),               # flow 8 + depth 4 + count 4 + out 8 + gout 8 | gin1 8 + gin2 4
     "bl_fwd_tiled<3": (32, SITES),                    # x 12 + flow 8 | out 12
