@@ -1070,7 +1070,10 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     constexpr int kMinW = (kWgCu * (16 * TH / 64) + 3) / 4 > 8 ? 8 : (kWgCu * (16 * TH / 64) + 3) / 4;
     if (flag && !legacy_owner) {
         if constexpr (kNewOk) {
-            const WalkPlan plan = make_walk_plan(ntx, nty, batch, sw);
+            WalkPlan plan = make_walk_plan(ntx, nty, batch, sw);
+#ifdef MEMC_MEASURE
+            if (variant == -43) plan.fast = 0;      // test arm: the kernel's own tile_walk (what grids beyond n * d < 2^32 take)
+#endif
 #ifdef MEMC_MEASURE
             only_part = variant == -5 || variant == -20 || variant == -41;
             skip_pending = variant == -42;          // timing arm: everything but proj_fill_pending (pending holes stay unfilled)

@@ -1214,7 +1214,8 @@ def test_projection_forward_needs_no_zero_fill(oracle, case):
         # 16 / 32 x walk in strips / stripes 2 / 4 tile columns wide: 10x-11x the production kernel, 40x-41x round 3's
         # production set -- proj_owner4 and the carry filler --, 13x-15x the LDS-ring kernel (tile height up to 64), 16x the
         # persistent one) and the round-1 owner kernel
-        for variant in (-1, 1, 0, 100, 104, 110, 112, -40, 400, 404, 412, 130, 142, 154, 160, 164, -10):
+        # (-43: the product kernel computing its tile coordinates itself, as grids too large for the host-made reciprocals do)
+        for variant in (-1, -43, 1, 0, 100, 104, 110, 112, -40, 400, 404, 412, 130, 142, 154, 160, 164, -10):
             M.set_variant("projection", variant)
             for fh in (0, 1):
                 cnt = torch.full((f.shape[0], 1, f.shape[2], f.shape[3]), float("nan"), device=dev())

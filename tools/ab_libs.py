@@ -47,13 +47,22 @@ def main():
     cnt, out = f.new_zeros((B, 1, H, W)), torch.zeros_like(f)
     o3 = torch.zeros_like(x)
     g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
+    g2src, gd = torch.rand_like(f), torch.zeros_like(d)
+    c2 = synth.torch_inputs(dev, 8, 3, 256, 448, flow_kind="smooth")
+    c2o = torch.zeros_like(c2["x"])
     ops = {
         "proj": lambda l: l.FlowProjectionLayer_gpu_forward(f, cnt, out, 0),
         "proj_fill": lambda l: l.FlowProjectionLayer_gpu_forward(f, cnt, out, 1),
         "depth_fill": lambda l: l.DepthFlowProjectionLayer_gpu_forward(f, d, cnt, out, 1),
         "fi_fwd": lambda l: l.FilterInterpolationLayer_gpu_forward(x, f, k, o3),
         "fi_bwd": lambda l: l.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3),
+        "interp_fwd": lambda l: l.InterpolationLayer_gpu_forward(x, f, o3),
+        "interp_bwd": lambda l: l.InterpolationLayer_gpu_backward(x, f, g, g1, g2),
+        "proj_bwd": lambda l: l.FlowProjectionLayer_gpu_backward(f, cnt, g2src, g2),
+        "depth_bwd": lambda l: l.DepthFlowProjectionLayer_gpu_backward(f, d, cnt, out, g2src, g2, gd),
+        "fi_fwd_c2": lambda l: l.FilterInterpolationLayer_gpu_forward(c2["x"], c2["flow"], c2["filt"], c2o),
     }
+    libs[0].FlowProjectionLayer_gpu_forward(f, cnt, out, 0)
     for _ in range(150):
         ops["proj"](libs[0])
     for op in a.op.split(","):
@@ -64,7 +73,7 @@ def main():
                 for _ in range(4):
                     fn(l)
                 for _ in range(a.iters):
-                    if op == "fi_bwd":
+                    if op in ("fi_bwd", "interp_bwd"):
                         g1.zero_()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(); fn(l); e1.record(); e1.synchronize()
