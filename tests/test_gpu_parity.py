@@ -588,6 +588,53 @@ def test_depth_flow_projection(oracle, case):
     close(N(dp.grad), g2, "gradinput2", 1e-4)
 
 
+def test_projection_forward_unusual_depths_and_flows(oracle):
+    """What the mask-based hole filling (proj_fill.hpp) must get right beyond the ordinary case, against the oracle (which
+    restates my_lib_kernel.cu:2053-2264 line by line): cells whose depth sum is NEGATIVE are holes (count <= 0, :2184) that
+    nevertheless stop a walk (count != 0, :2205-2224) and contribute nothing (flag = count > 0, :2238); zero depths add nothing;
+    a NaN / Inf flow makes its site invalid (every compare fails); NaN depths poison their four cells.  Several tile shapes:
+    one tile, tiles cut by the image edge, many tiles."""
+    import my_package._ext.my_lib as my_lib
+    for ci, (B, H, W) in enumerate(((1, 20, 64), (2, 45, 132), (1, 100, 260))):
+        rng = np.random.default_rng(900 + ci)
+        flow = synth.np_flow(rng, B, H, W, "smooth", 5.0)
+        depth = (rng.random((B, 1, H, W)) + 0.1).astype(np.float32)
+        depth[rng.random(depth.shape) < 0.15] *= -1.0                 # negative depths: negative and near-zero count cells
+        depth[rng.random(depth.shape) < 0.10] = 0.0
+        flow[0, :, 3:9, 10:30] = 200.0                                # an uncovered patch (its sources leave the image)
+        flow[0, 0, 12, 40] = np.nan
+        flow[-1, 1, 15, 20] = np.inf
+        for fill in (0, 1):
+            want_out, want_cnt = oracle.depth_flow_projection_forward(flow, depth, fill)
+            cnt, out = torch.full((B, 1, H, W), 7.0, device=dev()), torch.full((B, 2, H, W), 7.0, device=dev())
+            assert my_lib.DepthFlowProjectionLayer_gpu_forward(T(flow), T(depth), cnt, out, fill) == 0
+            close(N(cnt), want_cnt, "count, negative / zero depths, fill %d, case %d" % (fill, ci), RTOL)
+            # where the depth sum cancels to within rounding the two disagree on which side of zero it fell: compare the
+            # cells whose count is clearly non-zero or exactly zero in both
+            clear = (np.abs(want_cnt) > 1e-4) | ((want_cnt == 0) & (N(cnt) == 0))
+            assert clear.mean() > 0.9
+            sel = np.broadcast_to(clear, want_out.shape)
+            if fill == 0:
+                close(N(out)[sel], want_out[sel], "output, negative / zero depths, fill 0, case %d" % ci, 1e-4)
+            else:                                                      # a filled hole next to an ambiguous cell inherits the ambiguity
+                bad = np.abs(N(out) - want_out)[sel] > 1e-4 + 1e-4 * np.abs(want_out[sel])
+                assert bad.mean() < 0.02, "fill 1, case %d: %.2f %% of the clear cells differ" % (ci, 100 * bad.mean())
+        d2 = np.abs(depth) + 0.1
+        d2[0, 0, 5, 7] = np.nan
+        want_out, want_cnt = oracle.depth_flow_projection_forward(flow, d2, 1)
+        cnt, out = torch.zeros((B, 1, H, W), device=dev()), torch.zeros((B, 2, H, W), device=dev())
+        assert my_lib.DepthFlowProjectionLayer_gpu_forward(T(flow), T(d2), cnt, out, 1) == 0
+        assert np.array_equal(np.isnan(N(cnt)), np.isnan(want_cnt)) and 0 < np.isnan(want_cnt).sum() <= 4
+        ok = ~np.isnan(want_out)
+        close(N(out)[ok], want_out[ok], "output beside a NaN depth, case %d" % ci, RTOL)
+        # the plain operator with the same non-finite flows
+        want_out, want_cnt = oracle.flow_projection_forward(flow, 1)
+        cnt, out = torch.zeros((B, 1, H, W), device=dev()), torch.zeros((B, 2, H, W), device=dev())
+        assert my_lib.FlowProjectionLayer_gpu_forward(T(flow), cnt, out, 1) == 0
+        assert np.array_equal(N(cnt), want_cnt)
+        close(N(out), want_out, "FlowProjection with NaN / Inf flow and an uncovered patch, case %d" % ci)
+
+
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
                 if os.path.basename(p).startswith(("small_", "config1_")))   # the oracle-made operator fixtures
 
