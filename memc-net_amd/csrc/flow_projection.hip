@@ -373,8 +373,9 @@ __global__ __launch_bounds__(256) void proj_scatter_tiled(
 //
 // Reach: a source with |fx| >= kReach or |fy| >= kReach is invisible to the owners of its targets.  Such "far"
 // sources are skipped consistently by every owner, and the workgroup that is HOME to one raises a device flag.
-// The launcher then queues the general path (zero, scatter with atomics, average), whose kernels return at
-// once when the flag is clear: correctness never depends on the motion being small, only speed does.
+// The launcher queues proj_owner_far behind it (rounds 1-2: the general path), which returns at once when no flag is
+// up and otherwise redoes the flagged images exactly: correctness never depends on the motion being small, only
+// speed does.
 //
 // Round 2 (proj_owner2).  The round-1 kernel (kept as a measurement arm, proj_owner) scanned 7.6x the sources it
 // owned and ran the whole per-source body -- locate, window test, three fp64 LDS atomics -- under exec masks with
@@ -412,16 +413,18 @@ __device__ __forceinline__ void trace_mark_proj(int slot)
 #endif  // MEMC_MEASURE
 
 // --------------------------------------------------------------------------------------------------
-// The production owner kernels.  What proj_owner2's timing arms showed (tools/bench_ops.py variants 200..261,
-// DESIGN.md): the kernel is bound by how many workgroups a CU holds -- the scan's loads are issued at the start of a
+// The production owner kernels: proj_owner5 (proj_owner5.hpp, round 4) and proj_owner_far below.  What led to their
+// shape (rounds 2-3; the kernels named here live in arms/proj_owner_arms.hpp now).  proj_owner2's timing arms
+//  showed that the kernel was bound by how many workgroups a CU holds -- the scan's loads are issued at the start of a
 // workgroup's life and nothing is in flight while it tests, splats and reads out, so the bytes in flight per CU are
 // (workgroups per CU) x 64 KB.  With 71 KiB of LDS (three fp64 planes + the compaction rings) two 64x32 tiles fit a
 // CU: 240 us; the same kernel with two planes (53 KiB, three per CU): 183 us.  A persistent, software-pipelined form
 // (proj_owner3, next tile's fy prefetched) LOST (285 us): on gfx9 a wave's loads and stores share one in-order
 // counter, so the first wait of a tile also waits for the previous tile's stores.  Hence:
-//   * no LDS rings: a wave compacts its hits in REGISTERS.  ds_permute_b32 (the LDS crossbar, no LDS memory) pushes
-//     the hits of one ballot to consecutive lanes of a cyclic 64-entry batch kept in three (four) VGPRs; whenever
-//     the batch is full all 64 lanes splat it.  -16 KiB per workgroup.
+//   * no LDS rings: round 3's proj_owner4 compacted a wave's hits in REGISTERS (ds_permute_b32 pushes the hits of one
+//     ballot to consecutive lanes of a cyclic 64-entry batch); round 4's proj_owner5 drops the compaction altogether
+//     and splats under the exec mask -- the compaction was two thirds of the kernel's instructions;
+//     proj_owner_far still uses the register batch (OwnerTile::source).  -16 KiB per workgroup either way.
 //   * FlowProjection (count = number of sources, an integer) keeps TWO planes: A = count * 2^20 + sum(vx), B =
 //     sum(vy).  At most (2 kReach + 1)^2 = 2401 sources can reach one point and |vx| < kReach, so |sum(vx)| < 2^19
 //     splits off exactly (count = rint(A / 2^20)); a double holding count * 2^20 <= 2^32 still resolves 2^-20 px,
@@ -430,7 +433,7 @@ __device__ __forceinline__ void trace_mark_proj(int slot)
 //   * point-plane pitch 66 (65 columns used): the depth operator's three planes then leave room for three
 //     workgroups per CU (52.8 KiB), FlowProjection's two for four (35.3 KiB).
 //
-// Far sources (|f| >= kReach), round 2: proj_owner4 also records, per tile, the largest |fx| and |fy| of its own FAR
+// Far sources (|f| >= kReach), round 2: the owner kernel also records, per tile, the largest |fx| and |fy| of its own FAR
 // sources (in the cold branch that raises the flag: the hot loop pays nothing).  The images whose flag was raised are then redone by proj_owner_far -- the same owner-computes tile, but
 // scanning whole SOURCE TILES, and only those whose recorded motion bound lets them reach the window: exact for any
 // flow, no atomics, no zeroing or averaging pass, cost proportional to the actual motion.  One normally idle launch
@@ -441,7 +444,7 @@ constexpr double kCountUnit = 1048576.0;          // 2^20
 
 // One owned 64 x TH tile: its point planes, window bounds and the wave's register batch of waiting hits.
 // (Used by proj_owner_far.  Always THREE planes there: without a limit on |flow| the sum of vx at a point is not
-// bounded by 2^19, which the packed count * 2^20 + sum(vx) plane of proj_owner4 relies on.)
+// bounded by 2^19, which the packed count * 2^20 + sum(vx) plane of proj_owner5 relies on.)
 template <bool DEPTH, int TH>
 struct OwnerTile {
     static constexpr int NP = 3;                  // planes: count, vx, vy
