@@ -31,10 +31,17 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     constexpr int NT = 16 * TH;                   // one lane per four owned cells
     constexpr int NP = DEPTH ? 3 : 2;             // planes: (count, vx, vy) or (count * 2^20 + vx, vy)
     constexpr int kPtH = TH + 1, kPlane = kPtH * kPtW4;
-    constexpr int kScanPadX = kReach + 4;         // dilated tile: columns, kept 4-aligned
-    constexpr int kScanW = 64 + 2 * kScanPadX;    // source columns
-    constexpr int kScanH = TH + 2 * kReach + 1;   // source rows: [ty0 - kReach - 1, ty0 + TH + kReach)
-    constexpr int kCols4 = kScanW / 4, kSlots = kCols4 * kScanH, kIts = (kSlots + NT - 1) / NT;
+    // Scan region: the sources that can reach the tile's window, rows [ty0 - kReach - 1, ty0 + TH + kReach), columns
+    // [tx0 - kReach - 4, tx0 + 64 + kReach + 4) -- laid out 32 quads (128 columns, [tx0 - 32, tx0 + 96)) wide: a lane's
+    // column is tid % 32 for the whole scan and its row advances by NT / 32 per iteration, so a slot's coordinates,
+    // its "inside the image" test and its load offset are one add each (round 4's first version laid the 30 needed quads
+    // out densely: a division, a wrap test and a multiply per slot -- 180 of the kernel's 530 vector instructions per wave).
+    // The two outermost quads on either side are never needed; what they hit can only be a far source's point, and an image
+    // with a valid far source is redone anyway.
+    static_assert(kReach + 4 <= 32, "32 quads per scan row");
+    constexpr int kColsQ = 32, kRowsIt = NT / kColsQ;
+    constexpr int kScanH = TH + 2 * kReach + 1;   // source rows
+    constexpr int kIts = (kScanH + kRowsIt - 1) / kRowsIt;
     static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
     static_assert(NP * kPlane * 8 >= 3 * TH * 64 * 4 + TH * 64 * 2, "the fill epilogue stages three planes and the holes' list in P");
     static_assert((2 * kReach + 1) * (2 * kReach + 1) < 4096 && kReach <= 128, "count * 2^20 + sum(vx) must split exactly");
@@ -56,36 +63,33 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         for (int i = tid0; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // scan loads: slot -> (row, column) by one division and increments; fy of every slot now, fx / depth now only for
-    // the slots whose rows lie within kNearRows of the tile (the others almost never pass the row test and fetch theirs
-    // inside the branch); unconditional addresses (dead slots read pixel 0)
-    constexpr int kNearRows = 8;
+    // scan loads: fy of every slot now, fx / depth now only for the slots whose rows lie within kNearRows of the tile (the
+    // others almost never pass the row test and fetch theirs inside the branch); unconditional addresses (dead slots read
+    // pixel 0)
+    // near slots: rows less than 10 above / 7 below the tile (TH = 32: iterations 1 - 3 of six)
     auto far_it = [](int it) {
-        const int first = NT * it / kCols4, last = (NT * it + NT - 1) / kCols4;
-        return last <= kReach + 1 - kNearRows || first >= kReach + 1 + TH + kNearRows;
+        const int first = kRowsIt * it, last = kRowsIt * it + kRowsIt - 1;
+        return last <= kReach + 1 - 10 || first >= kReach + 1 + TH + 7;
     };
+    // the last iteration may hold a row or two only (TH = 32: row 80 of 81, half of the first wave): nothing of it is
+    // requested up front
+    auto partial_it = [](int it) { return kRowsIt * (it + 1) > kScanH; };
     const float *flow_b = flow + b * s1b;
     const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
     f32x4 fx[kIts], fy[kIts], dd[kIts];
-    int sx[kIts], sy[kIts];
     bool live[kIts];
-    int row = tid0 / kCols4, c4 = tid0 % kCols4;
+    const int sx = tx0 - 32 + 4 * (tid0 % kColsQ), sy0 = ty0 - kReach - 1 + tid0 / kColsQ;
+    const bool colok = sx >= 0 && sx < W;         // W % 4 == 0
+    const unsigned off0 = 4u * (unsigned)(sy0 * s1h + sx), offd0 = DEPTH ? 4u * (unsigned)(sy0 * sdh + sx) : 0u;
 #pragma unroll
     for (int it = 0; it < kIts; it++) {
-        sx[it] = tx0 - kScanPadX + 4 * c4;
-        sy[it] = ty0 - kReach - 1 + row;
-        live[it] = row < kScanH && sx[it] >= 0 && sx[it] < W && sy[it] >= 0 && sy[it] < H;   // W % 4 == 0
-        const unsigned off = live[it] ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
-        fy[it] = ld_cached4_u(flow_b + s1c, off);
-        if (!far_it(it)) {
+        const int sy = sy0 + kRowsIt * it;
+        live[it] = colok && sy >= 0 && sy < H && (kRowsIt * (it + 1) <= kScanH || tid0 / kColsQ + kRowsIt * it < kScanH);
+        const unsigned off = live[it] ? off0 + (unsigned)(4 * kRowsIt * it) * (unsigned)s1h : 0u;
+        if (!partial_it(it)) fy[it] = ld_cached4_u(flow_b + s1c, off);
+        if (!far_it(it) && !partial_it(it)) {
             fx[it] = ld_cached4_u(flow_b, off);
-            if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
-        }
-        row += NT / kCols4;
-        c4 += NT % kCols4;
-        if (c4 >= kCols4) {
-            c4 -= kCols4;
-            row++;
+            if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? offd0 + (unsigned)(4 * kRowsIt * it) * (unsigned)sdh : 0u);
         }
     }
     trace_mark_proj<TRACE>(1);                 // loads issued, P zeroed
@@ -109,17 +113,18 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     for (int it = 0; it < kIts; it++) {
         const bool lv = live[it];
         // dead slots (outside the image / the scan region) fail every window test: their row is NaN
-        const float syf = lv ? (float)sy[it] : __int_as_float(0x7fc00000), sxf = (float)sx[it];
+        const int sy = sy0 + kRowsIt * it;
+        const float syf = lv ? (float)sy : __int_as_float(0x7fc00000), sxf = (float)sx;
         // The quad lies inside the tile itself (tx0, the pad and sx are multiples of 4: all four sites or none) -- only
         // slots that can hold rows of the tile evaluate this (and the far-source test below) at all.
-        const bool kHomeIt = NT * it / kCols4 < kReach + 1 + TH && (NT * it + NT - 1) / kCols4 >= kReach + 1;   // folds: `it` is unrolled
+        const bool kHomeIt = kRowsIt * it < kReach + 1 + TH && kRowsIt * it + kRowsIt - 1 >= kReach + 1;       // folds: `it` is unrolled
         if (kHomeIt) {
             // A far source (|f| >= kReach) whose home is this tile: the image is redone by proj_owner_far.  The hit test
             // below does NOT ask for |f| < kReach: an image without a valid far source has only near hits, which every
             // owner of their point sees (they lie inside its scan region); in an image WITH one the owners may disagree
             // -- and every tile of that image is recomputed anyway.  One max chain and one compare per quad; NaN motion
             // takes the branch too and is found not valid.
-            const bool homeq = lv && (unsigned)(sy[it] - ty0) < (unsigned)TH && (unsigned)(sx[it] - tx0) < 64u;
+            const bool homeq = lv && (unsigned)(sy - ty0) < (unsigned)TH && (unsigned)(sx - tx0) < 64u;
             const f32x4 &a = fx[it], &c = fy[it];
             const float m = fmaxf(fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))),
                                   fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3]))));
@@ -137,6 +142,10 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
                 }
             }
         }
+        if (partial_it(it)) {                  // (wave-uniform: most waves have no slot here at all)
+            if (__builtin_amdgcn_ballot_w64(lv) == 0) continue;
+            fy[it] = ld_cached4_u(flow_b + s1c, lv ? off0 + (unsigned)(4 * kRowsIt * it) * (unsigned)s1h : 0u);
+        }
         float y2[4];
         bool wy[4], rowany = false;
 #pragma unroll
@@ -148,10 +157,10 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         // rows farther from the tile than the local motion: the whole wave leaves after the four y tests
         if (__builtin_amdgcn_ballot_w64(rowany) == 0) continue;
         f32x4 fxq = fx[it], ddq = dd[it];
-        if (far_it(it)) {                      // rare: requested only now (and consumed inside this branch)
-            const unsigned off = lv ? 4u * (unsigned)(sy[it] * s1h + sx[it]) : 0u;
+        if (far_it(it) || partial_it(it)) {    // rare: requested only now (and consumed inside this branch)
+            const unsigned off = lv ? off0 + (unsigned)(4 * kRowsIt * it) * (unsigned)s1h : 0u;
             fxq = ld_cached4_u(flow_b, off);
-            if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy[it] * sdh + sx[it]) : 0u);
+            if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? offd0 + (unsigned)(4 * kRowsIt * it) * (unsigned)sdh : 0u);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
