@@ -768,6 +768,150 @@ __global__ __launch_bounds__(256) void proj_owner(
 // ---- part C: round 3's production set -- proj_owner4 (register compaction of the hits), its far-source kernel, the
 // summaries from the count plane and the carry filler that re-read the counts of every tile holding a hole ----
 #ifdef MEMC_PROJ_ARMS_PART_C
+// rounds 2-3: the owner tile of proj_owner_far_r3 (register batch of waiting hits)
+// One owned 64 x TH tile: its point planes, window bounds and the wave's register batch of waiting hits.
+// (Used by proj_owner_far.  Always THREE planes there: without a limit on |flow| the sum of vx at a point is not
+// bounded by 2^19, which the packed count * 2^20 + sum(vx) plane of proj_owner5 relies on.)
+template <bool DEPTH, int TH>
+struct OwnerTile {
+    static constexpr int NP = 3;                  // planes: count, vx, vy
+    static constexpr int kPlane = (TH + 1) * kPtW4;
+    static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
+    double *P;
+    int tx0, ty0;
+    float xlo, ylo;
+    int xhi_bits, yhi_bits;
+    unsigned lane, fill;                          // fill: valid entries of the batch (wave-uniform); entry i in lane i
+    int p_cell;
+    float p_vx, p_vy, p_vc;
+
+    // Window bounds.  A source is a hit when its point (T, L) = ((int)y2, (int)x2) lies in the window
+    // [ty0 - 1, ty0 + TH - 1] x [tx0 - 1, tx0 + 63] and the site is valid (x2, y2 inside the image,
+    // my_lib_kernel.cu:1670): x2 >= max(tx0 - 1, 0) and x2 < tx0 + 64 and x2 <= W - 1.  For x2 >= 0 the float order
+    // is the order of the bit patterns, so the last two are ONE integer compare against
+    // min(bits(tx0 + 64), bits(W - 1) + 1).
+    __device__ __forceinline__ void begin(double *P_, int tx0_, int ty0_, int W, int H, unsigned lane_)
+    {
+        P = P_;  tx0 = tx0_;  ty0 = ty0_;  lane = lane_;  fill = 0;
+        p_cell = 0;  p_vx = p_vy = 0.0f;  p_vc = 1.0f;         // (FlowProjection: every source counts 1)
+        xlo = (float)max(tx0 - 1, 0);
+        ylo = (float)max(ty0 - 1, 0);
+        xhi_bits = min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1);
+        yhi_bits = min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1);
+    }
+    template <int NT>
+    __device__ __forceinline__ void zero(int tid) const
+    {
+        f32x4 *pz = reinterpret_cast<f32x4 *>(P);
+        for (int i = tid; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void splat(int cell, float vx, float vy, float vc) const
+    {
+        double *q = P + cell;
+        lds_add_f64(q, (double)vc);
+        lds_add_f64(q + kPlane, (double)vx);
+        lds_add_f64(q + 2 * kPlane, (double)vy);
+    }
+    // the four y tests of a quad of sources in row sy
+    __device__ __forceinline__ bool rows(bool lv, float syf, const f32x4 &fy4, float (&y2)[4], bool (&wy)[4]) const
+    {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            y2[j] = syf + fy4[j];
+            wy[j] = lv && y2[j] >= ylo && __float_as_int(y2[j]) < yhi_bits;
+            any = any || wy[j];
+        }
+        return any;
+    }
+    // One source per lane (`pre`: passed the y test and whatever else the caller demands): x test, then the hits of
+    // the wave are pushed to the consecutive lanes fill, fill + 1, ... (cyclically) of the batch -- lanes without
+    // a hit aim at the LAST slot of the cycle, which a hit only takes when all 64 lanes hit (no such lane then).
+    // Wave-uniform control flow: call from converged code only.
+    __device__ __forceinline__ void source(bool pre, float x2, float y2, float fxv, float fyv, float d)
+    {
+        const bool hit = pre && x2 >= xlo && __float_as_int(x2) < xhi_bits;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (m == 0) return;                    // wave-uniform
+        const unsigned n = (unsigned)__builtin_popcountll(m);
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        const int dst = (int)((fill + (hit ? rank : 63u)) & 63u) << 2;
+        const int py = (int)y2 - (ty0 - 1), px = (int)x2 - (tx0 - 1);                       // (garbage without a hit)
+        float vx = -fxv, vy = -fyv, vc = 1.0f;
+        if (DEPTH) {                           // my_lib_kernel.cu:2102-2114
+            vx = -d * fxv;
+            vy = -d * fyv;
+            vc = d * 1.0f;
+        }
+        const int r_cell = __builtin_amdgcn_ds_permute(dst, py * kPtW4 + px);
+        const float r_vx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vx)));
+        const float r_vy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vy)));
+        float r_vc = 1.0f;
+        if (DEPTH) r_vc = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vc)));
+        if (fill + n < (unsigned)kWave) {      // (wave-uniform) not full yet: lanes [fill, fill + n) take theirs
+            const bool recv = ((lane - fill) & 63u) < n;
+            p_cell = recv ? r_cell : p_cell;
+            p_vx = recv ? r_vx : p_vx;
+            p_vy = recv ? r_vy : p_vy;
+            if (DEPTH) p_vc = recv ? r_vc : p_vc;
+            fill += n;
+        } else {                               // full: lanes [fill, 64) hold new entries, lanes [0, fill) waiting ones
+            const bool fresh = lane >= fill;
+            splat(fresh ? r_cell : p_cell, fresh ? r_vx : p_vx, fresh ? r_vy : p_vy, fresh ? r_vc : p_vc);
+            fill = fill + n - (unsigned)kWave; // the entries that wrapped around: lanes [0, fill)
+            p_cell = r_cell;  p_vx = r_vx;  p_vy = r_vy;  p_vc = r_vc;
+        }
+    }
+    __device__ __forceinline__ void finish() const
+    {
+        if (lane < fill) splat(p_cell, p_vx, p_vy, p_vc);      // what is still waiting
+    }
+    // After a barrier: the lane's four cells (cx .. cx + 3, cy) -- 2x2 box sums of the points of columns c-1 .. c+3,
+    // rows cy-1 and cy (border duplicates as weights 2, see proj_scatter_tiled), normalised by the count.
+    __device__ __forceinline__ void readout(int cx, int cy, int W, int H, f32x4 &ox, f32x4 &oy, f32x4 &oc) const
+    {
+        const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
+        float top[3][5], bot[3][5];            // [count, vx, vy][column], each point sum rounded to fp32 once
+        typedef double f64x2 __attribute__((ext_vector_type(2)));
+        const double *r0 = P + (cy - ty0) * kPtW4 + (cx - tx0);   // column offset a multiple of 4: 16-byte pairs
+#pragma unroll
+        for (int pl = 0; pl < NP; pl++) {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const double *a = r0 + pl * kPlane + rr * kPtW4;
+                const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
+                const double v[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
+                float (&dst_c)[5] = rr ? bot[0] : top[0];
+                float (&dst_x)[5] = rr ? bot[1] : top[1];
+                float (&dst_y)[5] = rr ? bot[2] : top[2];
+#pragma unroll
+                for (int i = 0; i < 5; i++) (pl == 0 ? dst_c : (pl == 1 ? dst_x : dst_y))[i] = (float)v[i];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
+            float v[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                // the four contributions are added in a fixed order (the reference's order is arbitrary: fp32 atomics)
+                float t = 0.0f;
+                t += wy0 * wx0 * bot[pl][j + 1];
+                t += wy0 * bot[pl][j];
+                t += wx0 * top[pl][j + 1];
+                t += top[pl][j];
+                v[pl] = t;
+            }
+            if (v[0] > 0.0f) {                 // my_lib_kernel.cu:1730-1735; one reciprocal for both components
+                const float inv = 1.0f / v[0]; // (<= 1 ulp from the two divisions)
+                v[1] = v[1] * inv;
+                v[2] = v[2] * inv;
+            }
+            oc[j] = v[0];  ox[j] = v[1];  oy[j] = v[2];
+        }
+    }
+};
+
 // stores, and the hole filler's per-tile summaries (the counts are in registers: they are free)
 template <int TH>
 __device__ __forceinline__ void owner_store(TileSummary<TH> &sm, const FillWs &ws, int tid, int b, int tx, int ty, int W,

@@ -18,6 +18,7 @@
 
 namespace memc {
 
+constexpr int kFarWords = 8;                  // words per tile of the owner kernel's far table (proj_owner5.hpp)
 constexpr int kFlagWords = 256;               // far flags of the fast path: image b -> word b % 256, + 1 summary word
 
 // --------------------------------------------------------------------------------------------------
@@ -442,35 +443,27 @@ __device__ __forceinline__ void trace_mark_proj(int slot)
 constexpr int kPtW4 = 66;
 constexpr double kCountUnit = 1048576.0;          // 2^20
 
-// One owned 64 x TH tile: its point planes, window bounds and the wave's register batch of waiting hits.
-// (Used by proj_owner_far.  Always THREE planes there: without a limit on |flow| the sum of vx at a point is not
-// bounded by 2^19, which the packed count * 2^20 + sum(vx) plane of proj_owner5 relies on.)
+// One owned 64 x TH tile of the far-source kernel: three fp64 point planes (without a limit on |flow| the sum of vx at a
+// point is not bounded by 2^19, which the packed count * 2^20 + sum(vx) plane of proj_owner5 relies on), the window test of
+// proj_owner5 (one subtract and one unsigned compare per axis on the bit patterns) and hits splatted straight under their
+// exec mask.  (Rounds 2-3: OwnerTile with a register batch of waiting hits -- arms/proj_owner_arms.hpp.)
 template <bool DEPTH, int TH>
-struct OwnerTile {
+struct FarTile {
     static constexpr int NP = 3;                  // planes: count, vx, vy
     static constexpr int kPlane = (TH + 1) * kPtW4;
     static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
     double *P;
-    int tx0, ty0;
-    float xlo, ylo;
-    int xhi_bits, yhi_bits;
-    unsigned lane, fill;                          // fill: valid entries of the batch (wave-uniform); entry i in lane i
-    int p_cell;
-    float p_vx, p_vy, p_vc;
+    int tx0, ty0, xlo_b, ylo_b;
+    unsigned xrange, yrange, ucell8;
 
-    // Window bounds.  A source is a hit when its point (T, L) = ((int)y2, (int)x2) lies in the window
-    // [ty0 - 1, ty0 + TH - 1] x [tx0 - 1, tx0 + 63] and the site is valid (x2, y2 inside the image,
-    // my_lib_kernel.cu:1670): x2 >= max(tx0 - 1, 0) and x2 < tx0 + 64 and x2 <= W - 1.  For x2 >= 0 the float order
-    // is the order of the bit patterns, so the last two are ONE integer compare against
-    // min(bits(tx0 + 64), bits(W - 1) + 1).
-    __device__ __forceinline__ void begin(double *P_, int tx0_, int ty0_, int W, int H, unsigned lane_)
+    __device__ __forceinline__ void begin(double *P_, int tx0_, int ty0_, int W, int H)
     {
-        P = P_;  tx0 = tx0_;  ty0 = ty0_;  lane = lane_;  fill = 0;
-        p_cell = 0;  p_vx = p_vy = 0.0f;  p_vc = 1.0f;         // (FlowProjection: every source counts 1)
-        xlo = (float)max(tx0 - 1, 0);
-        ylo = (float)max(ty0 - 1, 0);
-        xhi_bits = min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1);
-        yhi_bits = min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1);
+        P = P_;  tx0 = tx0_;  ty0 = ty0_;
+        xlo_b = __float_as_int((float)max(tx0 - 1, 0));
+        ylo_b = __float_as_int((float)max(ty0 - 1, 0));
+        xrange = (unsigned)(min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1) - xlo_b);
+        yrange = (unsigned)(min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1) - ylo_b);
+        ucell8 = (unsigned)-(8 * ((ty0 - 1) * kPtW4 + (tx0 - 1)));
     }
     template <int NT>
     __device__ __forceinline__ void zero(int tid) const
@@ -478,169 +471,166 @@ struct OwnerTile {
         f32x4 *pz = reinterpret_cast<f32x4 *>(P);
         for (int i = tid; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    __device__ __forceinline__ void splat(int cell, float vx, float vy, float vc) const
+    // a quad of sources (sx .. sx + 3, sy); dead quads (outside the image) carry a NaN row
+    __device__ __forceinline__ void quad(float syf, float sxf, const f32x4 &fx4, const f32x4 &fy4, const f32x4 &d4) const
     {
-        double *q = P + cell;
-        lds_add_f64(q, (double)vc);
-        lds_add_f64(q + kPlane, (double)vx);
-        lds_add_f64(q + 2 * kPlane, (double)vy);
-    }
-    // the four y tests of a quad of sources in row sy
-    __device__ __forceinline__ bool rows(bool lv, float syf, const f32x4 &fy4, float (&y2)[4], bool (&wy)[4]) const
-    {
-        bool any = false;
+        float y2[4];
+        bool wy[4], rowany = false;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             y2[j] = syf + fy4[j];
-            wy[j] = lv && y2[j] >= ylo && __float_as_int(y2[j]) < yhi_bits;
-            any = any || wy[j];
+            wy[j] = (unsigned)(__float_as_int(y2[j]) - ylo_b) < yrange;
+            rowany = rowany || wy[j];
         }
-        return any;
-    }
-    // One source per lane (`pre`: passed the y test and whatever else the caller demands): x test, then the hits of
-    // the wave are pushed to the consecutive lanes fill, fill + 1, ... (cyclically) of the batch -- lanes without
-    // a hit aim at the LAST slot of the cycle, which a hit only takes when all 64 lanes hit (no such lane then).
-    // Wave-uniform control flow: call from converged code only.
-    __device__ __forceinline__ void source(bool pre, float x2, float y2, float fxv, float fyv, float d)
-    {
-        const bool hit = pre && x2 >= xlo && __float_as_int(x2) < xhi_bits;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
-        if (m == 0) return;                    // wave-uniform
-        const unsigned n = (unsigned)__builtin_popcountll(m);
-        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        const int dst = (int)((fill + (hit ? rank : 63u)) & 63u) << 2;
-        const int py = (int)y2 - (ty0 - 1), px = (int)x2 - (tx0 - 1);                       // (garbage without a hit)
-        float vx = -fxv, vy = -fyv, vc = 1.0f;
-        if (DEPTH) {                           // my_lib_kernel.cu:2102-2114
-            vx = -d * fxv;
-            vy = -d * fyv;
-            vc = d * 1.0f;
+        if (__builtin_amdgcn_ballot_w64(rowany) == 0) return;        // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float x2 = (sxf + (float)j) + fx4[j];                // (float)x + fx, as the reference rounds it
+            if (wy[j] && (unsigned)(__float_as_int(x2) - xlo_b) < xrange) {
+                const unsigned a = __umul24((unsigned)(int)y2[j], 8u * kPtW4) + ((((unsigned)(int)x2) << 3) + ucell8);
+                double *q = reinterpret_cast<double *>(reinterpret_cast<char *>(P) + a);
+                const float d = DEPTH ? d4[j] : 1.0f;                  // my_lib_kernel.cu:2102-2114: v = -d * f, count += d
+                lds_add_f64(q, (double)(d * 1.0f));
+                lds_add_f64(q + kPlane, -(double)(DEPTH ? d * fx4[j] : fx4[j]));
+                lds_add_f64(q + 2 * kPlane, -(double)(DEPTH ? d * fy4[j] : fy4[j]));
+            }
         }
-        const int r_cell = __builtin_amdgcn_ds_permute(dst, py * kPtW4 + px);
-        const float r_vx = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vx)));
-        const float r_vy = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vy)));
-        float r_vc = 1.0f;
-        if (DEPTH) r_vc = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(vc)));
-        if (fill + n < (unsigned)kWave) {      // (wave-uniform) not full yet: lanes [fill, fill + n) take theirs
-            const bool recv = ((lane - fill) & 63u) < n;
-            p_cell = recv ? r_cell : p_cell;
-            p_vx = recv ? r_vx : p_vx;
-            p_vy = recv ? r_vy : p_vy;
-            if (DEPTH) p_vc = recv ? r_vc : p_vc;
-            fill += n;
-        } else {                               // full: lanes [fill, 64) hold new entries, lanes [0, fill) waiting ones
-            const bool fresh = lane >= fill;
-            splat(fresh ? r_cell : p_cell, fresh ? r_vx : p_vx, fresh ? r_vy : p_vy, fresh ? r_vc : p_vc);
-            fill = fill + n - (unsigned)kWave; // the entries that wrapped around: lanes [0, fill)
-            p_cell = r_cell;  p_vx = r_vx;  p_vy = r_vy;  p_vc = r_vc;
-        }
-    }
-    __device__ __forceinline__ void finish() const
-    {
-        if (lane < fill) splat(p_cell, p_vx, p_vy, p_vc);      // what is still waiting
     }
     // After a barrier: the lane's four cells (cx .. cx + 3, cy) -- 2x2 box sums of the points of columns c-1 .. c+3,
     // rows cy-1 and cy (border duplicates as weights 2, see proj_scatter_tiled), normalised by the count.
     __device__ __forceinline__ void readout(int cx, int cy, int W, int H, f32x4 &ox, f32x4 &oy, f32x4 &oc) const
     {
-        const float wy0 = (cy == H - 1) ? 2.0f : 1.0f;
-        float top[3][5], bot[3][5];            // [count, vx, vy][column], each point sum rounded to fp32 once
+        const double wy0 = (cy == H - 1) ? 2.0 : 1.0;
         typedef double f64x2 __attribute__((ext_vector_type(2)));
         const double *r0 = P + (cy - ty0) * kPtW4 + (cx - tx0);   // column offset a multiple of 4: 16-byte pairs
+        float v[NP][4];
 #pragma unroll
         for (int pl = 0; pl < NP; pl++) {
+            const double *a = r0 + pl * kPlane, *c = a + kPtW4;
+            const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
+            const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
+            const double top[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
+            const double bot[5] = {c01[0], c01[1], c23[0], c23[1], c[4]};
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                const double *a = r0 + pl * kPlane + rr * kPtW4;
-                const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
-                const double v[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
-                float (&dst_c)[5] = rr ? bot[0] : top[0];
-                float (&dst_x)[5] = rr ? bot[1] : top[1];
-                float (&dst_y)[5] = rr ? bot[2] : top[2];
-#pragma unroll
-                for (int i = 0; i < 5; i++) (pl == 0 ? dst_c : (pl == 1 ? dst_x : dst_y))[i] = (float)v[i];
+            for (int j = 0; j < 4; j++) {
+                const double wx0 = (cx + j == W - 1) ? 2.0 : 1.0;
+                v[pl][j] = (float)__builtin_fma(wy0, __builtin_fma(wx0, bot[j + 1], bot[j]), __builtin_fma(wx0, top[j + 1], top[j]));
             }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const float wx0 = (cx + j == W - 1) ? 2.0f : 1.0f;
-            float v[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; pl++) {
-                // the four contributions are added in a fixed order (the reference's order is arbitrary: fp32 atomics)
-                float t = 0.0f;
-                t += wy0 * wx0 * bot[pl][j + 1];
-                t += wy0 * bot[pl][j];
-                t += wx0 * top[pl][j + 1];
-                t += top[pl][j];
-                v[pl] = t;
+            float v0 = v[0][j], v1 = v[1][j], v2 = v[2][j];
+            if (v0 > 0.0f) {                   // my_lib_kernel.cu:1730-1735; one reciprocal for both components
+                const float inv = 1.0f / v0;   // (<= 1 ulp from the two divisions)
+                v1 = v1 * inv;
+                v2 = v2 * inv;
             }
-            if (v[0] > 0.0f) {                 // my_lib_kernel.cu:1730-1735; one reciprocal for both components
-                const float inv = 1.0f / v[0]; // (<= 1 ulp from the two divisions)
-                v[1] = v[1] * inv;
-                v[2] = v[2] * inv;
-            }
-            oc[j] = v[0];  ox[j] = v[1];  oy[j] = v[2];
+            oc[j] = v0;  ox[j] = v1;  oy[j] = v2;
         }
     }
 };
-// The images flagged by the owner kernel, redone exactly: every tile of such an image scans whole source tiles -- those
-// whose motion bound (kReach, or what the owner kernel recorded in bounds[] for the tile's far sources: max |fx|,
-// max |fy|) lets one of their sources land in the window -- with no limit on |flow|.  Queued behind the owner kernel as a
-// short grid that strides over the tiles; returns at once when no flag was raised.
+
+// The images flagged by the owner kernel, completed exactly: the tiles of such an image in which a far source of another
+// tile lands (the owner kernel recorded in bounds[], per tile, the box its far sources land in) are recomputed from whole
+// source tiles -- those within kReach of the window and those whose far sources can land in it -- with no limit on |flow|.
+// Queued behind the owner kernel as a short grid that strides over the tiles; returns at once when no flag was raised.
+// Round 4 measured what this path cost: 4.0 ms for 32 x 720p as soon as one source per image moved 24 px -- 33x the fast
+// path (profiles/r04_proj_motion_sweep_before.txt), for what is ordinary motion in 720p video.  It walked ALL source tiles
+// of the image per target tile (460 scalar culling steps for ~9 candidates), one workgroup per CU, with round 3's
+// register compaction per source.  Now: a tile is redone only if a far source of another tile lands in it (landing boxes
+// instead of motion bounds: a fast object dirties the tiles it lands in, not its whole image); the culling is one source
+// tile per lane (a ballot names the ones to scan; per wave, its own four rows of a near tile), FarTile's cheap test and
+// direct splats, two workgroups per CU.
 template <bool DEPTH, int TH, int kReach>
-__global__ __launch_bounds__(16 * TH) void proj_owner_far(
+__global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per SIMD = two workgroups per CU
+
     int W, int H, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth,
     float *__restrict__ count, float *__restrict__ out, const int *__restrict__ far_flag,
     const int *__restrict__ bounds, FillWs ws, int nonce)
 {
-    using OT = OwnerTile<DEPTH, TH>;
+    using FT = FarTile<DEPTH, TH>;
     constexpr int NT = 16 * TH;
-    __shared__ __attribute__((aligned(16))) double P[OT::NP * OT::kPlane];
+    __shared__ __attribute__((aligned(16))) double P[FT::NP * FT::kPlane];
     __shared__ FillLds<TH> fl;
     if (far_flag[kFlagWords] != nonce) return;
     const unsigned per_image = (unsigned)tiles_x * tiles_y, ntiles = per_image * batch;
+    const int tid = tid_now(), lane = tid & (kWave - 1);
+    const int wrow0 = 4 * __builtin_amdgcn_readfirstlane(tid / kWave);   // the wave's four rows of a source tile
+    // Which tiles?  The owner kernel's result for a tile is complete unless a far source of ANOTHER tile lands in its
+    // window (it scanned every source within kReach of the tile, the tile's own among them, and splatted whatever landed,
+    // far or not): the tile that owns such a source stamped this call's nonce on the tiles its far sources' landing box
+    // meets.  Every other tile keeps what the owner kernel wrote -- outputs, summaries, masks.  The workgroup's tiles are
+    // blockIdx.x, + gridDim.x, ...: their stamps are read 64 at a time.
 #pragma unroll 1
-    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (unsigned k0 = 0; blockIdx.x + (uint64_t)k0 * gridDim.x < ntiles; k0 += kWave) {
+        const uint64_t mine = blockIdx.x + (uint64_t)(k0 + lane) * gridDim.x;
+        unsigned long long redo = __builtin_amdgcn_ballot_w64(mine < ntiles && bounds[kFarWords * (mine < ntiles ? mine : 0) + 4] == nonce);
+#pragma unroll 1
+    while (redo) {                             // (uniform over the workgroup: every wave reads the same stamps)
+        const unsigned tile = blockIdx.x + (k0 + (unsigned)__builtin_ctzll(redo)) * gridDim.x;
+        redo &= redo - 1;
         const int b = tile / per_image, tx = (tile % per_image) % tiles_x, ty = (tile % per_image) / tiles_x;
-        if (far_flag[b % kFlagWords] != nonce) continue;         // wave-uniform: this image was complete
-        const int tid = tid_now();
         const int tx0 = tx * 64, ty0 = ty * TH;
-        OT t;
-        t.begin(P, tx0, ty0, W, H, tid & (kWave - 1));
+        const int4 *boxes = reinterpret_cast<const int4 *>(bounds) + 2 * (int64_t)b * per_image;   // [2 * s]: tile s of the image
+        // Can a far source of a tile land in this tile's window?  box: where the tile's far sources land (min x2, max x2,
+        // min y2, max y2 as the owner kernel recorded them; max < 0: it has none).  The window takes x2 in
+        // [tx0 - 1, tx0 + 64), y2 in [ty0 - 1, ty0 + TH) (FarTile::begin).
+        auto far_hits = [&](const int4 &box) {
+            return box.y >= 0 && __int_as_float(box.y) >= (float)(tx0 - 1) && __int_as_float(box.x) < (float)(tx0 + 64) &&
+                   __int_as_float(box.w) >= (float)(ty0 - 1) && __int_as_float(box.z) < (float)(ty0 + TH);
+        };
+        // Can a source that moves by less than kReach (+1: the rounding of x + fx), from rows [y_lo, y_lo + y_n) of the
+        // tile column stx, land in the window?
+        auto near_hits = [&](int stx, int y_lo, int y_n) {
+            const float sx0 = (float)(stx * 64), sy0 = (float)y_lo, r = (float)kReach;
+            return sx0 + 64.0f + r >= (float)(tx0 - 1) && sx0 - r - 1.0f < (float)(tx0 + 64) &&
+                   sy0 + (float)y_n + r >= (float)(ty0 - 1) && sy0 - r - 1.0f < (float)(ty0 + TH);
+        };
+        FT t;
+        t.begin(P, tx0, ty0, W, H);
         fill_lds_init(fl, tid);
         t.template zero<NT>(tid);
         __syncthreads();
         const float *flow_b = flow + b * s1b;
         const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
-        const int *bnd = bounds + 2 * (int64_t)b * per_image;
+        // The source tiles to scan, one per lane and 64 at a time: a ballot names them.  Near sources: the wave's own rows
+        // of the tile; far ones: anywhere in it.
 #pragma unroll 1
-        for (unsigned s = 0; s < per_image; s++) {
-            const int stx = s % tiles_x, sty = s / tiles_x;
-            // (recorded: the tile's far sources; its other sources move by less than kReach)
-            const float mx = fmaxf(__int_as_float(bnd[2 * s]), (float)kReach), my = fmaxf(__int_as_float(bnd[2 * s + 1]), (float)kReach);
-            // can a source of tile s, moved by at most (mx, my) (+1: the rounding of x + fx), land in the window?
-            const float sx0 = (float)(stx * 64), sy0 = (float)(sty * TH);
-            const bool cand = sx0 + 64.0f + mx >= (float)(tx0 - 1) && sx0 - mx - 1.0f < (float)(tx0 + 64) &&
-                              sy0 + (float)TH + my >= (float)(ty0 - 1) && sy0 - my - 1.0f < (float)(ty0 + TH);
-            if (!cand) continue;               // wave-uniform (scalar data)
-            const int sx = stx * 64 + 4 * (tid % 16), sy = sty * TH + tid / 16;   // one quad of sources per lane
-            const bool lv = sx < W && sy < H;
-            const unsigned off = lv ? 4u * (unsigned)(sy * s1h + sx) : 0u;
-            const f32x4 fxq = ld_cached4_u(flow_b, off), fyq = ld_cached4_u(flow_b + s1c, off);
-            f32x4 ddq = {1.f, 1.f, 1.f, 1.f};
-            if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy * sdh + sx) : 0u);
-            float y2[4];
-            bool wy[4];
-            const bool rowany = t.rows(lv, (float)sy, fyq, y2, wy);
-            if (__builtin_amdgcn_ballot_w64(rowany) == 0) continue;
+        for (unsigned s0 = 0; s0 < per_image; s0 += kWave) {
+            const unsigned sl = s0 + lane;
+            bool c = false;
+            if (sl < per_image) {
+                const int sty = sl / (unsigned)tiles_x, stx = sl - sty * tiles_x;
+                c = near_hits(stx, sty * TH + wrow0, 4) || far_hits(boxes[2 * sl]);
+            }
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(c);
+#pragma unroll 1
+            while (todo) {                     // wave-uniform.  kBatch tiles' loads in flight before the first splat: this
+                constexpr int kBatch = 4;      // loop is a chain of L2 / HBM round trips otherwise
+                f32x4 fxq[kBatch], fyq[kBatch], ddq[kBatch];
+                float sxf[kBatch], syf[kBatch];
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                t.source(wy[j], ((float)sx + (float)j) + fxq[j], y2[j], fxq[j], fyq[j], ddq[j]);
+                for (int k = 0; k < kBatch; k++) {     // (past the last tile: dead slots -- a NaN row, loads of element 0)
+                    const bool have = todo != 0;
+                    const unsigned st = s0 + (unsigned)__builtin_ctzll(todo | (1ull << 63));
+                    todo &= todo - 1;          // (0 stays 0)
+                    const int sty = st / (unsigned)tiles_x, stx = st - sty * tiles_x;
+                    const int sx = stx * 64 + 4 * (tid % 16), sy = sty * TH + tid / 16;   // one quad of sources per lane
+                    const bool lv = have && sx < W && sy < H;
+                    const unsigned off = lv ? 4u * (unsigned)(sy * s1h + sx) : 0u;
+                    fxq[k] = ld_cached4_u(flow_b, off);
+                    fyq[k] = ld_cached4_u(flow_b + s1c, off);
+                    if (DEPTH) ddq[k] = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy * sdh + sx) : 0u);
+                    sxf[k] = (float)sx;
+                    syf[k] = lv ? (float)sy : __int_as_float(0x7fc00000);
+                }
+#pragma unroll
+                for (int k = 0; k < kBatch; k++)
+                    t.quad(syf[k], sxf[k], fxq[k], fyq[k], DEPTH ? ddq[k] : f32x4{1.f, 1.f, 1.f, 1.f});
+            }
         }
-        t.finish();
         __syncthreads();                       // every wave's points are in P
         const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
         const bool inb = cx < W && cy < H;     // (no early exit: barriers below)
@@ -656,6 +646,7 @@ __global__ __launch_bounds__(16 * TH) void proj_owner_far(
             *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
         }
         __syncthreads();                       // P and the masks are rebuilt by the next tile
+    }
     }
 }
 
@@ -1022,11 +1013,11 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     // (the owner kernel addresses the flow / depth planes with 32-bit offsets)
     const bool want_fast = variant != 1 && variant < 2 && plane_fits_u32(w, h, {s1h, sdh});
     const bool want_carry = a.fillhole && variant != -8 && variant != -9;
-    // scratch layout: [0, 320) ints of far flags (image b -> word b % 256, word 256 = "any"), the tiles' motion bounds
-    // (2 ints per tile), then -- with hole filling -- the three tables of per-tile summaries, the per-tile hole flags and
+    // scratch layout: [0, 320) ints of far flags (image b -> word b % 256, word 256 = "any"), the tiles' far table
+    // (kFarWords ints per tile: proj_owner5.hpp; rounds 2-3: 2 ints of motion bounds), then -- with hole filling -- the three tables of per-tile summaries, the per-tile hole flags and
     // (8-byte aligned) the tiles' masks
     constexpr size_t kHead = 320;
-    const size_t n_bnd = want_fast ? 2 * (size_t)ntiles : 0;
+    const size_t n_bnd = want_fast ? kFarWords * (size_t)ntiles : 0;
     const size_t n_up = (size_t)batch * nty * w, n_row = (size_t)batch * h * ntx;
     size_t ints = kHead + n_bnd + (want_carry ? n_up + 2 * n_row + (size_t)ntiles : 0);
     ints = (ints + 1) / 2 * 2;
@@ -1095,7 +1086,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                                nonce);
             if (launch_status() != 0) return -1;
             if (!only_part) {
-                const unsigned pg = persistent_grid(1);
+                const unsigned pg = r3_set ? persistent_grid(1) : persistent_grid(2);   // (53 KiB of LDS, 85 VGPRs: two per CU)
 #ifdef MEMC_MEASURE
                 if (r3_set)
                     hipLaunchKernelGGL((proj_owner_far_r3<DEPTH, TH, 24>), dim3(ntiles < pg ? ntiles : pg), dim3(16 * TH), 0,

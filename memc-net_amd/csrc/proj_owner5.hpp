@@ -17,7 +17,7 @@
 //   * far-source detection of the home quads is a max3 chain and one compare per quad.
 // Everything else is proj_owner4's: 64 x TH cell tiles, 16 TH lanes, the scan region dilated by kReach, deferred fx loads
 // for rows far from the tile, two planes (count * 2^20 + sum vx, sum vy) for FlowProjection and three for the depth
-// operator, box sums in double, one reciprocal per cell, far flags by nonce, per-tile motion bounds.
+// operator, box sums in double, one reciprocal per cell, far flags by nonce, per-tile landing boxes of the far sources.
 #pragma once
 
 template <bool DEPTH, int TH, int kReach, int MINW, bool TRACE = false>
@@ -47,7 +47,8 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     static_assert((2 * kReach + 1) * (2 * kReach + 1) < 4096 && kReach <= 128, "count * 2^20 + sum(vx) must split exactly");
     __shared__ __attribute__((aligned(16))) double P[NP * kPlane];
     __shared__ FillLds<TH> fl;                    // the hole filler's masks (fill epilogue only)
-    __shared__ int tile_max[2];                   // bit patterns of max |fx|, max |fy| over the tile's own FAR sources (0: none)
+    __shared__ int tile_box[4];                   // where the tile's own FAR sources land: bit patterns of min x2, max x2, min y2,
+                                                  // max y2 (all >= 0: ordered like ints); max < 0: the tile has none
 
     const TileCoord tc = plan.fast ? tile_walk_plan(blockIdx.x, plan)
                                    : tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, plan.sw > 1 || plan.stripes_x != (unsigned)tiles_x ? (int)plan.sw : 0);
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     const int wave_index = __builtin_amdgcn_readfirstlane(tid0 / kWave);
     trace_mark_proj<TRACE>(0);
     fill_lds_init(fl, tid0);
-    if (tid0 < 2) tile_max[tid0] = 0;
+    if (tid0 < 4) tile_box[tid0] = (tid0 & 1) ? -1 : 0x7fffffff;
     {
         f32x4 *pz = reinterpret_cast<f32x4 *>(P);
         for (int i = tid0; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -135,9 +136,11 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
                     const bool valid = homeq && !(fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach) && x2 >= 0.0f &&
                                        y2 >= 0.0f && x2 <= (float)(W - 1) && y2 <= (float)(H - 1);
                     far = far || valid;
-                    if (valid) {               // the tile's bound on its far sources' motion, for proj_owner_far:
-                        atomicMax(&tile_max[0], __float_as_int(fabsf(fxv)));      // non-negative floats order like their bits
-                        atomicMax(&tile_max[1], __float_as_int(fabsf(fyv)));
+                    if (valid) {               // where the tile's far sources land, for proj_owner_far (x2, y2 >= 0:
+                        atomicMin(&tile_box[0], __float_as_int(x2));              // non-negative floats order like their bits)
+                        atomicMax(&tile_box[1], __float_as_int(x2));
+                        atomicMin(&tile_box[2], __float_as_int(y2));
+                        atomicMax(&tile_box[3], __float_as_int(y2));
                     }
                 }
             }
@@ -186,12 +189,26 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         far_flag[kFlagWords] = nonce;          // or uninitialised words can at worst cause a needless redo, never a missed one
     }
     trace_mark_proj<TRACE>(3);                 // scan + splat done (wave 0)
-    __syncthreads();                           // every wave's points are in P (and the tile's motion bound in tile_max)
+    __syncthreads();                           // every wave's points are in P (and the tile's far landing box in tile_box)
     trace_mark_proj<TRACE>(4);
     // (from here on the thread index is REBUILT from the wave's index, a scalar, and the lane's rank in the wave:
     // it need not live through the scan)
     const int tid = wave_index * kWave + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if (tid < 2) bounds[2 * (((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx) + tid] = tile_max[tid];
+    // bounds[]: 8 words per tile -- the box its far sources land in (4), "a far source of another tile lands here" (1: this
+    // call's nonce, stamped by that tile), 3 unused
+    const int64_t tile_lin = ((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx;
+    if (tid < 4) bounds[kFarWords * tile_lin + tid] = tile_box[tid];
+    if (__builtin_expect(tile_box[1] >= 0, 0)) {   // cold: stamp the tiles whose window -- x2 in [tx0 - 1, tx0 + 64), y2 in
+        // [ty0 - 1, ty0 + TH) -- meets the box: proj_owner_far recomputes those.  Not this tile: it scanned its own sources.
+        const int xa = (int)__int_as_float(tile_box[0]), xb = (int)__int_as_float(tile_box[1]) + 1;
+        const int ya = (int)__int_as_float(tile_box[2]), yb = (int)__int_as_float(tile_box[3]) + 1;
+        const int txa = xa / 64, txb = min(xb / 64, tiles_x - 1), tya = ya / TH, tyb = min(yb / TH, tiles_y - 1);
+        const int nx = txb - txa + 1, n = nx * (tyb - tya + 1);
+        for (int i = tid; i < n; i += NT) {
+            const int ty = tya + i / nx, tx = txa + i % nx;
+            if (tx != tc.tx || ty != tc.ty) bounds[kFarWords * (((int64_t)b * tiles_y + ty) * tiles_x + tx) + 4] = nonce;
+        }
+    }
 
     // Every lane owns four cells of a row: 2x2 box sums of the points of columns c-1 .. c+3, rows cy-1 and cy (border
     // duplicates as weights 2, see proj_scatter_tiled), summed in DOUBLE -- exact, also for the packed plane:

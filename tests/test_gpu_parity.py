@@ -635,6 +635,45 @@ def test_projection_forward_unusual_depths_and_flows(oracle):
         close(N(out), want_out, "FlowProjection with NaN / Inf flow and an uncovered patch, case %d" % ci)
 
 
+def test_projection_with_a_few_far_sources(oracle):
+    """Sources that move 24 px or more are not seen by the owner kernel's scan unless they lie within 24 px of the tile they
+    land in: their image is flagged and proj_owner_far redoes the tiles such a source can reach -- and ONLY those (the other
+    tiles keep what the owner kernel wrote, summaries and hole masks included).  A few far sources in an otherwise gentle
+    image: single sites thrown across many tiles, a patch moving 40 px, far sources landing in what would otherwise be a
+    hole, one image with none (never flagged).  Counts bit-exact, outputs to 1e-4, both operators, with and without fill."""
+    import my_package._ext.my_lib as my_lib
+    B, H, W = 3, 170, 530                                              # 6 x 9 tiles of 64 x 32, cut by both edges
+    rng = np.random.default_rng(4711)
+    flow = synth.np_flow(rng, B, H, W, "smooth", 4.0)
+    depth = (rng.random((B, 1, H, W)) + 0.1).astype(np.float32)
+    flow[0, :, 60:70, 300:330] = 300.0                                 # a hole (its sources leave the image) ...
+    for (y, x, fx, fy) in ((5, 7, 150.0, 0.0), (100, 500, -200.5, 40.25), (160, 20, 30.0, -100.0), (64, 310, 0.0, 25.0),
+                           (40, 280, 35.5, 24.75), (90, 100, -24.0, 3.0), (12, 400, 23.99, -23.99)):
+        flow[0, 0, y, x], flow[0, 1, y, x] = fx, fy                    # ... that (40, 280) -> (315.5, 64.75) lands in
+    flow[2, 0, 120:128, 200:208] += 40.0                               # a patch moving 40 px right, 30 px up
+    flow[2, 1, 120:128, 200:208] -= 30.0
+    for fill in (0, 1):
+        want_out, want_cnt = oracle.flow_projection_forward(flow, fill)
+        cnt, out = torch.full((B, 1, H, W), 7.0, device=dev()), torch.full((B, 2, H, W), 7.0, device=dev())
+        assert my_lib.FlowProjectionLayer_gpu_forward(T(flow), cnt, out, fill) == 0
+        assert np.array_equal(N(cnt), want_cnt), "count, fill %d" % fill
+        close(N(out), want_out, "FlowProjection with a few far sources, fill %d" % fill)
+        want_out, want_cnt = oracle.depth_flow_projection_forward(flow, depth, fill)
+        cnt, out = torch.full((B, 1, H, W), 7.0, device=dev()), torch.full((B, 2, H, W), 7.0, device=dev())
+        assert my_lib.DepthFlowProjectionLayer_gpu_forward(T(flow), T(depth), cnt, out, fill) == 0
+        close(N(cnt), want_cnt, "depth count, fill %d" % fill, RTOL)
+        close(N(out), want_out, "DepthFlowProjection with a few far sources, fill %d" % fill, RTOL)
+    # every image far, by 30-90 px: every tile redone, with the reach the recorded bounds imply
+    for ci, sigma in enumerate((30.0, 90.0)):
+        big = synth.np_flow(rng, 2, 100, 300, "smooth", sigma)
+        for fill in (0, 1):
+            want_out, want_cnt = oracle.flow_projection_forward(big, fill)
+            cnt, out = torch.zeros((2, 1, 100, 300), device=dev()), torch.zeros((2, 2, 100, 300), device=dev())
+            assert my_lib.FlowProjectionLayer_gpu_forward(T(big), cnt, out, fill) == 0
+            assert np.array_equal(N(cnt), want_cnt), "count, sigma %g, fill %d" % (sigma, fill)
+            close(N(out), want_out, "FlowProjection, smooth flow of sigma %g, fill %d" % (sigma, fill))
+
+
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
                 if os.path.basename(p).startswith(("small_", "config1_")))   # the oracle-made operator fixtures
 

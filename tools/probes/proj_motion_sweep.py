@@ -37,3 +37,54 @@ for scale in (1.0, 1.5, 2.0, 3.0, 4.0, 6.0):
         ts.sort()
         row.append(ts[len(ts) // 2])
     print("%-7.1f %10.1f %12.3f %14.1f %14.1f %16.1f" % (scale, float(f.abs().max()), far, row[0], row[1], row[2]))
+
+
+def far_model(f, images=4, TH=32, R=24):
+    """What proj_owner_far decides for the first `images` images of f (numpy restatement of its culling): the share of tiles
+    it recomputes, and per recomputed tile the source quads its waves scan, in units of the owner kernel's scan
+    (128 x 81 sources)."""
+    import numpy as np
+    fn = f[:images].cpu().numpy()
+    B, _, H, W = fn.shape
+    ntx, nty = (W + 63) // 64, (H + TH - 1) // TH
+    redo = scanned = 0
+    for b in range(B):
+        fx, fy = fn[b, 0], fn[b, 1]
+        ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+        x2, y2 = xs + fx, ys + fy
+        valid = ~((np.abs(fx) < R) & (np.abs(fy) < R)) & (x2 >= 0) & (y2 >= 0) & (x2 <= W - 1) & (y2 <= H - 1)
+        box = np.full((nty, ntx, 4), np.nan, np.float32)
+        for ty in range(nty):
+            for tx in range(ntx):
+                v = valid[ty * TH:(ty + 1) * TH, tx * 64:(tx + 1) * 64]
+                if v.any():
+                    a, c = x2[ty * TH:(ty + 1) * TH, tx * 64:(tx + 1) * 64][v], y2[ty * TH:(ty + 1) * TH, tx * 64:(tx + 1) * 64][v]
+                    box[ty, tx] = (a.min(), a.max(), c.min(), c.max())
+        for ty in range(nty):
+            for tx in range(ntx):
+                tx0, ty0 = tx * 64, ty * TH
+                hit = (box[..., 1] >= tx0 - 1) & (box[..., 0] < tx0 + 64) & (box[..., 3] >= ty0 - 1) & (box[..., 2] < ty0 + TH)
+                other = hit.copy(); other[ty, tx] = False
+                if not other.any():
+                    continue
+                redo += 1
+                rows = 0
+                for sty in range(nty):
+                    for stx in range(ntx):
+                        sx0 = stx * 64
+                        if hit[sty, stx]:
+                            rows += TH
+                            continue
+                        if not (sx0 + 64 + R >= tx0 - 1 and sx0 - R - 1 < tx0 + 64):
+                            continue
+                        for w0 in range(0, TH, 4):
+                            sy0 = sty * TH + w0
+                            rows += 4 * (sy0 + 4 + R >= ty0 - 1 and sy0 - R - 1 < ty0 + TH)
+                scanned += rows * 64
+    return 100.0 * redo / (B * ntx * nty), scanned / max(redo, 1) / (128 * 81)
+
+
+print()
+print("the far kernel's decisions (first 4 images): tiles recomputed, sources scanned per recomputed tile / the owner kernel's 128 x 81")
+for scale in (1.5, 2.0, 3.0, 4.0, 6.0):
+    print("%-7.1f %8.1f %% %8.2f x" % ((scale,) + far_model(f0 * scale)))
