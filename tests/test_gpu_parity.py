@@ -663,7 +663,18 @@ def test_projection_with_a_few_far_sources(oracle):
         assert my_lib.DepthFlowProjectionLayer_gpu_forward(T(flow), T(depth), cnt, out, fill) == 0
         close(N(cnt), want_cnt, "depth count, fill %d" % fill, RTOL)
         close(N(out), want_out, "DepthFlowProjection with a few far sources, fill %d" % fill, RTOL)
-    # every image far, by 30-90 px: every tile redone, with the reach the recorded bounds imply
+    # more source tiles per image than proj_owner_far lists in one round (512): far sources at both ends of the table
+    Hb, Wb = 1060, 1030                                                # 34 x 17 = 578 tiles
+    big = synth.np_flow(rng, 1, Hb, Wb, "smooth", 3.0)
+    for (y, x, fx, fy) in ((3, 5, 900.0, 1000.0), (1050, 1020, -1000.25, -1040.5), (500, 500, 0.0, 540.0), (1040, 10, 64.0, -700.0),
+                           (30, 1000, -60.0, 1020.0)):
+        big[0, 0, y, x], big[0, 1, y, x] = fx, fy
+    want_out, want_cnt = oracle.flow_projection_forward(big, 1)
+    cnt, out = torch.zeros((1, 1, Hb, Wb), device=dev()), torch.zeros((1, 2, Hb, Wb), device=dev())
+    assert my_lib.FlowProjectionLayer_gpu_forward(T(big), cnt, out, 1) == 0
+    assert np.array_equal(N(cnt), want_cnt), "count, 578 tiles"
+    close(N(out), want_out, "FlowProjection, far sources across 578 tiles")
+    # every image far, by 30-90 px: (nearly) every tile redone
     for ci, sigma in enumerate((30.0, 90.0)):
         big = synth.np_flow(rng, 2, 100, 300, "smooth", sigma)
         for fill in (0, 1):

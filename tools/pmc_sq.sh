@@ -13,7 +13,8 @@ P3="SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INS
 i=0
 for CTRS in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $CTRS --kernel-trace -d $OUT/p$i -o r -- python $REPO/tools/bench_ops.py --only $ONLY $EXTRA --json $OUT/ops$i.json > $OUT/p$i.log 2>&1
+  # (PMC_CMD: another workload than bench_ops.py, e.g. "python tools/probes/proj_far_load.py 4")
+  timeout 300 rocprofv3 --pmc $CTRS --kernel-trace -d $OUT/p$i -o r -- ${PMC_CMD:-python $REPO/tools/bench_ops.py --only $ONLY $EXTRA --json $OUT/ops$i.json} > $OUT/p$i.log 2>&1
   python $REPO/tools/prof_summary.py pmc $OUT/p$i/r_results.db --match "$MATCH" --out $OUT/pmc$i.json > /dev/null
   rm -rf $OUT/p$i
 done

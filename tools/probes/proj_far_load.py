@@ -1,0 +1,26 @@
+#!/usr/bin/env python
+"""tools/probes/proj_far_load.py <scale> [depth] -- 30 FlowProjection (or DepthFlowProjection) forward calls, fill 0, on the
+benchmark's smooth flow times <scale>: a workload for rocprofv3 / tools/pmc_sq.sh (PMC_CMD) that exercises proj_owner_far."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for _p in (ROOT, os.path.join(ROOT, "memc-net_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+import torch  # noqa: E402
+
+import my_package._ext.my_lib as L  # noqa: E402
+from tools import synth  # noqa: E402
+
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
+dev = torch.device("cuda:0")
+t = synth.torch_inputs(dev, 32, 3, 720, 1280, flow_kind="smooth", with_depth=True)
+f, d = (t["flow"] * scale).contiguous(), t["depth"]
+cnt, out = f.new_zeros((32, 1, 720, 1280)), torch.zeros_like(f)
+for _ in range(30):
+    if len(sys.argv) > 2:
+        L.DepthFlowProjectionLayer_gpu_forward(f, d, cnt, out, 0)
+    else:
+        L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0)
+torch.cuda.synchronize()
