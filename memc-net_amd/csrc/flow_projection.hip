@@ -554,7 +554,8 @@ __global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per S
     constexpr int NT = 16 * TH;
     __shared__ __attribute__((aligned(16))) double P[FT::NP * FT::kPlane];
     __shared__ FillLds<TH> fl;
-    __shared__ unsigned cand[NT];              // the source tiles to scan (bit 31: its far sources can land in the window)
+    __shared__ unsigned cand[NT];              // the source tiles to scan (bit 31: its far sources can land in the window; bit 30:
+                                               // it has other sources, within reach of the window)
     __shared__ int ncand;
     if (far_flag[kFlagWords] != nonce) return;
     const unsigned per_image = (unsigned)tiles_x * tiles_y, ntiles = per_image * batch;
@@ -599,7 +600,8 @@ __global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per S
         const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
         // The source tiles to scan: listed once per tile by the whole workgroup, one source tile per lane (a single round
         // trip to the table), then walked by every wave -- near tiles only by the waves whose own four rows of the tile can
-        // reach the window, tiles whose far sources can land in it by all.
+        // reach the window, tiles whose far sources can land in it by all.  (A tile that recorded no source that is NOT far is
+        // not scanned for its near sources: after a camera pan that is every tile.)
 #pragma unroll 1
         for (unsigned s0 = 0; s0 < per_image; s0 += NT) {
             if (s0) __syncthreads();           // the previous round's list has been walked (images of more than NT tiles)
@@ -607,18 +609,19 @@ __global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per S
             __syncthreads();
             {
                 const unsigned sl = s0 + tid;
-                bool c = false, fh = false;
+                bool c = false, fh = false, nr = false;
                 if (sl < per_image) {
                     const int sty = sl / (unsigned)tiles_x, stx = sl - sty * tiles_x;
                     fh = far_hits(boxes[2 * sl]);
-                    c = fh || near_hits(stx, sty * TH, TH);
+                    nr = boxes[2 * sl + 1].y != 0 && near_hits(stx, sty * TH, TH);   // (.y: the tile has sources that are not far)
+                    c = fh || nr;
                 }
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
                 if (m) {                       // the wave's entries, in lane order, behind one atomic
                     int base = 0;
                     if (lane == 0) base = atomicAdd(&ncand, __builtin_popcountll(m));
                     base = __builtin_amdgcn_readfirstlane(base);
-                    if (c) cand[base + __builtin_popcountll(m & ((1ull << lane) - 1))] = sl | (fh ? 0x80000000u : 0u);
+                    if (c) cand[base + __builtin_popcountll(m & ((1ull << lane) - 1))] = sl | (fh ? 0x80000000u : 0u) | (nr ? 0x40000000u : 0u);
                 }
             }
             __syncthreads();
@@ -628,9 +631,9 @@ __global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per S
             const unsigned ent = e0 + lane < n ? cand[e0 + lane] : 0u;
             bool use = false;
             if (e0 + lane < n) {
-                const unsigned sl = ent & 0x7fffffffu;
+                const unsigned sl = ent & 0x3fffffffu;
                 const int sty = sl / (unsigned)tiles_x, stx = sl - sty * tiles_x;
-                use = (ent >> 31) != 0 || near_hits(stx, sty * TH + wrow0, 4);
+                use = (ent >> 31) != 0 || ((ent & 0x40000000u) != 0 && near_hits(stx, sty * TH + wrow0, 4));
             }
             unsigned long long todo = __builtin_amdgcn_ballot_w64(use);
 #pragma unroll 1
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per S
 #pragma unroll
                 for (int k = 0; k < kBatch; k++) {     // (past the last tile: dead slots -- a NaN row, loads of element 0)
                     const bool have = todo != 0;
-                    const unsigned st = (unsigned)__builtin_amdgcn_readlane((int)ent, __builtin_ctzll(todo | (1ull << 63))) & 0x7fffffffu;
+                    const unsigned st = (unsigned)__builtin_amdgcn_readlane((int)ent, __builtin_ctzll(todo | (1ull << 63))) & 0x3fffffffu;
                     todo &= todo - 1;          // (0 stays 0)
                     const int sty = st / (unsigned)tiles_x, stx = st - sty * tiles_x;
                     const int sx = stx * 64 + 4 * (tid % 16), sy = sty * TH + tid / 16;   // one quad of sources per lane

@@ -47,8 +47,9 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     static_assert((2 * kReach + 1) * (2 * kReach + 1) < 4096 && kReach <= 128, "count * 2^20 + sum(vx) must split exactly");
     __shared__ __attribute__((aligned(16))) double P[NP * kPlane];
     __shared__ FillLds<TH> fl;                    // the hole filler's masks (fill epilogue only)
-    __shared__ int tile_box[4];                   // where the tile's own FAR sources land: bit patterns of min x2, max x2, min y2,
-                                                  // max y2 (all >= 0: ordered like ints); max < 0: the tile has none
+    __shared__ int tile_box[5];                   // where the tile's own FAR sources land: bit patterns of min x2, max x2, min y2,
+                                                  // max y2 (all >= 0: ordered like ints); max < 0: the tile has none.  [4]: the
+                                                  // tile has sources that are NOT far (a camera pan leaves none)
 
     const TileCoord tc = plan.fast ? tile_walk_plan(blockIdx.x, plan)
                                    : tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, plan.sw > 1 || plan.stripes_x != (unsigned)tiles_x ? (int)plan.sw : 0);
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     const int wave_index = __builtin_amdgcn_readfirstlane(tid0 / kWave);
     trace_mark_proj<TRACE>(0);
     fill_lds_init(fl, tid0);
-    if (tid0 < 4) tile_box[tid0] = (tid0 & 1) ? -1 : 0x7fffffff;
+    if (tid0 < 5) tile_box[tid0] = tid0 == 4 ? 0 : (tid0 & 1) ? -1 : 0x7fffffff;
     {
         f32x4 *pz = reinterpret_cast<f32x4 *>(P);
         for (int i = tid0; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     double kunit = kCountUnit;
     asm volatile("" : "+s"(pitch8), "+s"(ucell8), "+s"(kunit));
     bool far = false;
+    unsigned long long near_seen = 0;             // (scalar) home quads of this wave that hold a source that is not far
 
 #pragma unroll
     for (int it = 0; it < kIts; it++) {
@@ -129,18 +131,38 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
             const f32x4 &a = fx[it], &c = fy[it];
             const float m = fmaxf(fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))),
                                   fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3]))));
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(homeq && !(m < (float)kReach)) != 0, 0)) {   // wave-uniform, cold
+            const unsigned long long farq = __builtin_amdgcn_ballot_w64(homeq && !(m < (float)kReach));
+            near_seen |= __builtin_amdgcn_ballot_w64(homeq) & ~farq;
+            if (__builtin_expect(farq != 0, 0)) {                                                         // wave-uniform, cold
+                // (the wave's box first, ONE lane's atomics then: 64 lanes on one LDS word serialise -- a camera pan, where
+                // every source is far, ran this kernel at 1.1 ms instead of 0.12)
+                int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
+                bool nearj = false;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float fxv = a[j], fyv = c[j], x2 = (sxf + (float)j) + fxv, y2 = syf + fyv;
-                    const bool valid = homeq && !(fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach) && x2 >= 0.0f &&
-                                       y2 >= 0.0f && x2 <= (float)(W - 1) && y2 <= (float)(H - 1);
-                    far = far || valid;
+                    const bool nr = fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach;
+                    nearj = nearj || (homeq && nr);
+                    const bool valid = homeq && !nr && x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(W - 1) && y2 <= (float)(H - 1);
                     if (valid) {               // where the tile's far sources land, for proj_owner_far (x2, y2 >= 0:
-                        atomicMin(&tile_box[0], __float_as_int(x2));              // non-negative floats order like their bits)
-                        atomicMax(&tile_box[1], __float_as_int(x2));
-                        atomicMin(&tile_box[2], __float_as_int(y2));
-                        atomicMax(&tile_box[3], __float_as_int(y2));
+                        bx0 = min(bx0, __float_as_int(x2));                       // non-negative floats order like their bits)
+                        bx1 = max(bx1, __float_as_int(x2));
+                        by0 = min(by0, __float_as_int(y2));
+                        by1 = max(by1, __float_as_int(y2));
+                    }
+                }
+                near_seen |= __builtin_amdgcn_ballot_w64(nearj);
+                bx1 = -wave_min_i32(-bx1);
+                if (bx1 >= 0) {                // wave-uniform: a valid far source
+                    far = true;
+                    bx0 = wave_min_i32(bx0);
+                    by0 = wave_min_i32(by0);
+                    by1 = -wave_min_i32(-by1);
+                    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+                        atomicMin(&tile_box[0], bx0);
+                        atomicMax(&tile_box[1], bx1);
+                        atomicMin(&tile_box[2], by0);
+                        atomicMax(&tile_box[3], by1);
                     }
                 }
             }
@@ -184,6 +206,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
             }
         }
     }
+    if (near_seen != 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) tile_box[4] = 1;
     if (far) {                                 // this image is redone by proj_owner_far.  The flag words are NOT cleared
         far_flag[b % kFlagWords] = nonce;      // before the call: "raised" = "holds this call's nonce" (launcher), so stale
         far_flag[kFlagWords] = nonce;          // or uninitialised words can at worst cause a needless redo, never a missed one
@@ -195,9 +218,9 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     // it need not live through the scan)
     const int tid = wave_index * kWave + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     // bounds[]: 8 words per tile -- the box its far sources land in (4), "a far source of another tile lands here" (1: this
-    // call's nonce, stamped by that tile), 3 unused
+    // call's nonce, stamped by that tile), "the tile has sources that are not far" (1), 2 unused
     const int64_t tile_lin = ((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx;
-    if (tid < 4) bounds[kFarWords * tile_lin + tid] = tile_box[tid];
+    if (tid < 6 && tid != 4) bounds[kFarWords * tile_lin + tid] = tile_box[tid < 4 ? tid : 4];
     if (__builtin_expect(tile_box[1] >= 0, 0)) {   // cold: stamp the tiles whose window -- x2 in [tx0 - 1, tx0 + 64), y2 in
         // [ty0 - 1, ty0 + TH) -- meets the box: proj_owner_far recomputes those.  Not this tile: it scanned its own sources.
         const int xa = (int)__int_as_float(tile_box[0]), xb = (int)__int_as_float(tile_box[1]) + 1;
