@@ -26,6 +26,9 @@ timeout 600 python tools/ab_variants.py --op projection --variants=-1,-40 --case
 timeout 300 python tools/probes/proj_burst.py 2>&1 | grep -v amdgpu.ids | tee "$OUT/proj_burst.txt"
 echo "== RGB backward: without the image gradient (gradinput1 NULL) next to the whole backward, one process"
 timeout 600 python tools/ab_variants.py --op fi_bwd --variants=-1 --cases fi_bwd_c2,fi_bwd_c2_nog1,fi_bwd,fi_bwd_nog1 --flows smooth 2>&1 | grep -v amdgpu.ids | tee "$OUT/fi_bwd_nog1.txt"
+echo "== large motion: the projection and every operator against flow scale and camera pans"
+timeout 300 python tools/probes/proj_motion_sweep.py 2>&1 | grep -v amdgpu.ids | tee "$OUT/proj_motion_sweep.txt"
+timeout 300 python tools/probes/motion_sweep_all.py 2>&1 | grep -v amdgpu.ids | tee "$OUT/motion_sweep_all.txt"
 echo "== race screen"; timeout 600 python tools/stress_projection.py 60 2>&1 | tail -3 | tee "$OUT/stress.log"
 echo "== projection kernels of a call (kernel trace)"
 ( cd /tmp && export TMPDIR=/tmp && for kind in smooth iid; do
