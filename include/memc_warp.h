@@ -38,7 +38,10 @@
  *     the next (one process-wide call COUNTER excepted: it only makes every call's "far source" flag value unique),
  *     nothing shared between concurrent calls (any number of streams / host threads), nothing read from the
  *     environment.  One exception to "never allocates": a (Depth)FlowProjection FORWARD call uses a scratch block on the
- *     device (1.3 KiB of per-image "far source" flags and 8 bytes per tile for its fast path; with hole filling also the
+ *     device (1.3 KiB of "far source" flags and 32 bytes per 64 x 32 tile for its fast path -- where the tile's sources that
+ *     move 24 px or more land, and whether such a source of another tile lands in it: those tiles are recomputed by a second
+ *     kernel, exact for any motion, at 1.1x (a fast object) to 4-6x (every source far: a camera pan of 40+ px) the time of a
+ *     call without; with hole filling also the
  *     filler's per-tile summaries and masks, about 0.8 bytes per pixel).  The block comes from a PRIVATE memory pool of
  *     the stream's device (created on the first such call; the device's default pool and its attributes are not
  *     touched) and is kept for the NEXT call on the same stream -- calls on one stream run in order, and a stream-ordered
