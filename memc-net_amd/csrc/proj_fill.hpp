@@ -284,10 +284,10 @@ __device__ __forceinline__ void table_walks(TableWalk (&w)[3])
     }
 }
 
-// The pending holes of the flagged tiles (flag 2).  One WAVE per tile -- the pending lists are short (the owner kernel filled
-// what it could), a tile's masks are 768 bytes, and nothing in a tile's chain of round trips (flag -> masks -> neighbours'
-// summaries -> counts and values -> store) has work for more than a few lanes: what matters is how many tiles are in
-// flight.  Wave g of the launch looks after the tiles g, g + waves, ... (one flag per lane).  Wave-synchronous: the LDS of a
+// The pending holes of the flagged tiles (flag 2).  One WAVE per tile -- the pending lists are mostly short (the owner kernel
+// filled what it could), a tile's masks are 768 bytes, and a tile's chain of round trips (flag -> masks -> neighbours'
+// summaries, per row and column -> counts and values, four holes per lane at a time -> store) is what matters: how many
+// tiles are in flight.  Wave g of the launch looks after the tiles g, g + waves, ... (one flag per lane).  Wave-synchronous: the LDS of a
 // wave is touched by that wave only.
 template <int TH>
 __global__ __launch_bounds__(256) void proj_fill_pending(
@@ -296,7 +296,9 @@ __global__ __launch_bounds__(256) void proj_fill_pending(
 {
     __shared__ TileMasks<TH> tms[4];
     __shared__ unsigned short lists[4][TH * 64];
+    __shared__ struct { int lr[kWave], up[kWave]; } edges[4];   // per wave: the walks' answers beyond the tile, per row side / column
     const int wv = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    auto &edge = edges[wv];
     TileMasks<TH> &tm = tms[wv];
     unsigned short *hole_list = lists[wv];
     const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(256) void proj_fill_pending(
         }
         tm.col[lane] = g->col[lane];
         // the list: lane r holds row r's pending bits; every lane appends its row's cells behind the rows before it
+        const unsigned long long pd0 = pd;
         const int mycount = __builtin_popcountll(pd);
         int before = 0;                                        // exclusive prefix sum over the lanes (6 DPP-free steps: shuffles)
         {
@@ -330,40 +333,91 @@ __global__ __launch_bounds__(256) void proj_fill_pending(
         for (int k = before; pd; pd &= pd - 1, k++) hole_list[k] = (unsigned short)((lane << 6) | __builtin_ctzll(pd));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // Beyond the tile a walk's answer depends on the hole's ROW (left, right) or COLUMN (up) only: the nearest non-zero
+        // cell of that row / column outside the tile.  One walk per row side and per column that holds a pending hole
+        // (lanes: TH rows left, TH rows right; 64 columns up; both directions of a lane advance together), kept in LDS --
+        // not one per hole: the uncovered band a camera pan of 18 px leaves along two image edges is 1000+ pending holes
+        // per border tile, and walked per hole that band cost 110 us on a 115 us call (profiles/r04_proj_small_pans.txt).
+        {
+            // Which walks?  Row r (lanes 0 .. TH-1 hold its pending bits pd0 and its non-zero mask): left iff its first
+            // pending hole has no non-zero cell before it in the tile, right iff its last one has none behind it (<=: a hole
+            // with a NEGATIVE depth sum is a non-zero cell itself).  Column c:
+            // up iff it holds a pending hole and no non-zero cell above the tile's FIRST pending row (conservative: the
+            // column's own first pending row may lie lower).
+            const unsigned long long rowm = lane < TH ? tm.row[lane] : 0ull;
+            const bool has = pd0 != 0;
+            const unsigned long long need_l = __builtin_amdgcn_ballot_w64(has && (rowm == 0 || __builtin_ctzll(pd0) <= __builtin_ctzll(rowm)));
+            const unsigned long long need_r = __builtin_amdgcn_ballot_w64(has && (rowm == 0 || __builtin_clzll(pd0) <= __builtin_clzll(rowm)));
+            const unsigned long long rows_pending = __builtin_amdgcn_ballot_w64(has);
+            unsigned lo32 = (unsigned)pd0, hi32 = (unsigned)(pd0 >> 32);           // columns with a pending hole: OR over the rows
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                lo32 |= (unsigned)__shfl_xor((int)lo32, off, kWave);
+                hi32 |= (unsigned)__shfl_xor((int)hi32, off, kWave);
+            }
+            const unsigned long long cols_pending = ((unsigned long long)hi32 << 32) | lo32;
+            const int first_row = rows_pending ? __builtin_ctzll(rows_pending) : 0;
+            const bool col_wanted = ((cols_pending >> lane) & 1) != 0 && (tm.col[lane] & ((1u << first_row) - 1u)) == 0;
+            const int r = lane % TH, side = lane / TH;     // side 0: left of row r, 1: right (TH = 16: lanes 32 .. 63 idle)
+            const bool row_wanted = side < 2 && (((side == 0 ? need_l : need_r) >> r) & 1) != 0;
+            const int64_t rowbase = (int64_t)b * tiles_x * H + ty0 + r;
+            TableWalk tw[3] = {side == 0 ? table_walk(row_wanted, ws.left + rowbase, H, tx - 1, -1, -1)
+                                         : table_walk(row_wanted, ws.right + rowbase, H, tx + 1, +1, tiles_x),
+                               table_walk(false, ws.up, 0, 0, -1, -1),
+                               table_walk(col_wanted, ws.up + (int64_t)b * tiles_y * W + tx0 + lane, W, ty - 1, -1, -1)};
+            table_walks(tw);
+            if (side < 2) edge.lr[lane] = tw[0].res;       // [r]: left of row r, [TH + r]: right
+            edge.up[lane] = tw[2].res;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         const float *cn = count + b * scb;
         float *o = out + b * s1b;
-        for (int i = lane; i < n; i += kWave) {
-            const int cell = hole_list[i], hx = cell & 63, hy = cell >> 6;
-            const int gx = tx0 + hx, gy = ty0 + hy;
-            const TileWalk w = tile_walk_masks(tm.row[hy], tm.col[hx], hy, hx, tx == 0, tx == tiles_x - 1, ty == 0);
-            // beyond the tile: the last / first non-zero column of each tile to the left / right in this row, the last
-            // non-zero row of each band above in this column, nearest first
-            TableWalk tw[3] = {table_walk(w.l == -2, ws.left + (int64_t)b * tiles_x * H + gy, H, tx - 1, -1, -1),
-                               table_walk(w.r == -2, ws.right + (int64_t)b * tiles_x * H + gy, H, tx + 1, +1, tiles_x),
-                               table_walk(w.u == -2, ws.up + (int64_t)b * tiles_y * W + gx, W, ty - 1, -1, -1)};
-            table_walks(tw);
-            const int lo = w.l >= 0 ? tx0 + w.l : tw[0].res, ro = w.r >= 0 ? tx0 + w.r : tw[1].res;
-            const int uo = w.u >= 0 ? ty0 + w.u : tw[2].res;
-            // a walk that found nothing ends at the border cell (column 0 / W-1, row 0): its flag is 0, but the reference
-            // still multiplies that cell's value by it -- keep the operand identical.  Counts and values are requested
-            // together (the values do not depend on the counts).
-            const int lc = lo >= 0 ? lo : 0, rc = ro >= 0 ? ro : W - 1, ur = uo >= 0 ? uo : 0;
-            const float cl = cn[(int64_t)gy * sch + lc], cr = cn[(int64_t)gy * sch + rc], cu = cn[(int64_t)ur * sch + gx];
-            float vl[2], vr[2], vu[2], self[2];
+        constexpr int kPer = 4;                                // holes per lane in flight: one round trip for their counts and values
+        for (int i0 = 0; i0 < n; i0 += kPer * kWave) {
+            int gxs[kPer], gys[kPer];
+            bool live[kPer];
+            float lt[kPer], rt[kPer], ut[kPer], vl[kPer][2], vr[kPer][2], vu[kPer][2], self[kPer][2];
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const float *pl = o + k * s1c;
-                vl[k] = pl[(int64_t)gy * s1h + lc];
-                vr[k] = pl[(int64_t)gy * s1h + rc];
-                vu[k] = pl[(int64_t)ur * s1h + gx];
-                self[k] = pl[(int64_t)gy * s1h + gx];
+            for (int k = 0; k < kPer; k++) {
+                const int i = i0 + k * kWave + lane;
+                live[k] = i < n;
+                if (i0 + k * kWave >= n) continue;             // (wave-uniform) nothing in this slot: no loads either
+                const int cell = live[k] ? hole_list[i] : 0, hx = cell & 63, hy = cell >> 6;
+                const int gx = tx0 + hx, gy = ty0 + hy;
+                const TileWalk w = tile_walk_masks(tm.row[hy], tm.col[hx], hy, hx, tx == 0, tx == tiles_x - 1, ty == 0);
+                // beyond the tile (-2): the row's / column's answer from above; -1: the walk ran into the image border
+                const int lo = w.l >= 0 ? tx0 + w.l : (w.l == -2 ? edge.lr[hy] : -1);
+                const int ro = w.r >= 0 ? tx0 + w.r : (w.r == -2 ? edge.lr[TH + hy] : -1);
+                const int uo = w.u >= 0 ? ty0 + w.u : (w.u == -2 ? edge.up[hx] : -1);
+                // a walk that found nothing ends at the border cell (column 0 / W-1, row 0): its flag is 0, but the reference
+                // still multiplies that cell's value by it -- keep the operand identical.  Counts and values are requested
+                // together (the values do not depend on the counts).
+                const int lc = lo >= 0 ? lo : 0, rc = ro >= 0 ? ro : W - 1, ur = uo >= 0 ? uo : 0;
+                const float cl = cn[(int64_t)gy * sch + lc], cr = cn[(int64_t)gy * sch + rc], cu = cn[(int64_t)ur * sch + gx];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const float *pl = o + c * s1c;
+                    vl[k][c] = pl[(int64_t)gy * s1h + lc];
+                    vr[k][c] = pl[(int64_t)gy * s1h + rc];
+                    vu[k][c] = pl[(int64_t)ur * s1h + gx];
+                    self[k][c] = pl[(int64_t)gy * s1h + gx];
+                }
+                // the counts the walks stopped at (0 when they ran into the image border)
+                lt[k] = lo >= 0 ? cl : 0.0f;
+                rt[k] = ro >= 0 ? cr : 0.0f;
+                ut[k] = uo >= 0 ? cu : 0.0f;
+                gxs[k] = gx;
+                gys[k] = gy;
             }
-            // the counts the walks stopped at (0 when they ran into the image border)
-            const float lt = lo >= 0 ? cl : 0.0f, rt = ro >= 0 ? cr : 0.0f, ut = uo >= 0 ? cu : 0.0f;
-            if (lt + rt + ut + 0.0f <= 0.0f) continue;
+            // (reads touch cells with a non-zero count -- or times 0 --, writes cells with count <= 0: no ordering needed)
 #pragma unroll
-            for (int k = 0; k < 2; k++)
-                o[k * s1c + (int64_t)gy * s1h + gx] = fill_value(lt, rt, ut, vl[k], vr[k], vu[k], self[k]);
+            for (int k = 0; k < kPer; k++) {
+                if (!live[k] || lt[k] + rt[k] + ut[k] + 0.0f <= 0.0f) continue;
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+                    o[c * s1c + (int64_t)gys[k] * s1h + gxs[k]] = fill_value(lt[k], rt[k], ut[k], vl[k][c], vr[k][c], vu[k][c], self[k][c]);
+            }
         }
         __builtin_amdgcn_wave_barrier();                       // the masks and the list are reused by the wave's next tile
     }

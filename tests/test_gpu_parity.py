@@ -674,6 +674,14 @@ def test_projection_with_a_few_far_sources(oracle):
     assert my_lib.FlowProjectionLayer_gpu_forward(T(big), cnt, out, 1) == 0
     assert np.array_equal(N(cnt), want_cnt), "count, 578 tiles"
     close(N(out), want_out, "FlowProjection, far sources across 578 tiles")
+    # more images than the owner kernel has per-image flag words (256): far sources in images 3 and 259 only
+    many = synth.np_flow(rng, 260, 40, 136, "smooth", 2.0)
+    many[3, 0, 10, 5], many[259, 1, 30, 100], many[259, 0, 30, 100] = 100.0, -27.0, -80.0
+    want_out, want_cnt = oracle.flow_projection_forward(many, 1)
+    cnt, out = torch.zeros((260, 1, 40, 136), device=dev()), torch.zeros((260, 2, 40, 136), device=dev())
+    assert my_lib.FlowProjectionLayer_gpu_forward(T(many), cnt, out, 1) == 0
+    assert np.array_equal(N(cnt), want_cnt), "count, 260 images"
+    close(N(out), want_out, "FlowProjection, 260 images, far sources in two of them")
     # every image far, by 30-90 px: (nearly) every tile redone
     for ci, sigma in enumerate((30.0, 90.0)):
         big = synth.np_flow(rng, 2, 100, 300, "smooth", sigma)
