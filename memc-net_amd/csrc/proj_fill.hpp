@@ -138,9 +138,27 @@ __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stag
     for (int j = 0; j < 4; j++)
         if ((nz >> j) & 1u) atomicOr(&fl.col[4 * q + j], 1u << r);
     unsigned short *const hole_list = reinterpret_cast<unsigned short *>(stage + 3 * TH * 64);
+    {   // one atomic per wave (a tile in an uncovered band is ALL holes: 64 lanes adding to one LDS word four times over)
+        unsigned long long m[4];
+        int tot = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-        if ((hole >> j) & 1u) hole_list[atomicAdd(&fl.n_holes, 1)] = (unsigned short)((r << 6) | (4 * q + j));
+        for (int j = 0; j < 4; j++) {
+            m[j] = __builtin_amdgcn_ballot_w64(((hole >> j) & 1u) != 0);
+            tot += __builtin_popcountll(m[j]);
+        }
+        if (tot) {                                             // (wave-uniform)
+            const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&fl.n_holes, tot);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if ((hole >> j) & 1u)
+                    hole_list[base + __builtin_popcountll(m[j] & ((1ull << lane) - 1))] = (unsigned short)((r << 6) | (4 * q + j));
+                base += __builtin_popcountll(m[j]);
+            }
+        }
+    }
     // planes staged for the gathers below: [count, x, y][r][64]
     *reinterpret_cast<f32x4 *>(stage + r * 64 + 4 * q) = oc;
     *reinterpret_cast<f32x4 *>(stage + TH * 64 + r * 64 + 4 * q) = ox;
