@@ -450,7 +450,8 @@ constexpr double kCountUnit = 1048576.0;          // 2^20
 template <bool DEPTH, int TH>
 struct FarTile {
     static constexpr int NP = 3;                  // planes: count, vx, vy
-    static constexpr int kPlane = (TH + 1) * kPtW4;
+    static constexpr int kPitch = 66;             // columns tx0 - 1 .. tx0 + 64 (proj_owner5 pads to 68)
+    static constexpr int kPlane = (TH + 1) * kPitch;
     static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
     double *P;
     int tx0, ty0, xlo_b, ylo_b;
@@ -463,7 +464,7 @@ struct FarTile {
         ylo_b = __float_as_int((float)max(ty0 - 1, 0));
         xrange = (unsigned)(min(__float_as_int((float)(tx0 + 64)), __float_as_int((float)(W - 1)) + 1) - xlo_b);
         yrange = (unsigned)(min(__float_as_int((float)(ty0 + TH)), __float_as_int((float)(H - 1)) + 1) - ylo_b);
-        ucell8 = (unsigned)-(8 * ((ty0 - 1) * kPtW4 + (tx0 - 1)));
+        ucell8 = (unsigned)-(8 * ((ty0 - 1) * kPitch + (tx0 - 1)));
     }
     template <int NT>
     __device__ __forceinline__ void zero(int tid) const
@@ -487,7 +488,7 @@ struct FarTile {
         for (int j = 0; j < 4; j++) {
             const float x2 = (sxf + (float)j) + fx4[j];                // (float)x + fx, as the reference rounds it
             if (wy[j] && (unsigned)(__float_as_int(x2) - xlo_b) < xrange) {
-                const unsigned a = __umul24((unsigned)(int)y2[j], 8u * kPtW4) + ((((unsigned)(int)x2) << 3) + ucell8);
+                const unsigned a = __umul24((unsigned)(int)y2[j], 8u * kPitch) + ((((unsigned)(int)x2) << 3) + ucell8);
                 double *q = reinterpret_cast<double *>(reinterpret_cast<char *>(P) + a);
                 const float d = DEPTH ? d4[j] : 1.0f;                  // my_lib_kernel.cu:2102-2114: v = -d * f, count += d
                 lds_add_f64(q, (double)(d * 1.0f));
@@ -502,11 +503,11 @@ struct FarTile {
     {
         const double wy0 = (cy == H - 1) ? 2.0 : 1.0;
         typedef double f64x2 __attribute__((ext_vector_type(2)));
-        const double *r0 = P + (cy - ty0) * kPtW4 + (cx - tx0);   // column offset a multiple of 4: 16-byte pairs
+        const double *r0 = P + (cy - ty0) * kPitch + (cx - tx0);   // column offset a multiple of 4: 16-byte pairs
         float v[NP][4];
 #pragma unroll
         for (int pl = 0; pl < NP; pl++) {
-            const double *a = r0 + pl * kPlane, *c = a + kPtW4;
+            const double *a = r0 + pl * kPlane, *c = a + kPitch;
             const f64x2 a01 = *reinterpret_cast<const f64x2 *>(a), a23 = *reinterpret_cast<const f64x2 *>(a + 2);
             const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
             const double top[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
@@ -542,7 +543,8 @@ struct FarTile {
 // tile per lane (a ballot names the ones to scan; per wave, its own four rows of a near tile), FarTile's cheap test and
 // direct splats, two workgroups per CU.
 template <bool DEPTH, int TH, int kReach>
-__global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per SIMD = two workgroups per CU
+__global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per SIMD = two workgroups per CU (three: the LDS would
+                                                                    // allow it, 80 VGPRs spill: 266 -> 373 us under a 40 px pan)
 
     int W, int H, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
@@ -553,9 +555,13 @@ __global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per S
     using FT = FarTile<DEPTH, TH>;
     constexpr int NT = 16 * TH;
     __shared__ __attribute__((aligned(16))) double P[FT::NP * FT::kPlane];
-    __shared__ FillLds<TH> fl;
-    __shared__ unsigned cand[NT];              // the source tiles to scan (bit 31: its far sources can land in the window; bit 30:
+    __shared__ union {                         // (the list is dead when the fill epilogue's masks come to life)
+        unsigned cand[NT];                     // the source tiles to scan (bit 31: its far sources can land in the window; bit 30:
                                                // it has other sources, within reach of the window)
+        FillLds<TH> fl;
+    } u;
+    unsigned *const cand = u.cand;
+    FillLds<TH> &fl = u.fl;
     __shared__ int ncand;
     if (far_flag[kFlagWords] != nonce) return;
     const unsigned per_image = (unsigned)tiles_x * tiles_y, ntiles = per_image * batch;
@@ -593,7 +599,6 @@ __global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per S
         };
         FT t;
         t.begin(P, tx0, ty0, W, H);
-        fill_lds_init(fl, tid);
         t.template zero<NT>(tid);
         __syncthreads();
         const float *flow_b = flow + b * s1b;
@@ -662,7 +667,8 @@ __global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per S
             }
             }
         }
-        __syncthreads();                       // every wave's points are in P
+        __syncthreads();                       // every wave's points are in P (and the list has been walked)
+        fill_lds_init(fl, tid);                // (in the list's bytes; the epilogue's vote is the barrier before its first use)
         const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
         const bool inb = cx < W && cy < H;     // (no early exit: barriers below)
         f32x4 ox, oy, oc;
@@ -1117,7 +1123,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                                nonce);
             if (launch_status() != 0) return -1;
             if (!only_part) {
-                const unsigned pg = r3_set ? persistent_grid(1) : persistent_grid(2);   // (53 KiB of LDS, 85 VGPRs: two per CU)
+                const unsigned pg = r3_set ? persistent_grid(1) : persistent_grid(2);   // (53 KiB of LDS, 114 VGPRs: two per CU)
 #ifdef MEMC_MEASURE
                 if (r3_set)
                     hipLaunchKernelGGL((proj_owner_far_r3<DEPTH, TH, 24>), dim3(ntiles < pg ? ntiles : pg), dim3(16 * TH), 0,

@@ -1337,11 +1337,13 @@ def test_projection_forward_needs_no_zero_fill(oracle, case):
         M.set_variant("projection", -1)
 
 
-@pytest.mark.parametrize("shift", [(10.3, 0.0), (7.5, -5.2), (-12.0, 9.0), (0.0, 20.0)])
+@pytest.mark.parametrize("shift", [(10.3, 0.0), (7.5, -5.2), (-12.0, 9.0), (0.0, 20.0), (40.0, -20.0), (-70.5, 3.0), (26.0, 30.5)])
 def test_hole_filling_on_camera_pans(oracle, shift):
     """A pan leaves an uncovered strip along one or two image borders: holes whose walks run the whole length of
     the strip (the carry tables of proj_fillhole_carry), and holes with no neighbour at all in a direction.
-    Both hole fillers -- the carry-based one and the literal walker kept for stream captures -- against the oracle."""
+    Both hole fillers -- the carry-based one and the literal walker kept for stream captures -- against the oracle.
+    Pans of 24 px and more: every source is far, no tile has a near source (proj_owner_far recomputes every tile the pan
+    lands in, from the tiles it comes from only)."""
     from tools import measure as M          # forced paths exist in the measurement build only
     my_lib = M.bound()                      # (the same sources, -DMEMC_MEASURE; my_package stays on the product library)
     rng = np.random.default_rng(41)
