@@ -61,20 +61,22 @@ def gradinput1_is_stored(filter_size, channel):
     return bool(_lib.memc_gradinput1_is_stored(int(filter_size), int(channel)))
 
 
-def _describe(t, name):
-    if not isinstance(t, torch.Tensor):
-        raise TypeError("%s: expected a torch.Tensor, got %s" % (name, type(t).__name__))
-    if not t.is_cuda:
-        raise TypeError("%s: expected a CUDA (HIP) tensor; these operators have no CPU path" % name)
-    if t.dtype != torch.float32:
-        raise TypeError("%s: expected float32, got %s" % (name, t.dtype))
-    if t.dim() != 4:
+def _describe(t, symbol, position):
+    """memc_tensor4 of a torch tensor.  (This runs for every tensor of every call: the checks in the order that lets a good
+    tensor through fastest, names formatted only when something is wrong, sizes and strides fetched as two tuples.)"""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
+        name = "%s arg %d" % (symbol, position)
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("%s: expected a torch.Tensor, got %s" % (name, type(t).__name__))
+        if not t.is_cuda:
+            raise TypeError("%s: expected a CUDA (HIP) tensor; these operators have no CPU path" % name)
+        if t.dtype != torch.float32:
+            raise TypeError("%s: expected float32, got %s" % (name, t.dtype))
         raise TypeError("%s: expected a 4-D NCHW tensor, got %d-D" % (name, t.dim()))
     d = _Tensor4()
     d.data = t.data_ptr()
-    for i in range(4):
-        d.size[i] = t.size(i)
-        d.stride[i] = t.stride(i)
+    d.size[:] = t.shape
+    d.stride[:] = t.stride()
     return d
 
 
@@ -84,22 +86,30 @@ def _bind(symbol, n_tensors, trailing_int=False, lib=None, optional=()):
     cfunc.restype = ctypes.c_int
     cfunc.argtypes = ([ctypes.c_void_p] + [ctypes.POINTER(_Tensor4)] * n_tensors
                       + ([ctypes.c_int] if trailing_int else []))
+    n_args = n_tensors + (1 if trailing_int else 0)
+    byref, current_device, current_stream = ctypes.byref, torch.cuda.current_device, torch.cuda.current_stream
 
     def call(*args):
-        if len(args) != n_tensors + (1 if trailing_int else 0):
-            raise TypeError("%s takes %d arguments (%d given)"
-                            % (symbol, n_tensors + (1 if trailing_int else 0), len(args)))
-        tensors = args[:n_tensors]
-        descs = [None if (t is None and i in optional) else _describe(t, "%s arg %d" % (symbol, i))
-                 for i, t in enumerate(tensors)]
-        dev = tensors[0].device
-        for t in tensors[1:]:
-            if t is not None and t.device != dev:
+        if len(args) != n_args:
+            raise TypeError("%s takes %d arguments (%d given)" % (symbol, n_args, len(args)))
+        cargs = []
+        dev = None
+        for i in range(n_tensors):
+            t = args[i]
+            if t is None and i in optional:
+                cargs.append(None)
+                continue
+            cargs.append(byref(_describe(t, symbol, i)))
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
                 raise TypeError("%s: all tensors must live on the same device" % symbol)
-        extra = [int(args[-1])] if trailing_int else []
+        if trailing_int:
+            cargs.append(int(args[-1]))
+        if dev.index == current_device():          # the usual case: no device switch (a context manager costs ~4 us)
+            return int(cfunc(current_stream(dev).cuda_stream, *cargs))
         with torch.cuda.device(dev):
-            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            return int(cfunc(stream, *[None if d is None else ctypes.byref(d) for d in descs], *extra))
+            return int(cfunc(current_stream(dev).cuda_stream, *cargs))
 
     call.__name__ = symbol
     call.__doc__ = "ctypes binding of %s (include/memc_warp.h)" % symbol
@@ -143,7 +153,7 @@ def _bind_upsample():
                       ctypes.c_float, ctypes.c_int]
 
     def call(input, output, mul, div, align_corners):
-        a, b = _describe(input, "FlowUpsample4Layer_gpu_forward arg 0"), _describe(output, "FlowUpsample4Layer_gpu_forward arg 1")
+        a, b = _describe(input, "FlowUpsample4Layer_gpu_forward", 0), _describe(output, "FlowUpsample4Layer_gpu_forward", 1)
         if input.device != output.device:
             raise TypeError("FlowUpsample4Layer_gpu_forward: all tensors must live on the same device")
         with torch.cuda.device(input.device):
