@@ -281,6 +281,13 @@ def secondary_rows(my_lib, synth, torch, device, seed):
             lambda: my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, fill), torch, device, burst=4), "bursts of 4")
     row("config3_depth_flow_projection_fwd_fillhole1_32x720x1280", "depth_proj_fwd", 0, sites, _avg_launch_s(
         lambda: my_lib.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, po, 1), torch, device, burst=4), "bursts of 4")
+    # ... and under LARGE motion (not a BASELINE config; sources that move 24 px or more take proj_owner_far):
+    # the same flow twice as large (fast objects: a few per cent of the tiles are recomputed) and under a camera pan of
+    # (40, -20) px (every source far, every tile recomputed, an uncovered band of holes along two edges)
+    for tag, fl in (("motion_x2", f * 2.0), ("pan40", f + torch.tensor([40.0, -20.0], device=device).view(1, 2, 1, 1))):
+        row("flow_projection_fwd_fillhole1_%s_32x720x1280" % tag, "proj_fwd", 0, sites, _avg_launch_s(
+            lambda: my_lib.FlowProjectionLayer_gpu_forward(fl, cnt, po, 1), torch, device, burst=4), "bursts of 4; large motion")
+    del fl
     # ... and their backward passes (the count / output planes of a forward without hole filling, as in training)
     gout, gin, gd = torch.rand_like(f), torch.zeros_like(f), torch.zeros_like(dep)
     cnt.zero_(); po.zero_()
