@@ -113,6 +113,44 @@ def test_config3_projection_scatter_1280x720_batch32(kind):
     close(g1, R.flow_projection_backward(f, cnt, gf), "config 3 FlowProjection backward (%s)" % kind)
 
 
+@pytest.mark.parametrize("motion", ["flow x3", "pan of 40 px", "a fast object"])
+def test_config3_projection_under_large_motion_against_reference_kernels(motion):
+    """Config 3's frames (1280 x 720, batch 8) with motion beyond the owner kernel's reach of 24 px -- the benchmark's flow
+    three times as large (most tiles recomputed by proj_owner_far), under a camera pan of (40, -20) px (every source far,
+    no tile has a near source, an uncovered band of holes along two edges), and with a rectangle moving (60, -35) px over a
+    slow background (a flow discontinuity: the object's tiles land on other tiles' cells) -- against the reference's own
+    kernels: counts bit for bit, outputs within 1e-4, with and without hole filling, both operators."""
+    import my_package._ext.my_lib as L
+    B, H, W = 8, 720, 1280
+    t = synth.torch_inputs(dev(), B, 3, H, W, flow_kind="smooth", seed=35, with_depth=True)
+    f, dep = t["flow"], t["depth"]
+    del t
+    if motion == "flow x3":
+        f = (f * 3.0).contiguous()
+    elif motion == "pan of 40 px":
+        f[:, 0] += 40.0
+        f[:, 1] -= 20.0
+    else:
+        f *= 0.5
+        for b in range(B):
+            y0, x0 = 100 + 40 * b, 150 + 90 * b
+            f[b, 0, y0:y0 + 200, x0:x0 + 300] = 60.0
+            f[b, 1, y0:y0 + 200, x0:x0 + 300] = -35.0
+    assert float(f.abs().max()) >= 24.0
+    for fh in (0, 1):
+        cnt, out = torch.full_like(dep, float("nan")), torch.full_like(f, float("nan"))
+        assert L.FlowProjectionLayer_gpu_forward(f, cnt, out, fh) == 0
+        assert L.last_kernel_path() == "proj_fwd:owner"
+        wo, wc = R.flow_projection_forward(f, fh)
+        assert torch.equal(cnt, wc), "count, fillhole %d (%s)" % (fh, motion)
+        close(out, wo, "FlowProjection, fillhole %d (%s)" % (fh, motion))
+        cnt, out = torch.full_like(dep, float("nan")), torch.full_like(f, float("nan"))
+        assert L.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, out, fh) == 0
+        wo, wc = R.depth_flow_projection_forward(f, dep, fh)
+        close(cnt, wc, "depth count, fillhole %d (%s)" % (fh, motion))
+        close(out, wo, "DepthFlowProjection, fillhole %d (%s)" % (fh, motion))
+
+
 @pytest.mark.parametrize("kind", ["smooth", "iid"])
 def test_headline_config_batch32_against_reference_kernels(kind):
     """The benchmark's own workload at its own size -- FilterInterpolation, C = 3, 32 x 720 x 1280 -- forward and
