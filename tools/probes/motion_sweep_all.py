@@ -70,3 +70,14 @@ for p in (0.0, 20.0, 40.0, 80.0, 160.0):
     q[:, 1] -= p / 2
     flows.append(("pan %g" % p, q))
 sweep("panned: the benchmark's flow + (p, -p/2)", flows)
+
+# a fast OBJECT over a slow background: the benchmark's flow x 0.5 with a rectangle of 300 x 200 px per image moving (v, -v/2)
+flows = []
+for v in (0.0, 20.0, 40.0, 80.0):
+    q = f0 * 0.5
+    for b in range(B):
+        y0, x0 = 60 + 13 * b, 100 + 27 * b
+        q[b, 0, y0:y0 + 200, x0:x0 + 300] = v
+        q[b, 1, y0:y0 + 200, x0:x0 + 300] = -v / 2
+    flows.append(("object %g" % v, q))
+sweep("a fast object: the benchmark's flow x 0.5, a rectangle of 300 x 200 px moving (v, -v/2)", flows)
