@@ -693,6 +693,47 @@ def test_projection_with_a_few_far_sources(oracle):
             close(N(out), want_out, "FlowProjection, smooth flow of sigma %g, fill %d" % (sigma, fill))
 
 
+def test_empty_batches_and_single_pixel_images(oracle):
+    """Nothing to do is not an error: an empty batch returns 0 from every entry point without touching anything (the
+    reference would launch a grid of zero blocks and report the launch error).  The smallest image there is -- one pixel,
+    and one row of four -- against the oracle, every operator."""
+    import my_package._ext.my_lib as my_lib
+    z = lambda c, h=8, w=16: torch.zeros((0, c, h, w), device=dev())          # noqa: E731
+    assert my_lib.FilterInterpolationLayer_gpu_forward(z(3), z(2), z(16), z(3)) == 0
+    assert my_lib.FilterInterpolationLayer_gpu_backward(z(3), z(2), z(16), z(3), z(3), z(2), z(16)) == 0
+    assert my_lib.InterpolationLayer_gpu_forward(z(3), z(2), z(3)) == 0
+    assert my_lib.InterpolationChLayer_gpu_backward(z(5), z(2), z(5), z(5), z(2)) == 0
+    assert my_lib.FlowProjectionLayer_gpu_forward(z(2), z(1), z(2), 1) == 0
+    assert my_lib.FlowProjectionLayer_gpu_backward(z(2), z(1), z(2), z(2)) == 0
+    assert my_lib.DepthFlowProjectionLayer_gpu_forward(z(2), z(1), z(1), z(2), 1) == 0
+    for ci, (H, W) in enumerate(((1, 1), (1, 4), (2, 2))):
+        rng = np.random.default_rng(70 + ci)
+        x, k, g = synth.np_image(rng, 2, 3, H, W), synth.np_filter(rng, 2, H, W), synth.np_image(rng, 2, 3, H, W)
+        f = (rng.random((2, 2, H, W), dtype=np.float32) - 0.5) * 1.5
+        dpt = synth.np_depth(rng, 2, H, W)
+        out = torch.full(x.shape, 7.0, device=dev())
+        assert my_lib.FilterInterpolationLayer_gpu_forward(T(x), T(f), T(k), out) == 0
+        close(N(out), oracle.filter_interpolation_forward(x, f, k), "FI forward %dx%d" % (H, W))
+        g1, g2, g3 = torch.zeros(x.shape, device=dev()), torch.full(f.shape, 7.0, device=dev()), torch.full(k.shape, 7.0, device=dev())
+        assert my_lib.FilterInterpolationLayer_gpu_backward(T(x), T(f), T(k), T(g), g1, g2, g3) == 0
+        for got, want, what in zip((g1, g2, g3), oracle.filter_interpolation_backward(x, f, k, g), ("gradinput1", "gradinput2", "gradinput3")):
+            close(N(got), want, "FI backward %s %dx%d" % (what, H, W), RTOL)
+        out = torch.full(x.shape, 7.0, device=dev())
+        assert my_lib.InterpolationLayer_gpu_forward(T(x), T(f), out) == 0
+        close(N(out), oracle.interpolation_forward(x, f), "Interpolation forward %dx%d" % (H, W))
+        for fill in (0, 1):
+            cnt, po = torch.full((2, 1, H, W), 7.0, device=dev()), torch.full(f.shape, 7.0, device=dev())
+            assert my_lib.FlowProjectionLayer_gpu_forward(T(f), cnt, po, fill) == 0
+            want_out, want_cnt = oracle.flow_projection_forward(f, fill)
+            assert np.array_equal(N(cnt), want_cnt)
+            close(N(po), want_out, "FlowProjection %dx%d fill %d" % (H, W, fill))
+            cnt, po = torch.full((2, 1, H, W), 7.0, device=dev()), torch.full(f.shape, 7.0, device=dev())
+            assert my_lib.DepthFlowProjectionLayer_gpu_forward(T(f), T(dpt), cnt, po, fill) == 0
+            want_out, want_cnt = oracle.depth_flow_projection_forward(f, dpt, fill)
+            close(N(cnt), want_cnt, "depth count %dx%d fill %d" % (H, W, fill), RTOL)
+            close(N(po), want_out, "DepthFlowProjection %dx%d fill %d" % (H, W, fill), RTOL)
+
+
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
                 if os.path.basename(p).startswith(("small_", "config1_")))   # the oracle-made operator fixtures
 
