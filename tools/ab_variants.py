@@ -55,7 +55,16 @@ def main():
             "fi_bwd_nog1": (lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, None, g2, g3), None, 1),
             "fi_bwd_c2_nog1": (lambda: L.FilterInterpolationLayer_gpu_backward(t2["x"], t2["flow"], t2["filt"], t2["gout"], None, h2, h3), None, 20),
             "bl_bwd": (lambda: L.InterpolationLayer_gpu_backward(x, f, g, g1, g2), g1, 1),
+            # (with --op walk: the stripe width of the tile walk, -1 = the default)
+            "bl_fwd": (lambda: L.InterpolationLayer_gpu_forward(x, f, g1), None, 1),
+            "proj_bwd": (lambda: L.FlowProjectionLayer_gpu_backward(f, cnt0, gf, g2), None, 1),
+            "depth_bwd": (lambda: L.DepthFlowProjectionLayer_gpu_backward(f, d, dcnt0, dout0, gf, g2, gd), None, 1),
         }
+        gf, gd = torch.rand_like(f), torch.zeros_like(d)
+        cnt0, out0 = torch.zeros_like(cnt), torch.zeros_like(out)
+        L.FlowProjectionLayer_gpu_forward(f, cnt0, out0, 0)
+        dcnt0, dout0 = torch.zeros_like(cnt), torch.zeros_like(out)
+        L.DepthFlowProjectionLayer_gpu_forward(f, d, dcnt0, dout0, 0)
         for _ in range(150):
             ops["proj"][0]()
         for case in a.cases.split(","):
