@@ -9,6 +9,7 @@ REF_CASES = [
     (2, 3, 19, 23, "iid", 3.0, 102),       # odd sizes, many holes, invalid sites at the borders
     (1, 3, 40, 64, "iid", 9.0, 103),       # large motion
     (1, 5, 16, 24, "smooth", 4.0, 104),    # not RGB (InterpolationCh, FI with C = 5)
+    (1, 3, 48, 136, "smooth", 30.0, 105),  # motion of up to ~80 px over 3 x 2 projection tiles: sources far beyond the owner kernel's reach
 ]
 
 
