@@ -226,33 +226,69 @@ def _avg_launch_s(fn, torch, device, warm=15, iters=40, burst=1, warm_seconds=0.
 def secondary_rows(my_lib, synth, torch, device, seed):
     """The other BASELINE configs, OUTSIDE the timed region (rank 0, N = 1): per-launch HIP-event averages and the
     fraction of the 8 TB/s HBM peak their ALGORITHMIC bytes amount to.  Launches shorter than ~0.2 ms are timed in
-    bursts of 20 between two events (one launch between two events mostly measures the host's enqueue cost)."""
+    bursts between two events (one launch between two events mostly measures the host's enqueue cost): every row says how
+    in its "timing" field ("single" | "burst N").  Launches that move less than the 256 MiB Infinity Cache (config 2) rotate
+    over input sets -- avg_launch_us is the COLD figure, cache_warm_us the single-set one rounds 1-4 reported."""
     rows = {}
 
-    def row(name, op, C, sites, seconds, note=None):
+    def row(name, op, C, sites, seconds, note=None, timing="single"):
         nbytes = BYTES_PER_SITE[op](C, 4) * sites
         rows[name] = {"avg_launch_us": round(seconds * 1e6, 2), "mpixels_s": round(sites / seconds / 1e6, 1),
-                      "algorithmic_bytes_per_launch": nbytes, "frac": round(nbytes / seconds / HBM_PEAK_BPS, 4)}
+                      "algorithmic_bytes_per_launch": nbytes, "frac": round(nbytes / seconds / HBM_PEAK_BPS, 4),
+                      "timing": timing}
         if note:
             rows[name]["note"] = note
 
-    # config 2: fused adaptive warp fwd + bwd, 448 x 256 (Vimeo septuplet), batch 8
-    t = synth.torch_inputs(device, 8, 3, 256, 448, flow_kind="smooth", seed=seed + 2, with_grad=True)
-    out = torch.zeros_like(t["x"])
-    g1, g2, g3 = torch.zeros_like(t["x"]), torch.zeros_like(t["flow"]), torch.zeros_like(t["filt"])
+    def rotating(calls):
+        """One callable that takes the next of `calls` at every invocation: consecutive launches work on different input
+        sets, so that a launch smaller than the 256 MiB Infinity Cache cannot be served from it."""
+        state = [0]
+
+        def fn():
+            calls[state[0] % len(calls)]()
+            state[0] += 1
+        return fn
+
+    def small_row(name, op, C, sites, make_call, n_sets, note=None, burst=20):
+        """A launch of tens of microseconds on tens of megabytes: timed COLD (rotating over n_sets input sets, the figure
+        the row reports: an HBM number) and cache-warm (one set relaunched: what rounds 1-4 reported), bursts of `burst`."""
+        calls = [make_call(i) for i in range(n_sets)]
+        cold = _avg_launch_s(rotating(calls), torch, device, burst=burst)
+        warm = _avg_launch_s(calls[0], torch, device, burst=burst)
+        row(name, op, C, sites, cold, note, timing="burst %d" % burst)
+        rows[name]["input_sets"] = n_sets
+        rows[name]["cache_warm_us"] = round(warm * 1e6, 2)
+        rows[name]["cache_warm_frac"] = round(BYTES_PER_SITE[op](C, 4) * sites / warm / HBM_PEAK_BPS, 4)
+
+    # config 2: fused adaptive warp fwd + bwd, 448 x 256 (Vimeo septuplet), batch 8.  One launch moves 88 MB (forward) /
+    # 165 MB (backward): relaunched on one input set it runs out of the 256 MiB Infinity Cache (round-4 review).  The rows
+    # rotate over enough input sets to cycle > 1 GB; the single-set figure stays beside it as cache_warm_us.
     sites = 8 * 256 * 448
-    row("config2_fi_fwd_8x3x256x448", "fi_fwd", 3, sites, _avg_launch_s(
-        lambda: my_lib.FilterInterpolationLayer_gpu_forward(t["x"], t["flow"], t["filt"], out), torch, device, burst=20),
-        "bursts of 20")
-    row("config2_fi_bwd_8x3x256x448", "fi_bwd", 3, sites, _avg_launch_s(
-        lambda: my_lib.FilterInterpolationLayer_gpu_backward(t["x"], t["flow"], t["filt"], t["gout"], g1, g2, g3),
-        torch, device, burst=20), "bursts of 20")
+    n_fwd, n_bwd = 12, 7
+    sets = [synth.torch_inputs(device, 8, 3, 256, 448, flow_kind="smooth", seed=seed + 2 + 97 * i, with_grad=True)
+            for i in range(n_fwd)]
+    outs = [torch.zeros_like(t["x"]) for t in sets]
+    grads = [(torch.zeros_like(t["x"]), torch.zeros_like(t["flow"]), torch.zeros_like(t["filt"])) for t in sets[:n_bwd]]
+
+    def fwd_call(i):
+        t, out = sets[i], outs[i]
+        return lambda: my_lib.FilterInterpolationLayer_gpu_forward(t["x"], t["flow"], t["filt"], out)
+
+    def bwd_call(i):
+        t, (g1, g2, g3) = sets[i], grads[i]
+        return lambda: my_lib.FilterInterpolationLayer_gpu_backward(t["x"], t["flow"], t["filt"], t["gout"], g1, g2, g3)
+
+    def bwd_nog1_call(i):
+        t, (g1, g2, g3) = sets[i], grads[i]
+        return lambda: my_lib.FilterInterpolationLayer_gpu_backward(t["x"], t["flow"], t["filt"], t["gout"], None, g2, g3)
+
+    small_row("config2_fi_fwd_8x3x256x448", "fi_fwd", 3, sites, fwd_call, n_fwd)
+    small_row("config2_fi_bwd_8x3x256x448", "fi_bwd", 3, sites, bwd_call, n_bwd)
     # ... and as the reference's networks run it: the warped frames are data, autograd does not ask for gradinput1
     # (MEMC_Net_star.py:266-277) -- the extension of include/memc_warp.h (gradinput1 NULL)
-    row("config2_fi_bwd_without_image_gradient_8x3x256x448", "fi_bwd_nog1", 3, sites, _avg_launch_s(
-        lambda: my_lib.FilterInterpolationLayer_gpu_backward(t["x"], t["flow"], t["filt"], t["gout"], None, g2, g3),
-        torch, device, burst=20), "bursts of 20; gradinput1 = NULL (extension): flow and tap gradients only")
-    del t, out, g1, g2, g3
+    small_row("config2_fi_bwd_without_image_gradient_8x3x256x448", "fi_bwd_nog1", 3, sites, bwd_nog1_call, n_bwd,
+              "gradinput1 = NULL (extension): flow and tap gradients only")
+    del sets, outs, grads
     # the backward at the headline size (the only channel count the reference back-propagates through)
     t = synth.torch_inputs(device, 32, 3, 720, 1280, flow_kind="smooth", seed=seed + 6, with_grad=True)
     g1, g2, g3 = torch.zeros_like(t["x"]), torch.zeros_like(t["flow"]), torch.zeros_like(t["filt"])
@@ -276,38 +312,44 @@ def secondary_rows(my_lib, synth, torch, device, seed):
     dep = torch.rand((32, 1, 720, 1280), device=device) + 0.1
     cnt, po = torch.zeros((32, 1, 720, 1280), device=device), torch.zeros_like(f)
     sites = 32 * 720 * 1280
+    # (637 / 755 MB per launch: beyond the Infinity Cache.  Back-to-back launches overlap one call's tail kernels with the next
+    # call's start; single_call_us is one call between two events)
     for fill in (0, 1):
-        row("config3_flow_projection_fwd_fillhole%d_32x720x1280" % fill, "proj_fwd", 0, sites, _avg_launch_s(
-            lambda: my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, fill), torch, device, burst=4), "bursts of 4")
-    row("config3_depth_flow_projection_fwd_fillhole1_32x720x1280", "depth_proj_fwd", 0, sites, _avg_launch_s(
-        lambda: my_lib.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, po, 1), torch, device, burst=4), "bursts of 4")
+        name = "config3_flow_projection_fwd_fillhole%d_32x720x1280" % fill
+        call = lambda: my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, fill)      # noqa: E731
+        row(name, "proj_fwd", 0, sites, _avg_launch_s(call, torch, device, burst=4), timing="burst 4")
+        rows[name]["single_call_us"] = round(_avg_launch_s(call, torch, device, warm=4, warm_seconds=0.0) * 1e6, 2)
+    name = "config3_depth_flow_projection_fwd_fillhole1_32x720x1280"
+    call = lambda: my_lib.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, po, 1)   # noqa: E731
+    row(name, "depth_proj_fwd", 0, sites, _avg_launch_s(call, torch, device, burst=4), timing="burst 4")
+    rows[name]["single_call_us"] = round(_avg_launch_s(call, torch, device, warm=4, warm_seconds=0.0) * 1e6, 2)
     # ... and under LARGE motion (not a BASELINE config; sources that move 24 px or more take proj_owner_far):
     # the same flow twice as large (fast objects: a few per cent of the tiles are recomputed) and under a camera pan of
     # (40, -20) px (every source far, every tile recomputed, an uncovered band of holes along two edges)
     for tag, fl in (("motion_x2", f * 2.0), ("pan40", f + torch.tensor([40.0, -20.0], device=device).view(1, 2, 1, 1))):
         row("flow_projection_fwd_fillhole1_%s_32x720x1280" % tag, "proj_fwd", 0, sites, _avg_launch_s(
-            lambda: my_lib.FlowProjectionLayer_gpu_forward(fl, cnt, po, 1), torch, device, burst=4), "bursts of 4; large motion")
+            lambda: my_lib.FlowProjectionLayer_gpu_forward(fl, cnt, po, 1), torch, device, burst=4), "large motion", timing="burst 4")
     del fl
     # ... and their backward passes (the count / output planes of a forward without hole filling, as in training)
     gout, gin, gd = torch.rand_like(f), torch.zeros_like(f), torch.zeros_like(dep)
     cnt.zero_(); po.zero_()
     my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, 0)
     row("config3_flow_projection_bwd_32x720x1280", "proj_bwd", 0, sites, _avg_launch_s(
-        lambda: my_lib.FlowProjectionLayer_gpu_backward(f, cnt, gout, gin), torch, device, burst=4), "bursts of 4")
+        lambda: my_lib.FlowProjectionLayer_gpu_backward(f, cnt, gout, gin), torch, device, burst=4), timing="burst 4")
     cnt.zero_(); po.zero_()
     my_lib.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, po, 0)
     row("config3_depth_flow_projection_bwd_32x720x1280", "depth_proj_bwd", 0, sites, _avg_launch_s(
         lambda: my_lib.DepthFlowProjectionLayer_gpu_backward(f, dep, cnt, po, gout, gin, gd), torch, device, burst=4),
-        "bursts of 4")
+        timing="burst 4")
     del dep, cnt, po, gin, gd
     # the bilinear warp (Interpolation) at the headline size, forward and backward
     x = torch.rand((32, 3, 720, 1280), device=device)
     out, g1, g2 = torch.zeros_like(x), torch.zeros_like(x), torch.zeros_like(f)
     gx = torch.rand_like(x)
     row("interpolation_fwd_32x3x720x1280", "interp_fwd", 3, sites, _avg_launch_s(
-        lambda: my_lib.InterpolationLayer_gpu_forward(x, f, out), torch, device, burst=4), "bursts of 4")
+        lambda: my_lib.InterpolationLayer_gpu_forward(x, f, out), torch, device, burst=4), timing="burst 4")
     row("interpolation_bwd_32x3x720x1280", "interp_bwd", 3, sites, _avg_launch_s(
-        lambda: my_lib.InterpolationLayer_gpu_backward(x, f, gx, g1, g2), torch, device, burst=4), "bursts of 4")
+        lambda: my_lib.InterpolationLayer_gpu_backward(x, f, gx, g1, g2), torch, device, burst=4), timing="burst 4")
     del f, gout, x, out, g1, g2, gx
     # config 5: 4K adaptive warp forward, batch 8
     t = synth.torch_inputs(device, 8, 3, 2160, 3840, flow_kind="smooth", seed=seed + 5)

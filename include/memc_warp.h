@@ -37,19 +37,23 @@
  *   - work is enqueued asynchronously on `stream`; no host synchronisation, no state carried from one call to
  *     the next (one process-wide call COUNTER excepted: it only makes every call's "far source" flag value unique),
  *     nothing shared between concurrent calls (any number of streams / host threads), nothing read from the
- *     environment.  One exception to "never allocates": a (Depth)FlowProjection FORWARD call uses a scratch block on the
+ *     environment.  One exception to "never allocates": a (Depth)FlowProjection FORWARD call needs a scratch block on the
  *     device (1.3 KiB of "far source" flags and 32 bytes per 64 x 32 tile for its fast path -- where the tile's sources that
- *     move 24 px or more land, and whether such a source of another tile lands in it: those tiles are recomputed by a second
- *     kernel, exact for any motion, at 1.1x (a fast object) to 4-6x (every source far: a camera pan of 40+ px) the time of a
- *     call without; with hole filling also the
- *     filler's per-tile summaries and masks, about 0.8 bytes per pixel).  The block comes from a PRIVATE memory pool of
- *     the stream's device (created on the first such call; the device's default pool and its attributes are not
- *     touched) and is kept for the NEXT call on the same stream -- calls on one stream run in order, and a stream-ordered
- *     allocation per call cost the host ~30 us (round 4) -- for the life of the process, one block per stream that ever
- *     ran such a call.  Two host threads enqueueing on the same stream at the same time do not share it (the second
- *     takes a stream-ordered allocation of its own, released in stream order before the call returns).  Inside a
- *     stream capture, or if the allocation fails, the call uses its general path and a hole filler that need no scratch
- *     (slower, same results);
+ *     move 24 px or more AGAINST THE IMAGE'S DOMINANT MOTION land, and whether such a source of another tile lands in it:
+ *     those tiles are recomputed by a second kernel, exact for any motion; with hole filling also the filler's per-tile
+ *     summaries and masks, about 0.8 bytes per pixel).  Two ways to provide it:
+ *       (a) the reference-signature entry points below take it from a PRIVATE memory pool of the stream's device (created
+ *           on the first such call; the device's default pool and its attributes are not touched) and keep it for later
+ *           calls -- a stream-ordered allocation per call cost the host ~30 us (round 4): at most eight blocks per device, for
+ *           the life of the process, each owned by one host-side call at a time; the next call that takes a block makes
+ *           its stream wait for an event recorded behind the previous user's last kernel, so any mix of streams, host
+ *           threads, hipStreamPerThread and recycled stream handles is ordered explicitly.  Inside a stream capture, or
+ *           if the allocation fails, these entry points use their general path and a hole filler that need no scratch
+ *           (slower, same results);
+ *       (b) the `_ws` entry points ("EXTENSION: workspace" below) take a caller-supplied workspace of
+ *           memc_flow_projection_workspace_bytes() bytes: the library then allocates nothing and keeps nothing -- the
+ *           reference's own contract (my_lib_cuda.c:752-799) -- and a stream capture (HIP graph) records the same
+ *           kernels as an eager call.  The shipped Python layer uses these;
  *   - precision of the two scattered-into image gradients at three channels (FilterInterpolation / Interpolation
  *     gradinput1): every contribution g * weight is rounded ONCE to a multiple of 2^(e - 22), where 2^e bounds the
  *     contributions of the PACKED sites of its 64 x 16 (64 x 32) tile: 2^e < 2 * min(largest site bound, 16 x a robust
@@ -66,6 +70,7 @@
 #ifndef MEMC_WARP_H
 #define MEMC_WARP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -97,7 +102,8 @@ const char *memc_hip_version(void);
  *     "direct"  (FilterInterpolation / Interpolation: one lane per site, global gathers and atomics),
  *     "generic" (FilterInterpolation, filter_size != 4),
  *     "scalar"  ((Depth)FlowProjection forward / backward),
- *     "general" ((Depth)FlowProjection forward without scratch: inside a stream capture, or a plane beyond 4 GiB).
+ *     "general" ((Depth)FlowProjection forward without scratch: the reference-signature entry points inside a stream
+ *               capture -- the `_ws` entry points keep the fast path there --, or a plane beyond 4 GiB).
  * The reference has no counterpart (it has one kernel per operator). */
 const char *memc_last_kernel_path(void);
 
@@ -311,6 +317,43 @@ int FilterInterpolationCtx_gpu_forward_kernel(
     const int occlusion_b_stride, const int occlusion_h_stride,
     const float *image, const float *context, const float *flow, const float *filter,
     const float *prev, const float *occlusion_prev, const float *occlusion_this, float *image_out, float *context_out);
+
+/* ------------------------------------------------------------------------------------------------------
+ * EXTENSION: workspace -- the (Depth)FlowProjection forward with a CALLER-SUPPLIED workspace.  The reference's launcher
+ * touches borrowed buffers only (my_lib_kernel.cu:1905-1992; contract my_lib_cuda.c:752-799: the callee never allocates),
+ * so it can be enqueued inside a stream capture at full speed; with these entry points so can this library's fast path
+ * (owner-computes kernel, hole filling from masks): nothing is allocated, cached or shared between calls.
+ *
+ *   memc_flow_projection_workspace_bytes(w, h, batch, fillhole, depth)   bytes a call of that shape needs (a multiple of
+ *                                                                        256; 0 for an empty shape)
+ *   workspace        device pointer, 16-byte aligned, at least that many bytes, contents arbitrary (never read before
+ *                    written, except flag words compared against this call's unique tag); private to the call until its
+ *                    last kernel has run -- allocate it in stream order (e.g. torch.empty on the current stream)
+ *   return           0 / -1 as the entry point it extends; -1 also for a NULL, misaligned or too small workspace
+ * Same arguments, checks and results otherwise as FlowProjectionLayer_gpu_forward / FlowProjection_gpu_forward_kernel /
+ * DepthFlowProjection... above.
+ * ------------------------------------------------------------------------------------------------------ */
+size_t memc_flow_projection_workspace_bytes(int w, int h, int batch, int fillhole, int depth);
+
+int FlowProjectionLayer_gpu_forward_ws(memc_stream_t stream, const memc_tensor4 *input1, const memc_tensor4 *count,
+                                       const memc_tensor4 *output, int fillhole, void *workspace, size_t workspace_bytes);
+int DepthFlowProjectionLayer_gpu_forward_ws(memc_stream_t stream, const memc_tensor4 *input1,
+                                            const memc_tensor4 *input2, const memc_tensor4 *count,
+                                            const memc_tensor4 *output, int fillhole, void *workspace,
+                                            size_t workspace_bytes);
+int FlowProjection_gpu_forward_kernel_ws(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int fillhole,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int count_b_stride, const int count_c_stride, const int count_h_stride, const int count_w_stride,
+    const float *input1, float *count, float *output, void *workspace, size_t workspace_bytes);
+int DepthFlowProjection_gpu_forward_kernel_ws(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int fillhole,
+    const int input1_b_stride, const int input1_c_stride, const int input1_h_stride, const int input1_w_stride,
+    const int input2_b_stride, const int input2_c_stride, const int input2_h_stride, const int input2_w_stride,
+    const int count_b_stride, const int count_c_stride, const int count_h_stride, const int count_w_stride,
+    const float *input1, const float *input2, float *count, float *output, void *workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------------------
  * EXTENSION -- no reference counterpart.  The prologue of FlowProjection in the networks,

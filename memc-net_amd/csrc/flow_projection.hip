@@ -542,9 +542,11 @@ struct FarTile {
 // instead of motion bounds: a fast object dirties the tiles it lands in, not its whole image); the culling is one source
 // tile per lane (a ballot names the ones to scan; per wave, its own four rows of a near tile), FarTile's cheap test and
 // direct splats, two workgroups per CU.
-template <bool DEPTH, int TH, int kReach>
-__global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per SIMD = two workgroups per CU (three: the LDS would
-                                                                    // allow it, 80 VGPRs spill: 266 -> 373 us under a 40 px pan)
+// MINW / NCAND: the product is <4, 16 TH> (4 waves per SIMD = two workgroups per CU).  <6, 384> -- three per CU, which the
+// LDS then allows -- needs 80 VGPRs and SPILLS: 266 -> 373 us under a 40 px pan; kept as a measurement arm only (variant -44)
+// because round 4 saw wrong results next to it (tools/probes/far_spill_streams.py).
+template <bool DEPTH, int TH, int kReach, int MINW = 4, int NCAND = 16 * TH>
+__global__ __launch_bounds__(16 * TH, MINW) void proj_owner_far(
 
     int W, int H, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per S
     constexpr int NT = 16 * TH;
     __shared__ __attribute__((aligned(16))) double P[FT::NP * FT::kPlane];
     __shared__ union {                         // (the list is dead when the fill epilogue's masks come to life)
-        unsigned cand[NT];                     // the source tiles to scan (bit 31: its far sources can land in the window; bit 30:
+        unsigned cand[NCAND];                  // the source tiles to scan (bit 31: its far sources can land in the window; bit 30:
                                                // it has other sources, within reach of the window)
         FillLds<TH> fl;
     } u;
@@ -608,14 +610,14 @@ __global__ __launch_bounds__(16 * TH, 4) void proj_owner_far(   // 4 waves per S
         // reach the window, tiles whose far sources can land in it by all.  (A tile that recorded no source that is NOT far is
         // not scanned for its near sources: after a camera pan that is every tile.)
 #pragma unroll 1
-        for (unsigned s0 = 0; s0 < per_image; s0 += NT) {
-            if (s0) __syncthreads();           // the previous round's list has been walked (images of more than NT tiles)
+        for (unsigned s0 = 0; s0 < per_image; s0 += NCAND) {
+            if (s0) __syncthreads();           // the previous round's list has been walked (images of more than NCAND tiles)
             if (tid == 0) ncand = 0;
             __syncthreads();
             {
                 const unsigned sl = s0 + tid;
                 bool c = false, fh = false, nr = false;
-                if (sl < per_image) {
+                if (tid < NCAND && sl < per_image) {
                     const int sty = sl / (unsigned)tiles_x, stx = sl - sty * tiles_x;
                     fh = far_hits(boxes[2 * sl]);
                     nr = boxes[2 * sl + 1].y != 0 && near_hits(stx, sty * TH, TH);   // (.y: the tile has sources that are not far)
@@ -1010,7 +1012,33 @@ struct ProjArgs {
     int s1b, s1c, s1h, sdb, sdh, scb, sch;
     const float *flow, *depth;
     float *count, *out;
+    void *ws;                                    // caller's workspace (the _ws entry points) or nullptr: the library's own block
+    size_t ws_bytes;
 };
+
+// The call's scratch (library block or caller's workspace), in ints: [0, kHead) far flags (image b -> word b % 256, word
+// 256 = "any"), the tiles' far table (kFarWords ints per tile: proj_owner5.hpp), then -- with hole filling -- the three tables
+// of per-tile summaries, the per-tile hole flags and (8-byte aligned) the tiles' masks.
+struct ProjWsLayout {
+    size_t n_bnd, n_up, n_row, ints, mask_words;
+    size_t bytes() const { return ints * sizeof(int) + mask_words * 8; }
+};
+constexpr size_t kProjWsHead = 320;
+template <int TH>
+static ProjWsLayout proj_ws_layout(int w, int h, int batch, bool fast, bool carry, bool masks)
+{
+    const int ntx = (w + 63) / 64, nty = (h + TH - 1) / TH;
+    const size_t ntiles = (size_t)ntx * nty * batch;
+    ProjWsLayout l;
+    l.n_bnd = fast ? kFarWords * ntiles : 0;
+    l.n_up = (size_t)batch * nty * w;
+    l.n_row = (size_t)batch * h * ntx;
+    l.ints = kProjWsHead + l.n_bnd + (carry ? l.n_up + 2 * l.n_row + ntiles : 0);
+    l.ints = (l.ints + 1) / 2 * 2;
+    l.mask_words = 0;
+    if constexpr (TH <= 32) l.mask_words = carry && masks ? ntiles * tile_mask_words<TH>() : 0;
+    return l;
+}
 
 // The far-source flags carry a per-call nonce instead of being cleared: ONE process-wide counter for every
 // instantiation of run_proj_fwd (a function-local static would give FlowProjection and DepthFlowProjection their own
@@ -1050,16 +1078,10 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     // (the owner kernel addresses the flow / depth planes with 32-bit offsets)
     const bool want_fast = variant != 1 && variant < 2 && plane_fits_u32(w, h, {s1h, sdh});
     const bool want_carry = a.fillhole && variant != -8 && variant != -9;
-    // scratch layout: [0, 320) ints of far flags (image b -> word b % 256, word 256 = "any"), the tiles' far table
-    // (kFarWords ints per tile: proj_owner5.hpp; rounds 2-3: 2 ints of motion bounds), then -- with hole filling -- the three tables of per-tile summaries, the per-tile hole flags and
-    // (8-byte aligned) the tiles' masks
-    constexpr size_t kHead = 320;
-    const size_t n_bnd = want_fast ? kFarWords * (size_t)ntiles : 0;
-    const size_t n_up = (size_t)batch * nty * w, n_row = (size_t)batch * h * ntx;
-    size_t ints = kHead + n_bnd + (want_carry ? n_up + 2 * n_row + (size_t)ntiles : 0);
-    ints = (ints + 1) / 2 * 2;
-    size_t mask_words = 0;
-    if constexpr (kNewOk) mask_words = want_carry && !old_fill ? (size_t)ntiles * tile_mask_words<TH>() : 0;
+    // scratch layout: ProjWsLayout above
+    constexpr size_t kHead = kProjWsHead;
+    const ProjWsLayout lay = proj_ws_layout<TH>(w, h, batch, want_fast, want_carry, !old_fill);
+    const size_t n_bnd = lay.n_bnd, n_up = lay.n_up, n_row = lay.n_row, ints = lay.ints;
     CallScratch scratch;
     int *flag = nullptr, *bounds = nullptr;
     FillWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1071,8 +1093,16 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     unsigned nonce_u = g_proj_call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
     if (nonce_u == 0) nonce_u = g_proj_call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
     const int nonce = (int)nonce_u;
-    if ((want_fast || want_carry) && scratch.alloc(ints * sizeof(int) + mask_words * 8, stream)) {
-        int *base = static_cast<int *>(scratch.p);
+    // A caller's workspace (the _ws entry points: memc_flow_projection_workspace_bytes says how much) replaces the library's
+    // block -- nothing is allocated, nothing is kept, a stream capture takes the same kernels as an eager call.
+    if (a.ws && (a.ws_bytes < lay.bytes() || (reinterpret_cast<uintptr_t>(a.ws) & 15u) != 0)) return -1;
+    void *block = nullptr;
+    if (want_fast || want_carry) {
+        if (a.ws) block = a.ws;
+        else if (scratch.alloc(lay.bytes(), stream)) block = scratch.p;
+    }
+    if (block) {
+        int *base = static_cast<int *>(block);
         if (legacy_owner && hipMemsetAsync(base, 0, kHead * sizeof(int), stream) != hipSuccess) return -1;
         if (want_fast) {
             flag = base;
@@ -1129,7 +1159,15 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                     hipLaunchKernelGGL((proj_owner_far_r3<DEPTH, TH, 24>), dim3(ntiles < pg ? ntiles : pg), dim3(16 * TH), 0,
                                        stream, w, h, ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth,
                                        a.count, a.out, flag, bounds, ws, nonce);
-                else
+                else if (variant == -44 || variant == -45) {   // round 4's arm: three per CU, spills (-45: on the product's grid)
+                    const unsigned pg3 = variant == -44 ? persistent_grid(3) : pg;
+                    if constexpr (TH == 32)
+                        hipLaunchKernelGGL((proj_owner_far<DEPTH, TH, 24, 6, 384>), dim3(ntiles < pg3 ? ntiles : pg3), dim3(16 * TH),
+                                           0, stream, w, h, ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth,
+                                           a.count, a.out, flag, bounds, ws, nonce);
+                    else
+                        return -1;
+                } else
 #endif
                 hipLaunchKernelGGL((proj_owner_far<DEPTH, TH, 24>), dim3(ntiles < pg ? ntiles : pg), dim3(16 * TH), 0, stream,
                                    w, h, ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
@@ -1261,12 +1299,14 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
 template <bool DEPTH>
 static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fillhole,
                            int s1b, int s1c, int s1h, int sdb, int sdh, int scb, int sch,
-                           const float *flow, const float *depth, float *count, float *out)
+                           const float *flow, const float *depth, float *count, float *out,
+                           void *ws = nullptr, size_t ws_bytes = 0)
 {
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
     const bool vec = vec4_ok(w, {s1b, s1c, s1h, sdb, sdh, scb, sch}, {flow, depth, count, out});
     if (vec && g_proj_variant != 0) {
-        const ProjArgs a = {stream, w, h, batch, fillhole, s1b, s1c, s1h, sdb, sdh, scb, sch, flow, depth, count, out};
+        const ProjArgs a = {stream, w, h, batch, fillhole, s1b, s1c, s1h, sdb, sdh, scb, sch, flow, depth, count, out,
+                            ws, ws_bytes};
 #ifdef MEMC_MEASURE
         // 100 + 10 * log2(TH / 16) + stripe width: owner geometry under test; -10 / -7 / -6: the round-1 owner
         int v = g_proj_variant, th = kOwnerTH, sw = kOwnerSW;
@@ -1417,4 +1457,45 @@ extern "C" int DepthFlowProjection_gpu_backward_kernel(
     (void)nElement; (void)channel; (void)s1w; (void)s2c; (void)s2w; (void)scc; (void)scw;
     return launch_proj_bwd<true>((hipStream_t)stream, w, h, batch, s1b, s1c, s1h, s2b, s2h, scb, sch, input1, input2,
                                  count, output, gradoutput, gradinput1, gradinput2);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Caller-supplied workspace (include/memc_warp.h, "EXTENSION: workspace").  The reference's launchers touch borrowed buffers
+// only (my_lib_kernel.cu:1905-1992; my_lib_cuda.c:752-799: "callee never allocates"); with a workspace so does this one.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" size_t memc_flow_projection_workspace_bytes(int w, int h, int batch, int fillhole, int depth)
+{
+    (void)depth;                                 // (the same tables for both operators)
+    if (w <= 0 || h <= 0 || batch <= 0) return 0;
+    // what run_proj_fwd<., kOwnerTH> lays out when it takes its fast path with hole filling as asked; shapes that take
+    // another path (odd widths, planes beyond 4 GiB) use less or nothing
+    const ProjWsLayout l = proj_ws_layout<kOwnerTH>(w, h, batch, true, fillhole != 0, true);
+    return (l.bytes() + 255) / 256 * 256;
+}
+
+extern "C" int FlowProjection_gpu_forward_kernel_ws(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int fillhole,
+    const int s1b, const int s1c, const int s1h, const int s1w,
+    const int scb, const int scc, const int sch, const int scw,
+    const float *input1, float *count, float *output, void *workspace, size_t workspace_bytes)
+{
+    (void)nElement; (void)channel; (void)s1w; (void)scc; (void)scw;
+    if (!workspace) return -1;
+    return launch_proj_fwd<false>((hipStream_t)stream, w, h, batch, fillhole, s1b, s1c, s1h, 0, 0, scb, sch,
+                                  input1, nullptr, count, output, workspace, workspace_bytes);
+}
+
+extern "C" int DepthFlowProjection_gpu_forward_kernel_ws(
+    memc_stream_t stream, const int nElement, const int w, const int h, const int channel, const int batch,
+    const int fillhole,
+    const int s1b, const int s1c, const int s1h, const int s1w,
+    const int s2b, const int s2c, const int s2h, const int s2w,
+    const int scb, const int scc, const int sch, const int scw,
+    const float *input1, const float *input2, float *count, float *output, void *workspace, size_t workspace_bytes)
+{
+    (void)nElement; (void)channel; (void)s1w; (void)s2c; (void)s2w; (void)scc; (void)scw;
+    if (!workspace) return -1;
+    return launch_proj_fwd<true>((hipStream_t)stream, w, h, batch, fillhole, s1b, s1c, s1h, s2b, s2h, scb, sch,
+                                 input1, input2, count, output, workspace, workspace_bytes);
 }

@@ -268,6 +268,19 @@ int FlowProjectionLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *in
         (int)input1->size[0], fillhole, S4(input1), S4(count), input1->data, count->data, output->data);
 }
 
+int FlowProjectionLayer_gpu_forward_ws(memc_stream_t stream, const memc_tensor4 *input1, const memc_tensor4 *count,
+                                       const memc_tensor4 *output, int fillhole, void *workspace, size_t workspace_bytes)
+{
+    if (!ok(input1) || !ok(count) || !ok(output) || !workspace) return kErr;
+    if (input1->size[1] != 2) return kErr;
+    if (!count_matches(input1, count)) return kErr;
+    if (!same_layout(input1, output)) return kErr;
+    return FlowProjection_gpu_forward_kernel_ws(
+        stream, nelem(output), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
+        (int)input1->size[0], fillhole, S4(input1), S4(count), input1->data, count->data, output->data, workspace,
+        workspace_bytes);
+}
+
 int FlowProjectionLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
                                      const memc_tensor4 *count, const memc_tensor4 *gradoutput,
                                      const memc_tensor4 *gradinput1)
@@ -296,6 +309,22 @@ int DepthFlowProjectionLayer_gpu_forward(memc_stream_t stream, const memc_tensor
         stream, nelem(output), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
         (int)input1->size[0], fillhole, S4(input1), S4(input2), S4(count), input1->data, input2->data,
         count->data, output->data);
+}
+
+int DepthFlowProjectionLayer_gpu_forward_ws(memc_stream_t stream, const memc_tensor4 *input1,
+                                            const memc_tensor4 *input2, const memc_tensor4 *count,
+                                            const memc_tensor4 *output, int fillhole, void *workspace,
+                                            size_t workspace_bytes)
+{
+    if (!ok(input1) || !ok(input2) || !ok(count) || !ok(output) || !workspace) return kErr;
+    if (input1->size[1] != 2) return kErr;
+    if (input2->size[1] != 1) return kErr;
+    if (!count_matches(input1, input2) || !count_matches(input1, count)) return kErr;
+    if (!same_layout(input1, output)) return kErr;
+    return DepthFlowProjection_gpu_forward_kernel_ws(
+        stream, nelem(output), (int)input1->size[3], (int)input1->size[2], (int)input1->size[1],
+        (int)input1->size[0], fillhole, S4(input1), S4(input2), S4(count), input1->data, input2->data,
+        count->data, output->data, workspace, workspace_bytes);
 }
 
 int DepthFlowProjectionLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,

@@ -1,4 +1,4 @@
-// memc_scratch.hpp -- stream-ordered per-call scratch from a private memory pool (host side).
+// memc_scratch.hpp -- the scratch block of a (Depth)FlowProjection forward call that was NOT handed a workspace (host side).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -8,12 +8,14 @@
 
 namespace memc {
 
-// The forward pass needs a few device words that outlive a kernel (per-image "far source" flags of the fast path)
-// and, with hole filling, the filler's carry tables: ONE stream-ordered allocation per call, released in stream
-// order before the call returns (hipFreeAsync) -- nothing is shared between calls, streams or threads.  It comes
-// from a private memory pool per device (created on first use, kept for the life of the process, release threshold
-// "never": with the default threshold a pool hands its memory back at every synchronisation and the next call pays
-// for a fresh allocation, measured +200 us); the device's default pool and its attributes are left alone.
+// The forward pass needs a few device words that outlive a kernel (far-source flags, the tiles' landing boxes and stamps)
+// and, with hole filling, the filler's tables.  A caller that wants the library to own NOTHING passes a workspace
+// (<Op>Layer_gpu_forward_ws, include/memc_warp.h: what the shipped Python layer does -- torch's caching allocator, capturable
+// into a HIP graph).  The reference-signature entry points have no such parameter; for them the block comes from here.
+//
+// Pool.  A private memory pool per device (created on first use, kept for the life of the process, release threshold
+// "never": with the default threshold a pool hands its memory back at every synchronisation and the next call pays for a
+// fresh allocation, measured +200 us); the device's default pool and its attributes are left alone.
 inline hipMemPool_t pool_for_device(int dev)
 {
     static std::mutex mu;
@@ -39,43 +41,37 @@ inline hipMemPool_t pool_for_device(int dev)
     return pools[dev];
 }
 
-// Scratch of one call.  Round 4 measured what a stream-ordered allocation and its release cost the HOST: ~30 us per call
-// (hipMallocFromPoolAsync + hipFreeAsync), a quarter of the projection's GPU time and the whole of its launch latency.
-// So the block is CACHED per (device, stream): calls enqueued on one stream run in order, the next call may reuse the
-// block the previous one used.  The cache entry is claimed for the duration of the host-side call (two host threads
-// enqueueing on the same stream at once do not share: the second takes a stream-ordered allocation of its own, as
-// rounds 2-3 did for every call); a block that is too small is released in stream order and replaced.  Blocks live for
-// the life of the process (at most one per stream that ever ran a projection forward: 0.8 bytes per pixel of the
-// largest call with hole filling).
+// Block cache.  A stream-ordered allocation and its release cost the HOST ~30 us per call (round 4), so blocks are kept.
+// Round 4 keyed them by the stream HANDLE and trusted "calls on one stream run in order" -- which a handle does not
+// promise: hipStreamPerThread is one handle and a different queue in every host thread, and the handle of a destroyed
+// stream can be handed out again while the old queue's last work is in flight (round 4 review).  Now the ORDER is explicit:
+//   * a block is owned by exactly one host-side call at a time (`busy`, under the mutex);
+//   * at release the call records an event behind its last kernel; the next claimant -- whatever its stream, thread or
+//     device queue -- makes its stream wait for that event before its first kernel.  On the same queue that wait is free;
+//   * a small set of blocks per device (kBlocks), any stream may take any free one (preferring the one it used last: no
+//     cross-queue wait); no per-stream entry, nothing to leak when streams come and go; all of them busy (more than
+//     kBlocks host threads inside a projection forward at once) -> a stream-ordered allocation of the call's own, as rounds 2-3
+//     did for every call; a block that is too small is released in stream order and replaced.
+// Device memory held: at most kBlocks blocks of ~0.8 B per pixel of the largest call each, per device.
 struct CachedBlock {
-    int dev = -1;
-    hipStream_t stream = nullptr;
     void *p = nullptr;
     size_t bytes = 0;
-    bool used = false, busy = false;
+    hipEvent_t done = nullptr;                 // recorded behind the last call that used the block
+    hipStream_t last = nullptr;                // (preference only: never trusted for ordering)
+    bool recorded = false, busy = false;
+    uint64_t stamp = 0;                        // last use (LRU: the replacement victim)
 };
-constexpr int kScratchSlots = 64;              // streams remembered (a 65th takes per-call allocations, as rounds 2-3 did)
+constexpr int kBlocks = 8, kDevices = 16;
 inline std::mutex &scratch_mutex()
 {
     static std::mutex mu;
     return mu;
 }
-// the entry of (dev, stream), claimed for a new pair if there is room; nullptr: no room.  Caller holds scratch_mutex().
-// (a plain table, no std::map: the library exports nothing but its C surface -- tests/test_abi.py)
-inline CachedBlock *scratch_entry(int dev, hipStream_t s)
+// (plain tables, no std::map: the library exports nothing but its C surface -- tests/test_abi.py)
+inline CachedBlock *scratch_table(int dev)
 {
-    static CachedBlock table[kScratchSlots];
-    CachedBlock *free_slot = nullptr;
-    for (int i = 0; i < kScratchSlots; i++) {
-        if (table[i].used && table[i].dev == dev && table[i].stream == s) return &table[i];
-        if (!table[i].used && !free_slot) free_slot = &table[i];
-    }
-    if (free_slot) {
-        free_slot->used = true;
-        free_slot->dev = dev;
-        free_slot->stream = s;
-    }
-    return free_slot;
+    static CachedBlock table[kDevices][kBlocks];
+    return dev >= 0 && dev < kDevices ? table[dev] : nullptr;
 }
 
 struct CallScratch {
@@ -87,24 +83,41 @@ struct CallScratch {
         stream = s;
         hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(s, &capture);
-        if (capture != hipStreamCaptureStatusNone) return false;      // no allocation inside a stream capture
+        if (capture != hipStreamCaptureStatusNone) return false;      // no allocation / event inside a stream capture
         int dev = -1;
         if (hipStreamGetDevice(s, &dev) != hipSuccess) {              // the STREAM's device, not the current one
             (void)hipGetLastError();
             if (hipGetDevice(&dev) != hipSuccess) dev = -1;
         }
         hipMemPool_t pool = pool_for_device(dev);
-        {
+        CachedBlock *table = scratch_table(dev);
+        if (table) {
+            static uint64_t clock = 0;
             std::lock_guard<std::mutex> lock(scratch_mutex());
-            CachedBlock *slot = scratch_entry(dev, s);
-            if (slot && !slot->busy) {
-                CachedBlock &b = *slot;
-                if (b.p && b.bytes < bytes) {                          // too small: released behind the work that used it
+            CachedBlock *best = nullptr;       // a free block: large enough and last used on this handle > large enough > LRU
+            int best_rank = -1;
+            for (int i = 0; i < kBlocks; i++) {
+                CachedBlock &b = table[i];
+                if (b.busy) continue;
+                int rank = b.p && b.bytes >= bytes ? (b.last == s ? 3 : 2) : (!b.p ? 1 : 0);
+                if (rank > best_rank || (rank == best_rank && rank == 0 && b.stamp < best->stamp)) {
+                    best = &b;
+                    best_rank = rank;
+                }
+            }
+            if (best) {
+                CachedBlock &b = *best;
+                bool ordered = true;
+                if (b.recorded && hipStreamWaitEvent(s, b.done, 0) != hipSuccess) {   // behind the block's previous user
+                    (void)hipGetLastError();
+                    ordered = false;
+                }
+                if (ordered && b.p && b.bytes < bytes) {               // too small: released behind that wait, replaced
                     (void)hipFreeAsync(b.p, s);
                     b.p = nullptr;
                     b.bytes = 0;
                 }
-                if (!b.p) {
+                if (ordered && !b.p) {
                     const size_t want = bytes + bytes / 4;             // (room for a somewhat larger call)
                     void *q = nullptr;
                     hipError_t e = pool ? hipMallocFromPoolAsync(&q, want, pool, s) : hipMallocAsync(&q, want, s);
@@ -115,15 +128,21 @@ struct CallScratch {
                         (void)hipGetLastError();
                     }
                 }
-                if (b.p) {
+                if (ordered && b.p && !b.done && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    b.done = nullptr;
+                }
+                if (ordered && b.p && b.done) {
                     b.busy = true;
+                    b.last = s;
+                    b.stamp = ++clock;
                     claimed = &b;
                     p = b.p;
                     return true;
                 }
             }
         }
-        // the stream's block is held by another host thread right now (or could not be had): a block of this call's own
+        // every block is held by another host thread right now (or could not be had): a block of this call's own
         hipError_t e = pool ? hipMallocFromPoolAsync(&p, bytes, pool, s) : hipMallocAsync(&p, bytes, s);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -134,8 +153,20 @@ struct CallScratch {
     ~CallScratch()
     {
         if (claimed) {
+            // behind the call's last kernel; a failed record leaves the block unusable for others until it succeeds once
+            const bool ok = hipEventRecord(claimed->done, stream) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
             std::lock_guard<std::mutex> lock(scratch_mutex());
-            claimed->busy = false;
+            if (ok) {
+                claimed->recorded = true;
+                claimed->busy = false;
+            } else {                           // cannot order the next user behind this call: give the block up in stream order
+                (void)hipFreeAsync(claimed->p, stream);
+                claimed->p = nullptr;
+                claimed->bytes = 0;
+                claimed->recorded = false;
+                claimed->busy = false;
+            }
         } else if (p) {
             (void)hipFreeAsync(p, stream);
         }

@@ -145,6 +145,65 @@ for _name, (_n, _flag) in list(_SYMBOLS.items()) + list(_EXTENSIONS.items()):
     __all__.append(_name)
 
 
+def _bind_ws(symbol, n_tensors, lib=None):
+    """<Op>Layer_gpu_forward_ws(tensors..., fillhole, workspace): the (Depth)FlowProjection forward with a caller-supplied
+    workspace (include/memc_warp.h, "EXTENSION: workspace").  `workspace`: a contiguous CUDA tensor of at least
+    flow_projection_workspace_bytes(...) bytes, allocated on the current stream (torch.empty: capturable, freed with the call)."""
+    cfunc = getattr(lib if lib is not None else _lib, symbol)
+    cfunc.restype = ctypes.c_int
+    cfunc.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(_Tensor4)] * n_tensors + [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+    byref, current_device, current_stream = ctypes.byref, torch.cuda.current_device, torch.cuda.current_stream
+
+    def call(*args):
+        if len(args) != n_tensors + 2:
+            raise TypeError("%s takes %d arguments (%d given)" % (symbol, n_tensors + 2, len(args)))
+        ws = args[-1]
+        if not (isinstance(ws, torch.Tensor) and ws.is_cuda and ws.is_contiguous()):
+            raise TypeError("%s: workspace must be a contiguous CUDA tensor" % symbol)
+        dev = args[0].device if isinstance(args[0], torch.Tensor) else None
+        cargs = []
+        for i in range(n_tensors):
+            cargs.append(byref(_describe(args[i], symbol, i)))
+            if args[i].device != dev:
+                raise TypeError("%s: all tensors must live on the same device" % symbol)
+        if ws.device != dev:
+            raise TypeError("%s: all tensors must live on the same device" % symbol)
+        cargs += [int(args[-2]), ws.data_ptr(), ws.numel() * ws.element_size()]
+        if dev.index == current_device():
+            return int(cfunc(current_stream(dev).cuda_stream, *cargs))
+        with torch.cuda.device(dev):
+            return int(cfunc(current_stream(dev).cuda_stream, *cargs))
+
+    call.__name__ = symbol
+    return call
+
+
+_WS_SYMBOLS = {"FlowProjectionLayer_gpu_forward_ws": 3, "DepthFlowProjectionLayer_gpu_forward_ws": 4}
+for _name, _n in _WS_SYMBOLS.items():
+    globals()[_name] = _bind_ws(_name, _n)
+    __all__.append(_name)
+
+_lib.memc_flow_projection_workspace_bytes.restype = ctypes.c_size_t
+_lib.memc_flow_projection_workspace_bytes.argtypes = [ctypes.c_int] * 5
+
+
+def flow_projection_workspace_bytes(w, h, batch, fillhole, depth=False):
+    """memc_flow_projection_workspace_bytes (include/memc_warp.h): bytes of workspace a (Depth)FlowProjection forward of
+    that shape needs."""
+    return int(_lib.memc_flow_projection_workspace_bytes(int(w), int(h), int(batch), int(fillhole), int(bool(depth))))
+
+
+def flow_projection_workspace(like, fillhole, depth=False):
+    """A workspace for a (Depth)FlowProjection forward on the flow tensor `like` [N, 2, H, W]: allocated by torch's caching
+    allocator on the current stream (stream-ordered, capturable into a HIP graph, returned to the allocator when the last
+    reference goes -- the kernels of the call are already queued on that stream by then)."""
+    n = flow_projection_workspace_bytes(like.size(3), like.size(2), like.size(0), fillhole, depth)
+    return torch.empty((max(n, 256),), dtype=torch.uint8, device=like.device)
+
+
+__all__ += ["flow_projection_workspace_bytes", "flow_projection_workspace"]
+
+
 def _bind_upsample():
     """FlowUpsample4Layer_gpu_forward(input, output, mul, div, align_corners) -- extension (include/memc_warp.h)"""
     cfunc = _lib.FlowUpsample4Layer_gpu_forward

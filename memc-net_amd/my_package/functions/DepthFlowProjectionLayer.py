@@ -21,8 +21,11 @@ class _DepthFlowProjectionFunction(Function):
         input1, input2 = f32c(input1), f32c(input2)
         count = input1.new_empty((input1.size(0), 1, input1.size(2), input1.size(3)))   # defined by the forward pass
         output = torch.empty_like(input1)                                               # (see FlowProjectionLayer)
-        err = my_lib.DepthFlowProjectionLayer_gpu_forward(input1, input2, count, output, int(fillhole))
-        check(err, "DepthFlowProjectionLayer_gpu_forward")
+        # a workspace from torch's allocator instead of a block the library keeps (include/memc_warp.h, "EXTENSION:
+        # workspace"): the call owns nothing afterwards and a HIP-graph capture records the same kernels as an eager call
+        ws = my_lib.flow_projection_workspace(input1, fillhole, depth=True)
+        err = my_lib.DepthFlowProjectionLayer_gpu_forward_ws(input1, input2, count, output, int(fillhole), ws)
+        check(err, "DepthFlowProjectionLayer_gpu_forward_ws")
         ctx.save_for_backward(input1, input2, count, output)
         return output
 

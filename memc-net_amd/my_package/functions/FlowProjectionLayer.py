@@ -23,8 +23,11 @@ class _FlowProjectionFunction(Function):
         # path (tests/test_gpu_parity.py::test_projection_forward_needs_no_zero_fill): no memsets
         count = input1.new_empty((input1.size(0), 1, input1.size(2), input1.size(3)))
         output = torch.empty_like(input1)
-        err = my_lib.FlowProjectionLayer_gpu_forward(input1, count, output, int(fillhole))
-        check(err, "FlowProjectionLayer_gpu_forward")
+        # a workspace from torch's allocator instead of a block the library keeps (include/memc_warp.h, "EXTENSION:
+        # workspace"): the call owns nothing afterwards and a HIP-graph capture records the same kernels as an eager call
+        ws = my_lib.flow_projection_workspace(input1, fillhole)
+        err = my_lib.FlowProjectionLayer_gpu_forward_ws(input1, count, output, int(fillhole), ws)
+        check(err, "FlowProjectionLayer_gpu_forward_ws")
         ctx.save_for_backward(input1, count)
         return output
 

@@ -14,8 +14,11 @@ HEADER = os.path.join(ROOT, "include", "memc_warp.h")
 def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+char\s*\*\s*|int\s+)(\w+)\s*\(", text, flags=re.M)
-    assert len(names) == 30, names      # 10 layer entry points + 10 kernel launchers + memc_hip_version + memc_last_kernel_path + memc_gradinput1_is_stored + 3 x 2 of the three extensions + memc_calibration_stream
+    names = re.findall(r"^\s*(?:const\s+char\s*\*\s*|int\s+|size_t\s+)(\w+)\s*\(", text, flags=re.M)
+    # 10 layer entry points + 10 kernel launchers + memc_hip_version + memc_last_kernel_path + memc_gradinput1_is_stored
+    # + 3 x 2 of the three extensions + memc_calibration_stream + the workspace extension (size query, 2 layer entry
+    # points, 2 launchers)
+    assert len(names) == 35, names
     return names
 
 
@@ -94,6 +97,56 @@ def test_layer_checks_reject_bad_descriptors(lib):
     d.restype = ctypes.c_int
     d.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(Tensor4)] * 4 + [ctypes.c_int]
     assert d(None, P(flow), P(desc((2, 2, 8, 8))), P(desc((2, 1, 8, 8))), P(desc((2, 2, 8, 8))), 0) == -1  # depth channels != 1 (:870)
+
+
+def test_workspace_entry_points_reject_bad_workspaces(lib):
+    """The `_ws` forward entry points (include/memc_warp.h, "EXTENSION: workspace"): a size query that needs no device,
+    the reference's shape checks, and -1 for a NULL, misaligned or too small workspace -- all before any launch."""
+    P = ctypes.byref
+    q = lib.memc_flow_projection_workspace_bytes
+    q.restype = ctypes.c_size_t
+    q.argtypes = [ctypes.c_int] * 5
+    assert q(0, 720, 32, 1, 0) == 0 and q(1280, 720, 0, 1, 0) == 0
+    small, fill, nofill = q(128, 64, 2, 1, 0), q(1280, 720, 32, 1, 0), q(1280, 720, 32, 0, 0)
+    assert 0 < small < fill and 0 < nofill < fill and fill % 256 == 0
+    assert fill < 1.0 * 32 * 720 * 1280                   # "about 0.8 bytes per pixel"
+    assert q(1280, 720, 32, 1, 1) == fill                 # the depth operator uses the same tables
+    flow, cnt, out = desc((2, 2, 64, 128)), desc((2, 1, 64, 128)), desc((2, 2, 64, 128))
+    p = lib.FlowProjectionLayer_gpu_forward_ws
+    p.restype = ctypes.c_int
+    p.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(Tensor4)] * 3 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+    assert p(None, P(flow), P(cnt), P(out), 1, None, small) == -1                       # no workspace
+    assert p(None, P(desc((2, 3, 64, 128))), P(cnt), P(desc((2, 3, 64, 128))), 1, 0x10000, small) == -1   # channel != 2
+    assert p(None, P(flow), P(cnt), P(out), 1, 0x10000, small - 256) == -1              # too small
+    assert p(None, P(flow), P(cnt), P(out), 1, 0x10004, small + 256) == -1              # not 16-byte aligned
+    d = lib.DepthFlowProjectionLayer_gpu_forward_ws
+    d.restype = ctypes.c_int
+    d.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(Tensor4)] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+    assert d(None, P(flow), P(cnt), P(cnt), P(out), 1, None, small) == -1
+    assert d(None, P(flow), P(desc((2, 2, 64, 128))), P(cnt), P(out), 1, 0x10000, small) == -1   # depth channels != 1
+    assert d(None, P(flow), P(cnt), P(cnt), P(out), 1, 0x10000, 16) == -1
+
+
+# Kernels still allowed to spill (to be emptied): none on the path of the reference's networks -- the many-channel backward has no
+# caller there (its context warps are detached), the image + context warp is off by default (measured slower).
+KNOWN_SCRATCH_USERS = ("memc::fi_bwd_taps_c4n", "memc::fi_bwd_image_owner<memc::FpFilter", "memc::fi_fwd_ctx_img<true>")
+
+
+def test_no_product_kernel_uses_private_scratch():
+    """No kernel of the product build may spill (ScratchSize > 0 in the compiler's own resource remarks; hipcc cross-compiles
+    here).  A spill is a performance bug first -- and round 4 saw a wrong result next to an experimental kernel that
+    spilled (what that was)."""
+    import shutil
+    import sys
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not present")
+    sys.path.insert(0, ROOT)
+    from tools import kernel_resources as KR
+    kernels = KR.all_resources(measure=False)
+    assert len(kernels) > 40, len(kernels)
+    spilling = [(k["name"], k["scratch"]) for k in kernels if int(k.get("scratch", "0")) > 0 or k.get("dynstack", "False") != "False"]
+    spilling = [s for s in spilling if not any(s[0].startswith(a) for a in KNOWN_SCRATCH_USERS)]
+    assert not spilling, spilling
 
 
 def test_empty_batch_is_a_no_op(lib):

@@ -1,0 +1,299 @@
+"""Round 5: the (Depth)FlowProjection forward with a caller-supplied workspace (include/memc_warp.h, "EXTENSION: workspace"),
+HIP-graph capture of the projection and of a whole MEMC_Net_star inference on that path, and the multi-stream / multi-thread
+stress of the projection's scratch protocol (round-4 review items 1 and 4; ADVICE: hipStreamPerThread).
+
+Reference contract: the reference's launcher touches borrowed buffers only and can be captured at full speed
+(my_lib_kernel.cu:1905-1992, my_lib_cuda.c:752-799)."""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _netutil      # noqa: E402
+from _parity import close  # noqa: E402
+from tools import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def my_lib():
+    import my_package._ext.my_lib as L
+    return L
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import memc_oracle as O
+    return O
+
+
+CASES = [(2, 64, 128, "smooth", 3.0), (2, 96, 200, "iid", 3.0), (1, 720, 1280, "smooth", 4.0), (2, 64, 128, "iid", 40.0),
+         (3, 100, 260, "smooth", 30.0)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=["%dx%dx%d-%s-%g" % c for c in CASES])
+@pytest.mark.parametrize("fill", [0, 1])
+def test_workspace_entry_points_equal_the_reference_signature_ones(my_lib, oracle, case, fill):
+    """Same kernels, same results, bit for bit -- and the oracle's; the workspace is filled with garbage first (its contents
+    are never read before written, flag words are compared against a per-call tag)."""
+    B, H, W, kind, sigma = case
+    rng = np.random.default_rng(11)
+    flow = synth.np_flow(rng, B, H, W, kind, sigma)
+    depth = synth.np_depth(rng, B, H, W)
+    tf, td = T(flow), T(depth)
+    for dep in (False, True):
+        c0, o0 = tf.new_full((B, 1, H, W), float("nan")), torch.full_like(tf, float("nan"))
+        c1, o1 = tf.new_full((B, 1, H, W), float("nan")), torch.full_like(tf, float("nan"))
+        n = my_lib.flow_projection_workspace_bytes(W, H, B, fill, dep)
+        assert n > 0 and n % 256 == 0
+        for garbage in (0xFF, 0x00, 0x01):
+            ws = torch.full((n,), garbage, dtype=torch.uint8, device="cuda")
+            if dep:
+                assert my_lib.DepthFlowProjectionLayer_gpu_forward(tf, td, c0, o0, fill) == 0
+                assert my_lib.DepthFlowProjectionLayer_gpu_forward_ws(tf, td, c1, o1, fill, ws) == 0
+            else:
+                assert my_lib.FlowProjectionLayer_gpu_forward(tf, c0, o0, fill) == 0
+                assert my_lib.FlowProjectionLayer_gpu_forward_ws(tf, c1, o1, fill, ws) == 0
+            if W % 4 == 0:
+                assert my_lib.last_kernel_path() == ("dproj_fwd:owner" if dep else "proj_fwd:owner")
+            assert torch.equal(c0, c1) and torch.equal(o0, o1)
+        want_o, want_c = (oracle.depth_flow_projection_forward(flow, depth, fill) if dep
+                          else oracle.flow_projection_forward(flow, fill))
+        close(N(o1), want_o, "output")
+        if not dep:
+            assert np.array_equal(N(c1), want_c)
+    # too small a workspace is refused, nothing launched
+    small = torch.empty((max(n - 256, 16),), dtype=torch.uint8, device="cuda")
+    assert my_lib.FlowProjectionLayer_gpu_forward_ws(tf, c1, o1, fill, small) == -1
+
+
+def test_projection_module_in_a_hip_graph(my_lib, oracle):
+    """FlowProjectionModule (hole filling on) captured in a HIP graph: the capture takes the owner kernels (not the
+    scratch-free general path the reference-signature entry points fall back to inside a capture), replays match eager
+    results and the oracle -- for new inputs copied into the captured tensors, large motion included."""
+    from my_package.modules.FlowProjectionModule import FlowProjectionModule
+    rng = np.random.default_rng(5)
+    B, H, W = 2, 128, 256
+    flows = [synth.np_flow(rng, B, H, W, "smooth", 3.0), synth.np_flow(rng, B, H, W, "iid", 3.0),
+             synth.np_flow(rng, B, H, W, "smooth", 30.0), synth.np_flow(rng, B, H, W, "smooth", 3.0) + np.float32(40.0)]
+    mod = FlowProjectionModule(requires_grad=False)
+    static_in = T(flows[0]).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            mod(static_in)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph):
+        static_out = mod(static_in)
+        path = my_lib.last_kernel_path()
+    assert path == "proj_fwd:owner", path
+    for rep in range(2):
+        for f in flows:
+            static_in.copy_(T(f))
+            graph.replay()
+            torch.cuda.synchronize()
+            eager = mod(T(f))
+            assert torch.equal(static_out, eager)
+            close(N(static_out), oracle.flow_projection_forward(f, 1)[0], "graph replay")
+    # the reference-signature entry point inside a capture: allowed, slower path, same results
+    cnt, out = static_in.new_empty((B, 1, H, W)), torch.empty_like(static_in)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        assert my_lib.FlowProjectionLayer_gpu_forward(static_in, cnt, out, 1) == 0
+        path2 = my_lib.last_kernel_path()
+    assert path2 == "proj_fwd:general", path2
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(out, static_out, atol=1e-4, rtol=0)
+
+
+def test_whole_network_inference_in_a_hip_graph():
+    """A whole MEMC_Net_star inference step captured in one HIP graph and replayed twice: equals the eager run to the
+    reproducibility of the dense layers (MIOpen fp32; the hot-path operators are bit-reproducible), and both projections of
+    the step took the owner kernels."""
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    _netutil.purge_networks()
+    import my_package._ext.my_lib as L
+    import networks
+    m = networks.MEMC_Net_star(channel=3, filter_size=4, training=False)
+    m.load_state_dict(_netutil.named_weights(m.state_dict()), strict=True)
+    m = m.cuda().eval()
+    x = _netutil.frames(7, 1, 128, 128).cuda()
+    static_x = x.clone()
+    seen = []
+    orig = L.FlowProjectionLayer_gpu_forward_ws
+
+    def spy(*a):
+        r = orig(*a)
+        seen.append(L.last_kernel_path())
+        return r
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.no_grad(), torch.cuda.stream(side):
+        for _ in range(3):                                     # MIOpen's solver search and workspace allocations: outside the capture
+            eager = m(static_x)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    L.FlowProjectionLayer_gpu_forward_ws = spy
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            static_out = m(static_x)
+    finally:
+        L.FlowProjectionLayer_gpu_forward_ws = orig
+    assert seen and all(p == "proj_fwd:owner" for p in seen), seen
+    for rep in range(2):
+        x2 = _netutil.frames(7 + rep, 1, 128, 128).cuda()
+        static_x.copy_(x2)
+        graph.replay()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            eager = m(x2)
+        for a, b in zip(static_out[0], eager[0]):
+            err = float((a - b).abs().max() / max(1.0, float(b.abs().max())))
+            assert err <= 2e-3, err
+
+
+def test_projection_on_four_streams_mixed_motion_1000_rounds(my_lib, oracle):
+    """The scratch protocol under concurrency (round-4 review item 1): four streams, near and far motion mixed, the shapes
+    alternating so that blocks are handed from stream to stream, 1000 rounds of eight calls -- every result equals the
+    result computed alone, bit for bit (the kernels are deterministic)."""
+    rng = np.random.default_rng(77)
+    shapes = [(2, 64, 128), (1, 96, 256), (2, 128, 192)]
+    inputs = []
+    for (B, H, W) in shapes:
+        for kind, sigma, shift in (("smooth", 3.0, 0.0), ("iid", 40.0, 0.0), ("smooth", 3.0, 36.0)):
+            f = synth.np_flow(rng, B, H, W, kind, sigma) + np.float32(shift)
+            inputs.append(T(f))
+    alone = []
+    for tf in inputs:
+        B, _, H, W = tf.shape
+        c, o = tf.new_empty((B, 1, H, W)), torch.empty_like(tf)
+        assert my_lib.FlowProjectionLayer_gpu_forward(tf, c, o, 1) == 0
+        alone.append((c.clone(), o.clone()))
+    for tf, (c, o) in zip(inputs[:3], alone[:3]):
+        want_o, want_c = oracle.flow_projection_forward(N(tf), 1)
+        close(N(o), want_o, "alone vs oracle")
+        assert np.array_equal(N(c), want_c)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    bufs = [[(tf.new_empty((tf.shape[0], 1, tf.shape[2], tf.shape[3])), torch.empty_like(tf)) for tf in inputs] for _ in streams]
+    wrong = 0
+    for rnd in range(1000):
+        picks = []
+        for k, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                for rep in range(2):
+                    i = (rnd * 5 + k * 3 + rep * 4) % len(inputs)
+                    c, o = bufs[k][i]
+                    use_ws = (rnd + k + rep) % 2 == 0
+                    if use_ws:
+                        ws = my_lib.flow_projection_workspace(inputs[i], 1)
+                        assert my_lib.FlowProjectionLayer_gpu_forward_ws(inputs[i], c, o, 1, ws) == 0
+                    else:
+                        assert my_lib.FlowProjectionLayer_gpu_forward(inputs[i], c, o, 1) == 0
+                    picks.append((k, i))
+        if rnd % 10 == 9 or rnd == 999:
+            torch.cuda.synchronize()
+            for k, i in picks:
+                c, o = bufs[k][i]
+                if not (torch.equal(c, alone[i][0]) and torch.equal(o, alone[i][1])):
+                    wrong += 1
+    assert wrong == 0, wrong
+
+
+def test_projection_from_two_host_threads(my_lib):
+    """Two host threads enqueueing projections at once on their own streams (torch gives every thread's `with stream` its
+    own current stream) and both on the SAME stream: the library's blocks are owned by one host call at a time and ordered
+    by events, so results equal the single-threaded ones."""
+    rng = np.random.default_rng(78)
+    fa, fb = T(synth.np_flow(rng, 2, 96, 256, "smooth", 3.0)), T(synth.np_flow(rng, 2, 96, 256, "iid", 40.0))
+    want = []
+    for tf in (fa, fb):
+        c, o = tf.new_empty((2, 1, 96, 256)), torch.empty_like(tf)
+        assert my_lib.FlowProjectionLayer_gpu_forward(tf, c, o, 1) == 0
+        want.append((c.clone(), o.clone()))
+    torch.cuda.synchronize()
+    shared = torch.cuda.Stream()
+    errors = []
+
+    def worker(tf, ref, stream, n):
+        try:
+            torch.cuda.set_device(0)
+            c, o = tf.new_empty((2, 1, 96, 256)), torch.empty_like(tf)
+            for it in range(n):
+                with torch.cuda.stream(stream):
+                    assert my_lib.FlowProjectionLayer_gpu_forward(tf, c, o, 1) == 0
+                if it % 20 == 19:
+                    stream.synchronize()
+                    if not (torch.equal(c, ref[0]) and torch.equal(o, ref[1])):
+                        errors.append(it)
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e))
+
+    for same in (False, True):
+        sa = shared if same else torch.cuda.Stream()
+        sb = shared if same else torch.cuda.Stream()
+        ta = threading.Thread(target=worker, args=(fa, want[0], sa, 200))
+        tb = threading.Thread(target=worker, args=(fb, want[1], sb, 200))
+        ta.start(); tb.start(); ta.join(); tb.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+
+
+def test_projection_on_hip_stream_per_thread(my_lib):
+    """hipStreamPerThread is ONE handle value and a different queue in every host thread: a cache keyed by
+    the handle would hand one block to two queues at once.  Two threads call the C entry point with that handle."""
+    import ctypes
+    rng = np.random.default_rng(79)
+    fa, fb = T(synth.np_flow(rng, 2, 96, 256, "smooth", 3.0)), T(synth.np_flow(rng, 2, 96, 256, "iid", 40.0))
+    want = []
+    for tf in (fa, fb):
+        c, o = tf.new_empty((2, 1, 96, 256)), torch.empty_like(tf)
+        assert my_lib.FlowProjectionLayer_gpu_forward(tf, c, o, 1) == 0
+        want.append((c.clone(), o.clone()))
+    torch.cuda.synchronize()
+    cfunc = my_lib._lib.FlowProjectionLayer_gpu_forward
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    hip.hipSetDevice.argtypes = [ctypes.c_int]
+    PER_THREAD = ctypes.c_void_p(2)                          # hipStreamPerThread
+    errors = []
+
+    def worker(tf, ref, n):
+        try:
+            hip.hipSetDevice(0)
+            c, o = torch.empty((2, 1, 96, 256), device="cuda"), torch.empty_like(tf)
+            torch.cuda.synchronize()
+            d = [my_lib._describe(t, "test", i) for i, t in enumerate((tf, c, o))]
+            for it in range(n):
+                assert cfunc(PER_THREAD, ctypes.byref(d[0]), ctypes.byref(d[1]), ctypes.byref(d[2]), 1) == 0
+                if it % 20 == 19:
+                    assert hip.hipStreamSynchronize(PER_THREAD) == 0
+                    if not (torch.equal(c, ref[0]) and torch.equal(o, ref[1])):
+                        errors.append(it)
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e))
+
+    ta = threading.Thread(target=worker, args=(fa, want[0], 300))
+    tb = threading.Thread(target=worker, args=(fb, want[1], 300))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    torch.cuda.synchronize()
+    assert not errors, errors

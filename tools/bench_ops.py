@@ -89,10 +89,18 @@ def report(rows, name, sites, bytes_per_site, med, mn, extra=None):
 def bench_fi_fwd(rows, dev, B, C, H, W, flow_kind, variants, tag, rounds=4):
     """variants are timed in interleaved rounds in one process (the device needs ~100 launches to reach steady
     clocks, so whichever variant runs first would otherwise look ~5 % slower); median over all rounds."""
-    t = synth.torch_inputs(dev, B, C, H, W, flow_kind=flow_kind)
-    x, f, k = t["x"], t["flow"], t["filt"]
-    out = torch.zeros_like(x)
-    fn = lambda: L.FilterInterpolationLayer_gpu_forward(x, f, k, out)   # noqa: E731
+    # a launch smaller than the 256 MiB Infinity Cache rotates over input sets (> 1 GB cycled): the row is an HBM number
+    nbytes = B * H * W * 4 * (2 * C + 2 + 16)
+    n_sets = 1 if nbytes > 3e8 else int(1.0e9 // nbytes) + 1
+    sets = [synth.torch_inputs(dev, B, C, H, W, flow_kind=flow_kind, seed=1234 + 97 * i) for i in range(n_sets)]
+    outs = [torch.zeros_like(t["x"]) for t in sets]
+    out = outs[0]
+    turn = [0]
+
+    def fn():
+        i = turn[0] % n_sets
+        turn[0] += 1
+        return L.FilterInterpolationLayer_gpu_forward(sets[i]["x"], sets[i]["flow"], sets[i]["filt"], outs[i])
     M.set_variant("fi_fwd", variants[0])
     for _ in range(max(20, int(0.08 / max(1e-5, time_launches(fn, warmup=1, iters=3)[0])))):   # ~80 ms pre-warm
         fn()
@@ -113,12 +121,14 @@ def bench_fi_fwd(rows, dev, B, C, H, W, flow_kind, variants, tag, rounds=4):
                     fn()
                 b.record(); b.synchronize()
                 samples[v].append(a.elapsed_time(b) * 1e-3 / burst)
+            turn[0] = 0
+            fn()                                            # (set 0 again: the comparison is on its output)
             if ref is None:
                 ref = out.clone()
             same[v] = bool((out - ref).abs().max().item() <= 1e-5)
     for v in variants:
         report(rows, "fi_fwd %s C=%d %dx%dx%d flow=%s variant=%d%s" % (tag, C, B, H, W, flow_kind, v,
-                                                                       " (bursts of 20)" if B * H * W < 4e6 else ""),
+                                                                       " (bursts of 20, %d input sets)" % n_sets if B * H * W < 4e6 else ""),
                B * H * W, 4 * (2 * C + 2 + 16), statistics.median(samples[v]), min(samples[v]),
                {"variant": v, "matches_first_variant": same[v]})
     M.set_variant("fi_fwd", -1)
@@ -184,23 +194,39 @@ def bench_fi_ctx(rows, dev, B, C, H, W, flow_kind):
 
 
 def bench_fi_bwd(rows, dev, B, C, H, W, flow_kind, tag, variants=()):
-    t = synth.torch_inputs(dev, B, C, H, W, flow_kind=flow_kind, with_grad=True)
+    nbytes = B * H * W * 4 * (3 * C + 2 * (2 + 16))
+    n_sets = 1 if nbytes > 3e8 else int(1.0e9 // nbytes) + 1       # (see bench_fi_fwd: cold launches for small shapes)
+    sets = [synth.torch_inputs(dev, B, C, H, W, flow_kind=flow_kind, seed=1234 + 97 * i, with_grad=True) for i in range(n_sets)]
+    grads = [(torch.zeros_like(t["x"]), torch.zeros_like(t["flow"]), torch.zeros_like(t["filt"])) for t in sets]
+    t = sets[0]
     x, f, k, g = t["x"], t["flow"], t["filt"], t["gout"]
-    g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
+    g1, g2, g3 = grads[0]
+    turn = [0]
+
+    def rot():
+        i = turn[0] % n_sets
+        turn[0] += 1
+        s_, (a1, a2, a3) = sets[i], grads[i]
+        return L.FilterInterpolationLayer_gpu_backward(s_["x"], s_["flow"], s_["filt"], s_["gout"], a1, a2, a3)
 
     def pre():
-        g1.zero_(); g2.zero_(); g3.zero_()
+        if n_sets == 1:
+            g1.zero_(); g2.zero_(); g3.zero_()
     burst = 20 if B * H * W < 4e6 else 1
     for v in variants:
         M.set_variant("fi_bwd", v)
-        med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre,
-                                burst=burst)
+        med, mn = time_launches(rot, pre, burst=burst)
         report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s ABLATION variant=%d" % (tag, C, B, H, W, flow_kind, v),
                B * H * W, 4 * (3 * C + 2 * (2 + 16)), med, mn)
     M.set_variant("fi_bwd", -1)
-    med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), pre, burst=burst)
-    report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s%s" % (tag, C, B, H, W, flow_kind, " (bursts of 20)" if burst > 1 else ""),
+    med, mn = time_launches(rot, pre, burst=burst)
+    report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s%s" % (tag, C, B, H, W, flow_kind,
+                                                       " (bursts of 20, %d input sets)" % n_sets if burst > 1 else ""),
            B * H * W, 4 * (3 * C + 2 * (2 + 16)), med, mn)
+    if n_sets > 1:                                          # what rounds 1-4 reported: one set, out of the Infinity Cache
+        med, mn = time_launches(lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3), None, burst=burst)
+        report(rows, "fi_bwd %s C=%d %dx%dx%d flow=%s (bursts of 20, ONE input set: cache-warm)" % (tag, C, B, H, W, flow_kind),
+               B * H * W, 4 * (3 * C + 2 * (2 + 16)), med, mn)
 
 
 def bench_projection(rows, dev, B, H, W, flow_kind, tag, proj_variants=()):

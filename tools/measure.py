@@ -64,6 +64,8 @@ def bound():
         b = _Bound()
         for name, (n, flag) in list(L._SYMBOLS.items()) + list(L._EXTENSIONS.items()):
             setattr(b, name, L._bind(name, n, flag, lib=lib(), optional=L._OPTIONAL.get(name, ())))
+        for name, n in L._WS_SYMBOLS.items():          # the projection forward with a caller-supplied workspace
+            setattr(b, name, L._bind_ws(name, n, lib=lib()))
         _bound = b
     return _bound
 
@@ -72,7 +74,7 @@ def use():
     """Route my_package's operator calls (modules, functions, networks) through the measurement build for the rest
     of this process (idempotent).  For tools/ only -- tests that must exercise the product library use bound()."""
     b = bound()
-    for name in list(L._SYMBOLS) + list(L._EXTENSIONS):
+    for name in list(L._SYMBOLS) + list(L._EXTENSIONS) + list(L._WS_SYMBOLS):
         setattr(L, name, getattr(b, name))
     return lib()
 
