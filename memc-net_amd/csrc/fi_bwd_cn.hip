@@ -564,8 +564,8 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         for (int c0 = 0; c0 < C; c0 += 4) {
             if (c0 + (int)my >= C) continue;               // ragged last chunk: this lane's channel does not exist
-            if (st0) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + c0 * s1c, wo0)) = z;
-            if (st1) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + c0 * s1c, wo1)) = z;
+            if (st0) *reinterpret_cast<MEMC_GLOBAL f32x4u *>(addr_u(gin1_b + c0 * s1c, wo0)) = z;
+            if (st1) *reinterpret_cast<MEMC_GLOBAL f32x4u *>(addr_u(gin1_b + c0 * s1c, wo1)) = z;
         }
     };
 
@@ -871,8 +871,8 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
             }
             const f32x4 t0 = quad_transpose(a0, my), t1 = quad_transpose(a1, my);
             const bool ch_ok = cp + (int)my < C;           // ragged last chunk: this lane's channel may not exist
-            if (st0 && ch_ok) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + cp * s1c, wo0)) = old0 + t0;
-            if (st1 && ch_ok) *reinterpret_cast<MEMC_GLOBAL f32x4 *>(addr_u(gin1_b + cp * s1c, wo1)) = old1 + t1;
+            if (st0 && ch_ok) *reinterpret_cast<MEMC_GLOBAL f32x4u *>(addr_u(gin1_b + cp * s1c, wo0)) = old0 + t0;
+            if (st1 && ch_ok) *reinterpret_cast<MEMC_GLOBAL f32x4u *>(addr_u(gin1_b + cp * s1c, wo1)) = old1 + t1;
         };
 #pragma unroll 1
         for (int c0 = 0; c0 < C; c0 += 4) {

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void fi_fwd_blend_c3(
             const float p0 = oc[0][j] * w0[j][c], p2 = oc[1][j] * w2[j][c];     // two products, one sum: the
             v[j] = p0 + p2;                                                      // reference's torch expression
         }
-        __builtin_nontemporal_store(v, reinterpret_cast<MEMC_GLOBAL f32x4 *>(out_u + (uintptr_t)(c * s1c) * 4u + o1));
+        __builtin_nontemporal_store(v, reinterpret_cast<MEMC_GLOBAL f32x4u *>(out_u + (uintptr_t)(c * s1c) * 4u + o1));
     }
 }
 

@@ -19,6 +19,7 @@
 namespace memc {
 
 constexpr int kFarWords = 8;                  // words per tile of the owner kernel's far table (proj_owner5.hpp)
+constexpr int kFarMaxTiles = 262144;          // tiles the owner-computes fast path serves (proj_owner_far deals the stamped ones out from a table in LDS)
 constexpr int kFlagWords = 256;               // far flags of the fast path: image b -> word b % 256, + 1 summary word
 
 // --------------------------------------------------------------------------------------------------
@@ -443,6 +444,86 @@ __device__ __forceinline__ void trace_mark_proj(int slot)
 constexpr int kPtW4 = 66;
 constexpr double kCountUnit = 1048576.0;          // 2^20
 
+// RAGGED rows (round 5): a width that is not a multiple of four.  The last quad of a row then holds W % 4 sites, and a 16-byte
+// access there would run past the row -- past the tensor, in its last row.  The load is moved left so that it ENDS at the
+// row's end and the registers are rotated back (the sites past the row read as `pad`); the store writes the sites inside
+// the row one by one.  Only the kernels' RAG instantiations pay for this (a wave-uniform branch: only the waves that hold a
+// row's last quad take it); widths that are multiples of four run the code they always ran.
+__device__ __forceinline__ int tail_shift(int x, int W) { return (x < W && x + 4 > W) ? x + 4 - W : 0; }   // sites past the row
+__device__ __forceinline__ f32x4 tail_fix(const f32x4 &v, int r, float pad)
+{
+    if (__builtin_amdgcn_ballot_w64(r != 0) == 0) return v;
+    f32x4 o;
+    o[0] = r == 0 ? v[0] : r == 1 ? v[1] : r == 2 ? v[2] : v[3];
+    o[1] = r == 0 ? v[1] : r == 1 ? v[2] : r == 2 ? v[3] : pad;
+    o[2] = r == 0 ? v[2] : r == 1 ? v[3] : pad;
+    o[3] = r == 0 ? v[3] : pad;
+    return o;
+}
+template <bool STREAM>
+__device__ __forceinline__ void st_tail4(float *p, const f32x4 &v, int r)
+{
+    if (__builtin_amdgcn_ballot_w64(r != 0) == 0) {
+        if (STREAM) st_stream4(p, v); else st_cached4(p, v);
+        return;
+    }
+    if (r == 0) {
+        if (STREAM) st_stream4(p, v); else st_cached4(p, v);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (j < 4 - r) p[j] = v[j];
+    }
+}
+
+// The image's dominant motion: mean flow over an 8 x 8 grid of sites, rounded to a multiple of 4 (quads stay quads),
+// 0 for anything non-finite or absurd.  One wave; lane l holds site l.  Deterministic: a butterfly of commutative adds.
+__device__ __forceinline__ void motion_sample_issue(const float *flow_b, int64_t s1c, int s1h, int W, int H, int lane,
+                                                    float &fxs, float &fys)
+{
+    const int xs = ((2 * (lane & 7) + 1) * W) >> 4, ys = ((2 * (lane >> 3) + 1) * H) >> 4;
+    const float *p = flow_b + (int64_t)ys * s1h + xs;
+    fxs = *p;
+    fys = p[s1c];
+}
+__device__ __forceinline__ int motion_round4(float sum)
+{
+    const float mean = sum * (1.0f / 64.0f);
+    if (!(fabsf(mean) < 4096.0f)) return 0;
+    return 4 * (int)__builtin_rintf(mean * 0.25f);
+}
+// sum over the 64 lanes of a wave in a FIXED order (every workgroup must arrive at the same bits): an inclusive scan inside
+// each row of 16 lanes (row_shr 1, 2, 4, 8 on the DPP path: a few cycles each -- ds_bpermute shuffles here put half a
+// microsecond of LDS round trips in front of every workgroup's first barrier: +8 % on the whole kernel, measured), then
+// the four row sums.
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return (a + b) + (c + d);
+}
+__device__ __forceinline__ void motion_reduce(float fxs, float fys, int &mx, int &my)
+{
+    mx = motion_round4(wave_sum_f32(fxs));
+    my = motion_round4(wave_sum_f32(fys));
+}
+
+// Tiles the owner-computes fast path serves: proj_owner_far deals the stamped ones out from two tables (4 + 8 bytes per 64
+// tiles) that live in its point planes' bytes; a call with more tiles takes the general path.
+template <int TH>
+constexpr int far_max_tiles()
+{
+    constexpr int plane_bytes = 3 * (TH + 1) * 66 * 8;
+    constexpr int groups = (plane_bytes - 16) / 12 / 64 * 64;
+    return 64 * (groups < kFarMaxTiles / 64 ? groups : kFarMaxTiles / 64);
+}
+
 // One owned 64 x TH tile of the far-source kernel: three fp64 point planes (without a limit on |flow| the sum of vx at a
 // point is not bounded by 2^19, which the packed count * 2^20 + sum(vx) plane of proj_owner5 relies on), the window test of
 // proj_owner5 (one subtract and one unsigned compare per axis on the bit patterns) and hits splatted straight under their
@@ -522,7 +603,7 @@ struct FarTile {
         for (int j = 0; j < 4; j++) {
             float v0 = v[0][j], v1 = v[1][j], v2 = v[2][j];
             if (v0 > 0.0f) {                   // my_lib_kernel.cu:1730-1735; one reciprocal for both components
-                const float inv = 1.0f / v0;   // (<= 1 ulp from the two divisions)
+                const float inv = DEPTH ? 1.0f / v0 : __builtin_amdgcn_rcpf(v0);   // as proj_owner5: a recomputed tile rounds like the others
                 v1 = v1 * inv;
                 v2 = v2 * inv;
             }
@@ -545,15 +626,16 @@ struct FarTile {
 // MINW / NCAND: the product is <4, 16 TH> (4 waves per SIMD = two workgroups per CU).  <6, 384> -- three per CU, which the
 // LDS then allows -- needs 80 VGPRs and SPILLS: 266 -> 373 us under a 40 px pan; kept as a measurement arm only (variant -44)
 // because round 4 saw wrong results next to it (tools/probes/far_spill_streams.py).
-template <bool DEPTH, int TH, int kReach, int MINW = 4, int NCAND = 16 * TH>
+template <bool DEPTH, int TH, int kReach, int MINW = 4, int NCAND = 16 * TH, bool RAG = false>
 __global__ __launch_bounds__(16 * TH, MINW) void proj_owner_far(
 
     int W, int H, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth,
     float *__restrict__ count, float *__restrict__ out, const int *__restrict__ far_flag,
-    const int *__restrict__ bounds, FillWs ws, int nonce)
+    const int *__restrict__ bounds, FillWs ws, int nonce_arg)
 {
+    const int nonce = nonce_arg ? nonce_arg : __builtin_amdgcn_readfirstlane(far_flag[kFlagWords + 1]);   // (see proj_owner5)
     using FT = FarTile<DEPTH, TH>;
     constexpr int NT = 16 * TH;
     __shared__ __attribute__((aligned(16))) double P[FT::NP * FT::kPlane];
@@ -565,25 +647,92 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner_far(
     unsigned *const cand = u.cand;
     FillLds<TH> &fl = u.fl;
     __shared__ int ncand;
+    __shared__ int motion[2];                  // the image's dominant motion (proj_owner5.hpp), per recomputed tile
+    constexpr int kGroups = far_max_tiles<TH>() / 64;   // 64-tile groups of the work list
+    __shared__ unsigned mytiles[NT];           // this workgroup's tiles (one per lane at most: see the launcher's grid)
+    // (the work list's tables live in the point planes' bytes: built before the first tile zeroes them)
+    unsigned *const gprefix = reinterpret_cast<unsigned *>(P);                                  // [kGroups + 1]
+    unsigned long long *const gmask = reinterpret_cast<unsigned long long *>(P) + (kGroups + 2) / 2;   // [kGroups]
+    static_assert(sizeof(P) >= (kGroups + 2) * 4 + kGroups * 8, "the work list's tables fit the planes");
     if (far_flag[kFlagWords] != nonce) return;
     const unsigned per_image = (unsigned)tiles_x * tiles_y, ntiles = per_image * batch;
     const int tid = tid_now(), lane = tid & (kWave - 1);
-    const int wrow0 = 4 * __builtin_amdgcn_readfirstlane(tid / kWave);   // the wave's four rows of a source tile
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int wrow0 = 4 * wave;                // the wave's four rows of a source tile
     // Which tiles?  The owner kernel's result for a tile is complete unless a far source of ANOTHER tile lands in its
-    // window (it scanned every source within kReach of the tile, the tile's own among them, and splatted whatever landed,
-    // far or not): the tile that owns such a source stamped this call's nonce on the tiles its far sources' landing box
-    // meets.  Every other tile keeps what the owner kernel wrote -- outputs, summaries, masks.  The workgroup's tiles are
-    // blockIdx.x, + gridDim.x, ...: their stamps are read 64 at a time.
+    // window (it scanned every source within kReach of the tile -- shifted by the image's motion --, and splatted whatever
+    // landed, far or not): the tile that owns such a source stamped this call's nonce on the tiles its far sources'
+    // landing box meets (itself included when the image's motion is not zero).  Every other tile keeps what the owner
+    // kernel wrote -- outputs, summaries, masks.
+    // Round 5: the stamped tiles are DEALT OUT.  Round 4 gave workgroup i the tiles i, i + grid, ... and let it recompute
+    // whichever of those were stamped: with 3 % of the tiles stamped (the benchmark's flow twice as large) the slowest of
+    // 512 workgroups found five, the average 0.9 -- the launch took five tiles' time.  Now every workgroup counts the
+    // stamps of all tiles (one ballot per 64 tiles, a prefix over the groups: ~30 loads per lane, cold path only) and takes
+    // the stamped tiles of rank i, i + grid, ...: the same work in max(1, n / grid) tiles' time.
+    const unsigned ngroups = (ntiles + 63u) / 64u;                           // <= kGroups (launcher)
+    for (unsigned g = wave; g < ngroups; g += NT / kWave) {
+        const unsigned t = g * 64u + lane;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(t < ntiles && bounds[kFarWords * (int64_t)(t < ntiles ? t : 0) + 4] == nonce);
+        if (lane == 0) {
+            gprefix[g] = (unsigned)__builtin_popcountll(m);
+            gmask[g] = m;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {                           // exclusive prefix over the groups: a run per lane, then across the lanes
+        constexpr int kPer = kGroups / kWave;
+        unsigned sum = 0;
 #pragma unroll 1
-    for (unsigned k0 = 0; blockIdx.x + (uint64_t)k0 * gridDim.x < ntiles; k0 += kWave) {
-        const uint64_t mine = blockIdx.x + (uint64_t)(k0 + lane) * gridDim.x;
-        unsigned long long redo = __builtin_amdgcn_ballot_w64(mine < ntiles && bounds[kFarWords * (mine < ntiles ? mine : 0) + 4] == nonce);
+        for (int k = 0; k < kPer; k++) {
+            const unsigned g = lane * kPer + k;
+            sum += g < ngroups ? gprefix[g] : 0u;
+        }
+        unsigned incl = sum;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned up = __shfl_up(incl, off, kWave);
+            incl += lane >= off ? up : 0u;
+        }
+        unsigned run = incl - sum;
 #pragma unroll 1
-    while (redo) {                             // (uniform over the workgroup: every wave reads the same stamps)
-        const unsigned tile = blockIdx.x + (k0 + (unsigned)__builtin_ctzll(redo)) * gridDim.x;
-        redo &= redo - 1;
+        for (int k = 0; k < kPer; k++) {
+            const unsigned g = lane * kPer + k;
+            if (g < ngroups) {
+                const unsigned c = gprefix[g];
+                gprefix[g] = run;
+                run += c;
+            }
+        }
+        if (lane == kWave - 1) gprefix[ngroups] = incl;
+    }
+    __syncthreads();
+    {                                          // lane k of the workgroup: the stamped tile of rank blockIdx.x + k gridDim.x
+        const unsigned total = gprefix[ngroups];
+        const uint64_t rank = blockIdx.x + (uint64_t)tid * gridDim.x;
+        unsigned tile = ~0u;
+        if (rank < total) {
+            unsigned glo = 0, ghi = ngroups;   // gprefix[glo] <= rank < gprefix[glo + 1]
+            while (ghi - glo > 1) {
+                const unsigned mid = (glo + ghi) / 2;
+                if (gprefix[mid] <= (unsigned)rank) glo = mid; else ghi = mid;
+            }
+            unsigned long long m = gmask[glo];
+            for (unsigned k = (unsigned)rank - gprefix[glo]; k; k--) m &= m - 1;         // its k-th stamped tile
+            tile = glo * 64u + (unsigned)__builtin_ctzll(m);
+        }
+        mytiles[tid] = tile;
+    }
+    __syncthreads();                           // (the tables are dead: the first tile zeroes the planes)
+#pragma unroll 1
+    for (int mine = 0; mine < NT; mine++) {
+        const unsigned tile = (unsigned)__builtin_amdgcn_readfirstlane((int)mytiles[mine]);   // (uniform: scalar registers)
+        if (tile == ~0u) break;
         const int b = tile / per_image, tx = (tile % per_image) % tiles_x, ty = (tile % per_image) / tiles_x;
         const int tx0 = tx * 64, ty0 = ty * TH;
+        const float *flow_b = flow + b * s1b;
+        const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
+        float msx = 0.0f, msy = 0.0f;          // the image's motion, as the owner kernel computed it (wave 0; posted below)
+        if (wave == 0) motion_sample_issue(flow_b, s1c, s1h, W, H, lane, msx, msy);
         const int4 *boxes = reinterpret_cast<const int4 *>(bounds) + 2 * (int64_t)b * per_image;   // [2 * s]: tile s of the image
         // Can a far source of a tile land in this tile's window?  box: where the tile's far sources land (min x2, max x2,
         // min y2, max y2 as the owner kernel recorded them; max < 0: it has none).  The window takes x2 in
@@ -592,19 +741,26 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner_far(
             return box.y >= 0 && __int_as_float(box.y) >= (float)(tx0 - 1) && __int_as_float(box.x) < (float)(tx0 + 64) &&
                    __int_as_float(box.w) >= (float)(ty0 - 1) && __int_as_float(box.z) < (float)(ty0 + TH);
         };
-        // Can a source that moves by less than kReach (+1: the rounding of x + fx), from rows [y_lo, y_lo + y_n) of the
-        // tile column stx, land in the window?
-        auto near_hits = [&](int stx, int y_lo, int y_n) {
-            const float sx0 = (float)(stx * 64), sy0 = (float)y_lo, r = (float)kReach;
-            return sx0 + 64.0f + r >= (float)(tx0 - 1) && sx0 - r - 1.0f < (float)(tx0 + 64) &&
-                   sy0 + (float)y_n + r >= (float)(ty0 - 1) && sy0 - r - 1.0f < (float)(ty0 + TH);
-        };
         FT t;
         t.begin(P, tx0, ty0, W, H);
         t.template zero<NT>(tid);
+        if (wave == 0) {
+            int mx, my;
+            motion_reduce(msx, msy, mx, my);
+            if (tid == 0) {
+                motion[0] = mx;
+                motion[1] = my;
+            }
+        }
         __syncthreads();
-        const float *flow_b = flow + b * s1b;
-        const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
+        const float mxf = (float)__builtin_amdgcn_readfirstlane(motion[0]), myf = (float)__builtin_amdgcn_readfirstlane(motion[1]);
+        // Can a source that is NOT far -- it moves by the image's motion give or take less than kReach (+1: the rounding of
+        // x + fx) -- from rows [y_lo, y_lo + y_n) of the tile column stx land in the window?
+        auto near_hits = [&](int stx, int y_lo, int y_n) {
+            const float sx0 = (float)(stx * 64) + mxf, sy0 = (float)y_lo + myf, r = (float)kReach;
+            return sx0 + 64.0f + r >= (float)(tx0 - 1) && sx0 - r - 1.0f < (float)(tx0 + 64) &&
+                   sy0 + (float)y_n + r >= (float)(ty0 - 1) && sy0 - r - 1.0f < (float)(ty0 + TH);
+        };
         // The source tiles to scan: listed once per tile by the whole workgroup, one source tile per lane (a single round
         // trip to the table), then walked by every wave -- near tiles only by the waves whose own four rows of the tile can
         // reach the window, tiles whose far sources can land in it by all.  (A tile that recorded no source that is NOT far is
@@ -656,16 +812,24 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner_far(
                     const int sty = st / (unsigned)tiles_x, stx = st - sty * tiles_x;
                     const int sx = stx * 64 + 4 * (tid % 16), sy = sty * TH + tid / 16;   // one quad of sources per lane
                     const bool lv = have && sx < W && sy < H;
-                    const unsigned off = lv ? 4u * (unsigned)(sy * s1h + sx) : 0u;
+                    const int rq = RAG ? tail_shift(sx, W) : 0;    // (the same for every tile of the batch: sx % 64 is the lane's)
+                    const unsigned off = lv ? 4u * (unsigned)(sy * s1h + sx - rq) : 0u;
                     fxq[k] = ld_cached4_u(flow_b, off);
                     fyq[k] = ld_cached4_u(flow_b + s1c, off);
-                    if (DEPTH) ddq[k] = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy * sdh + sx) : 0u);
+                    if (DEPTH) ddq[k] = ld_cached4_u(depth_b, lv ? 4u * (unsigned)(sy * sdh + sx - rq) : 0u);
                     sxf[k] = (float)sx;
                     syf[k] = lv ? (float)sy : __int_as_float(0x7fc00000);
                 }
 #pragma unroll
-                for (int k = 0; k < kBatch; k++)
+                for (int k = 0; k < kBatch; k++) {
+                    if (RAG) {                 // the row's last quad: rotated back, the sites past the row NaN (they hit nothing)
+                        const int rq = tail_shift((int)sxf[k], W);
+                        fxq[k] = tail_fix(fxq[k], rq, __int_as_float(0x7fc00000));
+                        fyq[k] = tail_fix(fyq[k], rq, __int_as_float(0x7fc00000));
+                        if (DEPTH) ddq[k] = tail_fix(ddq[k], rq, __int_as_float(0x7fc00000));
+                    }
                     t.quad(syf[k], sxf[k], fxq[k], fyq[k], DEPTH ? ddq[k] : f32x4{1.f, 1.f, 1.f, 1.f});
+                }
             }
             }
         }
@@ -680,16 +844,26 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner_far(
                                         oy, oc);
         if (inb) {
             float *o = out + b * s1b + (int64_t)cy * s1h + cx;
-            *reinterpret_cast<f32x4 *>(o) = ox;
-            *reinterpret_cast<f32x4 *>(o + s1c) = oy;
-            *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)cy * sch + cx) = oc;
+            const int rs = RAG ? tail_shift(cx, W) : 0;
+            st_tail4<false>(o, ox, rs);
+            st_tail4<false>(o + s1c, oy, rs);
+            st_tail4<false>(count + b * scb + (int64_t)cy * sch + cx, oc, rs);
         }
         __syncthreads();                       // P and the masks are rebuilt by the next tile
-    }
     }
 }
 
 #include "proj_owner5.hpp"               // the production owner kernel
+
+// A call recorded into a HIP graph is replayed with the kernel arguments it was recorded with: the per-call tag of the far
+// flags then comes from a counter in the call's workspace (flag word kFlagWords + 1; any initial value will do), advanced by
+// this one-lane kernel in front of the owner kernel -- with one tag for all replays the flags and stamps of earlier
+// replays would stay "raised" and ever more tiles would be recomputed (exact, and ever slower).
+__global__ void proj_bump_nonce(int *far_flag)
+{
+    // (sign bit set, as the host counter's tags: never one of the small non-negative numbers the tables hold)
+    far_flag[kFlagWords + 1] = (int)((((unsigned)far_flag[kFlagWords + 1] & 0x7fffffffu) + 1u) | 0x80000000u);
+}
 
 #ifdef MEMC_MEASURE
 #define MEMC_PROJ_ARMS_PART_C
@@ -718,9 +892,9 @@ __global__ __launch_bounds__(256) void proj_redo_zero(int W, int H, int64_t s1b,
         const int x = (int)(i % w4) * 4, y = (int)((i / w4) % H), b = (int)(i / ((int64_t)w4 * H));
         if (far_flag && far_flag[b % kFlagWords] == 0) continue;
         float *o = out + b * s1b + (int64_t)y * s1h + x;
-        *reinterpret_cast<f32x4 *>(o) = z;
-        *reinterpret_cast<f32x4 *>(o + s1c) = z;
-        *reinterpret_cast<f32x4 *>(count + b * scb + (int64_t)y * sch + x) = z;
+        *reinterpret_cast<f32x4u *>(o) = z;
+        *reinterpret_cast<f32x4u *>(o + s1c) = z;
+        *reinterpret_cast<f32x4u *>(count + b * scb + (int64_t)y * sch + x) = z;
     }
 }
 
@@ -762,8 +936,8 @@ __global__ __launch_bounds__(256) void proj_average_v4(
                 vx[j] = vx[j] / c[j];
                 vy[j] = vy[j] / c[j];
             }
-        *reinterpret_cast<f32x4 *>(o) = vx;
-        *reinterpret_cast<f32x4 *>(o + s1c) = vy;
+        *reinterpret_cast<f32x4u *>(o) = vx;
+        *reinterpret_cast<f32x4u *>(o + s1c) = vy;
     }
 }
 
@@ -996,9 +1170,9 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
         }
         acc_x[j] = gx;  acc_y[j] = gy;  acc_d[j] = gd;
     }
-    *reinterpret_cast<f32x4 *>(g1p) = acc_x;
-    *reinterpret_cast<f32x4 *>(g1p + s1c) = acc_y;
-    if (DEPTH) *reinterpret_cast<f32x4 *>(g2p) = acc_d;
+    *reinterpret_cast<f32x4u *>(g1p) = acc_x;
+    *reinterpret_cast<f32x4u *>(g1p + s1c) = acc_y;
+    if (DEPTH) *reinterpret_cast<f32x4u *>(g2p) = acc_d;
 }
 
 MEMC_KNOB_STATIC(g_proj_variant, -1);          // measurement build only (memc_common.hpp)
@@ -1049,7 +1223,9 @@ static std::atomic<unsigned> g_proj_call_counter{0};
 // device flag), hole filling from masks (proj_fill.hpp), with the tile height TH of the owner kernel and the filler;
 // without scratch the general path (zero, scatter with atomics, average) and the literal hole walker.
 // variant: measurement build only (-1 otherwise).
-template <bool DEPTH, int TH>
+// RAG: a width that is not a multiple of four (the owner kernels' ragged-row instantiations; returns 1 -- not served, the
+// caller takes the scalar kernels -- where the fast path cannot run: no scratch block, a plane beyond 4 GiB).
+template <bool DEPTH, int TH, bool RAG = false>
 static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
 {
     using A = AccGeom<16>;
@@ -1076,7 +1252,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     const bool old_fill = r3_set || legacy_owner;
 
     // (the owner kernel addresses the flow / depth planes with 32-bit offsets)
-    const bool want_fast = variant != 1 && variant < 2 && plane_fits_u32(w, h, {s1h, sdh});
+    const bool want_fast = variant != 1 && variant < 2 && plane_fits_u32(w, h, {s1h, sdh}) && ntiles <= (unsigned)far_max_tiles<TH>();
     const bool want_carry = a.fillhole && variant != -8 && variant != -9;
     // scratch layout: ProjWsLayout above
     constexpr size_t kHead = kProjWsHead;
@@ -1087,12 +1263,20 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     FillWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // The production pair (proj_owner5 / proj_owner_far) needs no cleared flag words: a flag is "raised" when it holds
     // this call's nonce -- a process-wide counter, never 0, so consecutive calls (which the pool hands the same block)
-    // never see each other's flags; a stale or uninitialised word equal to the nonce (2^-32) would only cause a
-    // needless redo.  That saves a 5 us memset launch per call.  The measurement build's older kernels keep 0 / 1
+    // never see each other's flags; a stale or uninitialised word equal to the nonce would only cause a needless redo (and
+    // cannot be one of the small numbers the tables hold: the tag's sign bit is set).  That saves a 5 us memset launch per call.  The measurement build's older kernels keep 0 / 1
     // flags and the memset.
     unsigned nonce_u = g_proj_call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
     if (nonce_u == 0) nonce_u = g_proj_call_counter.fetch_add(1, std::memory_order_relaxed) + 1u;
-    const int nonce = (int)nonce_u;
+    // (sign bit set: the block is reused across calls of different shapes and holds row / column indices, hole flags, -1 --
+    // a small sequential tag could meet one of those in a stale word and cause a needless recomputation)
+    int nonce = (int)((nonce_u & 0x7fffffffu) | 0x80000000u);
+    if (nonce == -1) nonce = (int)0x80000000u;
+    if (a.ws) {                                              // (only a caller's workspace can be inside a capture at all)
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &capture) != hipSuccess) (void)hipGetLastError();
+        if (capture != hipStreamCaptureStatusNone) nonce = 0;            // the device counter: proj_bump_nonce
+    }
     // A caller's workspace (the _ws entry points: memc_flow_projection_workspace_bytes says how much) replaces the library's
     // block -- nothing is allocated, nothing is kept, a stream capture takes the same kernels as an eager call.
     if (a.ws && (a.ws_bytes < lay.bytes() || (reinterpret_cast<uintptr_t>(a.ws) & 15u) != 0)) return -1;
@@ -1118,6 +1302,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     }
     // Without scratch (inside a stream capture, or the allocation failed): the general path on its own and the
     // literal hole walker -- slower, same results.
+    if (RAG && !(flag && (ws.up || !a.fillhole))) return 1;  // (the general path's kernels want whole quads: scalar kernels instead)
 
 #define MEMC_PROJ_SCATTER(ABL, FLAG)                                                                        \
     hipLaunchKernelGGL((proj_scatter_tiled<DEPTH, ABL>), dim3((FLAG) != nullptr && sntiles > gq ? gq : sntiles), \
@@ -1129,8 +1314,11 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     // CU at TH = 32 (2 planes, 35 KiB), the depth operator 3 (53 KiB)
     constexpr int kWgCu = TH == 16 ? (DEPTH ? 4 : 6) : (TH == 32 ? (DEPTH ? 3 : 4) : 1);
     constexpr int kMinW = (kWgCu * (16 * TH / 64) + 3) / 4 > 8 ? 8 : (kWgCu * (16 * TH / 64) + 3) / 4;
+    // (the ragged-row instantiation needs a few registers more: two waves per SIMD fewer rather than a spill)
+    [[maybe_unused]] constexpr int kMinWR = RAG && kMinW > 2 ? kMinW - 2 : kMinW;
     if (flag && !legacy_owner) {
         if constexpr (kNewOk) {
+            if (nonce == 0) hipLaunchKernelGGL(proj_bump_nonce, dim3(1), dim3(1), 0, stream, flag);
             WalkPlan plan = make_walk_plan(ntx, nty, batch, sw);
 #ifdef MEMC_MEASURE
             if (variant == -43) plan.fast = 0;      // test arm: the kernel's own tile_walk (what grids beyond n * d < 2^32 take)
@@ -1142,15 +1330,19 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                 hipLaunchKernelGGL((proj_owner4<DEPTH, TH, 24, kMinW>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(16 * TH),
                                    0, stream, w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
                                    a.out, flag, bounds, ws, sw, nonce);
+            } else if (variant == -46 && DEPTH) {   // timing arm: 64-bit fixed-point planes on ds_add_u64 (proj_owner5.hpp, FIX64)
+                hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinW, false, true>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w, h,
+                                   ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,
+                                   bounds, ws, plan, nonce);
             } else if (variant == -41) {       // timestamps (tools/trace_kernel.py proj5)
                 hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinW, true>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w, h,
                                    ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,
                                    bounds, ws, plan, nonce);
             } else
 #endif
-            hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinW>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w, h, ntx, nty,
-                               s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag, bounds, ws, plan,
-                               nonce);
+            hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinWR, false, false, RAG>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w,
+                               h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag, bounds, ws,
+                               plan, nonce);
             if (launch_status() != 0) return -1;
             if (!only_part) {
                 const unsigned pg = r3_set ? persistent_grid(1) : persistent_grid(2);   // (53 KiB of LDS, 114 VGPRs: two per CU)
@@ -1169,9 +1361,12 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                         return -1;
                 } else
 #endif
-                hipLaunchKernelGGL((proj_owner_far<DEPTH, TH, 24>), dim3(ntiles < pg ? ntiles : pg), dim3(16 * TH), 0, stream,
-                                   w, h, ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
-                                   a.out, flag, bounds, ws, nonce);
+                {   // (a lane of the grid per stamped tile at most: proj_owner_far's work list)
+                    const unsigned need = (ntiles + 16u * TH - 1u) / (16u * TH), fg0 = ntiles < pg ? ntiles : pg;
+                    hipLaunchKernelGGL((proj_owner_far<DEPTH, TH, 24, 4, 16 * TH, RAG>), dim3(fg0 > need ? fg0 : need), dim3(16 * TH), 0, stream,
+                                       w, h, ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
+                                       a.out, flag, bounds, ws, nonce);
+                }
                 if (launch_status() != 0) return -1;
             }
         }
@@ -1304,6 +1499,12 @@ static int launch_proj_fwd(hipStream_t stream, int w, int h, int batch, int fill
 {
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
     const bool vec = vec4_ok(w, {s1b, s1c, s1h, sdb, sdh, scb, sch}, {flow, depth, count, out});
+    if (!vec && w >= 8 && g_proj_variant < 0) {            // a ragged width: the owner kernels' RAG instantiations (round 5)
+        const ProjArgs a = {stream, w, h, batch, fillhole, s1b, s1c, s1h, sdb, sdh, scb, sch, flow, depth, count, out,
+                            ws, ws_bytes};
+        const int r = run_proj_fwd<DEPTH, kOwnerTH, true>(a, kOwnerSW, -1);
+        if (r <= 0) return r;                                // served (0) or failed (-1); 1: the scalar kernels below
+    }
     if (vec && g_proj_variant != 0) {
         const ProjArgs a = {stream, w, h, batch, fillhole, s1b, s1c, s1h, sdb, sdh, scb, sch, flow, depth, count, out,
                             ws, ws_bytes};

@@ -123,9 +123,9 @@ __device__ __forceinline__ void fi_bwd_zero_invalid(bool inb, unsigned valid, fl
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     float *q3 = gin3_b + (o3 >> 2), *q2 = gin2_b + (o2 >> 2);
 #pragma unroll 1
-    for (int k = 0; k < 16; k++) *reinterpret_cast<f32x4 *>(q3 + k * s3c) = z;
-    *reinterpret_cast<f32x4 *>(q2) = z;
-    *reinterpret_cast<f32x4 *>(q2 + s2c) = z;
+    for (int k = 0; k < 16; k++) *reinterpret_cast<f32x4u *>(q3 + k * s3c) = z;
+    *reinterpret_cast<f32x4u *>(q2) = z;
+    *reinterpret_cast<f32x4u *>(q2 + s2c) = z;
 }
 
 }  // namespace memc

@@ -114,8 +114,9 @@ __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stag
     unsigned nz = 0, hole = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        if (inb && oc[j] != 0.0f) nz |= 1u << j;               // what stops a walk (my_lib_kernel.cu:1778-1797)
-        if (inb && oc[j] <= 0.0f) hole |= 1u << j;             // what pass 3 fills (:1757)
+        const bool in_row = inb && tx0 + 4 * q + j < W;        // (a ragged row's last quad: the cells past the row are nothing)
+        if (in_row && oc[j] != 0.0f) nz |= 1u << j;            // what stops a walk (my_lib_kernel.cu:1778-1797)
+        if (in_row && oc[j] <= 0.0f) hole |= 1u << j;          // what pass 3 fills (:1757)
     }
     if (!__syncthreads_or(hole != 0)) {
         // No hole: every cell of the tile inside the image has a positive count -- every walk that enters the tile stops at

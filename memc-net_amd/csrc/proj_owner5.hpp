@@ -18,16 +18,38 @@
 // Everything else is proj_owner4's: 64 x TH cell tiles, 16 TH lanes, the scan region dilated by kReach, deferred fx loads
 // for rows far from the tile, two planes (count * 2^20 + sum vx, sum vy) for FlowProjection and three for the depth
 // operator, box sums in double, one reciprocal per cell, far flags by nonce, per-tile landing boxes of the far sources.
+//
+// Round 5: the scan region is SHIFTED by the image's dominant motion m (a camera pan).  A source s lands at s + f; the
+// sources that land in the tile T are those around T - m, so T scans [T - m] dilated by kReach, and "far" means
+// |f - m| >= kReach on an axis.  m is the mean flow of 64 fixed sites of the image, rounded to multiples of 4 px -- every
+// workgroup (and proj_owner_far) computes the same value from the same loads in the same order.  Exactness: (i) every valid
+// source with |f - m| < kReach on both axes lies inside the scan region of the tile that owns its point (s = p - f with p in
+// the window: the argument of the unshifted scan with f - m in place of f), and the hit test asks for the window only;
+// (ii) every other valid source is found by the tile it LIES in (its home), which raises the image's flag, records where
+// its far sources land and stamps the tiles that box meets -- itself included when m != 0, because its own scan no longer
+// covers its own sources then; proj_owner_far recomputes the stamped tiles from all sources.  m == 0 -- any flow without a
+// dominant motion of 2 px or more, the benchmark's among them -- is the round-4 kernel: the scan's loads are issued for
+// m = 0 before m is known (wave 0 requests the 64 samples FIRST, reduces them while the planes are zeroed and posts m
+// before the barrier that was there anyway); only m != 0 pays a second round of loads.
 #pragma once
 
-template <bool DEPTH, int TH, int kReach, int MINW, bool TRACE = false>
+// (motion_sample_issue / motion_reduce: flow_projection.hip, shared with proj_owner_far)
+// FIX64 (measurement build, projection variant -46; depth operator only): the three sums as 64-bit FIXED POINT on ds_add_u64
+// (9.0 against 6.7 lane-operations per clock for ds_add_f64), at a fixed scale of 2^30 -- right for the benchmark's depths
+// in [0.1, 1.1), a timing arm for anything else: what would the fixed-point planes of the round-4 review's item 5 buy
+// before their per-tile scale, its barrier and the outlier route are built?
+// RAG: rows whose width is not a multiple of four (tail_shift / tail_fix / st_tail4, flow_projection.hip).
+template <bool DEPTH, int TH, int kReach, int MINW, bool TRACE = false, bool FIX64 = false, bool RAG = false>
 __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth,
     float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, int *__restrict__ bounds,
-    FillWs ws, WalkPlan plan, int nonce)
+    FillWs ws, WalkPlan plan, int nonce_arg)
 {
+    // this call's tag: a host counter's value, or -- 0: the call was recorded into a HIP graph, every replay needs its own --
+    // the device counter proj_bump_nonce advanced in front of this kernel
+    const int nonce = nonce_arg ? nonce_arg : __builtin_amdgcn_readfirstlane(far_flag[kFlagWords + 1]);
     constexpr int NT = 16 * TH;                   // one lane per four owned cells
     constexpr int NP = DEPTH ? 3 : 2;             // planes: (count, vx, vy) or (count * 2^20 + vx, vy)
     constexpr int kPtH = TH + 1, kPlane = kPtH * kPtW4;
@@ -47,9 +69,9 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     static_assert((2 * kReach + 1) * (2 * kReach + 1) < 4096 && kReach <= 128, "count * 2^20 + sum(vx) must split exactly");
     __shared__ __attribute__((aligned(16))) double P[NP * kPlane];
     __shared__ FillLds<TH> fl;                    // the hole filler's masks (fill epilogue only)
-    __shared__ int tile_box[5];                   // where the tile's own FAR sources land: bit patterns of min x2, max x2, min y2,
+    __shared__ int tile_box[8];                   // where the tile's own FAR sources land: bit patterns of min x2, max x2, min y2,
                                                   // max y2 (all >= 0: ordered like ints); max < 0: the tile has none.  [4]: the
-                                                  // tile has sources that are NOT far (a camera pan leaves none)
+                                                  // tile has sources that are NOT far.  [6], [7]: the image's motion (mx, my)
 
     const TileCoord tc = plan.fast ? tile_walk_plan(blockIdx.x, plan)
                                    : tile_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, plan.sw > 1 || plan.stripes_x != (unsigned)tiles_x ? (int)plan.sw : 0);
@@ -58,8 +80,12 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     const int tid0 = threadIdx.x;                 // (thread index of the first half of the kernel, see below)
     const int wave_index = __builtin_amdgcn_readfirstlane(tid0 / kWave);
     trace_mark_proj<TRACE>(0);
+    const float *flow_b = flow + b * s1b;
+    const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
+    float msx = 0.0f, msy = 0.0f;                 // wave 0: the image's 64 motion samples, requested before anything else
+    if (wave_index == 0) motion_sample_issue(flow_b, s1c, s1h, W, H, tid0, msx, msy);
     fill_lds_init(fl, tid0);
-    if (tid0 < 5) tile_box[tid0] = tid0 == 4 ? 0 : (tid0 & 1) ? -1 : 0x7fffffff;
+    if (tid0 >= kWave && tid0 < kWave + 5) tile_box[tid0 - kWave] = tid0 == kWave + 4 ? 0 : (tid0 & 1) ? -1 : 0x7fffffff;   // (wave 1: wave 0 waits for its samples)
     {
         f32x4 *pz = reinterpret_cast<f32x4 *>(P);
         for (int i = tid0; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -76,28 +102,47 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     // the last iteration may hold a row or two only (TH = 32: row 80 of 81, half of the first wave): nothing of it is
     // requested up front
     auto partial_it = [](int it) { return kRowsIt * (it + 1) > kScanH; };
-    const float *flow_b = flow + b * s1b;
-    const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
     f32x4 fx[kIts], fy[kIts], dd[kIts];
     bool live[kIts];
-    const int sx = tx0 - 32 + 4 * (tid0 % kColsQ), sy0 = ty0 - kReach - 1 + tid0 / kColsQ;
-    const bool colok = sx >= 0 && sx < W;         // W % 4 == 0
-    const unsigned off0 = 4u * (unsigned)(sy0 * s1h + sx), offd0 = DEPTH ? 4u * (unsigned)(sy0 * sdh + sx) : 0u;
+    int sx, sy0, rt = 0;                       // rt (RAG): sites of the lane's quads that lie past the row's end
+    unsigned off0, offd0;
+    const float kNaN = __int_as_float(0x7fc00000);
+    // the scan's slots for the motion (mx, my) and their loads (first for (0, 0), before the motion is known; see the header)
+    auto scan_issue = [&](int mx, int my) {
+        sx = tx0 - mx - 32 + 4 * (tid0 % kColsQ);
+        sy0 = ty0 - my - kReach - 1 + tid0 / kColsQ;
+        const bool colok = sx >= 0 && sx < W;     // (W % 4 == 0, or RAG: the row's last quad is partly inside)
+        if (RAG) rt = tail_shift(sx, W);
+        off0 = 4u * (unsigned)(sy0 * s1h + sx - rt);
+        offd0 = DEPTH ? 4u * (unsigned)(sy0 * sdh + sx - rt) : 0u;
 #pragma unroll
-    for (int it = 0; it < kIts; it++) {
-        const int sy = sy0 + kRowsIt * it;
-        live[it] = colok && sy >= 0 && sy < H && (kRowsIt * (it + 1) <= kScanH || tid0 / kColsQ + kRowsIt * it < kScanH);
-        const unsigned off = live[it] ? off0 + (unsigned)(4 * kRowsIt * it) * (unsigned)s1h : 0u;
-        if (!partial_it(it)) fy[it] = ld_cached4_u(flow_b + s1c, off);
-        if (!far_it(it) && !partial_it(it)) {
-            fx[it] = ld_cached4_u(flow_b, off);
-            if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? offd0 + (unsigned)(4 * kRowsIt * it) * (unsigned)sdh : 0u);
+        for (int it = 0; it < kIts; it++) {
+            const int sy = sy0 + kRowsIt * it;
+            live[it] = colok && sy >= 0 && sy < H && (kRowsIt * (it + 1) <= kScanH || tid0 / kColsQ + kRowsIt * it < kScanH);
+            const unsigned off = live[it] ? off0 + (unsigned)(4 * kRowsIt * it) * (unsigned)s1h : 0u;
+            if (!partial_it(it)) fy[it] = ld_cached4_u(flow_b + s1c, off);
+            if (!far_it(it) && !partial_it(it)) {
+                fx[it] = ld_cached4_u(flow_b, off);
+                if (DEPTH) dd[it] = ld_cached4_u(depth_b, live[it] ? offd0 + (unsigned)(4 * kRowsIt * it) * (unsigned)sdh : 0u);
+            }
+        }
+    };
+    scan_issue(0, 0);
+    if (wave_index == 0) {                     // (the samples were requested before the scan's loads: waiting for them
+        int mx, my;                            // does not wait for the scan)
+        motion_reduce(msx, msy, mx, my);
+        if (tid0 == 0) {
+            tile_box[6] = mx;
+            tile_box[7] = my;
         }
     }
     trace_mark_proj<TRACE>(1);                 // loads issued, P zeroed
-    __syncthreads();                           // P is zero
+    __syncthreads();                           // P is zero, the image's motion is posted
     if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     trace_mark_proj<TRACE>(2);                 // loads arrived
+    const int mx = __builtin_amdgcn_readfirstlane(tile_box[6]), my = __builtin_amdgcn_readfirstlane(tile_box[7]);
+    const bool shifted = (mx | my) != 0;       // (scalar)
+    const float mxf = (float)mx, myf = (float)my;
 
     // Window [ty0 - 1, ty0 + TH - 1] x [tx0 - 1, tx0 + 63] of the points (T, L) = ((int)y2, (int)x2), and validity
     // (0 <= x2 <= W - 1, my_lib_kernel.cu:1670), as ONE range test per axis on the bit patterns.
@@ -112,6 +157,60 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     bool far = false;
     unsigned long long near_seen = 0;             // (scalar) home quads of this wave that hold a source that is not far
 
+    // The cold branch of the far test: the home quads of the wave that hold a far source (ballot farq != 0).  Where the
+    // tile's far sources land goes to tile_box (the wave's box first, ONE lane's atomics then: 64 lanes on one LDS word
+    // serialise -- a camera pan, where every source was far before round 5, ran this kernel at 1.1 ms instead of 0.12).
+    auto far_quads = [&](bool homeq, const f32x4 &a, const f32x4 &c, float sxf, float syf) {
+        int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
+        bool nearj = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float fxv = a[j], fyv = c[j], x2 = (sxf + (float)j) + fxv, y2 = syf + fyv;
+            const bool nr = fabsf(fxv - mxf) < (float)kReach && fabsf(fyv - myf) < (float)kReach;
+            nearj = nearj || (homeq && nr);
+            const bool valid = homeq && !nr && x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(W - 1) && y2 <= (float)(H - 1);
+            if (valid) {               // where the tile's far sources land, for proj_owner_far (x2, y2 >= 0:
+                bx0 = min(bx0, __float_as_int(x2));                       // non-negative floats order like their bits)
+                bx1 = max(bx1, __float_as_int(x2));
+                by0 = min(by0, __float_as_int(y2));
+                by1 = max(by1, __float_as_int(y2));
+            }
+        }
+        near_seen |= __builtin_amdgcn_ballot_w64(nearj);
+        bx1 = -wave_min_i32(-bx1);
+        if (bx1 >= 0) {                // wave-uniform: a valid far source
+            far = true;
+            bx0 = wave_min_i32(bx0);
+            by0 = wave_min_i32(by0);
+            by1 = -wave_min_i32(-by1);
+            if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+                atomicMin(&tile_box[0], bx0);
+                atomicMax(&tile_box[1], bx1);
+                atomicMin(&tile_box[2], by0);
+                atomicMax(&tile_box[3], by1);
+            }
+        }
+    };
+    if (__builtin_expect(shifted, 0)) {           // (scalar) the image moves as a whole: see the header
+        // the tile's own 64 x TH sources are no longer (all) inside its scan: one quad per lane, tested for far sources here
+        const int hx = tx0 + 4 * (tid0 % 16), hy = ty0 + tid0 / 16;
+        const bool homeq = hx < W && hy < H;
+        const int rh = RAG ? tail_shift(hx, W) : 0;
+        const unsigned offh = homeq ? 4u * (unsigned)(hy * s1h + hx - rh) : 0u;
+        f32x4 a = ld_cached4_u(flow_b, offh), c = ld_cached4_u(flow_b + s1c, offh);
+        if (RAG) {
+            a = tail_fix(a, rh, kNaN);
+            c = tail_fix(c, rh, kNaN);
+        }
+        float dmax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) dmax = fmaxf(dmax, fmaxf(fabsf(a[j] - mxf), fabsf(c[j] - myf)));
+        const unsigned long long farq = __builtin_amdgcn_ballot_w64(homeq && !(dmax < (float)kReach));   // (NaN: far, found not valid)
+        near_seen |= __builtin_amdgcn_ballot_w64(homeq) & ~farq;
+        if (farq != 0) far_quads(homeq, a, c, (float)hx, (float)hy);
+        scan_issue(mx, my);                       // ... and the scan again, where the sources that land here come from
+    }
+
 #pragma unroll
     for (int it = 0; it < kIts; it++) {
         const bool lv = live[it];
@@ -120,8 +219,15 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         const float syf = lv ? (float)sy : __int_as_float(0x7fc00000), sxf = (float)sx;
         // The quad lies inside the tile itself (tx0, the pad and sx are multiples of 4: all four sites or none) -- only
         // slots that can hold rows of the tile evaluate this (and the far-source test below) at all.
+        if (RAG && !partial_it(it)) {             // the row's last quad: registers rotated back, sites past the row NaN
+            fy[it] = tail_fix(fy[it], rt, kNaN);
+            if (!far_it(it)) {
+                fx[it] = tail_fix(fx[it], rt, kNaN);
+                if (DEPTH) dd[it] = tail_fix(dd[it], rt, kNaN);
+            }
+        }
         const bool kHomeIt = kRowsIt * it < kReach + 1 + TH && kRowsIt * it + kRowsIt - 1 >= kReach + 1;       // folds: `it` is unrolled
-        if (kHomeIt) {
+        if (kHomeIt && !shifted) {
             // A far source (|f| >= kReach) whose home is this tile: the image is redone by proj_owner_far.  The hit test
             // below does NOT ask for |f| < kReach: an image without a valid far source has only near hits, which every
             // owner of their point sees (they lie inside its scan region); in an image WITH one the owners may disagree
@@ -133,43 +239,12 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
                                   fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3]))));
             const unsigned long long farq = __builtin_amdgcn_ballot_w64(homeq && !(m < (float)kReach));
             near_seen |= __builtin_amdgcn_ballot_w64(homeq) & ~farq;
-            if (__builtin_expect(farq != 0, 0)) {                                                         // wave-uniform, cold
-                // (the wave's box first, ONE lane's atomics then: 64 lanes on one LDS word serialise -- a camera pan, where
-                // every source is far, ran this kernel at 1.1 ms instead of 0.12)
-                int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
-                bool nearj = false;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float fxv = a[j], fyv = c[j], x2 = (sxf + (float)j) + fxv, y2 = syf + fyv;
-                    const bool nr = fabsf(fxv) < (float)kReach && fabsf(fyv) < (float)kReach;
-                    nearj = nearj || (homeq && nr);
-                    const bool valid = homeq && !nr && x2 >= 0.0f && y2 >= 0.0f && x2 <= (float)(W - 1) && y2 <= (float)(H - 1);
-                    if (valid) {               // where the tile's far sources land, for proj_owner_far (x2, y2 >= 0:
-                        bx0 = min(bx0, __float_as_int(x2));                       // non-negative floats order like their bits)
-                        bx1 = max(bx1, __float_as_int(x2));
-                        by0 = min(by0, __float_as_int(y2));
-                        by1 = max(by1, __float_as_int(y2));
-                    }
-                }
-                near_seen |= __builtin_amdgcn_ballot_w64(nearj);
-                bx1 = -wave_min_i32(-bx1);
-                if (bx1 >= 0) {                // wave-uniform: a valid far source
-                    far = true;
-                    bx0 = wave_min_i32(bx0);
-                    by0 = wave_min_i32(by0);
-                    by1 = -wave_min_i32(-by1);
-                    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
-                        atomicMin(&tile_box[0], bx0);
-                        atomicMax(&tile_box[1], bx1);
-                        atomicMin(&tile_box[2], by0);
-                        atomicMax(&tile_box[3], by1);
-                    }
-                }
-            }
+            if (__builtin_expect(farq != 0, 0)) far_quads(homeq, a, c, sxf, syf);                         // wave-uniform, cold
         }
         if (partial_it(it)) {                  // (wave-uniform: most waves have no slot here at all)
             if (__builtin_amdgcn_ballot_w64(lv) == 0) continue;
             fy[it] = ld_cached4_u(flow_b + s1c, lv ? off0 + (unsigned)(4 * kRowsIt * it) * (unsigned)s1h : 0u);
+            if (RAG) fy[it] = tail_fix(fy[it], rt, kNaN);
         }
         float y2[4];
         bool wy[4], rowany = false;
@@ -186,6 +261,10 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
             const unsigned off = lv ? off0 + (unsigned)(4 * kRowsIt * it) * (unsigned)s1h : 0u;
             fxq = ld_cached4_u(flow_b, off);
             if (DEPTH) ddq = ld_cached4_u(depth_b, lv ? offd0 + (unsigned)(4 * kRowsIt * it) * (unsigned)sdh : 0u);
+            if (RAG) {
+                fxq = tail_fix(fxq, rt, kNaN);
+                if (DEPTH) ddq = tail_fix(ddq, rt, kNaN);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -194,7 +273,18 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
             if (wy[j] && (unsigned)(__float_as_int(x2) - xlo_b) < xrange) {
                 const unsigned a = __umul24((unsigned)(int)y2[j], pitch8) + ((((unsigned)(int)x2) << 3) + ucell8);
                 double *q = reinterpret_cast<double *>(reinterpret_cast<char *>(P) + a);
-                if (DEPTH) {                   // my_lib_kernel.cu:2102-2114: v = -d * f, count += d
+                if (DEPTH && FIX64) {          // (timing arm) x * 2^30 rounded to an integer: the low mantissa bits of x * 2^30 + 1.5 * 2^52
+                    const float d = ddq[j];
+                    const double kMagic = 6755399441055744.0, kScale = 1073741824.0;
+                    const long long kBits = __double_as_longlong(kMagic);
+                    unsigned long long *qu = reinterpret_cast<unsigned long long *>(q);
+                    __hip_atomic_fetch_add(qu, (unsigned long long)(__double_as_longlong(__builtin_fma((double)(d * 1.0f), kScale, kMagic)) - kBits),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(qu + kPlane, (unsigned long long)(__double_as_longlong(__builtin_fma(-(double)(d * fxv), kScale, kMagic)) - kBits),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(qu + 2 * kPlane, (unsigned long long)(__double_as_longlong(__builtin_fma(-(double)(d * fyv), kScale, kMagic)) - kBits),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (DEPTH) {            // my_lib_kernel.cu:2102-2114: v = -d * f, count += d
                     const float d = ddq[j];
                     lds_add_f64(q, (double)(d * 1.0f));
                     lds_add_f64(q + kPlane, -(double)(d * fxv));
@@ -229,7 +319,8 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         const int nx = txb - txa + 1, n = nx * (tyb - tya + 1);
         for (int i = tid; i < n; i += NT) {
             const int ty = tya + i / nx, tx = txa + i % nx;
-            if (tx != tc.tx || ty != tc.ty) bounds[kFarWords * (((int64_t)b * tiles_y + ty) * tiles_x + tx) + 4] = nonce;
+            // (not this tile when its scan covered its own sources: what they hit inside its window it splatted itself)
+            if (tx != tc.tx || ty != tc.ty || shifted) bounds[kFarWords * (((int64_t)b * tiles_y + ty) * tiles_x + tx) + 4] = nonce;
         }
     }
 
@@ -252,6 +343,16 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
             const f64x2 c01 = *reinterpret_cast<const f64x2 *>(c), c23 = *reinterpret_cast<const f64x2 *>(c + 2);
             const double top[5] = {a01[0], a01[1], a23[0], a23[1], a[4]};
             const double bot[5] = {c01[0], c01[1], c23[0], c23[1], c[4]};
+            if (DEPTH && FIX64) {              // (timing arm) the cells hold integers: box sums in integers, one conversion per cell
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int sx0 = (cx + j == W - 1) ? 1 : 0, sy0 = (cy == H - 1) ? 1 : 0;
+                    const long long t = (__double_as_longlong(top[j + 1]) << sx0) + __double_as_longlong(top[j]);
+                    const long long u = (__double_as_longlong(bot[j + 1]) << sx0) + __double_as_longlong(bot[j]);
+                    box[pl][j] = (double)((u << sy0) + t) * (1.0 / 1073741824.0);
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const double wx0 = (cx + j == W - 1) ? 2.0 : 1.0;
@@ -284,9 +385,16 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         owner_fill_epilogue<TH, NT>(fl, reinterpret_cast<float *>(P), ws, tid, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, inb,
                                     ox, oy, oc);
     if (inb) {                                 // single-use streams: nothing of this launch reads them back from cache
-        st_stream4(out + b * s1b + (int64_t)cy * s1h + cx, ox);
-        st_stream4(out + b * s1b + s1c + (int64_t)cy * s1h + cx, oy);
-        st_stream4(count + b * scb + (int64_t)cy * sch + cx, oc);
+        if (RAG) {
+            const int rs = tail_shift(cx, W);
+            st_tail4<true>(out + b * s1b + (int64_t)cy * s1h + cx, ox, rs);
+            st_tail4<true>(out + b * s1b + s1c + (int64_t)cy * s1h + cx, oy, rs);
+            st_tail4<true>(count + b * scb + (int64_t)cy * sch + cx, oc, rs);
+        } else {
+            st_stream4(out + b * s1b + (int64_t)cy * s1h + cx, ox);
+            st_stream4(out + b * s1b + s1c + (int64_t)cy * s1h + cx, oy);
+            st_stream4(count + b * scb + (int64_t)cy * sch + cx, oc);
+        }
     }
     trace_mark_proj<TRACE>(5);
 }

@@ -492,11 +492,95 @@ def test_shapes_take_the_documented_kernel_paths():
                                    "bl_bwd": "bl_bwd:owner", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
     assert run(1, 5, 40, 128) == {"fi_fwd": "fi_fwd:tiled_c4n_ragged", "fi_bwd": "fi_bwd:owner", "bl_fwd": "bl_fwd:tiled_chunks",
                                   "bl_bwd": "bl_bwd:owner", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
-    # width not a multiple of four, and an aligned width seen through a view that starts one element in
-    for odd in (run(1, 3, 20, 50), run(1, 3, 20, 64, sliced=True)):
-        assert odd == {"fi_fwd": "fi_fwd:direct", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:direct",
-                       "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:scalar", "proj_bwd": "proj_bwd:scalar"}
+    # a width that is not a multiple of four: the scalar kernels -- except the projection forward (the 40x cliff of round 4),
+    # whose owner kernels have a ragged-row instantiation since round 5
+    assert run(1, 3, 20, 50) == {"fi_fwd": "fi_fwd:direct", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:direct",
+                                 "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:scalar"}
+    assert run(1, 3, 20, 6)["proj_fwd"] == "proj_fwd:scalar"           # (narrower than two quads: scalar)
+    # ... but a multiple of four seen through a view that starts one element in (rows of 65 elements: every row at another
+    # alignment) takes the tiled kernels since round 5: a quad in global memory needs dword alignment only (memc_tile.hpp)
+    assert run(1, 3, 20, 64, sliced=True) == {"fi_fwd": "fi_fwd:tiled_c3", "fi_bwd": "fi_bwd:tiled_c3", "bl_fwd": "bl_fwd:tiled_c3",
+                                             "bl_bwd": "bl_bwd:tiled_c3", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
+    assert run(1, 8, 20, 64, sliced=True)["fi_bwd"] == "fi_bwd:owner"
     assert run(1, 3, 24, 64, fs=2) == {"fi_fwd": "fi_fwd:generic", "fi_bwd": "fi_bwd:generic"}
+
+
+@pytest.mark.parametrize("off", [1, 2, 3])
+@pytest.mark.parametrize("C", [3, 8])
+def test_unaligned_views_on_the_tiled_kernels(oracle, off, C):
+    """Round 5: the tiled kernels serve any view whose WIDTH is a multiple of four -- base pointers and row strides at any
+    dword boundary (a quad in global memory is loaded / stored with dword alignment, memc_tile.hpp: f32x4u).  Every operator,
+    forward and backward, on views that start `off` elements into rows of W + off elements (so every row sits at another
+    alignment), against the oracle; the reference serves every view with its one kernel per operator
+    (my_lib_kernel.cu:10-15).  Until round 5 these views took the scalar kernels: 13-41x slower for the scattering passes."""
+    import my_package._ext.my_lib as my_lib
+    rng = np.random.default_rng(100 * C + off)
+    B, H, W = 2, 70, 132
+
+    def view(a, fill=None):                                            # numpy [B, ch, H, W] -> a view into a wider tensor
+        t = torch.full((a.shape[0], a.shape[1], H, W + off), 123.0 if fill is None else fill, device=dev())
+        v = t[..., off:]
+        if a is not None:
+            v.copy_(T(a))
+        assert v.data_ptr() % 16 != 0 or (W + off) % 4 != 0
+        return v
+
+    def buf(ch, fill=0.0):
+        return view(np.zeros((B, ch, H, W), np.float32), fill)
+    xn, gn = synth.np_image(rng, B, C, H, W), synth.np_image(rng, B, C, H, W)
+    fn, kn = synth.np_flow(rng, B, H, W, "smooth", 5.0), synth.np_filter(rng, B, H, W)
+    dn = synth.np_depth(rng, B, H, W)
+    g2n = synth.np_flow(rng, B, H, W, "smooth", 1.0)
+    x, g, f, k, d, gf = view(xn), view(gn), view(fn), view(kn), view(dn), view(g2n)
+    # FilterInterpolation
+    out = buf(C, 7.0)
+    assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+    assert my_lib.last_kernel_path() in ("fi_fwd:tiled_c3", "fi_fwd:tiled_c4n")
+    close(N(out), oracle.filter_interpolation_forward(xn, fn, kn), "FI fwd, view + %d" % off)
+    g1, g2, g3 = buf(C), buf(2, 7.0), buf(16, 7.0)
+    assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+    assert my_lib.last_kernel_path() in ("fi_bwd:tiled_c3", "fi_bwd:owner")
+    w1, w2, w3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+    close(N(g1), w1, "FI gradinput1, view + %d" % off, RTOL)
+    close(N(g2), w2, "FI gradinput2, view + %d" % off, RTOL)
+    close(N(g3), w3, "FI gradinput3, view + %d" % off, RTOL)
+    # Interpolation(Ch)
+    out = buf(C, 7.0)
+    assert my_lib.InterpolationChLayer_gpu_forward(x, f, out) == 0
+    assert "tiled" in my_lib.last_kernel_path()
+    close(N(out), oracle.interpolation_ch_forward(xn, fn), "Interpolation fwd, view + %d" % off)
+    g1, g2 = buf(C), buf(2, 7.0)
+    assert my_lib.InterpolationChLayer_gpu_backward(x, f, g, g1, g2) == 0
+    assert my_lib.last_kernel_path() in ("bl_bwd:tiled_c3", "bl_bwd:owner")
+    w1, w2 = oracle.interpolation_ch_backward(xn, fn, gn)
+    close(N(g1), w1, "Interpolation gradinput1, view + %d" % off, RTOL)
+    close(N(g2), w2, "Interpolation gradinput2, view + %d" % off, RTOL)
+    if C != 3:
+        return
+    # (Depth)FlowProjection, forward with and without hole filling, backward
+    for fill in (0, 1):
+        cnt, po = buf(1, 7.0), buf(2, 7.0)
+        assert my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, fill) == 0
+        assert my_lib.last_kernel_path() == "proj_fwd:owner"
+        want_o, want_c = oracle.flow_projection_forward(fn, fill)
+        assert np.array_equal(N(cnt), want_c)
+        close(N(po), want_o, "FlowProjection fwd fill %d, view + %d" % (fill, off))
+        cnt, po = buf(1, 7.0), buf(2, 7.0)
+        assert my_lib.DepthFlowProjectionLayer_gpu_forward(f, d, cnt, po, fill) == 0
+        assert my_lib.last_kernel_path() == "dproj_fwd:owner"
+        want_o, want_c = oracle.depth_flow_projection_forward(fn, dn, fill)
+        close(N(cnt), want_c, "DepthFlowProjection count fill %d, view + %d" % (fill, off), RTOL)
+        close(N(po), want_o, "DepthFlowProjection fwd fill %d, view + %d" % (fill, off), RTOL)
+    gin = buf(2, 7.0)
+    assert my_lib.FlowProjectionLayer_gpu_backward(f, view(oracle.flow_projection_forward(fn, 0)[1]), gf, gin) == 0
+    assert my_lib.last_kernel_path() == "proj_bwd:tiled"
+    close(N(gin), oracle.flow_projection_backward(fn, oracle.flow_projection_forward(fn, 0)[1], g2n), "FlowProjection bwd, view + %d" % off, RTOL)
+    wo, wc = oracle.depth_flow_projection_forward(fn, dn, 0)
+    gin, gd = buf(2, 7.0), buf(1, 7.0)
+    assert my_lib.DepthFlowProjectionLayer_gpu_backward(f, d, view(wc), view(wo), gf, gin, gd) == 0
+    w1, w2 = oracle.depth_flow_projection_backward(fn, dn, wc, wo, g2n)
+    close(N(gin), w1, "DepthFlowProjection gradinput1, view + %d" % off, RTOL)
+    close(N(gd), w2, "DepthFlowProjection gradinput2, view + %d" % off, RTOL)
 
 
 @pytest.mark.parametrize("fs", [2, 3, 6])
@@ -691,6 +775,119 @@ def test_projection_with_a_few_far_sources(oracle):
             assert my_lib.FlowProjectionLayer_gpu_forward(T(big), cnt, out, fill) == 0
             assert np.array_equal(N(cnt), want_cnt), "count, sigma %g, fill %d" % (sigma, fill)
             close(N(out), want_out, "FlowProjection, smooth flow of sigma %g, fill %d" % (sigma, fill))
+
+
+PAN_CASES = [
+    # (pan x, pan y, local sigma): the image's dominant motion m is the mean of 64 sample sites rounded to 4 px
+    (40.0, -20.0, 3.0), (-37.5, 55.25, 3.0), (6.0, 0.0, 3.0), (2.1, -1.9, 3.0), (130.0, 0.0, 2.0), (0.0, -97.0, 2.0),
+    (600.0, 10.0, 1.0),            # beyond the image: nothing lands
+    (26.0, 30.5, 9.0),             # local motion up to ~24 px around the pan: some sources far FROM THE PAN
+]
+
+
+@pytest.mark.parametrize("case", PAN_CASES, ids=["pan%g_%g_s%g" % c for c in PAN_CASES])
+def test_projection_scan_shifted_by_the_dominant_motion(oracle, case):
+    """Round 5: the owner kernel scans [tile - m] for the image's dominant motion m, "far" means far from m.  Pans of any size
+    and direction on top of a gentle local flow, images of one batch moving differently (each has its own m), fast
+    objects against the pan (far sources: their landing tiles recomputed, the home tile itself included), a few NaN / Inf
+    samples (m falls back to 0 or is pulled off: results must not care) -- counts bit for bit, outputs to 1e-4, both
+    operators, with and without hole filling, against the oracle (the reference's cost and results are motion-independent,
+    my_lib_kernel.cu:1630-1690)."""
+    import my_package._ext.my_lib as my_lib
+    px, py, sigma = case
+    B, H, W = 3, 200, 456                                              # 7 x 8 tiles, cut by both edges; 8 x 8 sample sites
+    rng = np.random.default_rng(int(abs(px) * 7 + abs(py) * 13 + sigma))
+    flow = synth.np_flow(rng, B, H, W, "smooth", sigma)
+    flow[0, 0] += px;  flow[0, 1] += py                                # image 0: the pan
+    flow[1, 0] -= py;  flow[1, 1] += px * 0.5                          # image 1: another one
+    flow[2, 0] += px;  flow[2, 1] += py                                # image 2: the pan + objects moving against it
+    flow[2, :, 50:70, 100:140] = 0.0                                   #   a static patch (far from the pan when |pan| >= 24)
+    flow[2, 0, 120:130, 300:320] -= 60.0                               #   a fast object
+    flow[2, 1, 150, 40], flow[2, 0, 150, 40] = 190.0, -33.0           #   single far sites
+    flow[2, 0, 10, 400] = -395.5
+    depth = (rng.random((B, 1, H, W)) + 0.1).astype(np.float32)
+    for poison in (False, True):
+        if poison:                                                     # two of image 0's sample sites non-finite: m = 0 there
+            flow = flow.copy()
+            ys, xs = ((2 * 3 + 1) * H) >> 4, ((2 * 5 + 1) * W) >> 4
+            flow[0, 0, ys, xs] = np.nan
+            flow[0, 1, ((2 * 6 + 1) * H) >> 4, ((2 * 1 + 1) * W) >> 4] = np.inf
+        for fill in (0, 1):
+            want_out, want_cnt = oracle.flow_projection_forward(flow, fill)
+            cnt, out = torch.full((B, 1, H, W), 7.0, device=dev()), torch.full((B, 2, H, W), 7.0, device=dev())
+            assert my_lib.FlowProjectionLayer_gpu_forward(T(flow), cnt, out, fill) == 0
+            assert my_lib.last_kernel_path() == "proj_fwd:owner"
+            assert np.array_equal(N(cnt), want_cnt), "count, fill %d, poison %s" % (fill, poison)
+            close(N(out), want_out, "FlowProjection under pan %s, fill %d, poison %s" % (case, fill, poison))
+            want_out, want_cnt = oracle.depth_flow_projection_forward(flow, depth, fill)
+            cnt, out = torch.full((B, 1, H, W), 7.0, device=dev()), torch.full((B, 2, H, W), 7.0, device=dev())
+            assert my_lib.DepthFlowProjectionLayer_gpu_forward(T(flow), T(depth), cnt, out, fill) == 0
+            close(N(cnt), want_cnt, "depth count under pan %s, fill %d" % (case, fill), RTOL)
+            close(N(out), want_out, "DepthFlowProjection under pan %s, fill %d, poison %s" % (case, fill, poison), RTOL)
+
+
+RAGGED_CASES = [(2, 70, 130, 0.0), (1, 45, 67, 0.0), (2, 64, 133, 0.0), (1, 100, 1278, 0.0), (2, 70, 130, 37.0), (1, 33, 9, 0.0),
+                (2, 96, 255, -50.0)]
+
+
+@pytest.mark.parametrize("case", RAGGED_CASES, ids=["%dx%dx%d_pan%g" % c for c in RAGGED_CASES])
+def test_projection_on_widths_that_are_not_multiples_of_four(oracle, case):
+    """Round 5: the owner kernels' ragged-row instantiation (the row's last quad holds W % 4 sites: loads moved left and
+    rotated back, stores site by site) instead of the scalar kernels (40x slower at 1278 x 720, round 4) -- smooth and i.i.d.
+    flow, far sources, pans, hole filling, both operators, against the oracle; the reference serves every width with the
+    same kernel (my_lib_kernel.cu:10-15)."""
+    import my_package._ext.my_lib as my_lib
+    B, H, W, pan = case
+    rng = np.random.default_rng(W * 7 + H)
+    depth = synth.np_depth(rng, B, H, W)
+    for kind, sigma in (("smooth", 4.0), ("iid", 3.0), ("smooth", 30.0)):
+        flow = synth.np_flow(rng, B, H, W, kind, sigma)
+        flow[:, 0] += np.float32(pan)
+        flow[:, 1] -= np.float32(pan / 2)
+        flow[0, 0, H // 2, W - 1] = -float(W // 2)                     # a far source in the row's last (partial) quad
+        flow[0, 1, H // 3, W - 2] = 31.0
+        for fill in (0, 1):
+            want_out, want_cnt = oracle.flow_projection_forward(flow, fill)
+            cnt, out = torch.full((B, 1, H, W), 7.0, device=dev()), torch.full((B, 2, H, W), 7.0, device=dev())
+            assert my_lib.FlowProjectionLayer_gpu_forward(T(flow), cnt, out, fill) == 0
+            assert my_lib.last_kernel_path() == "proj_fwd:owner"
+            assert np.array_equal(N(cnt), want_cnt), "count, %s, fill %d" % (kind, fill)
+            close(N(out), want_out, "FlowProjection at width %d, %s, fill %d" % (W, kind, fill))
+            want_out, want_cnt = oracle.depth_flow_projection_forward(flow, depth, fill)
+            cnt, out = torch.full((B, 1, H, W), 7.0, device=dev()), torch.full((B, 2, H, W), 7.0, device=dev())
+            assert my_lib.DepthFlowProjectionLayer_gpu_forward(T(flow), T(depth), cnt, out, fill) == 0
+            close(N(cnt), want_cnt, "depth count at width %d, %s, fill %d" % (W, kind, fill), RTOL)
+            close(N(out), want_out, "DepthFlowProjection at width %d, %s, fill %d" % (W, kind, fill), RTOL)
+    # ... and seen through a view (row stride != width), with the buffer's bytes behind each row left alone
+    flow = synth.np_flow(rng, B, H, W, "smooth", 4.0)
+    wide = torch.full((B, 2, H, W + 3), 55.0, device=dev())
+    cw, ow = torch.full((B, 1, H, W + 3), 7.0, device=dev()), torch.full((B, 2, H, W + 3), 7.0, device=dev())
+    wide[..., :W].copy_(T(flow))
+    assert my_lib.FlowProjectionLayer_gpu_forward(wide[..., :W], cw[..., :W], ow[..., :W], 1) == 0
+    want_out, want_cnt = oracle.flow_projection_forward(flow, 1)
+    assert np.array_equal(N(cw[..., :W]), want_cnt)
+    close(N(ow[..., :W]), want_out, "FlowProjection at width %d through a view" % W)
+    assert float((cw[..., W:] - 7.0).abs().max()) == 0 and float((ow[..., W:] - 7.0).abs().max()) == 0
+
+
+def test_projection_far_tiles_are_dealt_out_evenly(oracle):
+    """proj_owner_far takes the STAMPED tiles by rank (round 5), whatever their number and position: a few (one workgroup
+    each), a run of consecutive ones, more than the grid holds workgroups (720p: 460 tiles per image, batch 3), all of
+    them -- against the oracle."""
+    import my_package._ext.my_lib as my_lib
+    rng = np.random.default_rng(99)
+    B, H, W = 3, 720, 1280
+    base = synth.np_flow(rng, B, H, W, "smooth", 3.0)
+    variants = []
+    f = base.copy();  f[1, 0, 100:110, 200:210] += 90.0;  variants.append(("one object", f))
+    f = base.copy();  f[:, 0, ::37, ::53] += 333.0;  f[:, 1, ::41, ::59] -= 111.0;  variants.append(("far sites everywhere", f))
+    f = base.copy();  f[0] *= 9.0;  variants.append(("image 0 far throughout", f))
+    for name, f in variants:
+        want_out, want_cnt = oracle.flow_projection_forward(f, 1)
+        cnt, out = torch.full((B, 1, H, W), 7.0, device=dev()), torch.full((B, 2, H, W), 7.0, device=dev())
+        assert my_lib.FlowProjectionLayer_gpu_forward(T(f), cnt, out, 1) == 0
+        assert np.array_equal(N(cnt), want_cnt), name
+        close(N(out), want_out, "FlowProjection, %s" % name)
 
 
 def test_empty_batches_and_single_pixel_images(oracle):

@@ -70,7 +70,8 @@ def test_workspace_entry_points_equal_the_reference_signature_ones(my_lib, oracl
                 assert my_lib.FlowProjectionLayer_gpu_forward_ws(tf, c1, o1, fill, ws) == 0
             if W % 4 == 0:
                 assert my_lib.last_kernel_path() == ("dproj_fwd:owner" if dep else "proj_fwd:owner")
-            assert torch.equal(c0, c1) and torch.equal(o0, o1)
+            assert torch.equal(c0, c1) if not dep else float((c0 - c1).abs().max()) <= 1e-6
+            assert float((o0 - o1).abs().max()) <= 1e-6              # (the LDS atomics add in hardware order: last bits may differ)
         want_o, want_c = (oracle.depth_flow_projection_forward(flow, depth, fill) if dep
                           else oracle.flow_projection_forward(flow, fill))
         close(N(o1), want_o, "output")
@@ -109,7 +110,7 @@ def test_projection_module_in_a_hip_graph(my_lib, oracle):
             graph.replay()
             torch.cuda.synchronize()
             eager = mod(T(f))
-            assert torch.equal(static_out, eager)
+            assert float((static_out - eager).abs().max()) <= 1e-6
             close(N(static_out), oracle.flow_projection_forward(f, 1)[0], "graph replay")
     # the reference-signature entry point inside a capture: allowed, slower path, same results
     cnt, out = static_in.new_empty((B, 1, H, W)), torch.empty_like(static_in)
@@ -174,7 +175,9 @@ def test_whole_network_inference_in_a_hip_graph():
 def test_projection_on_four_streams_mixed_motion_1000_rounds(my_lib, oracle):
     """The scratch protocol under concurrency (round-4 review item 1): four streams, near and far motion mixed, the shapes
     alternating so that blocks are handed from stream to stream, 1000 rounds of eight calls -- every result equals the
-    result computed alone, bit for bit (the kernels are deterministic)."""
+    result computed alone: counts bit for bit, outputs to 1e-6 (the fp64 LDS atomics add in hardware order; a sum of packed
+    count * 2^20 + vx terms differs in its last bit, 2^-33, from one run to the next: observed 1.2e-10).  Round 4's cache of
+    one block per stream HANDLE fails this test (profiles/r05_far_spill_*: what it did wrong)."""
     rng = np.random.default_rng(77)
     shapes = [(2, 64, 128), (1, 96, 256), (2, 128, 192)]
     inputs = []
@@ -195,7 +198,7 @@ def test_projection_on_four_streams_mixed_motion_1000_rounds(my_lib, oracle):
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream() for _ in range(4)]
     bufs = [[(tf.new_empty((tf.shape[0], 1, tf.shape[2], tf.shape[3])), torch.empty_like(tf)) for tf in inputs] for _ in streams]
-    wrong = 0
+    wrong, worst = 0, 0.0
     for rnd in range(1000):
         picks = []
         for k, s in enumerate(streams):
@@ -214,9 +217,11 @@ def test_projection_on_four_streams_mixed_motion_1000_rounds(my_lib, oracle):
             torch.cuda.synchronize()
             for k, i in picks:
                 c, o = bufs[k][i]
-                if not (torch.equal(c, alone[i][0]) and torch.equal(o, alone[i][1])):
+                diff = max(float((o - alone[i][1]).abs().max()), float((c - alone[i][0]).abs().max()))
+                worst = max(worst, diff)
+                if not torch.equal(c, alone[i][0]) or diff > 1e-6:
                     wrong += 1
-    assert wrong == 0, wrong
+    assert wrong == 0, "%d results differ from the ones computed alone, by up to %g" % (wrong, worst)
 
 
 def test_projection_from_two_host_threads(my_lib):
@@ -243,7 +248,7 @@ def test_projection_from_two_host_threads(my_lib):
                     assert my_lib.FlowProjectionLayer_gpu_forward(tf, c, o, 1) == 0
                 if it % 20 == 19:
                     stream.synchronize()
-                    if not (torch.equal(c, ref[0]) and torch.equal(o, ref[1])):
+                    if not torch.equal(c, ref[0]) or float((o - ref[1]).abs().max()) > 1e-6:
                         errors.append(it)
         except Exception as e:          # noqa: BLE001
             errors.append(repr(e))
@@ -287,7 +292,7 @@ def test_projection_on_hip_stream_per_thread(my_lib):
                 assert cfunc(PER_THREAD, ctypes.byref(d[0]), ctypes.byref(d[1]), ctypes.byref(d[2]), 1) == 0
                 if it % 20 == 19:
                     assert hip.hipStreamSynchronize(PER_THREAD) == 0
-                    if not (torch.equal(c, ref[0]) and torch.equal(o, ref[1])):
+                    if not torch.equal(c, ref[0]) or float((o - ref[1]).abs().max()) > 1e-6:
                         errors.append(it)
         except Exception as e:          # noqa: BLE001
             errors.append(repr(e))

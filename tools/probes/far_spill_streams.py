@@ -28,6 +28,7 @@ from tools import synth  # noqa: E402
 
 dev = torch.device("cuda:0")
 ML = M.bound()
+LAST_NOTES = []
 ATOL = 1e-4
 
 
@@ -53,31 +54,64 @@ def describe(got_out, got_cnt, want_out, want_cnt, H, W):
         info["of_them_at_holes"] = int(at_holes.sum())
         info["got_zero_there"] = int((np.abs(got_out[b, :, y, x]).max(axis=1) == 0).sum())
         info["got_nan_there"] = int(np.isnan(got_out[b, :, y, x]).any(axis=1).sum())
-        k = min(6, len(cells))
-        info["first"] = [{"b,y,x": [int(b[i]), int(y[i]), int(x[i])],
-                          "got": [float(v) for v in got_out[b[i], :, y[i], x[i]]] + [float(got_cnt[b[i], 0, y[i], x[i]])],
-                          "want": [float(v) for v in want_out[b[i], :, y[i], x[i]]] + [float(want_cnt[b[i], 0, y[i], x[i]])]}
-                         for i in range(k)]
+        def sample(idx):
+            return [{"b,y,x": [int(b[i]), int(y[i]), int(x[i])],
+                     "got": [float(v) for v in got_out[b[i], :, y[i], x[i]]] + [float(got_cnt[b[i], 0, y[i], x[i]])],
+                     "want": [float(v) for v in want_out[b[i], :, y[i], x[i]]] + [float(want_cnt[b[i], 0, y[i], x[i]])]}
+                    for i in idx]
+        info["first_at_holes"] = sample(np.nonzero(at_holes)[0][:3])
+        info["first_not_at_holes"] = sample(np.nonzero(~at_holes)[0][:5])
+        info["rows_of_wrong_non_hole_cells"] = sorted(set(int(v) for v in y[~at_holes]))[:12]
     return info
 
 
-def one_run(lib_near, lib_far, tn, tf, want_n, want_f, fill, iters, serial, log):
+def last_block():
+    """(pointer, bytes) of the scratch block the calling thread's last projection call used -- instrumented variants only."""
+    import ctypes
+    f = getattr(PL._lib, "memc_debug_last_scratch", None) if hasattr(PL, "_lib") else None
+    try:
+        f = PL._lib.memc_debug_last_scratch
+    except AttributeError:
+        return None
+    p, n = ctypes.c_void_p(), ctypes.c_size_t()
+    f.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+    f.restype = None
+    f(ctypes.byref(p), ctypes.byref(n))
+    return [p.value, n.value]
+
+
+def one_run(lib_near, lib_far, tn, tf, want_n, want_f, fill, iters, serial, log, streams=None, run=0):
     """tests/test_gpu_parity.py::test_concurrent_streams_projection, instrumented.  Returns (near wrong, far wrong) iterations."""
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1, s2 = streams if streams else (torch.cuda.Stream(), torch.cuda.Stream())
     H, W = tn.shape[2], tn.shape[3]
-    outs = []
+    outs, notes = [], []
     for it in range(iters):
         cn, on = tn.new_zeros(tn.shape[0], 1, H, W), torch.zeros_like(tn)
         cf, of = tf.new_zeros(tf.shape[0], 1, H, W), torch.zeros_like(tf)
         torch.cuda.synchronize()
+        e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
         with torch.cuda.stream(s1):
+            e0.record()
             assert lib_near.FlowProjectionLayer_gpu_forward(tn, cn, on, fill) == 0
+            e1.record()
+        blk_n = last_block()
         if serial:
             torch.cuda.synchronize()
         with torch.cuda.stream(s2):
+            e2.record()
             assert lib_far.FlowProjectionLayer_gpu_forward(tf, cf, of, fill) == 0
+            e3.record()
+        blk_f = last_block()
         outs.append((on, cn, of, cf))
+        if it < 2:
+            torch.cuda.synchronize()
+            notes.append({"near_stream": s1.cuda_stream, "far_stream": s2.cuda_stream, "near_block": blk_n, "far_block": blk_f, "near_call_us": round(e0.elapsed_time(e1) * 1e3, 1),
+                          "far_call_us": round(e2.elapsed_time(e3) * 1e3, 1),
+                          "far_starts_after_near_starts_us": round(e0.elapsed_time(e2) * 1e3, 1),
+                          "near_out": [on.data_ptr(), on.numel() * 4], "far_out": [of.data_ptr(), of.numel() * 4]})
     torch.cuda.synchronize()
+    del LAST_NOTES[:]
+    LAST_NOTES.extend(notes)
     bad_n = bad_f = 0
     for it, (on, cn, of, cf) in enumerate(outs):
         for name, o, c, (wo, wc) in (("near", on, cn, want_n), ("far", of, cf, want_f)):
@@ -89,7 +123,8 @@ def one_run(lib_near, lib_far, tn, tf, want_n, want_f, fill, iters, serial, log)
                 else:
                     bad_f += 1
                 if log is not None and len(log) < 6:
-                    log.append({"iteration": it, "stream": name, **describe(go, gc, wo, wc, H, W)})
+                    log.append({"run": run, "iteration": it, "stream": name, "calls": notes[it] if it < len(notes) else None,
+                                **describe(go, gc, wo, wc, H, W)})
     return bad_n, bad_f
 
 
@@ -97,6 +132,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "far_spill_streams.txt"))
+    ap.add_argument("--product", default="", help="label: run the test's loop on whatever lib/libmemc_hip.so is (a variant "
+                    "copied over it by the session script), with the diagnostics, instead of the measurement build's arms")
     a = ap.parse_args()
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     rng = np.random.default_rng(31)
@@ -129,25 +166,42 @@ def main():
         ("J  -44, 4 x 256 x 512 images", -44, ML, ML, "near_b", "far_b", 1, False),
         ("K  product kernels, 4 x 256 x 512 images", -1, ML, ML, "near_b", "far_b", 1, False),
     ]
+    fixed = None
+    if a.product:
+        arms = [("%s: near || far, fill 1, NEW streams every run" % a.product, None, Prod, Prod, "near", "far", 1, False),
+                ("%s: near || far, fill 1, the SAME two streams in every run" % a.product, "same", Prod, Prod, "near", "far", 1, False),
+                ("%s: near || far, fill 0, new streams" % a.product, None, Prod, Prod, "near", "far", 0, False),
+                ("%s: near || far, serialised, new streams" % a.product, None, Prod, Prod, "near", "far", 1, True),
+                ("%s: near || near, new streams" % a.product, None, Prod, Prod, "near", "near", 1, False)]
     lines = []
     for label, variant, ln, lf, kn, kf, fill, serial in arms:
-        M.set_variant("projection", variant)
+        if variant == "same":
+            fixed = (torch.cuda.Stream(), torch.cuda.Stream())
+        elif variant is not None:
+            M.set_variant("projection", variant)
         log = []
+        first_notes = []
         tot_n = tot_f = runs_bad = 0
         for r in range(a.rounds):
-            bn, bf = one_run(ln, lf, t[kn], t[kf], want[kn, fill], want[kf, fill], fill, 20, serial, log)
+            bn, bf = one_run(ln, lf, t[kn], t[kf], want[kn, fill], want[kf, fill], fill, 20, serial, log,
+                             streams=fixed if variant == "same" else None, run=r)
             tot_n += bn
             tot_f += bf
+            if r < 2 and LAST_NOTES:
+                first_notes.append(LAST_NOTES[0])
             runs_bad += 1 if (bn or bf) else 0
         line = "%-100s runs with a wrong result: %2d of %d   wrong iterations: stream 1 (%s) %3d, stream 2 (%s) %3d of %d" % (
             label, runs_bad, a.rounds, kn, tot_n, kf, tot_f, 20 * a.rounds)
         print(line, flush=True)
         lines.append(line)
+        for e in first_notes[:2]:
+            lines.append("      first iteration of a run: " + json.dumps(e))
+            print("      first iteration of a run: " + json.dumps(e), flush=True)
         for e in log:
             lines.append("      " + json.dumps(e))
             print("      " + json.dumps(e), flush=True)
     M.set_variant("projection", -1)
-    with open(a.out, "w") as f:
+    with open(a.out, "a") as f:
         f.write("\n".join(lines) + "\n")
 
 

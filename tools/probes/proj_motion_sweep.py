@@ -38,6 +38,28 @@ for scale in (1.0, 1.5, 2.0, 3.0, 4.0, 6.0):
         row.append(ts[len(ts) // 2])
     print("%-7.1f %10.1f %12.3f %14.1f %14.1f %16.1f" % (scale, float(f.abs().max()), far, row[0], row[1], row[2]))
 
+print()
+print("camera pans (p, -p/2) on top of the benchmark's flow (round 5: the scan is shifted by the image's dominant motion)")
+print("%-7s %14s %14s %16s" % ("pan px", "fill 0, us", "fill 1, us", "depth fill 1, us"))
+for pan in (0.0, 3.0, 8.0, 20.0, 40.0, 80.0, 160.0):
+    f = f0.clone()
+    f[:, 0] += pan
+    f[:, 1] -= pan / 2
+    row = []
+    for fn in (lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 0), lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, 1),
+               lambda: L.DepthFlowProjectionLayer_gpu_forward(f, d, cnt, out, 1)):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(8):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        ts.sort()
+        row.append(ts[len(ts) // 2])
+    print("%-7.1f %14.1f %14.1f %16.1f" % (pan, row[0], row[1], row[2]))
+sys.stdout.flush()
+
 
 def far_model(f, images=4, TH=32, R=24):
     """What proj_owner_far decides for the first `images` images of f (numpy restatement of its culling): the share of tiles

@@ -121,9 +121,104 @@ static long run(int nstreams, int mode, int rounds, const int *perm)
     return bad;
 }
 
+// Round 4's scratch cache took one stream-ordered allocation per STREAM from a private pool (hipMallocFromPoolAsync) and
+// kept it.  What does the pool hand two different streams that both hold their allocation?
+static void pool_probe()
+{
+    hipMemPoolProps props = {};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = 0;
+    hipMemPool_t pool = nullptr;
+    CHECK(hipMemPoolCreate(&pool, &props));
+    uint64_t keep = UINT64_MAX;
+    CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    hipStream_t s[3];
+    for (int k = 0; k < 3; k++) CHECK(hipStreamCreateWithFlags(&s[k], hipStreamNonBlocking));
+    for (size_t bytes : {(size_t)14760, (size_t)1 << 20, (size_t)40 << 20}) {
+        void *p[3] = {};
+        for (int k = 0; k < 3; k++) CHECK(hipMallocFromPoolAsync(&p[k], bytes, pool, s[k]));
+        printf("pool probe: %9zu B on three streams, none freed: %p %p %p%s\n", bytes, p[0], p[1], p[2],
+               (p[0] == p[1] || p[1] == p[2] || p[0] == p[2]) ? "   <-- THE SAME BLOCK TWICE" : "");
+        for (int k = 0; k < 3; k++) CHECK(hipStreamSynchronize(s[k]));
+        void *q[3] = {};
+        for (int k = 0; k < 3; k++) CHECK(hipMallocFromPoolAsync(&q[k], bytes, pool, s[k]));
+        printf("            a second round, the first still held:      %p %p %p\n", q[0], q[1], q[2]);
+        for (int k = 0; k < 3; k++) {
+            CHECK(hipFreeAsync(p[k], s[k]));
+            CHECK(hipFreeAsync(q[k], s[k]));
+        }
+        CHECK(hipDeviceSynchronize());
+    }
+    for (int k = 0; k < 3; k++) CHECK(hipStreamDestroy(s[k]));
+}
+
+// ... and what does it hand stream B when stream A has FREED its block (hipFreeAsync, in stream order) but A's kernels that
+// use the block are still running?  The runtime may give B the same memory only behind a dependency on A's free.  `hold`
+// fills the block, idles (~spin x 0.25 us) and verifies it; `scribble` on B overwrites whatever B was given at once.
+__global__ void hold(unsigned *p, int n, unsigned pat, int spin, unsigned *bad)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = pat ^ (unsigned)i;
+    for (int s = 0; s < spin; s++) __builtin_amdgcn_s_sleep(8);
+    __threadfence();
+    unsigned b = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) b += p[i] != (pat ^ (unsigned)i);
+    if (b) atomicAdd(bad, b);
+}
+__global__ void scribble(unsigned *q, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) q[i] = 0xDEADBEEFu;
+}
+static void reuse_probe(int rounds)
+{
+    hipMemPoolProps props = {};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = 0;
+    hipMemPool_t pool = nullptr;
+    CHECK(hipMemPoolCreate(&pool, &props));
+    uint64_t keep = UINT64_MAX;
+    CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    hipStream_t A, B;
+    CHECK(hipStreamCreateWithFlags(&A, hipStreamNonBlocking));
+    CHECK(hipStreamCreateWithFlags(&B, hipStreamNonBlocking));
+    unsigned *bad = nullptr;
+    CHECK(hipMalloc(&bad, sizeof(unsigned)));
+    CHECK(hipMemset(bad, 0, sizeof(unsigned)));
+    const int n = 4096;                        // 16 KiB: the size of a small projection call's block
+    for (int spin : {0, 400, 4000}) {          // A's kernel takes ~2 us / ~0.1 ms / ~1 ms
+        int same = 0;
+        CHECK(hipMemset(bad, 0, sizeof(unsigned)));
+        for (int r = 0; r < rounds; r++) {
+            void *p = nullptr, *q = nullptr;
+            CHECK(hipMallocFromPoolAsync(&p, n * sizeof(unsigned), pool, A));
+            hipLaunchKernelGGL(hold, dim3(4), dim3(256), 0, A, (unsigned *)p, n, 0x9E3779B1u * (unsigned)(r + 1), spin, bad);
+            CHECK(hipFreeAsync(p, A));         // (what rounds 2-3 of the library did at the end of every call)
+            CHECK(hipMallocFromPoolAsync(&q, n * sizeof(unsigned), pool, B));
+            hipLaunchKernelGGL(scribble, dim3(4), dim3(256), 0, B, (unsigned *)q, n);
+            CHECK(hipFreeAsync(q, B));
+            same += p == q;
+            if (r % 16 == 15) CHECK(hipDeviceSynchronize());
+        }
+        CHECK(hipDeviceSynchronize());
+        unsigned h = 0;
+        CHECK(hipMemcpy(&h, bad, sizeof(h), hipMemcpyDeviceToHost));
+        printf("reuse probe: A holds its block ~%4d sleeps, frees it in stream order; B allocates at once: B got A's block in %d of %d "
+               "rounds; words of A's block overwritten while A still used it: %u\n", spin, same, rounds, h);
+    }
+    CHECK(hipFree(bad));
+    CHECK(hipStreamDestroy(A));
+    CHECK(hipStreamDestroy(B));
+}
+
 int main(int argc, char **argv)
 {
     const int rounds = argc > 1 ? atoi(argv[1]) : 10000;
+    pool_probe();
+    reuse_probe(2000);
+    if (rounds <= 0) return 0;
     int h_perm[1024];
     for (int i = 0; i < 1024; i++) h_perm[i] = i;
     int *perm = nullptr;
