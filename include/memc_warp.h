@@ -96,9 +96,10 @@ const char *memc_hip_version(void);
 
 /* Which kernel family did the most recent operator call made BY THE CALLING THREAD take?  A static string
  * "<operator>:<family>", e.g. "fi_fwd:tiled_c3", "proj_fwd:owner", "bl_bwd:direct"; "" before the first call.
- * The production kernels need 16-byte aligned geometry (width, strides and base pointers multiples of four elements) and,
- * for FilterInterpolation, filter_size 4; anything else is served by scalar kernels -- same results, 2-3x slower
- * (profiles/r04_slow_paths.txt) -- whose family names are
+ * The production kernels need a WIDTH that is a multiple of four (base pointers and strides may be anything since round 5:
+ * quads are accessed at dword alignment; the (Depth)FlowProjection forward also serves other widths from 8 on) and, for
+ * FilterInterpolation, filter_size 4; anything else is served by scalar kernels -- same results, forward passes ~2x slower,
+ * the scattering backward passes 13-20x (profiles/r05_slow_paths.txt) -- whose family names are
  *     "direct"  (FilterInterpolation / Interpolation: one lane per site, global gathers and atomics),
  *     "generic" (FilterInterpolation, filter_size != 4),
  *     "scalar"  ((Depth)FlowProjection forward / backward),
@@ -142,7 +143,7 @@ int FilterInterpolationLayer_gpu_forward(memc_stream_t stream, const memc_tensor
                                          const memc_tensor4 *output);
 /* my_lib_cuda.h:77-85 / my_lib_cuda.c:669-749.
  * EXTENSION: gradinput1 may be NULL -- "the image gradient is not wanted" (the reference's networks never use it: the frames
- * they warp are data, networks/MEMC_Net_star.py:266-277): three channels, filter_size 4 and 16-byte aligned geometry
+ * they warp are data, networks/MEMC_Net_star.py:266-277): three channels, filter_size 4 and a width that is a multiple of four
  * then skip its accumulation and its zero fill; any other shape returns -1 with nothing written and the caller
  * passes a buffer.  The launcher below takes a NULL gradinput1 pointer the same way. */
 int FilterInterpolationLayer_gpu_backward(memc_stream_t stream, const memc_tensor4 *input1,
@@ -268,7 +269,7 @@ int DepthFlowProjection_gpu_backward_kernel(
  *
  * so that the two warped frames never exist in memory (188 instead of 236 bytes per site).  Forward only (the
  * shipped Python layer differentiates it through the reference-API entry points above).  RGB inputs,
- * filter_size 4, 16-byte aligned geometry: anything else returns -1 and the caller composes the result from two
+ * filter_size 4, a width that is a multiple of four: anything else returns -1 and the caller composes the result from two
  * FilterInterpolationLayer_gpu_forward calls.  input0 / input2 / output share one layout, flow0 / flow1 another,
  * filter0 / filter1 another, the occlusions ([B, 1, H, W]) another.  `output` need not be zero-filled.
  * ------------------------------------------------------------------------------------------------------ */
@@ -299,7 +300,7 @@ int FilterInterpolationBlend_gpu_forward_kernel(
  * the second form being MEMC_Net_star.py:277's blend with `prev` = the other direction's image_out.  image, prev,
  * image_out: [B, 3, H, W], one layout; context, context_out: [B, C, H, W], C a multiple of 4, one layout; the two
  * occlusions [B, 1, H, W], one layout; prev / occlusion_prev / occlusion_this all NULL or all given.  Forward only,
- * filter_size 4, 16-byte aligned geometry: anything else returns -1 and the caller uses the entry points above.
+ * filter_size 4, a width that is a multiple of four: anything else returns -1 and the caller uses the entry points above.
  * Outputs need not be zero-filled.
  * ------------------------------------------------------------------------------------------------------ */
 int FilterInterpolationCtxLayer_gpu_forward(memc_stream_t stream, const memc_tensor4 *image,

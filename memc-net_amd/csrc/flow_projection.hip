@@ -623,9 +623,11 @@ struct FarTile {
 // instead of motion bounds: a fast object dirties the tiles it lands in, not its whole image); the culling is one source
 // tile per lane (a ballot names the ones to scan; per wave, its own four rows of a near tile), FarTile's cheap test and
 // direct splats, two workgroups per CU.
-// MINW / NCAND: the product is <4, 16 TH> (4 waves per SIMD = two workgroups per CU).  <6, 384> -- three per CU, which the
-// LDS then allows -- needs 80 VGPRs and SPILLS: 266 -> 373 us under a 40 px pan; kept as a measurement arm only (variant -44)
-// because round 4 saw wrong results next to it (tools/probes/far_spill_streams.py).
+// MINW / NCAND: the product is <4, 16 TH> (4 waves per SIMD = two workgroups per CU).  Round 4 tried <6, 384> -- three per CU,
+// which its LDS then allowed; 80 VGPRs, 76 bytes of private scratch per lane: 266 -> 373 us under a 40 px pan -- and saw wrong
+// results next to it; round 5 rebuilt that arm from round 4's code and took it apart (DESIGN.md section 4f,
+// tools/probes/far_spill_streams.py, profiles/r05_far_spill_*): the spill only TRIGGERS (the runtime allocates a queue's
+// scratch at its first such dispatch, ~1.4 ms between two kernels of a call).  RAG: ragged rows (tail_fix above).
 template <bool DEPTH, int TH, int kReach, int MINW = 4, int NCAND = 16 * TH, bool RAG = false>
 __global__ __launch_bounds__(16 * TH, MINW) void proj_owner_far(
 
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner_far(
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth,
     float *__restrict__ count, float *__restrict__ out, const int *__restrict__ far_flag,
-    const int *__restrict__ bounds, FillWs ws, int nonce_arg)
+    const int *__restrict__ bounds, const int *__restrict__ stamps, FillWs ws, int nonce_arg)
 {
     const int nonce = nonce_arg ? nonce_arg : __builtin_amdgcn_readfirstlane(far_flag[kFlagWords + 1]);   // (see proj_owner5)
     using FT = FarTile<DEPTH, TH>;
@@ -670,12 +672,24 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner_far(
     // stamps of all tiles (one ballot per 64 tiles, a prefix over the groups: ~30 loads per lane, cold path only) and takes
     // the stamped tiles of rank i, i + grid, ...: the same work in max(1, n / grid) tiles' time.
     const unsigned ngroups = (ntiles + 63u) / 64u;                           // <= kGroups (launcher)
-    for (unsigned g = wave; g < ngroups; g += NT / kWave) {
-        const unsigned t = g * 64u + lane;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(t < ntiles && bounds[kFarWords * (int64_t)(t < ntiles ? t : 0) + 4] == nonce);
-        if (lane == 0) {
-            gprefix[g] = (unsigned)__builtin_popcountll(m);
-            gmask[g] = m;
+    {   // eight groups' stamps in flight per wave (one dependent round trip per group made this prologue most of the launch)
+        constexpr int kIn = 8;
+        for (unsigned g0 = wave * kIn; g0 < ngroups; g0 += (NT / kWave) * kIn) {
+            int st[kIn];
+#pragma unroll
+            for (int k = 0; k < kIn; k++) {
+                const unsigned t = (g0 + k) * 64u + lane;
+                st[k] = stamps[t < ntiles ? t : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < kIn; k++) {
+                const unsigned t = (g0 + k) * 64u + lane;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(t < ntiles && st[k] == nonce);
+                if (lane == 0 && g0 + k < ngroups) {
+                    gprefix[g0 + k] = (unsigned)__builtin_popcountll(m);
+                    gmask[g0 + k] = m;
+                }
+            }
         }
     }
     __syncthreads();
@@ -1176,6 +1190,19 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
 }
 
 MEMC_KNOB_STATIC(g_proj_variant, -1);          // measurement build only (memc_common.hpp)
+MEMC_KNOB_STATIC(g_proj_scratch_blocks, kBlocks);   // measurement build: how many cached scratch blocks a call may look at
+MEMC_KNOB_STATIC(g_proj_stall_us, 0);          // measurement build: idle this long between the owner kernel and what follows it
+
+#ifdef MEMC_MEASURE
+// What a queue's first dispatch with private scratch does to a call (round 4's spilling far kernel: the runtime allocates the
+// queue's scratch, ~1.4 ms): the call's later kernels start LATE.  Injected here to test that nothing the call relies on
+// can be touched by another stream's call in the gap (tests/test_gpu_workspace_and_streams.py).
+__global__ void proj_stall(int us)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();                       // (the 100 MHz real-time counter)
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(32);
+}
+#endif
 
 // Owner kernel geometry of the product build (measured): tile height and stripe width of the walk.
 constexpr int kOwnerTH = 32, kOwnerSW = 4;
@@ -1204,7 +1231,7 @@ static ProjWsLayout proj_ws_layout(int w, int h, int batch, bool fast, bool carr
     const int ntx = (w + 63) / 64, nty = (h + TH - 1) / TH;
     const size_t ntiles = (size_t)ntx * nty * batch;
     ProjWsLayout l;
-    l.n_bnd = fast ? kFarWords * ntiles : 0;
+    l.n_bnd = fast ? kFarWords * ntiles + (ntiles + 3) / 4 * 4 : 0;        // the tiles' far table, then their stamps (dense)
     l.n_up = (size_t)batch * nty * w;
     l.n_row = (size_t)batch * h * ntx;
     l.ints = kProjWsHead + l.n_bnd + (carry ? l.n_up + 2 * l.n_row + ntiles : 0);
@@ -1259,7 +1286,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     const ProjWsLayout lay = proj_ws_layout<TH>(w, h, batch, want_fast, want_carry, !old_fill);
     const size_t n_bnd = lay.n_bnd, n_up = lay.n_up, n_row = lay.n_row, ints = lay.ints;
     CallScratch scratch;
-    int *flag = nullptr, *bounds = nullptr;
+    int *flag = nullptr, *bounds = nullptr, *stamps = nullptr;
     FillWs ws = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // The production pair (proj_owner5 / proj_owner_far) needs no cleared flag words: a flag is "raised" when it holds
     // this call's nonce -- a process-wide counter, never 0, so consecutive calls (which the pool hands the same block)
@@ -1283,7 +1310,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
     void *block = nullptr;
     if (want_fast || want_carry) {
         if (a.ws) block = a.ws;
-        else if (scratch.alloc(lay.bytes(), stream)) block = scratch.p;
+        else if (scratch.alloc(lay.bytes(), stream, g_proj_scratch_blocks)) block = scratch.p;
     }
     if (block) {
         int *base = static_cast<int *>(block);
@@ -1291,6 +1318,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
         if (want_fast) {
             flag = base;
             bounds = base + kHead;
+            stamps = bounds + kFarWords * (size_t)ntiles;
         }
         if (want_carry) {
             ws.up = base + kHead + n_bnd;
@@ -1333,17 +1361,20 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             } else if (variant == -46 && DEPTH) {   // timing arm: 64-bit fixed-point planes on ds_add_u64 (proj_owner5.hpp, FIX64)
                 hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinW, false, true>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w, h,
                                    ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,
-                                   bounds, ws, plan, nonce);
+                                   bounds, stamps, ws, plan, nonce);
             } else if (variant == -41) {       // timestamps (tools/trace_kernel.py proj5)
                 hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinW, true>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w, h,
                                    ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,
-                                   bounds, ws, plan, nonce);
+                                   bounds, stamps, ws, plan, nonce);
             } else
 #endif
             hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinWR, false, false, RAG>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w,
-                               h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag, bounds, ws,
+                               h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag, bounds, stamps, ws,
                                plan, nonce);
             if (launch_status() != 0) return -1;
+#ifdef MEMC_MEASURE
+            if (g_proj_stall_us > 0) hipLaunchKernelGGL(proj_stall, dim3(1), dim3(64), 0, stream, g_proj_stall_us);
+#endif
             if (!only_part) {
                 const unsigned pg = r3_set ? persistent_grid(1) : persistent_grid(2);   // (53 KiB of LDS, 114 VGPRs: two per CU)
 #ifdef MEMC_MEASURE
@@ -1351,21 +1382,13 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                     hipLaunchKernelGGL((proj_owner_far_r3<DEPTH, TH, 24>), dim3(ntiles < pg ? ntiles : pg), dim3(16 * TH), 0,
                                        stream, w, h, ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth,
                                        a.count, a.out, flag, bounds, ws, nonce);
-                else if (variant == -44 || variant == -45) {   // round 4's arm: three per CU, spills (-45: on the product's grid)
-                    const unsigned pg3 = variant == -44 ? persistent_grid(3) : pg;
-                    if constexpr (TH == 32)
-                        hipLaunchKernelGGL((proj_owner_far<DEPTH, TH, 24, 6, 384>), dim3(ntiles < pg3 ? ntiles : pg3), dim3(16 * TH),
-                                           0, stream, w, h, ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth,
-                                           a.count, a.out, flag, bounds, ws, nonce);
-                    else
-                        return -1;
-                } else
+                else
 #endif
                 {   // (a lane of the grid per stamped tile at most: proj_owner_far's work list)
                     const unsigned need = (ntiles + 16u * TH - 1u) / (16u * TH), fg0 = ntiles < pg ? ntiles : pg;
                     hipLaunchKernelGGL((proj_owner_far<DEPTH, TH, 24, 4, 16 * TH, RAG>), dim3(fg0 > need ? fg0 : need), dim3(16 * TH), 0, stream,
                                        w, h, ntx, nty, batch, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count,
-                                       a.out, flag, bounds, ws, nonce);
+                                       a.out, flag, bounds, stamps, ws, nonce);
                 }
                 if (launch_status() != 0) return -1;
             }
@@ -1604,6 +1627,8 @@ using namespace memc;
 
 #ifdef MEMC_MEASURE
 extern "C" void memc_debug_set_projection_variant(int v) { g_proj_variant = v; }
+extern "C" void memc_debug_set_projection_scratch_blocks(int n) { g_proj_scratch_blocks = n < 1 ? 1 : (n > kBlocks ? kBlocks : n); }
+extern "C" void memc_debug_set_projection_stall_us(int us) { g_proj_stall_us = us; }
 extern "C" int memc_debug_set_trace_buffer_proj(void *p)
 {
     unsigned long long *q = (unsigned long long *)p;

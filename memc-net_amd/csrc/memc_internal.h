@@ -65,6 +65,8 @@ extern "C" {
 // A/B measurement hooks.  variant < 0 restores automatic selection.
 void memc_debug_set_fi_fwd_variant(int variant);
 void memc_debug_set_projection_variant(int variant);
+void memc_debug_set_projection_scratch_blocks(int n);   // (Depth)FlowProjection forward: cached scratch blocks a call may look at (1 .. 8)
+void memc_debug_set_projection_stall_us(int us);        // ... idle this long between the owner kernel and the kernels behind it
 void memc_debug_set_fi_bwd_variant(int variant);
 void memc_debug_set_extra_lds(int bytes);        // bilinear forward only: pads its LDS request (fewer workgroups per CU)
 void memc_debug_set_bl_cap(int which);           // 2x2-footprint kernels' LDS staging budget: < 0 each kernel's default, 0 = 48 KiB, 1 = 39 KiB, 2 = 31 KiB (bilinear forward only); RGB backward, packed planes: 3 / 4 = 64 x 16 tiles on 256 lanes in 39 / 48 KiB

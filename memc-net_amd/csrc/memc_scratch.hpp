@@ -78,7 +78,9 @@ struct CallScratch {
     void *p = nullptr;
     hipStream_t stream = nullptr;
     CachedBlock *claimed = nullptr;            // the cache entry this call holds (released, not freed, at the end)
-    bool alloc(size_t bytes, hipStream_t s)
+    // max_blocks: how many of the device's kBlocks this call may look at (the measurement build's test of the ordering:
+    // with one block every call takes the block of the call before it, whatever their streams)
+    bool alloc(size_t bytes, hipStream_t s, int max_blocks = kBlocks)
     {
         stream = s;
         hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
@@ -94,13 +96,27 @@ struct CallScratch {
         if (table) {
             static uint64_t clock = 0;
             std::lock_guard<std::mutex> lock(scratch_mutex());
-            CachedBlock *best = nullptr;       // a free block: large enough and last used on this handle > large enough > LRU
+            // Which free block?  (4) large enough and last used on this stream handle: the steady state of a caller with one
+            // stream -- found without asking the runtime anything; (3) large enough and its previous user's kernels are DONE
+            // (hipEventQuery): nothing to wait for; (2) a slot without memory yet: a fresh allocation, so that streams that
+            // run side by side each end up with a block of their own instead of queueing behind one; (1) large enough, its
+            // previous user still running on another stream: this call's kernels wait for it (correct, not concurrent); (0)
+            // too small: released behind that wait and replaced.  Ties: least recently used.
+            CachedBlock *best = nullptr;
             int best_rank = -1;
-            for (int i = 0; i < kBlocks; i++) {
+            for (int i = 0; i < kBlocks && i < max_blocks && best_rank < 4; i++) {
                 CachedBlock &b = table[i];
                 if (b.busy) continue;
-                int rank = b.p && b.bytes >= bytes ? (b.last == s ? 3 : 2) : (!b.p ? 1 : 0);
-                if (rank > best_rank || (rank == best_rank && rank == 0 && b.stamp < best->stamp)) {
+                int rank;
+                if (!b.p) rank = 2;
+                else if (b.bytes < bytes) rank = 0;
+                else if (b.last == s) rank = 4;
+                else if (!b.recorded || hipEventQuery(b.done) == hipSuccess) rank = 3;
+                else {
+                    (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+                    rank = 1;
+                }
+                if (rank > best_rank || (rank == best_rank && b.stamp < best->stamp)) {
                     best = &b;
                     best_rank = rank;
                 }

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth,
     float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, int *__restrict__ bounds,
-    FillWs ws, WalkPlan plan, int nonce_arg)
+    int *__restrict__ stamps, FillWs ws, WalkPlan plan, int nonce_arg)
 {
     // this call's tag: a host counter's value, or -- 0: the call was recorded into a HIP graph, every replay needs its own --
     // the device counter proj_bump_nonce advanced in front of this kernel
@@ -198,6 +198,8 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         const int rh = RAG ? tail_shift(hx, W) : 0;
         const unsigned offh = homeq ? 4u * (unsigned)(hy * s1h + hx - rh) : 0u;
         f32x4 a = ld_cached4_u(flow_b, offh), c = ld_cached4_u(flow_b + s1c, offh);
+        scan_issue(mx, my);                       // ... and the scan again, where the sources that land here come from (requested
+                                                  // behind the home quad: ONE more round trip under a pan, not two)
         if (RAG) {
             a = tail_fix(a, rh, kNaN);
             c = tail_fix(c, rh, kNaN);
@@ -208,7 +210,6 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         const unsigned long long farq = __builtin_amdgcn_ballot_w64(homeq && !(dmax < (float)kReach));   // (NaN: far, found not valid)
         near_seen |= __builtin_amdgcn_ballot_w64(homeq) & ~farq;
         if (farq != 0) far_quads(homeq, a, c, (float)hx, (float)hy);
-        scan_issue(mx, my);                       // ... and the scan again, where the sources that land here come from
     }
 
 #pragma unroll
@@ -307,8 +308,9 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     // (from here on the thread index is REBUILT from the wave's index, a scalar, and the lane's rank in the wave:
     // it need not live through the scan)
     const int tid = wave_index * kWave + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    // bounds[]: 8 words per tile -- the box its far sources land in (4), "a far source of another tile lands here" (1: this
-    // call's nonce, stamped by that tile), "the tile has sources that are not far" (1), 2 unused
+    // bounds[]: 8 words per tile -- the box its far sources land in (4), one unused, "the tile has sources that are not far"
+    // (1), 2 unused; stamps[]: one word per tile, "a far source of another tile lands here": this call's nonce, stamped by
+    // that tile (a dense array: proj_owner_far reads ALL of them, 64 consecutive words per wave and load)
     const int64_t tile_lin = ((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx;
     if (tid < 6 && tid != 4) bounds[kFarWords * tile_lin + tid] = tile_box[tid < 4 ? tid : 4];
     if (__builtin_expect(tile_box[1] >= 0, 0)) {   // cold: stamp the tiles whose window -- x2 in [tx0 - 1, tx0 + 64), y2 in
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         for (int i = tid; i < n; i += NT) {
             const int ty = tya + i / nx, tx = txa + i % nx;
             // (not this tile when its scan covered its own sources: what they hit inside its window it splatted itself)
-            if (tx != tc.tx || ty != tc.ty || shifted) bounds[kFarWords * (((int64_t)b * tiles_y + ty) * tiles_x + tx) + 4] = nonce;
+            if (tx != tc.tx || ty != tc.ty || shifted) stamps[((int64_t)b * tiles_y + ty) * tiles_x + tx] = nonce;
         }
     }
 

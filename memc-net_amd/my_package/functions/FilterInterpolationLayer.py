@@ -45,9 +45,15 @@ class _FilterInterpolationFunction(Function):
         stored = my_lib.gradinput1_is_stored(int(input3.size(1) ** 0.5 + 1e-6), input1.size(1))     # fs as my_lib.c:925
         # the warped frames are data in the reference's networks (MEMC_Net_star.py:266-277): when autograd does not ask
         # for gradinput1, the RGB kernel skips its accumulation and this layer its zero fill (a NULL gradinput1,
-        # include/memc_warp.h; shapes the extension does not serve return -1 and are redone with a buffer)
+        # include/memc_warp.h)
+        # (decided up front -- the library serves a NULL gradinput1 for three channels, the 4x4 filter and a width that is a
+        # multiple of four, include/memc_warp.h; anything else gets a buffer that is thrown away: no failed first call)
         want1 = ctx.needs_input_grad[0]
-        gradinput1 = None if not want1 else (torch.empty_like(input1) if stored else torch.zeros_like(input1))
+        null_ok = input1.size(1) == 3 and input3.size(1) == 16 and input1.size(3) % 4 == 0
+        if want1 or not null_ok:
+            gradinput1 = torch.empty_like(input1) if stored else torch.zeros_like(input1)
+        else:
+            gradinput1 = None
         # the reference zero-fills these two as well (:47-48); the backward kernels DEFINE every element of them
         # (invalid sites store zero; tests/test_gpu_parity.py::test_backward_defines_flow_and_tap_gradients), so
         # 72 B/site of memsets -- a seventh of the call at 720p -- are skipped
@@ -55,12 +61,8 @@ class _FilterInterpolationFunction(Function):
         gradinput3 = torch.empty_like(input3)
         err = my_lib.FilterInterpolationLayer_gpu_backward(
             input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)
-        if err != 0 and gradinput1 is None:
-            scratch1 = torch.empty_like(input1) if stored else torch.zeros_like(input1)
-            err = my_lib.FilterInterpolationLayer_gpu_backward(
-                input1, input2, input3, gradoutput, scratch1, gradinput2, gradinput3)
         check(err, "FilterInterpolationLayer_gpu_backward")
-        return gradinput1, gradinput2, gradinput3
+        return (gradinput1 if want1 else None), gradinput2, gradinput3
 
 
 class FilterInterpolationLayer(object):

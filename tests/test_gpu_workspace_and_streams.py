@@ -224,6 +224,55 @@ def test_projection_on_four_streams_mixed_motion_1000_rounds(my_lib, oracle):
     assert wrong == 0, "%d results differ from the ones computed alone, by up to %g" % (wrong, worst)
 
 
+@pytest.mark.parametrize("blocks", [8, 1])
+def test_a_call_stalled_between_its_kernels_keeps_its_tables(oracle, blocks):
+    """What round 4's failure turned out to be made of: a queue's first dispatch with private scratch
+    makes the runtime allocate that queue's scratch -- ~1.4 ms during which the call's later kernels wait -- and if another
+    stream's call can touch the first call's tables in that gap, the first call's hole filler reads the other call's tables.
+    The measurement build injects that stall (2 ms between the owner kernel and the kernels behind it) into the call on
+    stream 1 while stream 2 runs a projection with far sources: with the library's blocks (8: each stream ends up with its
+    own; 1: both calls MUST take the same block, so the second waits for the event recorded behind the first) and with a
+    caller's workspace, the stalled call's result is right."""
+    from tools import measure as M
+    ML = M.bound()
+    rng = np.random.default_rng(31)
+    near = synth.np_flow(rng, 2, 64, 128, "smooth", 3.0)
+    far = synth.np_flow(rng, 2, 64, 128, "iid", 40.0)
+    want_near, wcn = oracle.flow_projection_forward(near, 1)
+    want_far, wcf = oracle.flow_projection_forward(far, 1)
+    tn, tf = T(near), T(far)
+    try:
+        M.set_variant("proj_scratch_blocks", blocks)
+        for use_ws in (False, True):
+            s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+            outs = []
+            for it in range(6):
+                cn, on = tn.new_zeros(2, 1, 64, 128), torch.zeros_like(tn)
+                cf, of = tf.new_zeros(2, 1, 64, 128), torch.zeros_like(tf)
+                torch.cuda.synchronize()
+                M.set_variant("proj_stall_us", 2000)
+                with torch.cuda.stream(s1):
+                    if use_ws:
+                        assert ML.FlowProjectionLayer_gpu_forward_ws(tn, cn, on, 1, torch.empty(1 << 16, dtype=torch.uint8, device="cuda")) == 0
+                    else:
+                        assert ML.FlowProjectionLayer_gpu_forward(tn, cn, on, 1) == 0
+                M.set_variant("proj_stall_us", 0)
+                with torch.cuda.stream(s2):
+                    if use_ws:
+                        assert ML.FlowProjectionLayer_gpu_forward_ws(tf, cf, of, 1, torch.empty(1 << 16, dtype=torch.uint8, device="cuda")) == 0
+                    else:
+                        assert ML.FlowProjectionLayer_gpu_forward(tf, cf, of, 1) == 0
+                outs.append((on, cn, of, cf))
+            torch.cuda.synchronize()
+            for on, cn, of, cf in outs:
+                assert np.array_equal(N(cn), wcn) and np.array_equal(N(cf), wcf)
+                close(N(on), want_near, "the stalled call (%d blocks, workspace %s)" % (blocks, use_ws))
+                close(N(of), want_far, "the other stream's call (%d blocks, workspace %s)" % (blocks, use_ws))
+    finally:
+        M.set_variant("proj_stall_us", 0)
+        M.set_variant("proj_scratch_blocks", 8)
+
+
 def test_projection_from_two_host_threads(my_lib):
     """Two host threads enqueueing projections at once on their own streams (torch gives every thread's `with stream` its
     own current stream) and both on the SAME stream: the library's blocks are owned by one host call at a time and ordered

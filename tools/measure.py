@@ -23,6 +23,8 @@ _SETTERS = {
     "fi_fwd": "memc_debug_set_fi_fwd_variant",
     "fi_bwd": "memc_debug_set_fi_bwd_variant",
     "projection": "memc_debug_set_projection_variant",
+    "proj_scratch_blocks": "memc_debug_set_projection_scratch_blocks",
+    "proj_stall_us": "memc_debug_set_projection_stall_us",
     "walk": "memc_debug_set_walk",
     "extra_lds": "memc_debug_set_extra_lds",
     "bl_cap": "memc_debug_set_bl_cap",
@@ -89,4 +91,4 @@ def set_variant(op, variant):
 
 def reset():
     for op in _SETTERS:
-        set_variant(op, 0 if op in ("extra_lds", "bl_bwd_direct") else -1)
+        set_variant(op, 0 if op in ("extra_lds", "bl_bwd_direct", "proj_stall_us") else 8 if op == "proj_scratch_blocks" else -1)

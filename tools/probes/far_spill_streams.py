@@ -77,7 +77,17 @@ def last_block():
     f.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
     f.restype = None
     f(ctypes.byref(p), ctypes.byref(n))
-    return [p.value, n.value]
+    out = [p.value, n.value]
+    try:
+        g = PL._lib.memc_debug_last_scratch2
+        a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        g.argtypes = [ctypes.POINTER(ctypes.c_void_p)] * 3
+        g.restype = None
+        g(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        out += [{"stream_seen_by_library": a.value, "cache_entry": b.value, "entry_stream": c.value}]
+    except AttributeError:
+        pass
+    return out
 
 
 def one_run(lib_near, lib_far, tn, tf, want_n, want_f, fill, iters, serial, log, streams=None, run=0):
