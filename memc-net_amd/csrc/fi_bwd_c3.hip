@@ -187,8 +187,11 @@ constexpr bool kPartThree = true;              // (experiment: the halves at thr
 #else                                          //  96 / 160 B per lane, reloaded inside the add loop and phase 1)
 constexpr bool kPartThree = false;
 #endif
-template <bool TR, int NT = 256, int PART = 0>
-__global__ __launch_bounds__(NT, PART == 0 || !kPartThree ? 2 : 3) void fi_bwd_c3_pk(
+// RAG: a ragged width (W % 4 != 0, round 5) -- the whole quads here (sites x < W & ~3; the image's true width in every clamp,
+// validity test and box, the box's last quad staged ragged-safely: memc_tile.hpp), the one to three columns behind them in
+// fi_bwd_direct_fs4 (launcher); both ADD into gradinput1.  One workgroup per CU: the kernel has no registers left for it.
+template <bool TR, int NT = 256, int PART = 0, bool RAG = false>
+__global__ __launch_bounds__(NT, RAG ? 1 : (PART == 0 || !kPartThree ? 2 : 3)) void fi_bwd_c3_pk(
     int W, int H, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
@@ -210,8 +213,9 @@ __global__ __launch_bounds__(NT, PART == 0 || !kPartThree ? 2 : 3) void fi_bwd_c
     const int b = tc.b;
     const unsigned tid = tid_now();
     const int x = tc.tx * G::kTW + 4 * (int)(tid % LX), y = tc.ty * G::kTH + (int)(tid / LX);
-    const bool inb = x < W && y < H;
-    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const int Ws = RAG ? W & ~3 : W;
+    const bool inb = x < Ws && y < H;
+    const int xs = min(x, Ws - 4), ys = min(y, H - 1);
     const float *flow_b = flow + b * s2b, *filt_b = filt + b * s3b, *gout_b = gout + b * s1b;
     float *gin2_b = gin2 + b * s2b, *gin3_b = gin3 + b * s3b;
     const unsigned o1 = 4u * (unsigned)(ys * s1h + xs), o2 = 4u * (unsigned)(ys * s2h + xs),
@@ -302,14 +306,14 @@ __global__ __launch_bounds__(NT, PART == 0 || !kPartThree ? 2 : 3) void fi_bwd_c
     };
 #pragma unroll 1
     for (int bi = 0; bi < bands.n; bi++) {
-    const Region r = band_region(box, bands, bi);
+    const Region r = band_region(box, bands, bi, RAG ? W : 0);
     const unsigned fast = inb ? fi_covered(r, g, W, H) & ~done : 0u;
     // later bands run only if some site still needs them; the vote is also the barrier that frees the LDS
     if (bi > 0 && !__syncthreads_or(fast != 0)) continue;
     done |= fast;
     const StageSlot sl = stage_slots<NT>(r);
     StageRegs<3> sr;
-    if (PART != 1) tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);     // in flight during adds and flush
+    if (PART != 1) tile_stage_load<3, RAG>(r, sl, in_b, s1c, s1h, sr);   // in flight during adds and flush
     if (PART != 2 && mode == 1) {
         if (bi > 0) {                      // (band 0: zeroed at the top, ordered by the barrier of tile_bbox)
             zero_planes(r.h * r.pitch);
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(NT, PART == 0 || !kPartThree ? 2 : 3) void fi_bwd_c
     }
     if (PART != 2 && (fast & outl)) image_atomics(fast & outl);
     if (PART != 1) {
-        tile_stage_store<3>(r, sl, sr, tile);
+        tile_stage_store<3, RAG>(r, sl, sr, tile);
         __syncthreads();
         if (bi == 0) trace_mark<TR>(5);                    // image staged
         phase1(r, fast);
@@ -354,19 +358,19 @@ __global__ __launch_bounds__(NT, PART == 0 || !kPartThree ? 2 : 3) void fi_bwd_c
                              filt_b + o3 / 4 + j, gin3_b + o3 / 4 + j, s3c, gout_b + o1 / 4 + j);
     }
 }
-// 1: taken, 0: geometry not 16-byte aligned (the caller takes the direct kernel), -1: launch error.  `variant` >= 0
+// 1: taken; 2: taken for the whole quads of a ragged width (w % 4 != 0): the caller runs the direct kernel on the columns
+// from w & ~3 on; 0: not taken (the caller takes the direct kernel for everything); -1: launch error.  `variant` >= 0
 // selects a measurement arm (measurement build only; the product passes -1).
 int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
                      int s1b, int s1c, int s1h, int s2b, int s2c, int s2h, int s3b, int s3c, int s3h,
                      const float *input1, const float *input2, const float *input3, const float *gradoutput,
                      float *gradinput1, float *gradinput2, float *gradinput3, int variant)
 {
-    if (!plane_fits_u32(w, h, {s1h, s2h, s3h}) ||
-        !vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
-                 {input1, input2, input3, gradoutput, gradinput1 /* may be NULL: aligned */, gradinput2, gradinput3}))
-        return 0;
+    const int ws = w & ~3;
+    if (!plane_fits_u32(w, h, {s1h, s2h, s3h}) || ws < 4) return 0;
+    if (ws < w && (gradinput1 == nullptr || variant >= 0)) return 0;   // (the tail's direct kernel needs the buffer; arms: whole widths)
     using G = TileGeom<16>;
-    const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+    const int ntx = (ws + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
     const unsigned ntiles = (unsigned)ntx * nty * batch;
 #define MEMC_FI_BWD_PK(TR, NT_, NTY, NTILES) MEMC_FI_BWD_PK_PART(TR, NT_, NTY, NTILES, 0)
 #define MEMC_FI_BWD_PK_PART(TR, NT_, NTY, NTILES, PART_)                                                           \
@@ -402,12 +406,16 @@ int fi_bwd_c3_launch(hipStream_t stream, int w, int h, int batch,
         MEMC_FI_BWD_PK_PART(false, 256, nty, ntiles, 2);
     }
 #endif
-    else {
+    else if (ws < w) {                                     // a ragged width: the RAG instantiation (+ the caller's tail launch)
+        hipLaunchKernelGGL((fi_bwd_c3_pk<false, 256, 0, true>), dim3(ntiles), dim3(256), PkGeomT<256>::kLds, stream, w, h, ntx, nty,
+                           batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c,
+                           s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3);
+    } else {
         MEMC_FI_BWD_PK(false, 256, nty, ntiles);
     }
 #undef MEMC_FI_BWD_PK_PART
 #undef MEMC_FI_BWD_PK
-    return launch_status() == 0 ? 1 : -1;
+    return launch_status() == 0 ? (ws < w ? 2 : 1) : -1;
 }
 
 }  // namespace memc

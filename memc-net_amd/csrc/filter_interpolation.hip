@@ -920,13 +920,14 @@ __global__ __launch_bounds__(64 * ROWS) void fi_bwd_direct_fs4(
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
     const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2,
-    float *__restrict__ gin3)
+    float *__restrict__ gin3, int x0)
 {
+    // x0: the first column this launch serves (0; w & ~3 when fi_bwd_c3_pk took the whole quads of a ragged width)
     const unsigned tile = xcd_chunked_id(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x;
     const int ty = (tile / tiles_x) % tiles_y;
     const int b = tile / (tiles_x * tiles_y);
-    const int x = tx * kWave + (threadIdx.x & (kWave - 1));
+    const int x = x0 + tx * kWave + (threadIdx.x & (kWave - 1));
     const int y = ty * ROWS + (threadIdx.x / kWave);
     if (x >= W || y >= H) return;
 
@@ -1290,6 +1291,13 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
 #endif
                                          )) != 0) {
         MEMC_PATH("fi_bwd:tiled_c3");
+        if (taken == 2) {                                  // a ragged width: the columns behind the whole quads (both ADD into gradinput1)
+            const int ws = w & ~3, tail_y = (h + 3) / 4;
+            hipLaunchKernelGGL((fi_bwd_direct_fs4<3, 4>), dim3((unsigned)tail_y * batch), dim3(256), 0, stream, w, h, channel, 1,
+                               tail_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,
+                               (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3, ws);
+            return launch_status();
+        }
         return taken > 0 ? 0 : -1;                         // RGB: fi_bwd_c3.hip
     } else if (channel != 3 &&
                (taken = fi_bwd_cn_launch(stream, w, h, channel, batch, s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h, input1,
@@ -1303,13 +1311,13 @@ extern "C" int FilterInterpolationLayer_gpu_backward_kernel(
         hipLaunchKernelGGL((fi_bwd_direct_fs4<3, 4>), dim3(nwg), dim3(256), 0, stream, w, h, channel,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput,
-                           gradinput1, gradinput2, gradinput3);
+                           gradinput1, gradinput2, gradinput3, 0);
     } else {
         MEMC_PATH("fi_bwd:direct");
         hipLaunchKernelGGL((fi_bwd_direct_fs4<0, 4>), dim3(nwg), dim3(256), 0, stream, w, h, channel,
                            tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput,
-                           gradinput1, gradinput2, gradinput3);
+                           gradinput1, gradinput2, gradinput3, 0);
     }
     return launch_status();
 }

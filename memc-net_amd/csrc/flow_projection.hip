@@ -444,38 +444,7 @@ __device__ __forceinline__ void trace_mark_proj(int slot)
 constexpr int kPtW4 = 66;
 constexpr double kCountUnit = 1048576.0;          // 2^20
 
-// RAGGED rows (round 5): a width that is not a multiple of four.  The last quad of a row then holds W % 4 sites, and a 16-byte
-// access there would run past the row -- past the tensor, in its last row.  The load is moved left so that it ENDS at the
-// row's end and the registers are rotated back (the sites past the row read as `pad`); the store writes the sites inside
-// the row one by one.  Only the kernels' RAG instantiations pay for this (a wave-uniform branch: only the waves that hold a
-// row's last quad take it); widths that are multiples of four run the code they always ran.
-__device__ __forceinline__ int tail_shift(int x, int W) { return (x < W && x + 4 > W) ? x + 4 - W : 0; }   // sites past the row
-__device__ __forceinline__ f32x4 tail_fix(const f32x4 &v, int r, float pad)
-{
-    if (__builtin_amdgcn_ballot_w64(r != 0) == 0) return v;
-    f32x4 o;
-    o[0] = r == 0 ? v[0] : r == 1 ? v[1] : r == 2 ? v[2] : v[3];
-    o[1] = r == 0 ? v[1] : r == 1 ? v[2] : r == 2 ? v[3] : pad;
-    o[2] = r == 0 ? v[2] : r == 1 ? v[3] : pad;
-    o[3] = r == 0 ? v[3] : pad;
-    return o;
-}
-template <bool STREAM>
-__device__ __forceinline__ void st_tail4(float *p, const f32x4 &v, int r)
-{
-    if (__builtin_amdgcn_ballot_w64(r != 0) == 0) {
-        if (STREAM) st_stream4(p, v); else st_cached4(p, v);
-        return;
-    }
-    if (r == 0) {
-        if (STREAM) st_stream4(p, v); else st_cached4(p, v);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            if (j < 4 - r) p[j] = v[j];
-    }
-}
-
+// (tail_shift / tail_fix / st_tail4 -- ragged rows -- live in memc_tile.hpp)
 // The image's dominant motion: mean flow over an 8 x 8 grid of sites, rounded to a multiple of 4 (quads stay quads),
 // 0 for anything non-finite or absurd.  One wave; lane l holds site l.  Deterministic: a butterfly of commutative adds.
 __device__ __forceinline__ void motion_sample_issue(const float *flow_b, int64_t s1c, int s1h, int W, int H, int lane,

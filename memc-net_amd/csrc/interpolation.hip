@@ -20,13 +20,14 @@ template <int CT>
 __global__ __launch_bounds__(256) void bl_fwd(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
-    const float *__restrict__ in1, const float *__restrict__ flow, float *__restrict__ out)
+    const float *__restrict__ in1, const float *__restrict__ flow, float *__restrict__ out, int x0)
 {
+    // x0: the first column this launch serves (0; W & ~3 when the tiled kernel took the whole quads of a ragged width)
     const unsigned tile = xcd_chunked_id(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x;
     const int ty = (tile / tiles_x) % tiles_y;
     const int b = tile / (tiles_x * tiles_y);
-    const int x = tx * kWave + (threadIdx.x & (kWave - 1));
+    const int x = x0 + tx * kWave + (threadIdx.x & (kWave - 1));
     const int y = ty * 4 + (threadIdx.x / kWave);
     if (x >= W || y >= H) return;
 
@@ -58,13 +59,13 @@ __global__ __launch_bounds__(256) void bl_bwd(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
-    float *__restrict__ gin1, float *__restrict__ gin2)
+    float *__restrict__ gin1, float *__restrict__ gin2, int x0)
 {
     const unsigned tile = xcd_chunked_id(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x;
     const int ty = (tile / tiles_x) % tiles_y;
     const int b = tile / (tiles_x * tiles_y);
-    const int x = tx * kWave + (threadIdx.x & (kWave - 1));
+    const int x = x0 + tx * kWave + (threadIdx.x & (kWave - 1));   // (x0: see bl_fwd)
     const int y = ty * 4 + (threadIdx.x / kWave);
     if (x >= W || y >= H) return;
 
@@ -122,12 +123,12 @@ struct BlSite4 {
     unsigned valid, staged;
 };
 
-template <int NCH>
+template <int NCH, bool RAG = false>
 __device__ __forceinline__ void bl_fwd_chunk(const Region &r, const BlSite4 &g, const BlSite (&st)[4], bool inb,
                                              const float *__restrict__ plane0, float *__restrict__ out_p,
                                              int64_t s1c, int s1h, f32x4 *tile)
 {
-    tile_stage<16, NCH>(r, plane0, s1c, s1h, tile);
+    tile_stage<16, NCH, 256, RAG>(r, plane0, s1c, s1h, tile);
     __syncthreads();
     if (!inb) return;
     f32x4 res[4];
@@ -154,7 +155,10 @@ __device__ __forceinline__ void bl_fwd_chunk(const Region &r, const BlSite4 &g, 
 
 // (64 x 32 tiles on 512 lanes, which pay for the RGB backward, lose here: 234 against 201 us -- this kernel is bound by the
 // number of independent tile chains per CU, see the launcher -- profiles/r03_bl_bwd_ab.txt.)
-template <int CT, int CAP>
+// RAG: a ragged width (W % 4 != 0, round 5) -- this kernel serves the whole quads, sites x < W & ~3, with the image's true
+// width in every clamp, validity test and staged box (whose last quad is loaded ragged-safely: memc_tile.hpp); the one to
+// three columns behind them go to the one-lane-per-site kernel (launcher).
+template <int CT, int CAP, bool RAG = false>
 __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
@@ -170,8 +174,9 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
     if (tc.tx >= tiles_x) return;
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
     const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
-    const bool inb = x < W && y < H;
-    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const int Ws = RAG ? W & ~3 : W;
+    const bool inb = x < Ws && y < H;
+    const int xs = min(x, Ws - 4), ys = min(y, H - 1);
     const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
     const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s2c);
 
@@ -186,7 +191,8 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
             rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
         }
     }
-    const Region r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    Region r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    r.wimg = RAG ? W : 0;
     BlSite4 g;
     g.valid = g.staged = 0;
 #pragma unroll
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
     const float *in_b = in1 + b * s1b;
     float *out_p = out + b * s1b + (int64_t)y * s1h + x;
     if (CT == 3) {
-        bl_fwd_chunk<3>(r, g, st, inb, in_b, out_p, s1c, s1h, tile);
+        bl_fwd_chunk<3, RAG>(r, g, st, inb, in_b, out_p, s1c, s1h, tile);
     } else {
         int c0 = 0;
 #pragma unroll 1
@@ -217,14 +223,14 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
                 asm volatile("" : "+v"(g.oTL[j]), "+v"(g.oTR[j]), "+v"(g.oBL[j]), "+v"(g.oBR[j]));
                 asm volatile("" : "+v"(st[j].L), "+v"(st[j].R), "+v"(st[j].T), "+v"(st[j].Bm));
             }
-            bl_fwd_chunk<4>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
+            bl_fwd_chunk<4, RAG>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
         }
         if (c0 < C) {
             if (c0 > 0) __syncthreads();
             const int nch = C - c0;
-            if (nch == 3)      bl_fwd_chunk<3>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
-            else if (nch == 2) bl_fwd_chunk<2>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
-            else               bl_fwd_chunk<1>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
+            if (nch == 3)      bl_fwd_chunk<3, RAG>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
+            else if (nch == 2) bl_fwd_chunk<2, RAG>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
+            else               bl_fwd_chunk<1, RAG>(r, g, st, inb, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
         }
     }
 }
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void bl_fwd_tiled(
 // --------------------------------------------------------------------------------------------------
 // NT lanes take a tile of 64 x NT/16 sites; CAP is the staging budget in cells.  Product: 512 lanes, 64 x 32 tiles, 4096 cells
 // (64 KiB, two workgroups of eight waves per CU).  Measurement arms: 256 lanes with 3072 (48 KiB, 3 per CU) or 2496 (39 KiB, 4).
-template <int CAP, int NT = 256>
+template <int CAP, int NT = 256, bool RAG = false>          // RAG: a ragged width, see bl_fwd_tiled; both kernels ADD into gradinput1
 __global__ __launch_bounds__(NT, NT == 256 && CAP == 3072 ? 3 : 4) void bl_bwd_c3_pk(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
@@ -265,8 +271,9 @@ __global__ __launch_bounds__(NT, NT == 256 && CAP == 3072 ? 3 : 4) void bl_bwd_c
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
     const unsigned tid = tid_now();
     const int x = tile_x0 + 4 * (int)(tid % LX), y = tile_y0 + (int)(tid / LX);
-    const bool inb = x < W && y < H;
-    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const int Ws = RAG ? W & ~3 : W;
+    const bool inb = x < Ws && y < H;
+    const int xs = min(x, Ws - 4), ys = min(y, H - 1);
     const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
     const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s2c);
     const float *gout_p = gout + b * s1b + (int64_t)ys * s1h + xs;
@@ -304,7 +311,8 @@ __global__ __launch_bounds__(NT, NT == 256 && CAP == 3072 ? 3 : 4) void bl_bwd_c
         vmask |= (st[j].valid ? 1u : 0u) << j;
     }
     pk_tile_publish(mx, tid, sbits, sbits, vmask, 0x3F800000);
-    const Region r = tile_region<LX, true, CAP, NT>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    Region r = tile_region<LX, true, CAP, NT>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    r.wimg = RAG ? W : 0;
     const PkTile ps = pk_tile_resolve<NT / kWave>(mx);
     // packed: through the planes; everything else with a non-zero bound (beyond the tile's block exponent, or not finite)
     // scatters with global atomics, exactly as the reference does
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(NT, NT == 256 && CAP == 3072 ? 3 : 4) void bl_bwd_c
     float *gin1_b = gin1 + b * s1b;
     const StageSlot sl = stage_slots<NT>(r);
     StageRegs<3> sr;
-    tile_stage_load<3>(r, sl, in_b, s1c, s1h, sr);             // in flight during adds and flush
+    tile_stage_load<3, RAG>(r, sl, in_b, s1c, s1h, sr);        // in flight during adds and flush
 
     // ---- image gradient: 4 corners x 3 colours per site = 8 packed LDS adds
     unsigned staged_mask = 0;
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(NT, NT == 256 && CAP == 3072 ? 3 : 4) void bl_bwd_c
         pk_flush<NT>(r, accA, accB, ps.inv, gin1_b, s1c, s1h);
     }
     __syncthreads();                           // the planes have been read (or never used): the LDS becomes the image
-    tile_stage_store<3>(r, sl, sr, tile);
+    tile_stage_store<3, RAG>(r, sl, sr, tile);
     __syncthreads();
 
     // ---- flow gradient from the four corner values
@@ -408,15 +416,24 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
                          int s2b, int s2c, int s2h, const float *input1, const float *input2, float *output)
 {
     if (w <= 0 || h <= 0 || channel <= 0 || batch <= 0) return 0;
-    if (vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, output})) {
+    // A width that is not a multiple of four (round 5): the tiled kernel takes the whole quads (sites x < ws), the one-lane-
+    // per-site kernel the one to three columns behind them.
+    const int ws = w & ~3;
+    const int tail_y = (h + 3) / 4;
+    if (ws >= 4) {
         using G = TileGeom<16>;
-        const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+        const int ntx = (ws + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         MEMC_PATH(channel == 3 ? "bl_fwd:tiled_c3" : "bl_fwd:tiled_chunks");
-#define MEMC_BL_FWD(CT, CAP)                                                                                    \
-            hipLaunchKernelGGL((bl_fwd_tiled<CT, CAP>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(256),            \
+#define MEMC_BL_FWD_R(CT, CAP, RAG)                                                                             \
+            hipLaunchKernelGGL((bl_fwd_tiled<CT, CAP, RAG>), dim3(walk_grid(ntx, nty, batch, sw)), dim3(256),       \
                                (tile_lds_bytes<16, CAP>() + g_extra_lds), stream, w, h, channel, ntx, nty, (int64_t)s1b, \
                                (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, output, sw)
+#define MEMC_BL_FWD(CT, CAP)                                                                                    \
+            do {                                                                                                    \
+                if (ws < w) MEMC_BL_FWD_R(CT, CAP, true);                                                           \
+                else MEMC_BL_FWD_R(CT, CAP, false);                                                                 \
+            } while (0)
         if (channel == 3) {
             // 39 KiB instead of 48: 4 workgroups per CU.  The kernel is bound by the latency of a tile's serial chain
             // (1 / 2 / 3 per CU: 483 / 280 / 215 us), its 2x2 footprint rarely needs the rows given up: 218 -> 190 us
@@ -430,6 +447,15 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
             MEMC_BL_FWD(0, 3072);
         }
 #undef MEMC_BL_FWD
+#undef MEMC_BL_FWD_R
+        if (ws < w) {                          // the ragged row's last columns
+            if (channel == 3)
+                hipLaunchKernelGGL(bl_fwd<3>, dim3((unsigned)tail_y * batch), dim3(256), 0, stream, w, h, channel, 1, tail_y,
+                                   (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, output, ws);
+            else
+                hipLaunchKernelGGL(bl_fwd<0>, dim3((unsigned)tail_y * batch), dim3(256), 0, stream, w, h, channel, 1, tail_y,
+                                   (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, output, ws);
+        }
         return launch_status();
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
@@ -437,10 +463,10 @@ static int launch_bl_fwd(hipStream_t stream, int w, int h, int channel, int batc
     MEMC_PATH("bl_fwd:direct");
     if (channel == 3)
         hipLaunchKernelGGL(bl_fwd<3>, dim3(nwg), dim3(256), 0, stream, w, h, channel, tiles_x, tiles_y,
-                           (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, output);
+                           (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, output, 0);
     else
         hipLaunchKernelGGL(bl_fwd<0>, dim3(nwg), dim3(256), 0, stream, w, h, channel, tiles_x, tiles_y,
-                           (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, output);
+                           (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2, output, 0);
     return launch_status();
 }
 
@@ -453,10 +479,16 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
                          const float *gradoutput, float *gradinput1, float *gradinput2)
 {
     if (w <= 0 || h <= 0 || channel <= 0 || batch <= 0) return 0;
-    if (channel == 3 && g_cap_sel != 5 && plane_fits_u32(w, h, {s1h}) &&
-        vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2})) {
+    const int ws = w & ~3;                                 // (a ragged width: see launch_bl_fwd)
+    const int tail_y = (h + 3) / 4;
+#ifdef MEMC_MEASURE
+    const bool arm_needs_quads = (g_cap_sel == 0 || g_cap_sel == 1) && ws < w;    // (the rounds 1-2 kernel: whole widths only)
+#else
+    constexpr bool arm_needs_quads = false;
+#endif
+    if (channel == 3 && g_cap_sel != 5 && plane_fits_u32(w, h, {s1h}) && ws >= 4 && !arm_needs_quads) {
         using G = TileGeom<16>;
-        const int ntx = (w + G::kTW - 1) / G::kTW;
+        const int ntx = (ws + G::kTW - 1) / G::kTW;
         [[maybe_unused]] const int nty = (h + G::kTH - 1) / G::kTH;
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         MEMC_PATH("bl_bwd:tiled_c3");
@@ -473,14 +505,19 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
         else if (g_cap_sel == 0) MEMC_BL_BWD(3072);
         else
 #endif
-#define MEMC_BL_BWD_PK(CAP, NT)                                                                                 \
+#define MEMC_BL_BWD_PK_R(CAP, NT, RAG)                                                                          \
         do {                                                                                                       \
             constexpr size_t lds = CAP * 16 + 32 * (NT / kWave);    /* image or planes; 32 bytes per wave: box, bounds */ \
-            allow_big_lds(bl_bwd_c3_pk<CAP, NT>, lds);    /* per launch: the attribute belongs to the CURRENT device */ \
+            allow_big_lds(bl_bwd_c3_pk<CAP, NT, RAG>, lds);    /* per launch: the attribute belongs to the CURRENT device */ \
             const int ntyk = (h + NT / 16 - 1) / (NT / 16);                                                        \
-            hipLaunchKernelGGL((bl_bwd_c3_pk<CAP, NT>), dim3(walk_grid(ntx, ntyk, batch, sw)), dim3(NT), lds,      \
+            hipLaunchKernelGGL((bl_bwd_c3_pk<CAP, NT, RAG>), dim3(walk_grid(ntx, ntyk, batch, sw)), dim3(NT), lds, \
                                stream, w, h, ntx, ntyk, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, \
                                s2h, input1, input2, gradoutput, gradinput1, gradinput2, sw);                       \
+        } while (0)
+#define MEMC_BL_BWD_PK(CAP, NT)                                                                                 \
+        do {                                                                                                       \
+            if (ws < w) MEMC_BL_BWD_PK_R(CAP, NT, true);                                                           \
+            else MEMC_BL_BWD_PK_R(CAP, NT, false);                                                                 \
         } while (0)
         // 64 x 32 tiles on 512 lanes, 64 KiB, two workgroups per CU.  The flush's global atomics bound this kernel, and a
         // bigger tile's box holds fewer cells per site: against 64 x 16 tiles on 256 lanes (bl_cap 4; 3: the same in
@@ -493,7 +530,12 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
 #endif
         MEMC_BL_BWD_PK(4096, 512);
 #undef MEMC_BL_BWD_PK
+#undef MEMC_BL_BWD_PK_R
 #undef MEMC_BL_BWD
+        if (ws < w)                            // the ragged row's last columns: both kernels ADD into gradinput1
+            hipLaunchKernelGGL(bl_bwd<3>, dim3((unsigned)tail_y * batch), dim3(256), 0, stream, w, h, channel, 1, tail_y,
+                               (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2,
+                               gradoutput, gradinput1, gradinput2, ws);
         return launch_status();
     }
 #ifdef MEMC_MEASURE
@@ -520,11 +562,11 @@ static int launch_bl_bwd(hipStream_t stream, int w, int h, int channel, int batc
     if (channel == 3)
         hipLaunchKernelGGL(bl_bwd<3>, dim3(nwg), dim3(256), 0, stream, w, h, channel, tiles_x, tiles_y,
                            (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2,
-                           gradoutput, gradinput1, gradinput2);
+                           gradoutput, gradinput1, gradinput2, 0);
     else
         hipLaunchKernelGGL(bl_bwd<0>, dim3(nwg), dim3(256), 0, stream, w, h, channel, tiles_x, tiles_y,
                            (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1, input2,
-                           gradoutput, gradinput1, gradinput2);
+                           gradoutput, gradinput1, gradinput2, 0);
     return launch_status();
 }
 

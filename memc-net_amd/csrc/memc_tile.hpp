@@ -91,6 +91,38 @@ __device__ __forceinline__ MEMC_GLOBAL float *at_u(float *ubase, unsigned byte_o
     return reinterpret_cast<MEMC_GLOBAL float *>(addr_u(ubase, byte_off));
 }
 
+// RAGGED rows (round 5): a width that is not a multiple of four.  The last quad of a row then holds W % 4 sites, and a 16-byte
+// access there would run past the row -- past the tensor, in its last row.  The load is moved left so that it ENDS at the
+// row's end and the registers are rotated back (the sites past the row read as `pad`); the store writes the sites inside
+// the row one by one.  Only the kernels' RAG instantiations pay for this (a wave-uniform branch: only the waves that hold a
+// row's last quad take it); widths that are multiples of four run the code they always ran.
+__device__ __forceinline__ int tail_shift(int x, int W) { return (x < W && x + 4 > W) ? x + 4 - W : 0; }   // sites past the row
+__device__ __forceinline__ f32x4 tail_fix(const f32x4 &v, int r, float pad)
+{
+    if (__builtin_amdgcn_ballot_w64(r != 0) == 0) return v;
+    f32x4 o;
+    o[0] = r == 0 ? v[0] : r == 1 ? v[1] : r == 2 ? v[2] : v[3];
+    o[1] = r == 0 ? v[1] : r == 1 ? v[2] : r == 2 ? v[3] : pad;
+    o[2] = r == 0 ? v[2] : r == 1 ? v[3] : pad;
+    o[3] = r == 0 ? v[3] : pad;
+    return o;
+}
+template <bool STREAM>
+__device__ __forceinline__ void st_tail4(float *p, const f32x4 &v, int r)
+{
+    if (__builtin_amdgcn_ballot_w64(r != 0) == 0) {
+        if (STREAM) st_stream4(p, v); else st_cached4(p, v);
+        return;
+    }
+    if (r == 0) {
+        if (STREAM) st_stream4(p, v); else st_cached4(p, v);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (j < 4 - r) p[j] = v[j];
+    }
+}
+
 __device__ __forceinline__ int swz_col(int c) { return c ^ ((c >> 2) & 15); }
 
 // Kernels that address a plane as wave-uniform base + 32-bit byte offset (ld_stream4_u & co.) need every in-plane
@@ -150,6 +182,8 @@ struct Region {
     int x0, y0;      // image coordinates of LDS pixel (0,0); x0 % 4 == 0
     int w, h;        // staged extent (w % 4 == 0); 0 when nothing is staged
     int pitch;       // LDS row pitch of the pixel-quad image, a multiple of 16 pixels (swizzle span)
+    int wimg;        // 0, or the image's width when that is NOT a multiple of four: the staged box's last quad may then
+                     // reach past the row's end and the staging loads take care (tile_stage_load_planes); set by the kernel
     __device__ __forceinline__ bool covers(int cmin, int cmax, int rmin, int rmax) const
     {
         return cmin >= x0 && cmax < x0 + w && rmin >= y0 && rmax < y0 + h;
@@ -194,6 +228,7 @@ __device__ __forceinline__ Region tile_region(int cmin, int cmax, int rmin, int 
     rmin = __builtin_amdgcn_readfirstlane(rmin);
     rmax = __builtin_amdgcn_readfirstlane(rmax);
     Region r;
+    r.wimg = 0;
     if (cmin > cmax) {          // no valid site in this tile
         r.x0 = r.y0 = r.w = r.h = 0;
         r.pitch = G::kPitch;
@@ -302,7 +337,7 @@ __device__ __forceinline__ Bands make_bands(const BBox &b)
     return d;
 }
 
-__device__ __forceinline__ Region band_region(const BBox &b, const Bands &d, int i)
+__device__ __forceinline__ Region band_region(const BBox &b, const Bands &d, int i, int wimg = 0)
 {
     Region r;
     const int bi = i % d.nbx, bj = i / d.nbx;
@@ -311,6 +346,7 @@ __device__ __forceinline__ Region band_region(const BBox &b, const Bands &d, int
     r.w = d.bw;
     r.h = d.bh;
     r.pitch = d.pitch;
+    r.wimg = wimg;             // (the image's width when it is ragged and the kernel stages ragged-safely, else 0: see Region)
     return r;
 }
 
@@ -348,7 +384,10 @@ struct StageRegs {
     f32x4 v[kStageIts][NCH];
 };
 
-template <int NCH>
+// RAG: a ragged image (r.wimg = its width, not a multiple of four): the box's last quad may reach past the row's end.  It
+// is loaded to END at the row's end (rs sites further left) and rotated back where it is consumed (tile_stage_store);
+// what lies past the row is never gathered: coordinates are clamped.  Kernels instantiate RAG only for such widths.
+template <int NCH, bool RAG = false>
 __device__ __forceinline__ void tile_stage_load_planes(const Region &r, const StageSlot &sl,
                                                        const float *const (&plane)[NCH], const int (&hstride)[NCH],
                                                        StageRegs<NCH> &sr)
@@ -356,15 +395,16 @@ __device__ __forceinline__ void tile_stage_load_planes(const Region &r, const St
 #pragma unroll
     for (int it = 0; it < kStageIts; it++) {
         const bool on = sl.row[it] < r.h;
+        const int rs = RAG ? tail_shift(r.x0 + 4 * sl.q[it], r.wimg) : 0;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            const float *p = on ? plane[c] + (int64_t)(r.y0 + sl.row[it]) * hstride[c] + r.x0 + 4 * sl.q[it] : plane[c];
+            const float *p = on ? plane[c] + (int64_t)(r.y0 + sl.row[it]) * hstride[c] + r.x0 + 4 * sl.q[it] - rs : plane[c];
             sr.v[it][c] = ld_cached4(p);
         }
     }
 }
 
-template <int NCH>
+template <int NCH, bool RAG = false>
 __device__ __forceinline__ void tile_stage_store(const Region &r, const StageSlot &sl, const StageRegs<NCH> &sr,
                                                  f32x4 *tile)
 {
@@ -372,18 +412,26 @@ __device__ __forceinline__ void tile_stage_store(const Region &r, const StageSlo
     for (int it = 0; it < kStageIts; it++) {
         if (sl.row[it] < r.h) {
             f32x4 *dst = tile + sl.row[it] * r.pitch;
+            f32x4 v[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) v[c] = sr.v[it][c];
+            if (RAG) {                         // the row's last quad, rotated back (see the loads)
+                const int rs = tail_shift(r.x0 + 4 * sl.q[it], r.wimg);
+#pragma unroll
+                for (int c = 0; c < NCH; c++) v[c] = tail_fix(v[c], rs, 0.0f);
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 f32x4 px = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < NCH; c++) px[c] = sr.v[it][c][i];
+                for (int c = 0; c < NCH; c++) px[c] = v[c][i];
                 dst[swz_col(4 * sl.q[it] + i)] = px;
             }
         }
     }
 }
 
-template <int NCH>
+template <int NCH, bool RAG = false>
 __device__ __forceinline__ void tile_stage_load(const Region &r, const StageSlot &sl, const float *plane0,
                                                 int64_t cstride, int hstride, StageRegs<NCH> &sr)
 {
@@ -394,22 +442,22 @@ __device__ __forceinline__ void tile_stage_load(const Region &r, const StageSlot
         plane[c] = plane0 + c * cstride;
         hs[c] = hstride;
     }
-    tile_stage_load_planes<NCH>(r, sl, plane, hs, sr);
+    tile_stage_load_planes<NCH, RAG>(r, sl, plane, hs, sr);
 }
 
-template <int LX, int NCH, int NT = 256>
+template <int LX, int NCH, int NT = 256, bool RAG = false>
 __device__ __forceinline__ void tile_stage_planes(const Region &r, const float *const (&plane)[NCH],
                                                   const int (&hstride)[NCH], f32x4 *tile)
 {
     static_assert(TileGeom<LX>::kCapPx <= kStageIts * 256 * 4, "three float4 slots per lane cover the budget");
     const StageSlot sl = stage_slots<NT>(r);
     StageRegs<NCH> sr;
-    tile_stage_load_planes<NCH>(r, sl, plane, hstride, sr);
-    tile_stage_store<NCH>(r, sl, sr, tile);
+    tile_stage_load_planes<NCH, RAG>(r, sl, plane, hstride, sr);
+    tile_stage_store<NCH, RAG>(r, sl, sr, tile);
 }
 
 // channel planes of ONE tensor: plane c = plane0 + c * cstride, common row stride
-template <int LX, int NCH, int NT = 256>
+template <int LX, int NCH, int NT = 256, bool RAG = false>
 __device__ __forceinline__ void tile_stage(const Region &r, const float *plane0, int64_t cstride, int hstride,
                                            f32x4 *tile)
 {
@@ -420,7 +468,7 @@ __device__ __forceinline__ void tile_stage(const Region &r, const float *plane0,
         plane[c] = plane0 + c * cstride;
         hs[c] = hstride;
     }
-    tile_stage_planes<LX, NCH, NT>(r, plane, hs, tile);
+    tile_stage_planes<LX, NCH, NT, RAG>(r, plane, hs, tile);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -201,8 +201,10 @@ def test_product_library_has_no_measurement_arms(hip_lib_path):
     # the RGB backward: the packed-plane kernel without timestamps, and none of the round-1/2 kernels (arms/)
     assert not [k for k in kernels if "15fi_bwd_tiled_c3" in k]
     bwd = [k for k in kernels if "12fi_bwd_c3_pk" in k]
-    # no timestamps, 64 x 16 tiles only; the whole backward (PART 0) and the one without the image gradient (PART 2)
-    assert bwd and all("ILb0ELi256ELi0EEE" in k or "ILb0ELi256ELi2EEE" in k for k in bwd), bwd
+    # no timestamps, 64 x 16 tiles only; the whole backward (PART 0: for whole-quad and for ragged widths) and the one without
+    # the image gradient (PART 2)
+    assert bwd and all(any(t in k for t in ("ILb0ELi256ELi0ELb0EEE", "ILb0ELi256ELi0ELb1EEE", "ILb0ELi256ELi2ELb0EEE"))
+                       for k in bwd), bwd
 
 
 def test_measurement_library_is_separate_and_says_so(hip_lib_path):

@@ -492,11 +492,15 @@ def test_shapes_take_the_documented_kernel_paths():
                                    "bl_bwd": "bl_bwd:owner", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
     assert run(1, 5, 40, 128) == {"fi_fwd": "fi_fwd:tiled_c4n_ragged", "fi_bwd": "fi_bwd:owner", "bl_fwd": "bl_fwd:tiled_chunks",
                                   "bl_bwd": "bl_bwd:owner", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
-    # a width that is not a multiple of four: the scalar kernels -- except the projection forward (the 40x cliff of round 4),
-    # whose owner kernels have a ragged-row instantiation since round 5
-    assert run(1, 3, 20, 50) == {"fi_fwd": "fi_fwd:direct", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:direct",
-                                 "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:scalar"}
+    # a width that is not a multiple of four: the scalar kernels for the gathers that were 2x slower there -- the scattering
+    # passes (13-41x slower in round 4) stay on their tiled kernels since round 5: the projection forward's owner kernels have
+    # a ragged-row instantiation, the RGB backward passes and the bilinear warp take the whole quads in the tiled kernel and
+    # the one to three columns behind them in the one-lane-per-site kernel
+    assert run(1, 3, 20, 50) == {"fi_fwd": "fi_fwd:direct", "fi_bwd": "fi_bwd:tiled_c3", "bl_fwd": "bl_fwd:tiled_c3",
+                                 "bl_bwd": "bl_bwd:tiled_c3", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:scalar"}
     assert run(1, 3, 20, 6)["proj_fwd"] == "proj_fwd:scalar"           # (narrower than two quads: scalar)
+    assert run(1, 3, 20, 3) == {"fi_fwd": "fi_fwd:direct", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:direct",
+                                "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:scalar", "proj_bwd": "proj_bwd:scalar"}
     # ... but a multiple of four seen through a view that starts one element in (rows of 65 elements: every row at another
     # alignment) takes the tiled kernels since round 5: a quad in global memory needs dword alignment only (memc_tile.hpp)
     assert run(1, 3, 20, 64, sliced=True) == {"fi_fwd": "fi_fwd:tiled_c3", "fi_bwd": "fi_bwd:tiled_c3", "bl_fwd": "bl_fwd:tiled_c3",
@@ -868,6 +872,53 @@ def test_projection_on_widths_that_are_not_multiples_of_four(oracle, case):
     assert np.array_equal(N(cw[..., :W]), want_cnt)
     close(N(ow[..., :W]), want_out, "FlowProjection at width %d through a view" % W)
     assert float((cw[..., W:] - 7.0).abs().max()) == 0 and float((ow[..., W:] - 7.0).abs().max()) == 0
+
+
+@pytest.mark.parametrize("W", [50, 133, 258, 1278])
+def test_ragged_widths_on_the_tiled_backward_passes(oracle, W):
+    """Round 5: a width that is not a multiple of four no longer sends the RGB backward passes (and the bilinear warp) to the
+    one-lane-per-site kernels (FilterInterpolation backward 20x, Interpolation backward 13x slower at 1278 x 720): the
+    tiled kernel serves the whole quads of every row -- the image's true width in every clamp, validity test and staged box,
+    the box's last quad loaded to end at the row's end --, the direct kernel the one to three columns behind them, both
+    adding into gradinput1.  Against the oracle, smooth and i.i.d. flow (boxes across the ragged edge), through a view
+    whose rows are longer than the width (the elements behind each row must stay untouched)."""
+    import my_package._ext.my_lib as my_lib
+    rng = np.random.default_rng(W)
+    B, C, H = 2, 3, 40 if W > 1000 else 70
+    for kind, sigma in (("smooth", 5.0), ("iid", 4.0)):
+        xn, gn = synth.np_image(rng, B, C, H, W), synth.np_image(rng, B, C, H, W)
+        fn, kn = synth.np_flow(rng, B, H, W, kind, sigma), synth.np_filter(rng, B, H, W)
+        pad = 3
+
+        def wide(a, fill):
+            t = torch.full((a.shape[0], a.shape[1], H, W + pad), fill, device=dev())
+            t[..., :W].copy_(T(a))
+            return t
+        x, g, f, k = wide(xn, 9.0), wide(gn, 9.0), wide(fn, 9.0), wide(kn, 9.0)
+        v = lambda t: t[..., :W]                                             # noqa: E731
+        g1, g2, g3 = wide(np.zeros_like(xn), 0.0), wide(np.zeros_like(fn), 7.0), wide(np.zeros_like(kn), 7.0)
+        g1[..., W:] = 7.0
+        assert my_lib.FilterInterpolationLayer_gpu_backward(v(x), v(f), v(k), v(g), v(g1), v(g2), v(g3)) == 0
+        assert my_lib.last_kernel_path() == "fi_bwd:tiled_c3"
+        w1, w2, w3 = oracle.filter_interpolation_backward(xn, fn, kn, gn)
+        close(N(v(g1)), w1, "FI gradinput1 at width %d, %s" % (W, kind), RTOL)
+        close(N(v(g2)), w2, "FI gradinput2 at width %d, %s" % (W, kind), RTOL)
+        close(N(v(g3)), w3, "FI gradinput3 at width %d, %s" % (W, kind), RTOL)
+        for t in (g1, g2, g3):
+            assert float((t[..., W:] - 7.0).abs().max()) == 0
+        out = wide(np.zeros_like(xn), 7.0)
+        assert my_lib.InterpolationLayer_gpu_forward(v(x), v(f), v(out)) == 0
+        assert my_lib.last_kernel_path() == "bl_fwd:tiled_c3"
+        close(N(v(out)), oracle.interpolation_forward(xn, fn), "Interpolation fwd at width %d, %s" % (W, kind))
+        g1, g2 = wide(np.zeros_like(xn), 0.0), wide(np.zeros_like(fn), 7.0)
+        g1[..., W:] = 7.0
+        assert my_lib.InterpolationLayer_gpu_backward(v(x), v(f), v(g), v(g1), v(g2)) == 0
+        assert my_lib.last_kernel_path() == "bl_bwd:tiled_c3"
+        w1, w2 = oracle.interpolation_backward(xn, fn, gn)
+        close(N(v(g1)), w1, "Interpolation gradinput1 at width %d, %s" % (W, kind), RTOL)
+        close(N(v(g2)), w2, "Interpolation gradinput2 at width %d, %s" % (W, kind), RTOL)
+        for t in (out, g1, g2):
+            assert float((t[..., W:] - 7.0).abs().max()) == 0
 
 
 def test_projection_far_tiles_are_dealt_out_evenly(oracle):
