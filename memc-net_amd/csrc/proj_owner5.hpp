@@ -136,6 +136,8 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
             tile_box[7] = my;
         }
     }
+    // (posting m BEHIND the barrier and letting the other waves poll the LDS word, so that nobody sits at the barrier for the
+    // samples' round trip, was measured: +5.1 % against round 4's kernel instead of +2.2 % -- profiles/r05_proj_motion_polled_ab.txt)
     trace_mark_proj<TRACE>(1);                 // loads issued, P zeroed
     __syncthreads();                           // P is zero, the image's motion is posted
     if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

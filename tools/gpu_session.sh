@@ -4,7 +4,7 @@
 # 4 slots, they cost 3 + 2).
 # Usage (from the repo root, via gpurun):  bash tools/gpu_session.sh <tag> [quick]
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 QUICK=${2:-}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
