@@ -2,7 +2,7 @@
 # tools/publish_session.sh <tag> [round] -- copy what a full GPU session (tools/gpu_session.sh <tag>) left under gpurun_out/<tag>/
 # into profiles/ under the round's names (gpurun_out/ is scratch and untracked; profiles/ is what is committed and cited).
 set -eu
-TAG=$1; R=${2:-r04}
+TAG=$1; R=${2:-r05}
 S=gpurun_out/$TAG; P=profiles
 c() { [ -f "$S/$1" ] && cp "$S/$1" "$P/${R}_$2" || echo "missing: $S/$1"; }
 c baselines.json baselines.json;            c baselines.log baselines.txt
