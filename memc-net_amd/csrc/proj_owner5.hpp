@@ -260,6 +260,10 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         // rows farther from the tile than the local motion: the whole wave leaves after the four y tests
         if (__builtin_amdgcn_ballot_w64(rowany) == 0) continue;
         f32x4 fxq = fx[it], ddq = dd[it];
+        // (round 5 tried the near rows FIRST and the far rows' row tests early -- the j-th far iteration's behind the j-th near
+        // one --, so that this request has the remaining near iterations to arrive in: the owner kernel at twice the
+        // benchmark's motion stayed at 185 us (182), the benchmark's flow lost 3 % more -- the 28 us that motion costs are not
+        // these round trips; profiles/r05_proj_scan_reordered_early_far_rows_ab.txt.  Reverted.)
         if (far_it(it) || partial_it(it)) {    // rare: requested only now (and consumed inside this branch)
             const unsigned off = lv ? off0 + (unsigned)(4 * kRowsIt * it) * (unsigned)s1h : 0u;
             fxq = ld_cached4_u(flow_b, off);
