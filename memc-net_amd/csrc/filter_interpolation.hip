@@ -156,12 +156,12 @@ __device__ __forceinline__ void fi_gather_store(
         st_stream4(out_p + c * s1c, f32x4{res[0][c], res[1][c], res[2][c], res[3][c]});
 }
 
-template <int LX, int NCH>
+template <int LX, int NCH, bool RAGW = false>
 __device__ __forceinline__ void fi_fwd_chunk(
     const Region &r, const FiSite4 &g, const f32x4 (&tp)[16], bool inb, int x, int y, int W, int H,
     const float *__restrict__ plane0, float *__restrict__ out_p, int64_t s1c, int s1h, f32x4 *tile)
 {
-    tile_stage<LX, NCH>(r, plane0, s1c, s1h, tile);
+    tile_stage<LX, NCH, 256, RAGW>(r, plane0, s1c, s1h, tile);
     __syncthreads();
     fi_gather_store<LX, NCH>(r, g, tp, inb, x, y, W, H, plane0, out_p, s1c, s1h, tile);
 }
@@ -326,7 +326,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
 // (Round 1-2 also timed, and dropped: an L2 prefetch of a future tile's flow 32 / 64 / 96 positions ahead (+6 %: the XCD's
 // L2 turns over in ~6 us, the lines are gone before use); the second half of the tap planes requested behind the staging
 // loads (+-0.3 %); the kernel without its LDS gathers (526 us) / without its staging loads: DESIGN.md section 4.)
-template <int LX, int CT, int MINW, int WALK>
+// RAGW: a ragged width (W % 4 != 0, round 5) -- this kernel serves the whole quads, sites x < W & ~3, with the image's true
+// width in every clamp, validity test and staged box (whose last quad is loaded ragged-safely: memc_tile.hpp); the one to
+// three columns behind them go to fi_fwd_direct_fs4 (launcher).
+template <int LX, int CT, int MINW, int WALK, bool RAGW = false>
 __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
@@ -357,12 +360,13 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     const int tile_x0 = tx * G::kTW, tile_y0 = ty * G::kTH;
     const int x = tile_x0 + 4 * (threadIdx.x % LX);
     const int y = tile_y0 + threadIdx.x / LX;
-    const bool inb = x < W && y < H;          // W % 4 == 0: a lane's four sites are in or out together
+    const int Ws = RAGW ? W & ~3 : W;
+    const bool inb = x < Ws && y < H;         // Ws % 4 == 0: a lane's four sites are in or out together
 
     // 1. streams.  Loads are UNCONDITIONAL (lanes past the image edge read a clamped, in-range address and are
     // masked at the store): a load under `if` or `?:` makes its result a phi, and the compiler then waits
     // for it (s_waitcnt vmcnt(0)) at the join instead of at its first use, serialising every phase.
-    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const int xs = min(x, Ws - 4), ys = min(y, H - 1);
     const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
     const float *tap_p = filt + b * s3b + (int64_t)ys * s3h + xs;
     const f32x4 fx4 = ld_stream4(flow_p);
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     // 3. source box, swept in bands when it does not fit the LDS budget (memc_tile.hpp)
     const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
     const Bands bands = make_bands<LX>(box);
-    const Region r = band_region(box, bands, 0);
+    const Region r = band_region(box, bands, 0, RAGW ? W : 0);
     unsigned slow = inb ? g.valid & ~fi_covered(r, g, W, H) : 0u;   // sites outside the first band
 
     // 3./4. channels, four at a time
@@ -402,11 +406,11 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
         unsigned done = 0;
 #pragma unroll 1
         for (int bi = 0; bi < bands.n; bi++) {
-            const Region rb = band_region(box, bands, bi);
+            const Region rb = band_region(box, bands, bi, RAGW ? W : 0);
             const unsigned sel = inb ? fi_covered(rb, g, W, H) & ~done : 0u;
             if (bi > 0 && !__syncthreads_or(sel != 0)) continue;
             done |= sel;
-            tile_stage<LX, 3>(rb, in_b, s1c, s1h, tile);
+            tile_stage<LX, 3, 256, RAGW>(rb, in_b, s1c, s1h, tile);
             __syncthreads();
             // keep tap splats / blend weights inside the loop (hoisted, they spill: see the chunk loop below)
 #pragma unroll
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
                 asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
 #pragma unroll
             for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
-            fi_fwd_chunk<LX, 4>(r, g, tp, inb, x, y, W, H, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
+            fi_fwd_chunk<LX, 4, RAGW>(r, g, tp, inb, x, y, W, H, in_b + c0 * s1c, out_p + c0 * s1c, s1c, s1h, tile);
         }
         if (c0 < C) {                                      // tail of 1..3 channels
             if (c0 > 0) __syncthreads();
@@ -457,9 +461,9 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
                 asm volatile("" : "+v"(tp[k][0]), "+v"(tp[k][1]), "+v"(tp[k][2]), "+v"(tp[k][3]));
 #pragma unroll
             for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]), "+v"(g.a[j]), "+v"(g.b[j]));
-            if (nch == 3)      fi_fwd_chunk<LX, 3>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
-            else if (nch == 2) fi_fwd_chunk<LX, 2>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
-            else               fi_fwd_chunk<LX, 1>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
+            if (nch == 3)      fi_fwd_chunk<LX, 3, RAGW>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
+            else if (nch == 2) fi_fwd_chunk<LX, 2, RAGW>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
+            else               fi_fwd_chunk<LX, 1, RAGW>(r, g, tp, inb, x, y, W, H, plane0, o, s1c, s1h, tile);
         }
     }
     while (slow) {                            // rare: redo those sites from global memory, all channels
@@ -802,13 +806,14 @@ __global__ __launch_bounds__(64 * ROWS) void fi_fwd_direct_fs4(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
-    float *__restrict__ out)
+    float *__restrict__ out, int x0)
 {
+    // (x0: first column served -- 0, or the first column behind a ragged width's whole quads, which the tiled kernel takes)
     const unsigned tile = xcd_chunked_id(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x;
     const int ty = (tile / tiles_x) % tiles_y;
     const int b = tile / (tiles_x * tiles_y);
-    const int x = tx * kWave + (threadIdx.x & (kWave - 1));
+    const int x = x0 + tx * kWave + (threadIdx.x & (kWave - 1));
     const int y = ty * ROWS + (threadIdx.x / kWave);
     if (x >= W || y >= H) return;
 
@@ -1134,9 +1139,14 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
         hipLaunchKernelGGL((fi_fwd_direct_fs4<CT, ROWS>), dim3(nwg), dim3(64 * (ROWS)), 0, stream, w, h,   \
                            channel, tiles_x, tiles_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b,       \
                            (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3,     \
-                           output);                                                                        \
+                           output, 0);                                                                     \
     } while (0)
 
+#ifdef MEMC_MEASURE
+#define MEMC_FI_FWD_NO_ARM && g_fi_fwd_variant < 0
+#else
+#define MEMC_FI_FWD_NO_ARM
+#endif
 #ifdef MEMC_MEASURE
     // ---- measurement build only: A/B and ablation arms (tools/bench_ops.py); several return WRONG results ----
     const int variant = g_fi_fwd_variant;
@@ -1238,11 +1248,40 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
         return launch_status();
     }
-    // odd widths / unaligned views: scalar direct-gather kernels
+    // A width that is not a multiple of four (round 5), one to three channels: the tiled kernel takes the whole quads
+    // (sites x < ws), the one-lane-per-site kernel the one to three columns behind them.  (Four channels and more at such a
+    // width stay on the one-lane-per-site kernel: the chunk pipeline of fi_fwd_tiled_c4n has no ragged-row instantiation.)
+    const int ws = w & ~3;
+    if (filter_size == 4 && !vec && ws >= 8 && channel <= 3 MEMC_FI_FWD_NO_ARM) {
+        using G = TileGeom<16>;
+        const int ntx = (ws + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+        const int tail_y = (h + 3) / 4;
+        MEMC_PATH(channel == 3 ? "fi_fwd:tiled_c3" : "fi_fwd:tiled_chunks");
+#define MEMC_FI_TILED_RAGW(CT)                                                                                  \
+        hipLaunchKernelGGL((fi_fwd_tiled_fs4<16, CT, 2, 0, true>), dim3((unsigned)ntx * nty * batch), dim3(256),    \
+                           tile_lds_bytes<16>(), stream, w, h, channel, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h,   \
+                           (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output)
+#define MEMC_FI_TAIL(CT)                                                                                        \
+        hipLaunchKernelGGL((fi_fwd_direct_fs4<CT, 4>), dim3((unsigned)tail_y * batch), dim3(256), 0, stream, w, h,  \
+                           channel, 1, tail_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,     \
+                           (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output, ws)
+        if (channel == 3) {
+            MEMC_FI_TILED_RAGW(3);
+            MEMC_FI_TAIL(3);
+        } else {
+            MEMC_FI_TILED_RAGW(0);
+            MEMC_FI_TAIL(0);
+        }
+#undef MEMC_FI_TILED_RAGW
+#undef MEMC_FI_TAIL
+        return launch_status();
+    }
+    // everything else: the one-lane-per-site kernels
     MEMC_PATH("fi_fwd:direct");
     if (channel == 3) MEMC_FI_FWD_LAUNCH(3, 4);
     else MEMC_FI_FWD_LAUNCH(0, 4);
 #undef MEMC_FI_FWD_LAUNCH
+#undef MEMC_FI_FWD_NO_ARM
 #undef MEMC_FI_C4N
 #undef MEMC_FI_C4N_NT
 #undef MEMC_FI_C4N_LX

@@ -136,13 +136,14 @@ __global__ __launch_bounds__(256) void proj_bwd(
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
     const float *__restrict__ flow, const float *__restrict__ depth, const float *__restrict__ count,
     const float *__restrict__ fwd_out, const float *__restrict__ gout,
-    float *__restrict__ gin1, float *__restrict__ gin2)
+    float *__restrict__ gin1, float *__restrict__ gin2, int x0)
 {
+    // (x0: first column served -- 0, or the first column behind a ragged width's whole quads)
     const unsigned tile = xcd_chunked_id(blockIdx.x, gridDim.x);
     const int tx = tile % tiles_x;
     const int ty = (tile / tiles_x) % tiles_y;
     const int b = tile / (tiles_x * tiles_y);
-    const int x = tx * kWave + (threadIdx.x & (kWave - 1));
+    const int x = x0 + tx * kWave + (threadIdx.x & (kWave - 1));
     const int y = ty * 4 + (threadIdx.x / kWave);
     if (x >= W || y >= H) return;
 
@@ -1035,7 +1036,9 @@ __global__ __launch_bounds__(256) void proj_fillhole_v4(
 // Backward, tiled: the four corner reads of gradoutput / count (/ forward output) come from an LDS image of
 // the tile's target box -- one pixel quad (gx, gy, count, ox) per cell, plus a planar oy for the depth
 // operator -- instead of 8..16 scattered global loads per site.
-template <bool DEPTH, int CAP>
+// RAG: a ragged width (W % 4 != 0, round 5) -- the whole quads (sites x < W & ~3) here, with the image's true width in every
+// clamp and in the staged box (ragged-safe loads of a row's last quad, memc_tile.hpp); the columns behind them on proj_bwd.
+template <bool DEPTH, int CAP, bool RAG = false>
 __global__ __launch_bounds__(256) void proj_bwd_tiled(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
@@ -1053,8 +1056,9 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
     if (tc.tx >= tiles_x) return;
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
     const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
-    const bool inb = x < W && y < H;
-    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const int Ws = RAG ? W & ~3 : W;
+    const bool inb = x < Ws && y < H;
+    const int xs = min(x, Ws - 4), ys = min(y, H - 1);
     const float *flow_p = flow + b * s1b + (int64_t)ys * s1h + xs;
     const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s1c);
     f32x4 d4 = {1.f, 1.f, 1.f, 1.f};
@@ -1076,7 +1080,8 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
             rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
         }
     }
-    const Region r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    Region r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    r.wimg = RAG ? W : 0;
     const float *go = gout + b * s1b, *cn = count + b * scb, *fo = DEPTH ? fwd_out + b * s1b : nullptr;
     // Every use of a corner is gout / count (times something of the site) or the forward output: the staged pixel
     // quad is therefore (gout_x / count, gout_y / count, out_x, out_y) -- the divisions (~12 VALU instructions
@@ -1090,16 +1095,21 @@ __global__ __launch_bounds__(256) void proj_bwd_tiled(
         if constexpr (DEPTH) {
             const float *const planes[5] = {go, go + s1c, cn, fo, fo + s1c};
             const int hs[5] = {s1h, s1h, sch, s1h, s1h};
-            tile_stage_load_planes<5>(r, sl, planes, hs, sr);
+            tile_stage_load_planes<5, RAG>(r, sl, planes, hs, sr);
         } else {
             const float *const planes[3] = {go, go + s1c, cn};
             const int hs[3] = {s1h, s1h, sch};
-            tile_stage_load_planes<3>(r, sl, planes, hs, sr);
+            tile_stage_load_planes<3, RAG>(r, sl, planes, hs, sr);
         }
 #pragma unroll
         for (int it = 0; it < kStageIts; it++) {
             if (sl.row[it] < r.h) {
                 f32x4 *dst = tile + sl.row[it] * r.pitch;
+                if (RAG) {                     // the row's last quad was loaded to END at the row's end: rotated back
+                    const int rs = tail_shift(r.x0 + 4 * sl.q[it], r.wimg);
+#pragma unroll
+                    for (int c = 0; c < NP; c++) sr.v[it][c] = tail_fix(sr.v[it][c], rs, 0.0f);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const float inv = 1.0f / sr.v[it][2][i];       // cells nobody projected to: inf, never read
@@ -1462,9 +1472,21 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
         if (ws.up) {
             // round 3's filler: workgroup i looks after the tiles i, i + grid, ... (one flag per lane of a wave)
             [[maybe_unused]] const unsigned fg = ntiles < 4096u ? ntiles : (ntiles + 63u) / 64u > 4096u ? (ntiles + 63u) / 64u : 4096u;
-            // proj_fill_pending: one WAVE per tile, four to a workgroup; 8192 waves are what the chip holds at once
-            const unsigned pw = ntiles < 8192u ? ntiles : ((ntiles + 63u) / 64u > 8192u ? (ntiles + 63u) / 64u : 8192u);
-            const unsigned pg = (pw + 3u) / 4u;
+            // proj_fill_pending: workgroup i lists the flagged ones among the tiles i, i + grid, ... and its sixteen waves take
+            // one tile at a time; one workgroup per CU is what the chip holds at once (LDS, registers).  The grid is
+            // coprime to the tiles per row: the tiles of an image's left or right edge (a camera pan's uncovered band: the
+            // heavy ones) are tiles_x apart and would otherwise meet in a few workgroups.
+            constexpr unsigned kW = (unsigned)kFillWaves;
+            unsigned pg = (ntiles + kW - 1u) / kW < 256u ? (ntiles + kW - 1u) / kW : 256u;
+            auto coprime = [](unsigned x, unsigned y) {
+                while (y) {
+                    const unsigned t = x % y;
+                    x = y;
+                    y = t;
+                }
+                return x == 1u;
+            };
+            while (pg > 1u && !coprime(pg, (unsigned)ntx)) pg--;
 #ifdef MEMC_MEASURE
             if (old_fill)
                 hipLaunchKernelGGL(proj_fillhole_carry<TH>, dim3(fg), dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c,
@@ -1472,7 +1494,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
             else
 #endif
             if constexpr (kNewOk)
-                hipLaunchKernelGGL(proj_fill_pending<TH>, dim3(pg), dim3(256), 0, stream, w, h, ntx, nty, batch, s1b, s1c, s1h,
+                hipLaunchKernelGGL(proj_fill_pending<TH>, dim3(pg), dim3(kFillWaves * kWave), 0, stream, w, h, ntx, nty, batch, s1b, s1c, s1h,
                                    scb, sch, a.count, a.out, ws);
         } else {
             hipLaunchKernelGGL(proj_fillhole_v4, dim3(sntiles), dim3(256), 0, stream, w, h, ntx, snty, s1b, s1c, s1h,
@@ -1561,16 +1583,24 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
 {
     if (w <= 0 || h <= 0 || batch <= 0) return 0;
     const bool vec = vec4_ok(w, {s1b, s1c, s1h, sdb, sdh, scb, sch}, {flow, depth, count, fwd_out, gout, gin1, gin2});
-    if (vec && g_proj_variant != 0) {
+    // A width that is not a multiple of four (round 5): the tiled kernel takes the whole quads (sites x < ws), the one-lane-
+    // per-site kernel the one to three columns behind them.
+    const int ws = w & ~3;
+    if ((vec || (ws >= 8 && g_proj_variant < 0)) && g_proj_variant != 0) {
         using G = TileGeom<16>;
-        const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+        const int ntx = (ws + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const int sw = g_tile_walk_sw >= 0 ? g_tile_walk_sw : kDefaultStripe;
         const unsigned nwg = walk_grid(ntx, nty, batch, sw);
         MEMC_PATH(DEPTH ? "dproj_bwd:tiled" : "proj_bwd:tiled");
-#define MEMC_PROJ_BWD(CAP)                                                                                      \
-        hipLaunchKernelGGL((proj_bwd_tiled<DEPTH, CAP>), dim3(nwg), dim3(256), (tile_lds_bytes<16, CAP>()), stream, w, \
+#define MEMC_PROJ_BWD_R(CAP, RAG)                                                                               \
+        hipLaunchKernelGGL((proj_bwd_tiled<DEPTH, CAP, RAG>), dim3(nwg), dim3(256), (tile_lds_bytes<16, CAP>()), stream, w, \
                            h, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow,   \
                            depth, count, fwd_out, gout, gin1, gin2, sw)
+#define MEMC_PROJ_BWD(CAP)                                                                                      \
+        do {                                                                                                        \
+            if (ws < w) MEMC_PROJ_BWD_R(CAP, true);                                                                 \
+            else MEMC_PROJ_BWD_R(CAP, false);                                                                       \
+        } while (0)
         // 39 KiB of staged cells instead of 48 -> 4 workgroups per CU: 205 -> 180 us (depth 271 -> 256), same results
 #ifdef MEMC_MEASURE
         if (g_cap_sel == 0) MEMC_PROJ_BWD(3072);
@@ -1579,6 +1609,13 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
 #endif
         MEMC_PROJ_BWD(2496);
 #undef MEMC_PROJ_BWD
+#undef MEMC_PROJ_BWD_R
+        if (ws < w) {                          // the ragged row's last columns
+            const int tail_y = (h + 3) / 4;
+            hipLaunchKernelGGL(proj_bwd<DEPTH>, dim3((unsigned)tail_y * batch), dim3(256), 0, stream, w, h, 1, tail_y,
+                               (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count,
+                               fwd_out, gout, gin1, gin2, ws);
+        }
         return launch_status();
     }
     const int tiles_x = (w + kWave - 1) / kWave, tiles_y = (h + 3) / 4;
@@ -1586,7 +1623,7 @@ static int launch_proj_bwd(hipStream_t stream, int w, int h, int batch,
     MEMC_PATH(DEPTH ? "dproj_bwd:scalar" : "proj_bwd:scalar");
     hipLaunchKernelGGL(proj_bwd<DEPTH>, dim3(nwg), dim3(256), 0, stream, w, h, tiles_x, tiles_y,
                        (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)sdb, sdh, (int64_t)scb, sch, flow, depth, count,
-                       fwd_out, gout, gin1, gin2);
+                       fwd_out, gout, gin1, gin2, 0);
     return launch_status();
 }
 

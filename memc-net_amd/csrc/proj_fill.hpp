@@ -102,7 +102,7 @@ __device__ __forceinline__ float fill_value(float lt, float rt, float ut, float 
 // cell of a lane) with a lane or two active.  They are LISTED in LDS and dealt out one per lane instead -- with the
 // benchmark's flows the whole list is one pass of the first wave -- and the owners read their cells back from the stage.
 // Converged code only (barriers).  ws.hole[tile]: 0 no hole, 1 holes, all filled here, 2 holes pending.
-template <int TH, int NT>
+template <int TH, int NT, bool TRACE = false>
 __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stage, const FillWs &ws, int tid, int b, int tx,
                                                     int ty, int W, int H, int tiles_x, int tiles_y, bool inb, f32x4 &ox,
                                                     f32x4 &oy, const f32x4 &oc)
@@ -118,7 +118,9 @@ __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stag
         if (in_row && oc[j] != 0.0f) nz |= 1u << j;            // what stops a walk (my_lib_kernel.cu:1778-1797)
         if (in_row && oc[j] <= 0.0f) hole |= 1u << j;          // what pass 3 fills (:1757)
     }
-    if (!__syncthreads_or(hole != 0)) {
+    const bool any_hole = __syncthreads_or(hole != 0);
+    trace_mark_proj<TRACE>(6);                 // (timestamp instance: tools/probes/proj_pan_phases.py)
+    if (!any_hole) {
         // No hole: every cell of the tile inside the image has a positive count -- every walk that enters the tile stops at
         // its first cell.  The trivial summaries, no masks.
         if (tid < 64 && tx0 + tid < W) ws.up[((int64_t)b * tiles_y + ty) * W + tx0 + tid] = min(ty0 + TH - 1, H - 1);
@@ -128,6 +130,9 @@ __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stag
             ws.left[i] = min(tx0 + 63, W - 1);
         }
         if (tid == 0) ws.hole[tile_id] = 0;
+        trace_mark_proj<TRACE>(7);
+        trace_mark_proj<TRACE>(8);
+        trace_mark_proj<TRACE>(9);
         return;
     }
     // masks: the row's 64 bits (an OR over the 16 lanes of a row), the columns' TH bits (LDS); the holes' list
@@ -138,6 +143,8 @@ __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stag
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if ((nz >> j) & 1u) atomicOr(&fl.col[4 * q + j], 1u << r);
+    // (round 5: the column masks from four ballots, one conflict-free LDS atomic per wave instead of these four with four
+    // lanes on every word -- no difference in the phase's clocks, tools/probes/proj_pan_phases.py; left as it was)
     unsigned short *const hole_list = reinterpret_cast<unsigned short *>(stage + 3 * TH * 64);
     {   // one atomic per wave (a tile in an uncovered band is ALL holes: 64 lanes adding to one LDS word four times over)
         unsigned long long m[4];
@@ -165,6 +172,7 @@ __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stag
     *reinterpret_cast<f32x4 *>(stage + TH * 64 + r * 64 + 4 * q) = ox;
     *reinterpret_cast<f32x4 *>(stage + 2 * TH * 64 + r * 64 + 4 * q) = oy;
     __syncthreads();
+    trace_mark_proj<TRACE>(7);
     const int n = fl.n_holes;
     float *const sx = stage + TH * 64, *const sy = stage + 2 * TH * 64;
     for (int i = tid; i < n; i += NT) {
@@ -186,6 +194,7 @@ __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stag
         sy[cell] = vy;
     }
     __syncthreads();
+    trace_mark_proj<TRACE>(8);
     ox = *reinterpret_cast<const f32x4 *>(sx + r * 64 + 4 * q);     // the owners take their cells back
     oy = *reinterpret_cast<const f32x4 *>(sy + r * 64 + 4 * q);
     // summaries (what a walk from ANOTHER tile needs) and, for proj_fill_pending, the masks of a tile with pending holes
@@ -212,6 +221,7 @@ __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stag
         if (tid < 64) tm->col[tid] = fl.col[tid];
     }
     if (tid == 0) ws.hole[tile_id] = pending ? 2 : 1;
+    trace_mark_proj<TRACE>(9);
 }
 
 // Summaries and masks from the count plane, for the paths on which no owner kernel wrote them: the general path on its own
@@ -306,26 +316,53 @@ __device__ __forceinline__ void table_walks(TableWalk (&w)[3])
 // The pending holes of the flagged tiles (flag 2).  One WAVE per tile -- the pending lists are mostly short (the owner kernel
 // filled what it could), a tile's masks are 768 bytes, and a tile's chain of round trips (flag -> masks -> neighbours'
 // summaries, per row and column -> counts and values, four holes per lane at a time -> store) is what matters: how many
-// tiles are in flight.  Wave g of the launch looks after the tiles g, g + waves, ... (one flag per lane).  Wave-synchronous: the LDS of a
-// wave is touched by that wave only.
+// tiles are in flight.  Wave-synchronous from the list on: the LDS of a wave is touched by that wave only.
+// Which wave takes which tile (round 5): workgroup i reads the flags of the tiles i, i + grid, i + 2 grid, ... (one per
+// thread), lists the flagged ones in LDS, and its SIXTEEN waves draw from that list until it is empty; one workgroup per CU.
+// Before, wave g owned the tiles g and g + 8192 whether flagged or not: at this kernel's 120 VGPRs the chip holds 4096
+// waves, so the launch ran as two rounds, and a camera pan -- whose uncovered bands are runs of tiles with 1000+ pending
+// holes each, 15-20 us of dependent round trips per tile -- put such tiles in both rounds (55 us for the pan of 40 px, against
+// 14 us for the benchmark's flow).  Lists per workgroup of four waves made it one round but left the luck of the draw:
+// 1.35 heavy tiles per workgroup on average, six in the unluckiest, four waves to take them (41 us).  With sixteen waves
+// sharing one list the heavy tiles of a pan are 5-6 per workgroup, nearly evenly (the grid is coprime to the tiles per
+// row), and no wave takes two.
+constexpr int kFillWaves = 16;
 template <int TH>
-__global__ __launch_bounds__(256) void proj_fill_pending(
+__global__ __launch_bounds__(kFillWaves * kWave) void proj_fill_pending(
     int W, int H, int tiles_x, int tiles_y, int batch, int64_t s1b, int64_t s1c, int s1h, int64_t scb, int sch,
     const float *__restrict__ count, float *out, FillWs ws)
 {
-    __shared__ TileMasks<TH> tms[4];
-    __shared__ unsigned short lists[4][TH * 64];
-    __shared__ struct { int lr[kWave], up[kWave]; } edges[4];   // per wave: the walks' answers beyond the tile, per row side / column
+    constexpr unsigned kNT = kFillWaves * kWave;
+    __shared__ TileMasks<TH> tms[kFillWaves];
+    __shared__ unsigned short lists[kFillWaves][TH * 64];
+    __shared__ struct { int lr[kWave], up[kWave]; } edges[kFillWaves];   // per wave: the walks' answers beyond the tile, per row side / column
+    __shared__ unsigned flagged[kNT];
+    __shared__ int nflagged, next_flagged;
     const int wv = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     auto &edge = edges[wv];
     TileMasks<TH> &tm = tms[wv];
     unsigned short *hole_list = lists[wv];
     const unsigned ntiles = (unsigned)tiles_x * tiles_y * batch;
-    const unsigned nwaves = gridDim.x * 4u, gw = blockIdx.x * 4u + wv;
-    const unsigned mine = gw + (unsigned)lane * nwaves;
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(mine < ntiles && ws.hole[mine < ntiles ? mine : 0] == 2);
-    for (; todo; todo &= todo - 1) {
-        const unsigned tile = gw + (unsigned)__builtin_ctzll(todo) * nwaves;
+    for (unsigned span = 0; span < ntiles; span += kNT * gridDim.x) {         // (one span: up to 262144 tiles)
+    if (threadIdx.x == 0) nflagged = next_flagged = 0;
+    __syncthreads();
+    {
+        const unsigned mine = span + blockIdx.x + threadIdx.x * gridDim.x;
+        const bool is = mine < ntiles && ws.hole[mine < ntiles ? mine : 0] == 2;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(is);
+        int at = 0;
+        if (lane == 0 && m) at = atomicAdd(&nflagged, __builtin_popcountll(m));
+        at = __builtin_amdgcn_readfirstlane(at);
+        if (is) flagged[at + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = mine;
+    }
+    __syncthreads();
+    const int nfl = nflagged;
+    for (;;) {
+        int pick = 0;
+        if (lane == 0) pick = atomicAdd(&next_flagged, 1);
+        pick = __builtin_amdgcn_readfirstlane(pick);
+        if (pick >= nfl) break;
+        const unsigned tile = flagged[pick];
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / ((unsigned)tiles_x * tiles_y);
         const int tx0 = tx * 64, ty0 = ty * TH;
         const TileMasks<TH> *g = reinterpret_cast<const TileMasks<TH> *>(ws.masks) + tile;
@@ -394,7 +431,7 @@ __global__ __launch_bounds__(256) void proj_fill_pending(
         float *o = out + b * s1b;
         constexpr int kPer = 4;                                // holes per lane in flight: one round trip for their counts and values
         for (int i0 = 0; i0 < n; i0 += kPer * kWave) {
-            int gxs[kPer], gys[kPer];
+            int gxs[kPer], gys[kPer], found[kPer];
             bool live[kPer];
             float lt[kPer], rt[kPer], ut[kPer], vl[kPer][2], vr[kPer][2], vu[kPer][2], self[kPer][2];
 #pragma unroll
@@ -413,7 +450,12 @@ __global__ __launch_bounds__(256) void proj_fill_pending(
                 // still multiplies that cell's value by it -- keep the operand identical.  Counts and values are requested
                 // together (the values do not depend on the counts).
                 const int lc = lo >= 0 ? lo : 0, rc = ro >= 0 ? ro : W - 1, ur = uo >= 0 ? uo : 0;
-                const float cl = cn[(int64_t)gy * sch + lc], cr = cn[(int64_t)gy * sch + rc], cu = cn[(int64_t)ur * sch + gx];
+                // (NOTHING below may look at a loaded value before the last slot's requests are out: `lo >= 0 ? cl : 0` here
+                // made every slot wait for its counts -- one round trip per 64 holes, 35 of the kernel's 40 us under a pan)
+                lt[k] = cn[(int64_t)gy * sch + lc];
+                rt[k] = cn[(int64_t)gy * sch + rc];
+                ut[k] = cn[(int64_t)ur * sch + gx];
+                found[k] = (lo >= 0 ? 1 : 0) | (ro >= 0 ? 2 : 0) | (uo >= 0 ? 4 : 0);
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     const float *pl = o + c * s1c;
@@ -422,22 +464,23 @@ __global__ __launch_bounds__(256) void proj_fill_pending(
                     vu[k][c] = pl[(int64_t)ur * s1h + gx];
                     self[k][c] = pl[(int64_t)gy * s1h + gx];
                 }
-                // the counts the walks stopped at (0 when they ran into the image border)
-                lt[k] = lo >= 0 ? cl : 0.0f;
-                rt[k] = ro >= 0 ? cr : 0.0f;
-                ut[k] = uo >= 0 ? cu : 0.0f;
                 gxs[k] = gx;
                 gys[k] = gy;
             }
             // (reads touch cells with a non-zero count -- or times 0 --, writes cells with count <= 0: no ordering needed)
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
-                if (!live[k] || lt[k] + rt[k] + ut[k] + 0.0f <= 0.0f) continue;
+                if (!live[k]) continue;
+                // the counts the walks stopped at (0 when they ran into the image border)
+                const float l = (found[k] & 1) ? lt[k] : 0.0f, r = (found[k] & 2) ? rt[k] : 0.0f, u = (found[k] & 4) ? ut[k] : 0.0f;
+                if (l + r + u + 0.0f <= 0.0f) continue;
 #pragma unroll
                 for (int c = 0; c < 2; c++)
-                    o[c * s1c + (int64_t)gys[k] * s1h + gxs[k]] = fill_value(lt[k], rt[k], ut[k], vl[k][c], vr[k][c], vu[k][c], self[k][c]);
+                    o[c * s1c + (int64_t)gys[k] * s1h + gxs[k]] = fill_value(l, r, u, vl[k][c], vr[k][c], vu[k][c], self[k][c]);
             }
         }
         __builtin_amdgcn_wave_barrier();                       // the masks and the list are reused by the wave's next tile
+    }
+    __syncthreads();                                           // (the list is rebuilt by the next span)
     }
 }

@@ -389,8 +389,9 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
             oc[j] = v0;  ox[j] = v1;  oy[j] = v2;
         }
     }
+    trace_mark_proj<TRACE>(10);                // (box sums done)
     if (ws.up)                                 // pass 3 (hole filling) follows: fill what the tile can, summaries, masks
-        owner_fill_epilogue<TH, NT>(fl, reinterpret_cast<float *>(P), ws, tid, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, inb,
+        owner_fill_epilogue<TH, NT, TRACE>(fl, reinterpret_cast<float *>(P), ws, tid, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, inb,
                                     ox, oy, oc);
     if (inb) {                                 // single-use streams: nothing of this launch reads them back from cache
         if (RAG) {

@@ -492,12 +492,13 @@ def test_shapes_take_the_documented_kernel_paths():
                                    "bl_bwd": "bl_bwd:owner", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
     assert run(1, 5, 40, 128) == {"fi_fwd": "fi_fwd:tiled_c4n_ragged", "fi_bwd": "fi_bwd:owner", "bl_fwd": "bl_fwd:tiled_chunks",
                                   "bl_bwd": "bl_bwd:owner", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
-    # a width that is not a multiple of four: the scalar kernels for the gathers that were 2x slower there -- the scattering
-    # passes (13-41x slower in round 4) stay on their tiled kernels since round 5: the projection forward's owner kernels have
-    # a ragged-row instantiation, the RGB backward passes and the bilinear warp take the whole quads in the tiled kernel and
-    # the one to three columns behind them in the one-lane-per-site kernel
-    assert run(1, 3, 20, 50) == {"fi_fwd": "fi_fwd:direct", "fi_bwd": "fi_bwd:tiled_c3", "bl_fwd": "bl_fwd:tiled_c3",
-                                 "bl_bwd": "bl_bwd:tiled_c3", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:scalar"}
+    # a width that is not a multiple of four stays on the tiled kernels since round 5 (the scattering passes were 13-41x
+    # slower on the scalar ones in round 4, the gathers 2x): the projection forward's owner kernels have a ragged-row
+    # instantiation, every other operator takes the whole quads in its tiled kernel and the one to three columns behind
+    # them in the one-lane-per-site kernel (exception: FilterInterpolation forward with four channels or more)
+    assert run(1, 3, 20, 50) == {"fi_fwd": "fi_fwd:tiled_c3", "fi_bwd": "fi_bwd:tiled_c3", "bl_fwd": "bl_fwd:tiled_c3",
+                                 "bl_bwd": "bl_bwd:tiled_c3", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
+    assert run(1, 8, 20, 50)["fi_fwd"] == "fi_fwd:direct"
     assert run(1, 3, 20, 6)["proj_fwd"] == "proj_fwd:scalar"           # (narrower than two quads: scalar)
     assert run(1, 3, 20, 3) == {"fi_fwd": "fi_fwd:direct", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:direct",
                                 "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:scalar", "proj_bwd": "proj_bwd:scalar"}
@@ -918,6 +919,51 @@ def test_ragged_widths_on_the_tiled_backward_passes(oracle, W):
         close(N(v(g1)), w1, "Interpolation gradinput1 at width %d, %s" % (W, kind), RTOL)
         close(N(v(g2)), w2, "Interpolation gradinput2 at width %d, %s" % (W, kind), RTOL)
         for t in (out, g1, g2):
+            assert float((t[..., W:] - 7.0).abs().max()) == 0
+
+
+@pytest.mark.parametrize("W", [50, 133, 258, 1278])
+def test_ragged_widths_on_the_tiled_gathers(oracle, W):
+    """Round 5, second half: the two gathers that had kept their one-lane-per-site kernels at widths that are not multiples of
+    four (FilterInterpolation forward 2.4x, the projections' backward 1.8x slower at 1278 x 720) take the same split -- the
+    tiled kernel on the whole quads with the image's true width in every clamp and staged box, the scalar kernel on the one
+    to three columns behind them.  Against the oracle, smooth and i.i.d. flow, through views whose rows are longer than the
+    width: what lies behind a row stays untouched."""
+    import my_package._ext.my_lib as my_lib
+    rng = np.random.default_rng(1000 + W)
+    B, H = 2, 40 if W > 1000 else 70
+    pad = 3
+
+    def wide(a, fill):
+        t = torch.full((a.shape[0], a.shape[1], H, W + pad), fill, device=dev())
+        t[..., :W].copy_(T(a))
+        return t
+    v = lambda t: t[..., :W]                                                 # noqa: E731
+    for kind, sigma in (("smooth", 5.0), ("iid", 4.0)):
+        for C, path in ((3, "fi_fwd:tiled_c3"), (2, "fi_fwd:tiled_chunks"), (5, "fi_fwd:direct")):
+            xn, fn, kn = synth.np_image(rng, B, C, H, W), synth.np_flow(rng, B, H, W, kind, sigma), synth.np_filter(rng, B, H, W)
+            x, f, k, out = wide(xn, 9.0), wide(fn, 9.0), wide(kn, 9.0), wide(np.zeros_like(xn), 7.0)
+            assert my_lib.FilterInterpolationLayer_gpu_forward(v(x), v(f), v(k), v(out)) == 0
+            assert my_lib.last_kernel_path() == path
+            close(N(v(out)), oracle.filter_interpolation_forward(xn, fn, kn), "FI fwd, %d channels, width %d, %s" % (C, W, kind))
+            assert float((out[..., W:] - 7.0).abs().max()) == 0
+        # the projections' backward passes: the forward results from the oracle (so that only the backward is under test)
+        fn, dn, gn = synth.np_flow(rng, B, H, W, kind, sigma), synth.np_depth(rng, B, H, W), synth.np_flow(rng, B, H, W, "iid", 1.0)
+        won, wcn = oracle.flow_projection_forward(fn, 0)
+        f, cnt, g, gin = wide(fn, 9.0), wide(wcn, 9.0), wide(gn, 9.0), wide(np.zeros_like(fn), 7.0)
+        assert my_lib.FlowProjectionLayer_gpu_backward(v(f), v(cnt), v(g), v(gin)) == 0
+        assert my_lib.last_kernel_path() == "proj_bwd:tiled"
+        close(N(v(gin)), oracle.flow_projection_backward(fn, wcn, gn), "FlowProjection bwd at width %d, %s" % (W, kind), RTOL)
+        assert float((gin[..., W:] - 7.0).abs().max()) == 0
+        won, wcn = oracle.depth_flow_projection_forward(fn, dn, 0)
+        d, cnt, fo = wide(dn, 9.0), wide(wcn, 9.0), wide(won, 9.0)
+        gin, gd = wide(np.zeros_like(fn), 7.0), wide(np.zeros_like(dn), 7.0)
+        assert my_lib.DepthFlowProjectionLayer_gpu_backward(v(f), v(d), v(cnt), v(fo), v(g), v(gin), v(gd)) == 0
+        assert my_lib.last_kernel_path() == "dproj_bwd:tiled"
+        w1, w2 = oracle.depth_flow_projection_backward(fn, dn, wcn, won, gn)
+        close(N(v(gin)), w1, "DepthFlowProjection gradinput1 at width %d, %s" % (W, kind), RTOL)
+        close(N(v(gd)), w2, "DepthFlowProjection gradinput2 at width %d, %s" % (W, kind), RTOL)
+        for t in (gin, gd):
             assert float((t[..., W:] - 7.0).abs().max()) == 0
 
 

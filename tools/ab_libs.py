@@ -2,7 +2,7 @@
 """tools/ab_libs.py -- same-session A/B of two BUILDS of the library (box-to-box spread on the pool is +-3 %, more
 than most single changes are worth: two builds can only be compared inside one process on one GPU).
 
-    python tools/ab_libs.py <libA.so> <libB.so> [--op proj|proj_fill|depth_fill|fi_fwd|fi_bwd] [--rounds 6]
+    python tools/ab_libs.py <libA.so> <libB.so> [--op proj|proj_fill|depth_fill|fi_fwd|fi_bwd] [--rounds 6] [--pan 40] [--scale 2]
 
 Both libraries are loaded side by side (RTLD_LOCAL) and bound with my_package's own binder; launches alternate
 A, B, A, B ... in rounds, the median of each is printed."""
@@ -38,12 +38,18 @@ def main():
     ap.add_argument("--op", default="proj,proj_fill,depth_fill")
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--pan", type=float, default=0.0, help="camera pan (p, -p/2) px added to the benchmark's flow")
+    ap.add_argument("--scale", type=float, default=1.0, help="the benchmark's flow times this")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     libs = [Bound(os.path.abspath(p)) for p in a.libs]
     B, H, W = 32, 720, 1280
     t = synth.torch_inputs(dev, B, 3, H, W, flow_kind="smooth", with_depth=True, with_grad=True)
     x, f, k, g, d = t["x"], t["flow"], t["filt"], t["gout"], t["depth"]
+    if a.scale != 1.0 or a.pan != 0.0:
+        f = (f * a.scale).contiguous()
+        f[:, 0] += a.pan
+        f[:, 1] -= a.pan / 2
     cnt, out = f.new_zeros((B, 1, H, W)), torch.zeros_like(f)
     o3 = torch.zeros_like(x)
     g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
