@@ -98,12 +98,11 @@ const char *memc_hip_version(void);
  * "<operator>:<family>", e.g. "fi_fwd:tiled_c3", "proj_fwd:owner", "bl_bwd:direct"; "" before the first call.
  * Base pointers and strides may be anything (round 5: quads are accessed at dword alignment).  A WIDTH that is not a multiple of
  * four is served by the same families, from width 8 on: the (Depth)FlowProjection forward by ragged-row instantiations, the
- * FilterInterpolation forward (one to three channels) and RGB backward, the Interpolation forward / backward and the
- * (Depth)FlowProjection backward by the whole quads of every row on the tiled kernel and the one to three columns behind them
- * on the one-lane-per-site kernel (1.1-2.0x the aligned time at 1278 x 720, profiles/r05_slow_paths.txt); the
- * FilterInterpolation forward with four channels or more and the many-channel backward passes at such widths, widths below
- * 8 and FilterInterpolation with filter_size != 4 take scalar kernels -- same results, ~2x slower (the many-channel
- * backward more) -- whose family names are
+ * FilterInterpolation forward and RGB backward, the Interpolation forward / backward and the (Depth)FlowProjection backward
+ * by the whole quads of every row on the tiled kernel and the one to three columns behind them on the one-lane-per-site
+ * kernel (1.1-2.0x the aligned time at 1278 x 720, profiles/r05_slow_paths.txt); the many-channel backward passes at such
+ * widths, widths below 8 and FilterInterpolation with filter_size != 4 take scalar kernels -- same results, ~2x slower (the
+ * many-channel backward more) -- whose family names are
  *     "direct"  (FilterInterpolation / Interpolation: one lane per site, global gathers and atomics),
  *     "generic" (FilterInterpolation, filter_size != 4),
  *     "scalar"  ((Depth)FlowProjection forward / backward),

@@ -181,8 +181,11 @@ __device__ __forceinline__ void fi_fwd_chunk(
 // (1289 us; round 3, removed): it is not the barriers of the eight-wave workgroup, and not the box traffic, that bind.
 // RAGGED: any channel count >= 4 -- the last chunk re-reads the last plane for the channels it does not have and does not
 // store them (a separate instantiation: the C % 4 == 0 kernel, at 239 registers, is left exactly as it was).
-template <int SW, int NT = 256, bool RAGGED = false, int LX = 16, int ABL = 0>   // SW 0: one tile column per XCD strip; 2 / 4: stripes
-__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
+// RAGW: a ragged WIDTH (W % 4 != 0, round 5; instantiated together with RAGGED only) -- the whole quads of every row here, the
+// image's true width in every clamp and staged box (memc_tile.hpp), the columns behind them on fi_fwd_direct_fs4 (launcher);
+// one workgroup per CU (at two, the rotation of a row's last quad spills 32 B per lane).
+template <int SW, int NT = 256, bool RAGGED = false, int LX = 16, int ABL = 0, bool RAGW = false>   // SW 0: one tile column per XCD strip; 2 / 4: stripes
+__global__ __launch_bounds__(NT, (NT == 256 && !RAGW) ? 2 : 1) void fi_fwd_tiled_c4n(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
@@ -202,8 +205,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
     if (SW && tc.tx >= tiles_x) return;
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
     const int x = tile_x0 + 4 * (threadIdx.x % LX), y = tile_y0 + threadIdx.x / LX;
-    const bool inb = x < W && y < H;
-    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const int Ws = RAGW ? W & ~3 : W;
+    const bool inb = x < Ws && y < H;
+    const int xs = min(x, Ws - 4), ys = min(y, H - 1);
     const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
     const float *tap_p = filt + b * s3b + (int64_t)ys * s3h + xs;
     const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s2c);
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
     unsigned done = 0;
 #pragma unroll 1
     for (int bi = 0; bi < bands.n; bi++) {
-        const Region r = band_region(box, bands, bi);
+        const Region r = band_region(box, bands, bi, RAGW ? W : 0);
         const unsigned sel = inb ? fi_covered(r, g, W, H) & ~done : 0u;
         // later bands only run when somebody still needs them; the vote is also the barrier that frees the LDS
         if (bi > 0 && !__syncthreads_or(sel != 0)) continue;
@@ -251,13 +255,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void fi_fwd_tiled_c4n(
                     plane[c] = in_b + min(cb + c, C - 1) * s1c;
                     hs[c] = s1h;
                 }
-                tile_stage_load_planes<4>(r, sl, plane, hs, sr);
+                tile_stage_load_planes<4, RAGW>(r, sl, plane, hs, sr);
             }
         };
         stage_load(0);
 #pragma unroll 1
         for (int c0 = 0; c0 < C; c0 += 4) {
-            tile_stage_store<4>(r, sl, sr, tile);
+            tile_stage_store<4, RAGW>(r, sl, sr, tile);
             __syncthreads();
             // next chunk's rows: in flight while this chunk is gathered (the last iteration re-reads its own
             // chunk -- harmless, keeps the loads unconditional)
@@ -1248,15 +1252,14 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
         return launch_status();
     }
-    // A width that is not a multiple of four (round 5), one to three channels: the tiled kernel takes the whole quads
-    // (sites x < ws), the one-lane-per-site kernel the one to three columns behind them.  (Four channels and more at such a
-    // width stay on the one-lane-per-site kernel: the chunk pipeline of fi_fwd_tiled_c4n has no ragged-row instantiation.)
+    // A width that is not a multiple of four (round 5): the tiled kernel takes the whole quads (sites x < ws), the one-lane-
+    // per-site kernel the one to three columns behind them.
     const int ws = w & ~3;
-    if (filter_size == 4 && !vec && ws >= 8 && channel <= 3 MEMC_FI_FWD_NO_ARM) {
+    if (filter_size == 4 && !vec && ws >= 8 MEMC_FI_FWD_NO_ARM) {
         using G = TileGeom<16>;
         const int ntx = (ws + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
         const int tail_y = (h + 3) / 4;
-        MEMC_PATH(channel == 3 ? "fi_fwd:tiled_c3" : "fi_fwd:tiled_chunks");
+        MEMC_PATH(channel == 3 ? "fi_fwd:tiled_c3" : channel >= 4 ? "fi_fwd:tiled_c4n_ragged" : "fi_fwd:tiled_chunks");
 #define MEMC_FI_TILED_RAGW(CT)                                                                                  \
         hipLaunchKernelGGL((fi_fwd_tiled_fs4<16, CT, 2, 0, true>), dim3((unsigned)ntx * nty * batch), dim3(256),    \
                            tile_lds_bytes<16>(), stream, w, h, channel, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h,   \
@@ -1265,7 +1268,15 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
         hipLaunchKernelGGL((fi_fwd_direct_fs4<CT, 4>), dim3((unsigned)tail_y * batch), dim3(256), 0, stream, w, h,  \
                            channel, 1, tail_y, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,     \
                            (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output, ws)
-        if (channel == 3) {
+        if (channel >= 4) {                    // the chunk pipeline's any-channel-count instantiation, ragged rows
+            using G4 = TileGeom<16, 3072, 256>;
+            const int lds = G4::kCapPx * 16 + 4 * 4 * (256 / 64);
+            allow_big_lds(fi_fwd_tiled_c4n<0, 256, true, 16, 0, true>, lds);
+            hipLaunchKernelGGL((fi_fwd_tiled_c4n<0, 256, true, 16, 0, true>), dim3((unsigned)ntx * nty * batch), dim3(256), lds,
+                               stream, w, h, channel, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                               (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
+            MEMC_FI_TAIL(0);
+        } else if (channel == 3) {
             MEMC_FI_TILED_RAGW(3);
             MEMC_FI_TAIL(3);
         } else {

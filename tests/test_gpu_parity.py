@@ -495,10 +495,11 @@ def test_shapes_take_the_documented_kernel_paths():
     # a width that is not a multiple of four stays on the tiled kernels since round 5 (the scattering passes were 13-41x
     # slower on the scalar ones in round 4, the gathers 2x): the projection forward's owner kernels have a ragged-row
     # instantiation, every other operator takes the whole quads in its tiled kernel and the one to three columns behind
-    # them in the one-lane-per-site kernel (exception: FilterInterpolation forward with four channels or more)
+    # them in the one-lane-per-site kernel (exception: the many-channel backward passes)
     assert run(1, 3, 20, 50) == {"fi_fwd": "fi_fwd:tiled_c3", "fi_bwd": "fi_bwd:tiled_c3", "bl_fwd": "bl_fwd:tiled_c3",
                                  "bl_bwd": "bl_bwd:tiled_c3", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
-    assert run(1, 8, 20, 50)["fi_fwd"] == "fi_fwd:direct"
+    got = run(1, 8, 20, 50)
+    assert got["fi_fwd"] == "fi_fwd:tiled_c4n_ragged" and got["fi_bwd"] == "fi_bwd:direct"
     assert run(1, 3, 20, 6)["proj_fwd"] == "proj_fwd:scalar"           # (narrower than two quads: scalar)
     assert run(1, 3, 20, 3) == {"fi_fwd": "fi_fwd:direct", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:direct",
                                 "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:scalar", "proj_bwd": "proj_bwd:scalar"}
@@ -925,7 +926,8 @@ def test_ragged_widths_on_the_tiled_backward_passes(oracle, W):
 @pytest.mark.parametrize("W", [50, 133, 258, 1278])
 def test_ragged_widths_on_the_tiled_gathers(oracle, W):
     """Round 5, second half: the two gathers that had kept their one-lane-per-site kernels at widths that are not multiples of
-    four (FilterInterpolation forward 2.4x, the projections' backward 1.8x slower at 1278 x 720) take the same split -- the
+    four (FilterInterpolation forward 2.4x, the projections' backward 1.8x slower at 1278 x 720) take the same split (the
+    forward at any channel count: RGB kernel, chunk loop, chunk pipeline) -- the
     tiled kernel on the whole quads with the image's true width in every clamp and staged box, the scalar kernel on the one
     to three columns behind them.  Against the oracle, smooth and i.i.d. flow, through views whose rows are longer than the
     width: what lies behind a row stays untouched."""
@@ -940,7 +942,7 @@ def test_ragged_widths_on_the_tiled_gathers(oracle, W):
         return t
     v = lambda t: t[..., :W]                                                 # noqa: E731
     for kind, sigma in (("smooth", 5.0), ("iid", 4.0)):
-        for C, path in ((3, "fi_fwd:tiled_c3"), (2, "fi_fwd:tiled_chunks"), (5, "fi_fwd:direct")):
+        for C, path in ((3, "fi_fwd:tiled_c3"), (2, "fi_fwd:tiled_chunks"), (5, "fi_fwd:tiled_c4n_ragged"), (8, "fi_fwd:tiled_c4n_ragged")):
             xn, fn, kn = synth.np_image(rng, B, C, H, W), synth.np_flow(rng, B, H, W, kind, sigma), synth.np_filter(rng, B, H, W)
             x, f, k, out = wide(xn, 9.0), wide(fn, 9.0), wide(kn, 9.0), wide(np.zeros_like(xn), 7.0)
             assert my_lib.FilterInterpolationLayer_gpu_forward(v(x), v(f), v(k), v(out)) == 0
