@@ -21,7 +21,7 @@
 //
 // Round 5: the scan region is SHIFTED by the image's dominant motion m (a camera pan).  A source s lands at s + f; the
 // sources that land in the tile T are those around T - m, so T scans [T - m] dilated by kReach, and "far" means
-// |f - m| >= kReach on an axis.  m is the mean flow of 64 fixed sites of the image, rounded to multiples of 4 px -- every
+// |f - m| >= kReach on an axis.  m is the mean flow of 64 fixed sites of the image, rounded to multiples of 4 px (0 below 6 px) -- every
 // workgroup (and proj_owner_far) computes the same value from the same loads in the same order.  Exactness: (i) every valid
 // source with |f - m| < kReach on both axes lies inside the scan region of the tile that owns its point (s = p - f with p in
 // the window: the argument of the unshifted scan with f - m in place of f), and the hit test asks for the window only;
