@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--pan", type=float, default=0.0, help="camera pan (p, -p/2) px added to the benchmark's flow")
     ap.add_argument("--scale", type=float, default=1.0, help="the benchmark's flow times this")
+    ap.add_argument("--prezero", action="store_true", help="zero-fill the projection's outputs in front of every timed call, outside "
+                    "the timed span (what a caller that follows the reference's contract does: FlowProjectionLayer.py:27-28)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     libs = [Bound(os.path.abspath(p)) for p in a.libs]
@@ -81,6 +83,8 @@ def main():
                 for _ in range(a.iters):
                     if op in ("fi_bwd", "interp_bwd"):
                         g1.zero_()
+                    if a.prezero and op in ("proj", "proj_fill", "depth_fill"):
+                        cnt.zero_(); out.zero_()
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(); fn(l); e1.record(); e1.synchronize()
                     ts[i].append(e0.elapsed_time(e1) * 1e3)
