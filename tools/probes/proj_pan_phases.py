@@ -32,9 +32,10 @@ MARKS = [(1, "issue scan loads + zero P"), (2, "barrier + wait for the loads"), 
          (7, "fill: masks + hole list + stage (barrier)"), (8, "fill: walks in the tile (barrier)"),
          (9, "fill: read back, summaries, masks"), (5, "store")]
 FILL_SLOTS = (6, 7, 8, 9)
-for pan in (0.0, 40.0):
+CASES = [(1.0, 0.0), (1.0, 40.0)] if len(sys.argv) < 2 else [(float(a.split(":")[0]), float(a.split(":")[1])) for a in sys.argv[1:]]
+for scale, pan in CASES:                       # (argv: scale:pan pairs, e.g. 1:0 2:0 1:40)
     for fill in (0, 1):
-        f = f0.clone()
+        f = f0 * scale
         f[:, 0] += pan
         f[:, 1] -= pan / 2
         fn = lambda: L.FlowProjectionLayer_gpu_forward(f, cnt, out, fill)      # noqa: E731
@@ -48,7 +49,7 @@ for pan in (0.0, 40.0):
         M.set_variant("projection", -1)
         ts = buf.cpu().numpy().reshape(ntiles, 16).astype(np.int64)
         ts = ts[ts[:, 5] > 0]
-        print("pan %g px, fillhole %d: %d workgroups; clocks per phase: mean | p50 | p90 | p99 | max" % (pan, fill, len(ts)))
+        print("flow x %g, pan %g px, fillhole %d: %d workgroups; clocks per phase: mean | p50 | p90 | p99 | max" % (scale, pan, fill, len(ts)))
         prev = 0
         for slot, nm in MARKS:
             if slot in FILL_SLOTS and not fill:
