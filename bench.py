@@ -92,25 +92,77 @@ def barrier_sync(world, device):
         torch.cuda.synchronize(device)
 
 
-def timed_steps(step_fn, steps, warmup, world, device):
-    """`warmup` untimed steps, then exactly `steps` steps bracketed by barrier + synchronize on both sides.
-    Returns (max-over-ranks wall seconds, local wall seconds)."""
+def _drain(device, last_event=None):
+    """The closing synchronize of a window.  On a GPU the host first spins on the window's last event (a
+    hipEventQuery loop sees completion within a microsecond or two; hipDeviceSynchronize alone may yield the core first),
+    then calls torch.cuda.synchronize -- which is what the contract asks for and returns at once by then."""
     import torch
-    for _ in range(warmup):
-        step_fn(None)
-    barrier_sync(world, device)
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step_fn(i)
-    barrier_sync(world, device)
-    local = time.perf_counter() - t0
-    worst = local
+    if device.type == "cuda":
+        if last_event is not None:
+            while not last_event.query():
+                pass
+        torch.cuda.synchronize(device)
+
+
+def timed_windows(window_fn, windows, world, device):
+    """`windows` repetitions of ONE timed window.  A window is: barrier + synchronize (every rank starts together, outside
+    the clock), t0, `window_fn(r)` (enqueues exactly K steps and returns the event that closes them, or None), this
+    rank's own synchronize, t1.  Nothing collective sits inside [t0, t1]: the ranks never talk on the data path, so a
+    rank's window is over when ITS device is idle -- a closing dist.barrier() inside the clock would add the
+    collective's latency (and, at the driver's 20 steps of a 66 us shard, 10-20 % of the window) to every rank's time.
+    The max over ranks is taken AFTER the last window, in one all_reduce(MAX) over the vector of local window times.
+    Returns (per-window max-over-ranks seconds, this rank's per-window seconds)."""
+    import torch
+    local = []
+    for r in range(windows):
+        barrier_sync(world, device)
+        t0 = time.perf_counter()
+        last = window_fn(r)
+        _drain(device, last)
+        local.append(time.perf_counter() - t0)
+    worst = list(local)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([local], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        worst = float(t.item())
+        t = torch.tensor(local, dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the closing collective: outside every window
+        worst = [float(v) for v in t.tolist()]
     return worst, local
+
+
+def median(values):
+    v = sorted(values)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
+def timed_steps(step_fn, steps, warmup, world, device, windows=1):
+    """`warmup` untimed steps, then `windows` windows of exactly `steps` steps each (timed_windows); step_fn gets the step
+    index inside a window, None while warming up.  Returns (median over windows of the max-over-ranks wall seconds of
+    one window, this rank's median)."""
+    for _ in range(warmup):
+        step_fn(None)
+
+    def window(_r):
+        for i in range(steps):
+            step_fn(i)
+        return None
+    worst, local = timed_windows(window, windows, world, device)
+    return median(worst), median(local)
+
+
+def barrier_cost_us(world, device, reps=9):
+    """Evidence only: what one empty dist.barrier() costs on this job (median of `reps`), i.e. what every window would
+    carry if the barrier were inside the clock."""
+    if world == 1:
+        return None
+    import torch.distributed as dist
+    barrier_sync(world, device)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dist.barrier()
+        ts.append(time.perf_counter() - t0)
+    return round(median(ts) * 1e6, 1)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -307,6 +359,8 @@ def secondary_rows(my_lib, synth, torch, device, seed):
         torch, device), "gradinput1 = NULL (extension): what a training step of the reference's networks needs")
     del g1, g2, g3
     # config 3: FlowProjection / DepthFlowProjection scatter, 1280 x 720, batch 32 (same flow; + depth)
+    from my_package.modules.FlowProjectionModule import FlowProjectionModule
+    from my_package.modules.DepthFlowProjectionModule import DepthFlowProjectionModule
     f = t["flow"]
     del t
     dep = torch.rand((32, 1, 720, 1280), device=device) + 0.1
@@ -319,10 +373,18 @@ def secondary_rows(my_lib, synth, torch, device, seed):
         call = lambda: my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, fill)      # noqa: E731
         row(name, "proj_fwd", 0, sites, _avg_launch_s(call, torch, device, burst=4), timing="burst 4")
         rows[name]["single_call_us"] = round(_avg_launch_s(call, torch, device, warm=4, warm_seconds=0.0) * 1e6, 2)
+        # ... and as the package runs it (my_package.modules.FlowProjectionModule: torch.empty outputs, a torch.empty
+        # workspace, the `_ws` entry point, no block kept by the library), same bursts
+        layer = FlowProjectionModule(requires_grad=(fill == 0))
+        with torch.no_grad():
+            rows[name]["layer_call_us"] = round(_avg_launch_s(lambda: layer(f), torch, device, burst=4) * 1e6, 2)
     name = "config3_depth_flow_projection_fwd_fillhole1_32x720x1280"
     call = lambda: my_lib.DepthFlowProjectionLayer_gpu_forward(f, dep, cnt, po, 1)   # noqa: E731
     row(name, "depth_proj_fwd", 0, sites, _avg_launch_s(call, torch, device, burst=4), timing="burst 4")
     rows[name]["single_call_us"] = round(_avg_launch_s(call, torch, device, warm=4, warm_seconds=0.0) * 1e6, 2)
+    dlayer = DepthFlowProjectionModule(requires_grad=False)
+    with torch.no_grad():
+        rows[name]["layer_call_us"] = round(_avg_launch_s(lambda: dlayer(f, dep), torch, device, burst=4) * 1e6, 2)
     # ... and under LARGE motion (not a BASELINE config; sources that move 24 px or more take proj_owner_far):
     # the same flow twice as large (fast objects: a few per cent of the tiles are recomputed) and under a camera pan of
     # (40, -20) px (every source far, every tile recomputed, an uncovered band of holes along two edges)
@@ -367,11 +429,64 @@ def secondary_rows(my_lib, synth, torch, device, seed):
     return rows
 
 
+def config4_row(my_lib, torch, device, seed, pairs=4, height=720, width=1280, warm=2, steps=3):
+    """BASELINE config 4 as one GPU of the 8-GPU job sees it: MEMC_Net_star inference (random weights, seeded) on its shard
+    of 32 / 8 = 4 frame pairs of 1280 x 720, through networks/inference.py (pad to multiples of 128 the way
+    demo_HD720p.py:88-118 does, network MEMC_Net_star.py:78-150, crop) on the HIP operators.  One untimed pass first (MIOpen
+    picks its convolution solvers on first use), then `warm` warm-up and `steps` timed steps; hot_path_* are HIP-event spans
+    around the operator entry points in one more pass (tools/bench_model.py).  The dense layers are stock torch.nn on
+    MIOpen / rocBLAS: they are the reference's, not this repository's, and they are 99 % of the step."""
+    import networks
+    from tools.bench_model import instrumented_pass
+    t_setup = time.perf_counter()
+    torch.manual_seed(seed)
+    with torch.device(device):
+        net = networks.MEMC_Net_star(channel=3, filter_size=4, training=False)
+    net = net.to(device).eval()
+    g = torch.Generator(device=device).manual_seed(seed + 99)
+    frames = torch.rand((2, pairs, 3, height, width), device=device, generator=g)
+
+    def one_step():
+        return networks.interpolate_pairs(net, frames[0], frames[1])
+    with torch.no_grad():
+        first = one_step()                               # MIOpen warm-up
+        torch.cuda.synchronize(device)
+        setup_s = time.perf_counter() - t_setup
+        for _ in range(warm):
+            one_step()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for a0, a1 in ev:
+            a0.record()
+            out = one_step()
+            a1.record()
+        torch.cuda.synchronize(device)
+        wall = time.perf_counter() - t0
+        per_op, n_calls, pass_ms = instrumented_pass(my_lib, torch, device, one_step)
+    step_ms = sum(a0.elapsed_time(a1) for a0, a1 in ev) / steps
+    hot_ms = sum(per_op.values())
+    finite = bool(torch.isfinite(out).all()) and tuple(out.shape) == (pairs, 3, height, width)
+    row = {"frames_per_s": round(pairs * steps / wall, 3), "ms_per_step": round(wall / steps * 1e3, 2),
+           "gpu_ms_per_step": round(step_ms, 2), "pairs_per_step": pairs, "steps": steps, "warmup": warm,
+           "hot_path_ms": round(hot_ms, 3), "hot_path_share": round(hot_ms / pass_ms, 4), "hot_path_calls": n_calls,
+           "hot_path_ops_ms": {k: round(v, 3) for k, v in sorted(per_op.items())},
+           "instrumented_pass_ms": round(pass_ms, 2), "setup_s": round(setup_s, 2), "output_finite": finite,
+           "repeatable": bool(torch.equal(first, out)),
+           "note": "one GPU's shard (32 pairs / 8 GPUs) of config 4; random weights; dense layers = stock torch.nn (MIOpen), "
+                   "hot path = this repository's HIP operators; frames_per_s counts interpolated frames"}
+    del net, frames, out, first
+    torch.cuda.empty_cache()
+    return row
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--windows", type=int, default=7,
+                    help="repetitions of the K-step timed window; `value` is the MEDIAN window (max over ranks per window)")
     ap.add_argument("--prewarm", type=int, default=200,
                     help="untimed launches before the warm-up steps: the device needs ~100 launches (60 ms) to "
                          "reach its steady clocks (tools/timeline.py); never part of the timed region")
@@ -420,7 +535,7 @@ def main(argv=None):
 
     cfg = broadcast_config({"batch": args.batch, "height": args.height, "width": args.width,
                             "channels": args.channels, "seed": 1234, "steps": args.steps,
-                            "warmup": args.warmup}, world, device)
+                            "warmup": args.warmup, "windows": max(1, args.windows)}, world, device)
     C, H, W, fs = cfg["channels"], cfg["height"], cfg["width"], 4
     plan = shard_plan(rank, world, cfg["batch"], cfg["seed"], args.scaling)
     B = plan["items"]                           # this rank's shard
@@ -434,60 +549,73 @@ def main(argv=None):
         t = synth.torch_inputs(device, B, C, H, W, fs=fs, flow_kind=args.flow, seed=plan["seed"] + 7919 * k)
         sets.append((t["x"], t["flow"], t["filt"], torch.zeros_like(t["x"])))   # caller-allocated, caller-zeroed output
     x, flow, filt, out = sets[0]
-    steps, warmup = cfg["steps"], cfg["warmup"]
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    steps, warmup, windows = cfg["steps"], cfg["warmup"], cfg["windows"]
+    w0 = [torch.cuda.Event(enable_timing=True) for _ in range(windows)]       # bracket each window on the launch stream
+    w1 = [torch.cuda.Event(enable_timing=True) for _ in range(windows)]
     counter = [0]
 
-    def step(i):
-        # one pass of the hot path over the batch; events sit on the stream the kernel is launched on
+    def step(ev=None):
+        # one pass of the hot path over the batch; events (instrumented pass only) sit on the stream the kernel is launched on
         xi, fi, ki, oi = sets[counter[0] % nsets]
         counter[0] += 1
-        if i is not None:
-            starts[i].record()
+        if ev is not None:
+            ev[0].record()
         err = my_lib.FilterInterpolationLayer_gpu_forward(xi, fi, ki, oi)
-        if i is not None:
-            stops[i].record()
+        if ev is not None:
+            ev[1].record()
         if err != 0:
             raise RuntimeError("FilterInterpolationLayer_gpu_forward returned %d" % err)
 
     use_graph = args.launch == "graph" or (args.launch == "auto" and sites_per_launch < 8_000_000)
     for _ in range(args.prewarm):
-        step(None)
+        step()
     if use_graph:
-        # the K timed steps as ONE graph of K kernel nodes on a side stream; HIP events bracket the replay on that
-        # stream (an event inside a captured graph cannot be timed), so the per-launch duration below includes the
-        # ~1.5 us boundary between two dependent kernels
+        # the K steps of a window as ONE graph of K kernel nodes on a side stream, replayed once per window; HIP events
+        # bracket the replay on that stream (an event inside a captured graph cannot be timed), so the per-launch
+        # duration below includes the ~1.5 us boundary between two dependent kernels
         side = torch.cuda.Stream(device)
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(device)
         with torch.cuda.graph(graph, stream=side):
             for _ in range(steps):
-                step(None)
-        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                step()
         for _ in range(warmup):
-            step(None)
+            step()
         with torch.cuda.stream(side):
             graph.replay()                      # one untimed replay (first replay uploads the graph)
-        barrier_sync(world, device)
-        t0 = time.perf_counter()
-        with torch.cuda.stream(side):
-            g0.record()
-            graph.replay()
-            g1.record()
-        barrier_sync(world, device)
-        local = time.perf_counter() - t0
-        worst = local
-        if world > 1:
-            import torch.distributed as dist
-            tt = torch.tensor([local], dtype=torch.float64, device=device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            worst = float(tt.item())
-        avg_kernel_s = g0.elapsed_time(g1) / steps / 1e3
+
+        def window(r):
+            with torch.cuda.stream(side):
+                w0[r].record()
+                graph.replay()
+                w1[r].record()
+            return w1[r]
     else:
-        worst, local = timed_steps(step, steps, warmup, world, device)
-        kernel_ms = [a.elapsed_time(b) for a, b in zip(starts, stops)]
-        avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+        for _ in range(warmup):
+            step()
+
+        def window(r):
+            # K launches and nothing else between the two clock readings: the per-launch events of rounds 1-5 cost
+            # 6-10 us of stream time per step (BENCH_r05: 524.6 us per step around 514.2 us kernels) and now live in
+            # the instrumented pass below, outside the clock
+            w0[r].record()
+            for _ in range(steps):
+                step()
+            w1[r].record()
+            return w1[r]
+    worst_w, local_w = timed_windows(window, windows, world, device)
+    worst, local = median(worst_w), median(local_w)
+    window_gpu_s = median([a.elapsed_time(b) for a, b in zip(w0, w1)]) / 1e3     # K steps on the stream, HIP events
+    if use_graph:
+        avg_kernel_s = window_gpu_s / steps
+    else:
+        # the dominant kernel's own duration: one more pass of the same K launches with a HIP event pair around each
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for e in ev:
+            step(e)
+        torch.cuda.synchronize(device)
+        avg_kernel_s = sum(a.elapsed_time(b) for a, b in ev) / steps / 1e3
+    barrier_us = barrier_cost_us(world, device)
     achieved = alg_bytes / avg_kernel_s                                 # B/s, this rank's dominant kernel
     total_sites = plan["global_batch"] * H * W                          # all ranks' sites per step
     value = total_sites * steps / worst / 1e6
@@ -496,7 +624,8 @@ def main(argv=None):
         # what the collective layer actually saw (evidence fields; nothing here is on the data path)
         import torch.distributed as dist
         gdev = device if dist.get_backend() == "nccl" else torch.device("cpu")      # gloo gathers host tensors only
-        mine = torch.tensor([local / steps * 1e3, avg_kernel_s * 1e6, float(B)], dtype=torch.float64, device=gdev)
+        mine = torch.tensor([local / steps * 1e3, avg_kernel_s * 1e6, float(B), window_gpu_s / steps * 1e6],
+                            dtype=torch.float64, device=gdev)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         rows = [g.tolist() for g in gathered]
@@ -504,8 +633,13 @@ def main(argv=None):
                      "per_rank_ms_per_step": [round(r[0], 4) for r in rows],
                      "per_rank_avg_launch_us": [round(r[1], 2) for r in rows],
                      "per_rank_items": [int(r[2]) for r in rows],
-                     "collectives": "1 broadcast of 7 int64 (configuration), 2 barriers, 1 max all-reduce of one double "
-                                    "(time), 1 all-gather of 3 doubles (this record); none between the two barriers"}
+                     "per_rank_window_gpu_us_per_step": [round(r[3], 2) for r in rows],
+                     "barrier_us": barrier_us,
+                     "worst_window_ms": [round(w * 1e3, 4) for w in worst_w],
+                     "collectives": "1 broadcast of 8 int64 (configuration); per window 1 barrier BEFORE the clock starts and "
+                                    "none before it stops (each rank stops its clock on its own synchronize); after the last "
+                                    "window 1 max all-reduce of %d doubles (the window times), %d timed empty barriers "
+                                    "(barrier_us), 1 all-gather of 4 doubles (this record)" % (windows, 9)}
         if dist.get_backend() == "nccl":
             try:
                 dist_seen["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -536,6 +670,10 @@ def main(argv=None):
                 secondary["rows"] = secondary_rows(my_lib, synth, torch, device, plan["seed"])
             except Exception as exc:            # noqa: BLE001 -- rows outside the timed region must not cost the headline its line
                 secondary["rows"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            try:
+                secondary["rows"]["config4_memc_net_star_4x1280x720"] = config4_row(my_lib, torch, device, plan["seed"])
+            except Exception as exc:            # noqa: BLE001
+                secondary["rows"]["config4_memc_net_star_4x1280x720"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     if rank == 0:
         workload = "FilterInterpolation fwd fs=4 C=%d batch=%d %dx%d fp32 flow=%s" % (C, cfg["batch"], W, H, args.flow)
@@ -548,6 +686,11 @@ def main(argv=None):
             "data": "synthetic" if not args.share_gpu else "synthetic; PLUMBING TEST (ranks share a GPU), not a measurement",
             "config": {"workload": workload, "batch_per_gpu": B, "global_batch": plan["global_batch"],
                        "prewarm_launches": args.prewarm, "launch": "hip_graph" if use_graph else "eager",
+                       "windows": windows, "window": "median of %d windows of %d steps; clock: barrier + synchronize | t0 | "
+                                                     "%d steps | this rank's synchronize | t1; max over ranks per window" % (
+                                                         windows, steps, steps),
+                       "window_ms_min_max": [round(min(worst_w) * 1e3, 4), round(max(worst_w) * 1e3, 4)],
+                       "window_gpu_us_per_step": round(window_gpu_s / steps * 1e6, 2),
                        "input_sets": nsets,
                        "sharding": "independent frame pairs, contiguous shards per rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9,

@@ -154,7 +154,17 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     // point (py, px) -> byte offset 8 (py * pitch + px - cell0) into a plane (the constants pinned in SGPRs: rematerialised at every use
     // they cost the scalar pipe, which is as busy as the vector one here, two or three moves per source)
     unsigned pitch8 = 8 * kPtW4, ucell8 = (unsigned)-(8 * ((ty0 - 1) * kPtW4 + (tx0 - 1)));
-    double kunit = kCountUnit;
+    // The packed plane holds count * 2^20 + sum(mx - fx): the RESIDUAL of the image's motion, not -fx itself.  A source
+    // that is not far has |fx - mx| < kReach whatever the pan, so |sum w S| < 2^19 holds under any shift (with -fx in the
+    // plane a 47 x 24 block converging on a corner cell under a 216 px pan summed to 975 k and the split came out one count
+    // off -- round-5 review).  One source adds (2^20 + mx) - fx: the same two instructions as before, mx folded into the
+    // unit (exact: an integer below 2^13 on 2^20); the readout takes cnt * (2^20 + mx) off again.
+    // (built from integers -- scalar instructions; a conversion and an add would be vector ones.  n = 2^20 + mx lies in
+    // (2^19, 2^21): a double with exponent 20 or 19 and the integer's low bits at the top of its mantissa)
+    const unsigned kunit_n = (unsigned)(1048576 + mx);
+    const unsigned kunit_hi = kunit_n >= 1048576u ? (1043u << 20) | (kunit_n - 1048576u)        // 2^20 (1 + (n - 2^20) / 2^20)
+                                                  : (1042u << 20) | ((kunit_n - 524288u) << 1);  // 2^19 (1 + (n - 2^19) / 2^19)
+    double kunit = __longlong_as_double((long long)((unsigned long long)kunit_hi << 32));
     asm volatile("" : "+s"(pitch8), "+s"(ucell8), "+s"(kunit));
     bool far = false;
     unsigned long long near_seen = 0;             // (scalar) home quads of this wave that hold a source that is not far
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
                     lds_add_f64(q, (double)(d * 1.0f));
                     lds_add_f64(q + kPlane, -(double)(d * fxv));
                     lds_add_f64(q + 2 * kPlane, -(double)(d * fyv));
-                } else {                       // one source: count += 1, sum(vx) += -fx
+                } else {                       // one source: count += 1, sum(vx - mx) += mx - fx
                     lds_add_f64(q, kunit - (double)fxv);
                     lds_add_f64(q + kPlane, -(double)fyv);
                 }
@@ -334,8 +344,10 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
 
     // Every lane owns four cells of a row: 2x2 box sums of the points of columns c-1 .. c+3, rows cy-1 and cy (border
     // duplicates as weights 2, see proj_scatter_tiled), summed in DOUBLE -- exact, also for the packed plane:
-    // sum_i w_i (count_i 2^20 + S_i) = (sum w count) 2^20 + sum w S with |sum w S| < 2^19 (at most 2500 sources reach a
-    // 2x2 block, weights <= 4, |v| < kReach) -- then split and rounded to fp32 ONCE per cell.
+    // sum_i w_i (count_i 2^20 + S_i) = (sum w count) 2^20 + sum w S with |sum w S| < 2^19 -- S the residual mx - fx: at most
+    // 2401 sources that are not far reach a point, weights <= 4, |mx - fx| < kReach: 230 k; the tile's OWN far sources (m = 0
+    // only: a tile is not stamped for those) add at most 4 * 32 * (1 + ... + 64) = 266 k -- then split and rounded to fp32
+    // ONCE per cell.
     const int cx = tx0 + 4 * (tid % 16), cy = ty0 + tid / 16;
     const bool inb = cx < W && cy < H;            // (no early exit: the epilogue below has barriers)
     const double wy0 = (cy == H - 1) ? 2.0 : 1.0;
@@ -372,10 +384,10 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
             float v0, v1, v2;
             if (DEPTH) {
                 v0 = (float)box[0][j];  v1 = (float)box[1][j];  v2 = (float)box[NP - 1][j];
-            } else {                           // A = count * 2^20 + sum(vx): split exactly
+            } else {                           // A = count * 2^20 + sum(mx - fx): split exactly, the motion taken off again
                 const double cnt = __builtin_rint(box[0][j] * (1.0 / kCountUnit));
                 v0 = (float)cnt;
-                v1 = (float)__builtin_fma(cnt, -kCountUnit, box[0][j]);
+                v1 = (float)__builtin_fma(cnt, -kunit, box[0][j]);
                 v2 = (float)box[1][j];
             }
             if (v0 > 0.0f) {                   // my_lib_kernel.cu:1730-1735; one reciprocal for both components

@@ -68,6 +68,76 @@ def test_two_rank_orchestration():
     assert worst0 >= max(local0, local1) - 1e-9 and worst0 >= 4 * 0.05
 
 
+def _window_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import time
+    import torch
+    import torch.distributed as dist
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    if rank == 1:
+        # rank 1 is late into EVERY collective by 50 ms: a collective inside the clock would put those 50 ms into
+        # rank 0's window (it waits for rank 1 there)
+        real_barrier, real_all_reduce = dist.barrier, dist.all_reduce
+
+        def late_barrier(*a, **k):
+            time.sleep(0.05)
+            return real_barrier(*a, **k)
+
+        def late_all_reduce(*a, **k):
+            time.sleep(0.05)
+            return real_all_reduce(*a, **k)
+        dist.barrier, dist.all_reduce = late_barrier, late_all_reduce
+    order = []
+
+    def window(r):
+        order.append(("window", r))
+        time.sleep(0.010 if rank == 0 else 0.020)        # the window's own work; rank 1 is the slow one
+        return None
+    worst, local = bench.timed_windows(window, 5, world, dev)
+    cost = bench.barrier_cost_us(world, dev, reps=3)
+    dist.destroy_process_group()
+    q.put((rank, worst, local, order, cost))
+
+
+def test_closing_collective_is_outside_the_timed_window():
+    """a window ends on the rank's own synchronize; the max over ranks is taken afterwards.  Rank 1
+    enters every collective 50 ms late -- none of that may appear in any window time, on either rank."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_window_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, worst0, local0, order0, cost0), (_, worst1, local1, order1, cost1) = res
+    assert order0 == order1 == [("window", r) for r in range(5)]
+    assert worst0 == worst1 and len(worst0) == 5                       # one max-over-ranks time per window, same on both
+    for w, l0, l1 in zip(worst0, local0, local1):
+        assert w == max(l0, l1)
+        assert 0.020 <= w < 0.045, (w, "a 50 ms collective delay leaked into the window")
+        assert 0.010 <= l0 < 0.035                                       # rank 0 never waited for rank 1 inside its clock
+    assert sorted(worst0)[2] < 0.045
+    assert cost0 is not None and cost0 > 0                             # barrier_us: evidence field, outside the windows
+
+
+def test_median_and_windowed_steps_single_rank():
+    sys.path.insert(0, ROOT)
+    import torch
+    import bench
+    assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0, 2.0, 3.0]) == 2.5
+    calls = []
+    worst, local = bench.timed_steps(calls.append, steps=3, warmup=2, world=1, device=torch.device("cpu"), windows=4)
+    assert calls == [None, None] + [0, 1, 2] * 4 and worst == local and worst >= 0
+    assert bench.barrier_cost_us(1, torch.device("cpu")) is None
+
+
 def test_single_rank_plan():
     sys.path.insert(0, ROOT)
     import bench

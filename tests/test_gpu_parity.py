@@ -832,6 +832,39 @@ def test_projection_scan_shifted_by_the_dominant_motion(oracle, case):
             close(N(out), want_out, "DepthFlowProjection under pan %s, fill %d, poison %s" % (case, fill, poison), RTOL)
 
 
+@pytest.mark.parametrize("pan", [216.0, 48.0, -120.0, 0.0])
+def test_projection_pan_with_heavy_convergence_on_a_corner_cell(oracle, pan):
+    """Round-5 review (proj_owner5.hpp, packed plane): FlowProjection keeps count * 2^20 + sum(vx) in ONE double per point and
+    splits it at the readout, which needs |sum of the weighted vx| < 2^19.  Under a pan m the sources that are "not far" carry
+    |fx| up to |m| + 24: a block of 47 x 24 sources converging on the image's bottom-right cell (border weights 4) under a
+    216 px pan sums to 975 k -- the count came out wrong by one or more, silently.  The plane now holds the residual mx - fx.
+    Counts bit for bit, outputs against the oracle; the reference has no such limit (fp32 atomics, my_lib_kernel.cu:1676-1689)."""
+    import my_package._ext.my_lib as my_lib
+    B, H, W = 2, 128, 512
+    flow = np.zeros((B, 2, H, W), np.float32)
+    flow[:, 0] = pan
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    # image 0: every source within 24 px of (the corner - pan) lands exactly on the corner cell (W - 1, H - 1) -- or, for a
+    # negative pan, on (0, H - 1): column weight 1, row weight 2
+    tx = float(W - 1) if pan >= 0 else 0.0
+    block = (np.abs((tx - xs) - pan) < 23.5) & ((H - 1) - ys < 23.5)
+    flow[0, 0][block] = (tx - xs)[block]
+    flow[0, 1][block] = ((H - 1) - ys)[block]
+    # image 1: convergence on an interior point under the same pan, sub-pixel landing (all four cells get it)
+    cx, cy = (W // 2 + 0.5 if abs(pan) < 100 else (W - 40.25 if pan > 0 else 40.25)), 70.25
+    block = (np.abs((cx - xs) - pan) < 23.0) & (np.abs(cy - ys) < 23.0)
+    flow[1, 0][block] = (cx - xs)[block]
+    flow[1, 1][block] = (cy - ys)[block]
+    for fill in (0, 1):
+        want_out, want_cnt = oracle.flow_projection_forward(flow, fill)
+        assert want_cnt[0].max() >= 4 * 24 * 40 and want_cnt[1].max() >= 40 * 40       # the test is what it says it is
+        cnt, out = torch.full((B, 1, H, W), 7.0, device=dev()), torch.full((B, 2, H, W), 7.0, device=dev())
+        assert my_lib.FlowProjectionLayer_gpu_forward(T(flow), cnt, out, fill) == 0
+        assert my_lib.last_kernel_path() == "proj_fwd:owner"
+        assert np.array_equal(N(cnt), want_cnt), "count under pan %g with convergence, fill %d" % (pan, fill)
+        close(N(out), want_out, "FlowProjection under pan %g with convergence, fill %d" % (pan, fill))
+
+
 RAGGED_CASES = [(2, 70, 130, 0.0), (1, 45, 67, 0.0), (2, 64, 133, 0.0), (1, 100, 1278, 0.0), (2, 70, 130, 37.0), (1, 33, 9, 0.0),
                 (2, 96, 255, -50.0)]
 
