@@ -13,9 +13,13 @@ Multi-GPU: frame pairs are independent, so the batch is sharded over the ranks a
 data path; RCCL is used only to broadcast the run configuration from rank 0 before the timed region and to take the
 max of the per-rank times after it.  Default = STRONG scaling, as BASELINE.json / SURVEY.md section 8(e) state it:
 the global batch stays 32 frame pairs and rank r owns the contiguous shard of 32 / N of them (32 / 16 / 8 / 4 per GPU
-at N = 1 / 2 / 4 / 8); `--scaling weak` gives every rank its own batch of 32 instead (global batch 32 N).  A shard of
-4 frames is a 67 us launch: below ~8 M sites per launch the K timed steps are replayed from ONE captured HIP graph
-(`--launch graph`, automatic), so that the host's per-launch cost (~4 us through ctypes) is not what is measured.
+at N = 1 / 2 / 4 / 8); `--scaling weak` gives every rank its own batch of 32 instead (global batch 32 N).
+
+Timing: W warm-up steps, then R (`--windows`, 7) windows of exactly K steps.  A window is  barrier + synchronize | t0 | K
+launches | the rank's own synchronize | t1  -- no collective and no event inside the clock; `value` comes from the MEDIAN
+window, each window's time being the max over the ranks (one all-reduce after the last window).  A shard of 4 frames is a
+66 us launch and the host enqueues one in ~10 us: eager launches keep the queue full (`--launch graph` replays the K steps
+from one captured HIP graph instead; it starts a 20-step window ~35 us later and is no faster at 300 steps).
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md "Measurement" for the field definitions).
 """
@@ -92,21 +96,21 @@ def barrier_sync(world, device):
         torch.cuda.synchronize(device)
 
 
-def _drain(device, last_event=None):
-    """The closing synchronize of a window.  On a GPU the host first spins on the window's last event (a
-    hipEventQuery loop sees completion within a microsecond or two; hipDeviceSynchronize alone may yield the core first),
+def _drain(device, stream=None):
+    """The closing synchronize of a window.  On a GPU the host first spins on the stream the steps were enqueued on (a
+    hipStreamQuery loop sees completion within a microsecond or two; hipDeviceSynchronize alone may yield the core first),
     then calls torch.cuda.synchronize -- which is what the contract asks for and returns at once by then."""
     import torch
     if device.type == "cuda":
-        if last_event is not None:
-            while not last_event.query():
+        if stream is not None:
+            while not stream.query():
                 pass
         torch.cuda.synchronize(device)
 
 
 def timed_windows(window_fn, windows, world, device):
     """`windows` repetitions of ONE timed window.  A window is: barrier + synchronize (every rank starts together, outside
-    the clock), t0, `window_fn(r)` (enqueues exactly K steps and returns the event that closes them, or None), this
+    the clock), t0, `window_fn(r)` (enqueues exactly K steps and returns the stream they went to, or None), this
     rank's own synchronize, t1.  Nothing collective sits inside [t0, t1]: the ranks never talk on the data path, so a
     rank's window is over when ITS device is idle -- a closing dist.barrier() inside the clock would add the
     collective's latency (and, at the driver's 20 steps of a 66 us shard, 10-20 % of the window) to every rank's time.
@@ -114,12 +118,16 @@ def timed_windows(window_fn, windows, world, device):
     Returns (per-window max-over-ranks seconds, this rank's per-window seconds)."""
     import torch
     local = []
+    enqueue = []                                          # host time to enqueue the window's work (evidence: GPU-bound or not)
     for r in range(windows):
         barrier_sync(world, device)
         t0 = time.perf_counter()
         last = window_fn(r)
+        t_enq = time.perf_counter()
         _drain(device, last)
         local.append(time.perf_counter() - t0)
+        enqueue.append(t_enq - t0)
+    timed_windows.last_enqueue_s = enqueue
     worst = list(local)
     if world > 1:
         import torch.distributed as dist
@@ -438,6 +446,22 @@ def config4_row(my_lib, torch, device, seed, pairs=4, height=720, width=1280, wa
     MIOpen / rocBLAS: they are the reference's, not this repository's, and they are 99 % of the step."""
     import networks
     from tools.bench_model import instrumented_pass
+    # MIOpen compiles (and times) its convolution kernels on first use -- 65 s for this network on a fresh box, whose image has no
+    # kernel database.  memc-net_amd/networks/miopen_cache/ holds what such a first pass leaves behind (344 KB, see its README);
+    # MIOpen gets a private copy, unless the caller already chose a cache directory.
+    cache_src = os.path.join(ROOT, "memc-net_amd", "networks", "miopen_cache")
+    cache = "caller's"
+    if "MIOPEN_USER_DB_PATH" not in os.environ and "MIOPEN_CUSTOM_CACHE_DIR" not in os.environ:
+        cache = "none"
+        if os.path.isdir(cache_src):
+            import shutil
+            import tempfile
+            tmp = tempfile.mkdtemp(prefix="memc_miopen_")
+            for name in os.listdir(cache_src):
+                if not name.endswith(".md"):
+                    shutil.copy(os.path.join(cache_src, name), tmp)
+            os.environ["MIOPEN_USER_DB_PATH"] = os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = tmp
+            cache = "in-tree copy"
     t_setup = time.perf_counter()
     torch.manual_seed(seed)
     with torch.device(device):
@@ -471,7 +495,7 @@ def config4_row(my_lib, torch, device, seed, pairs=4, height=720, width=1280, wa
            "gpu_ms_per_step": round(step_ms, 2), "pairs_per_step": pairs, "steps": steps, "warmup": warm,
            "hot_path_ms": round(hot_ms, 3), "hot_path_share": round(hot_ms / pass_ms, 4), "hot_path_calls": n_calls,
            "hot_path_ops_ms": {k: round(v, 3) for k, v in sorted(per_op.items())},
-           "instrumented_pass_ms": round(pass_ms, 2), "setup_s": round(setup_s, 2), "output_finite": finite,
+           "instrumented_pass_ms": round(pass_ms, 2), "setup_s": round(setup_s, 2), "miopen_cache": cache, "output_finite": finite,
            "repeatable": bool(torch.equal(first, out)),
            "note": "one GPU's shard (32 pairs / 8 GPUs) of config 4; random weights; dense layers = stock torch.nn (MIOpen), "
                    "hot path = this repository's HIP operators; frames_per_s counts interpolated frames"}
@@ -492,8 +516,8 @@ def main(argv=None):
                          "reach its steady clocks (tools/timeline.py); never part of the timed region")
     ap.add_argument("--batch", type=int, default=32, help="frame pairs: the GLOBAL batch (strong) / per GPU (weak)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
-    ap.add_argument("--launch", default="auto", choices=["auto", "eager", "graph"],
-                    help="graph: the K timed steps are one captured HIP graph replay (auto: below 8 M sites per launch)")
+    ap.add_argument("--launch", default="eager", choices=["auto", "eager", "graph"],
+                    help="graph: the K steps of a window are one captured HIP graph replay (auto = eager: see main)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the rows outside the timed region (i.i.d. flow, the other BASELINE configs, copy calibration)")
     ap.add_argument("--input-sets", type=int, default=0,
@@ -550,8 +574,6 @@ def main(argv=None):
         sets.append((t["x"], t["flow"], t["filt"], torch.zeros_like(t["x"])))   # caller-allocated, caller-zeroed output
     x, flow, filt, out = sets[0]
     steps, warmup, windows = cfg["steps"], cfg["warmup"], cfg["windows"]
-    w0 = [torch.cuda.Event(enable_timing=True) for _ in range(windows)]       # bracket each window on the launch stream
-    w1 = [torch.cuda.Event(enable_timing=True) for _ in range(windows)]
     counter = [0]
 
     def step(ev=None):
@@ -566,13 +588,16 @@ def main(argv=None):
         if err != 0:
             raise RuntimeError("FilterInterpolationLayer_gpu_forward returned %d" % err)
 
-    use_graph = args.launch == "graph" or (args.launch == "auto" and sites_per_launch < 8_000_000)
+    # Launch mode.  Rounds 2-5 replayed small shards from a HIP graph; measured in round 6 (profiles/r06_window_costs.txt):
+    # the host needs ~10 us to enqueue a launch and a 4-frame shard runs 66 us -- eager launches keep the queue full, 300
+    # eager steps take what 300 graph nodes take (65.2 / 64.8 us per step), and a 20-step window starts 35 us sooner (a graph
+    # launch spends ~45 us between the stream reaching it and its first kernel).  Eager is the default for every shard size.
+    use_graph = args.launch == "graph"
     for _ in range(args.prewarm):
         step()
+    launch_stream = torch.cuda.current_stream(device)
     if use_graph:
-        # the K steps of a window as ONE graph of K kernel nodes on a side stream, replayed once per window; HIP events
-        # bracket the replay on that stream (an event inside a captured graph cannot be timed), so the per-launch
-        # duration below includes the ~1.5 us boundary between two dependent kernels
+        # the K steps of a window as ONE graph of K kernel nodes on a side stream, replayed once per window
         side = torch.cuda.Stream(device)
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(device)
@@ -583,38 +608,50 @@ def main(argv=None):
             step()
         with torch.cuda.stream(side):
             graph.replay()                      # one untimed replay (first replay uploads the graph)
+        launch_stream = side
 
         def window(r):
             with torch.cuda.stream(side):
-                w0[r].record()
                 graph.replay()
-                w1[r].record()
-            return w1[r]
+            return side
     else:
         for _ in range(warmup):
             step()
 
         def window(r):
-            # K launches and nothing else between the two clock readings: the per-launch events of rounds 1-5 cost
-            # 6-10 us of stream time per step (BENCH_r05: 524.6 us per step around 514.2 us kernels) and now live in
-            # the instrumented pass below, outside the clock
-            w0[r].record()
+            # K launches and NOTHING else between the two clock readings: no event is recorded inside the clock (rounds 1-5
+            # put a pair around every launch: 6-10 us of stream time per step, BENCH_r05: 524.6 us per step around 514.2 us
+            # kernels); the kernel's own duration comes from the instrumented passes below
             for _ in range(steps):
                 step()
-            w1[r].record()
-            return w1[r]
+            return launch_stream
     worst_w, local_w = timed_windows(window, windows, world, device)
     worst, local = median(worst_w), median(local_w)
-    window_gpu_s = median([a.elapsed_time(b) for a, b in zip(w0, w1)]) / 1e3     # K steps on the stream, HIP events
+    # Outside the clock: (i) the same K steps bracketed by ONE HIP event pair on the launch stream -- the GPU-side span of a
+    # window; (ii) eager: the same K launches with an event pair around EACH -- the dominant kernel's own duration
+    spans = []
+    for r in range(3):
+        barrier_sync(world, device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(launch_stream):
+            e0.record()
+        window(r)
+        with torch.cuda.stream(launch_stream):
+            e1.record()
+        torch.cuda.synchronize(device)
+        spans.append(e0.elapsed_time(e1) / 1e3)
+    window_gpu_s = median(spans)
+    per_launch_us = None
     if use_graph:
-        avg_kernel_s = window_gpu_s / steps
+        avg_kernel_s = window_gpu_s / steps                 # (includes the ~1.5 us boundary between two dependent kernels)
     else:
-        # the dominant kernel's own duration: one more pass of the same K launches with a HIP event pair around each
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier_sync(world, device)
         for e in ev:
             step(e)
         torch.cuda.synchronize(device)
-        avg_kernel_s = sum(a.elapsed_time(b) for a, b in ev) / steps / 1e3
+        per_launch_us = [a.elapsed_time(b) * 1e3 for a, b in ev]
+        avg_kernel_s = sum(per_launch_us) / steps / 1e6
     barrier_us = barrier_cost_us(world, device)
     achieved = alg_bytes / avg_kernel_s                                 # B/s, this rank's dominant kernel
     total_sites = plan["global_batch"] * H * W                          # all ranks' sites per step
@@ -691,13 +728,16 @@ def main(argv=None):
                                                          windows, steps, steps),
                        "window_ms_min_max": [round(min(worst_w) * 1e3, 4), round(max(worst_w) * 1e3, 4)],
                        "window_gpu_us_per_step": round(window_gpu_s / steps * 1e6, 2),
+                       "window_host_enqueue_us": round(median(timed_windows.last_enqueue_s) * 1e6, 1),
+                       "window_fixed_cost_us": round((worst - window_gpu_s) * 1e6, 1),   # wall - GPU span of the median window
                        "input_sets": nsets,
                        "sharding": "independent frame pairs, contiguous shards per rank, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK_BPS / 1e9,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_BPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "fi_fwd", "algorithmic_bytes_per_launch": alg_bytes,
-                         "avg_launch_us": round(avg_kernel_s * 1e6, 2)},
+                         "avg_launch_us": round(avg_kernel_s * 1e6, 2),
+                         "first_launches_us": [round(v, 2) for v in per_launch_us[:4]] if per_launch_us else None},
         }
         if secondary:
             # achievable_peak: what this box's HBM gives the tiled kernels' access pattern in this run (the better of a copy

@@ -252,6 +252,11 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
 #pragma unroll 1
     for (int bi = 0; bi < bands.n; bi++) {
         const Region r = band_region(box, bands, bi);
+        // the window corners fi_covered derives from ix / iy (sixteen clamped values) are loop-invariant: hoisted out of the
+        // band loop they lived in private scratch through the channel loop (28 dwords per lane, rounds 2-5); opaque here,
+        // they are recomputed per band -- sixteen integer instructions
+#pragma unroll
+        for (int j = 0; j < 4; j++) asm volatile("" : "+v"(g.ix[j]), "+v"(g.iy[j]));
         const unsigned sel = inb ? fi_covered(r, g, W, H) & ~done : 0u;
         if (bi > 0 && !__syncthreads_or(sel != 0)) continue;
         done |= sel;
@@ -553,14 +558,29 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
 
     // this lane's two cells (rows r and r + TH / 2 of the tile) and, after the quad transpose, its channel of four cells;
     // the channel (my) is folded into the lane's byte offset: 4 * (my * s1c + row * s1h + col)
-    const unsigned my = tid & 3;
-    const int cell_x = tx0 + (int)(tid & 63 & ~3u), cell_y = ty0 + (int)(tid >> 6);
-    const bool st0 = cell_x < W && cell_y < H, st1 = cell_x < W && cell_y + TH / 2 < H;
-    const unsigned wo0 = st0 ? 4u * (unsigned)((int64_t)my * s1c + (int64_t)cell_y * s1h + cell_x) : 0u;
-    const unsigned wo1 = st1 ? 4u * (unsigned)((int64_t)my * s1c + (int64_t)(cell_y + TH / 2) * s1h + cell_x) : 0u;
+    // (computed where they are used -- by store_zeros and in front of every slab's replay, from a laundered copy of the thread
+    // index: defined once up here they lived through the count / fill phases, whose tap registers pushed them, half
+    // computed, into private scratch: 108 bytes per lane, rounds 2-5)
+    struct CellOffsets {
+        unsigned my, wo0, wo1;
+        bool st0, st1;
+    };
+    auto cell_offsets = [&](unsigned t) {
+        CellOffsets o;
+        o.my = t & 3;
+        const int cell_x = tx0 + (int)(t & 63 & ~3u), cell_y = ty0 + (int)(t >> 6);
+        o.st0 = cell_x < W && cell_y < H;
+        o.st1 = cell_x < W && cell_y + TH / 2 < H;
+        o.wo0 = o.st0 ? 4u * (unsigned)((int64_t)o.my * s1c + (int64_t)cell_y * s1h + cell_x) : 0u;
+        o.wo1 = o.st1 ? 4u * (unsigned)((int64_t)o.my * s1c + (int64_t)(cell_y + TH / 2) * s1h + cell_x) : 0u;
+        return o;
+    };
     float *gin1_b = gin1 + b * s1b;
     // gradinput1 is STORED by this kernel (the first slab assigns, later slabs add): cells nobody reaches get zeros
     auto store_zeros = [&]() {
+        const CellOffsets co = cell_offsets(tid);
+        const unsigned my = co.my, wo0 = co.wo0, wo1 = co.wo1;
+        const bool st0 = co.st0, st1 = co.st1;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         for (int c0 = 0; c0 < C; c0 += 4) {
             if (c0 + (int)my >= C) continue;               // ragged last chunk: this lane's channel does not exist
@@ -652,6 +672,13 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
 
 #pragma unroll 1
     for (int y_lo = ay0; y_lo <= ay1;) {
+        // Everything a slab derives from the thread index (LDS addresses of its cells' counters, heads and offsets, the
+        // staging slots) is invariant over the slab loop: hoisted in front of it, those ~30 registers sat in private scratch
+        // across the replay -- stored once, reloaded after every slab (108 bytes per lane, rounds 2-5).  An opaque copy of the
+        // index per slab keeps them inside the loop body: recomputed per slab, a few dozen integer instructions.
+        unsigned tid_slab = tid;
+        asm volatile("" : "+v"(tid_slab));
+        const unsigned tid = tid_slab;                     // (hides the kernel's `tid` for the body of the loop)
         const int y_hi = min(y_lo + rows - 1, ay1);
         const int nqs = (y_hi - y_lo + 1) * nqw;           // float4 slots of this slab's site box (<= 2 per lane)
         const int i0 = (int)tid, i1 = (int)tid + kOwnThreads;
@@ -701,8 +728,9 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
             }
             // head table: unclaimed (become K = 0 on the zero slot when the heads are read)
             {
-                const f32x4 z4 = {__uint_as_float(kHeadEmpty), __uint_as_float(kHeadEmpty), __uint_as_float(kHeadEmpty),
-                                  __uint_as_float(kHeadEmpty)};
+                float he = __uint_as_float(kHeadEmpty);   // (made per slab: the constant quad, hoisted, was kept in scratch)
+                asm volatile("" : "+v"(he));
+                const f32x4 z4 = {he, he, he, he};
                 f32x4 *k4 = reinterpret_cast<f32x4 *>(HK);
 #pragma unroll
                 for (int i = 0; i < kListHead * kOwnCells / 4 / kOwnThreads; i++) k4[tid + i * kOwnThreads] = z4;
@@ -804,7 +832,11 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
                          ((unsigned)HS[(t + 1) * kOwnCells + tid + kOwnThreads] << 16);
         }
         __syncthreads();
-        if (tid == 0) g4[kSlotCap] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid == 0) {                                     // (the zero made HERE: as a hoisted constant quad it was spilled)
+            float zero = 0.0f;
+            asm volatile("" : "+v"(zero));
+            g4[kSlotCap] = f32x4{zero, zero, zero, zero};
+        }
         const unsigned sb1 = sb0 + (unsigned)ns0;
         if (!serial_tails) {                               // the owners describe their tails' segments: start | length << 16
             for (int i = 0; i < ns0; i++)
@@ -820,6 +852,7 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
         {
             const unsigned d0 = has0 ? segtab[tid] : 0u, d1 = has1 ? segtab[tid + kOwnThreads] : 0u;
             const int b0 = (int)(d0 & 0xffffu), l0 = (int)(d0 >> 16), b1 = (int)(d1 & 0xffffu), l1 = (int)(d1 >> 16);
+            unsigned z0[kSegLen], z1[kSegLen];
 #pragma unroll
             for (int i = 0; i < kSegLen; i++) {
                 const bool h0 = i < l0, h1 = i < l1;
@@ -827,14 +860,13 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
                 const unsigned s0 = TS[h0 ? b0 + i : 0], s1 = TS[h1 ? b1 + i : 0];
                 ks0[i] = h0 ? k0 : 0.0f;
                 ks1[i] = h1 ? k1 : 0.0f;
-                const unsigned z0 = h0 ? s0 : (unsigned)kSlotCap, z1 = h1 ? s1 : (unsigned)kSlotCap;
-                if (i & 1) {
-                    sg0[i / 2] |= z0 << 16;
-                    sg1[i / 2] |= z1 << 16;
-                } else {
-                    sg0[i / 2] = z0;
-                    sg1[i / 2] = z1;
-                }
+                z0[i] = h0 ? s0 : (unsigned)kSlotCap;
+                z1[i] = h1 ? s1 : (unsigned)kSlotCap;
+            }
+#pragma unroll
+            for (int i = 0; i < kSegLen / 2; i++) {        // two slots per register, each register defined in ONE assignment
+                sg0[i] = z0[2 * i] | (z0[2 * i + 1] << 16);
+                sg1[i] = z1[2 * i] | (z1[2 * i + 1] << 16);
             }
         }
         const bool any_seg = nseg_total != 0;              // workgroup-uniform
@@ -842,6 +874,9 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
 
         // 5. replay, four channels at a time.  Wave-uniform plane bases + 32-bit byte offsets (per-lane 64-bit
         //    pointers would not fit next to the lists: a spilled pointer's reload waits for every load in flight)
+        const CellOffsets co = cell_offsets(tid);
+        const unsigned my = co.my, wo0 = co.wo0, wo1 = co.wo1;
+        const bool st0 = co.st0, st1 = co.st1;
         const unsigned go0 = on0 ? 4u * (unsigned)(yq0 * s1h + xq0) : 0u, go1 = on1 ? 4u * (unsigned)(yq1 * s1h + xq1) : 0u;
         const int gs0 = on0 ? r0 * aw + 4 * q0 : 0, gs1 = on1 ? r1 * aw + 4 * q1 : 0;      // first of four slots
         f32x4 v0[4], v1[4];

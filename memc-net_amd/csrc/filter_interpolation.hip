@@ -680,6 +680,10 @@ __global__ __launch_bounds__(256, 2) void fi_fwd_ctx_img(
     // fi_fwd_blend_c3).  Addresses are rebuilt at the use: six more live pointer registers do not fit this kernel.
     auto blend1 = [&](float w, int c, int j) {
         if (!BLEND) return w;
+        // (the lane's coordinates rebuilt from its index, opaque: hoisted out of the chunk loop, these addresses were spilled)
+        unsigned t = tid_now();
+        asm volatile("" : "+v"(t));
+        const int x = tile_x0 + 4 * (int)(t % LX), y = tile_y0 + (int)(t / LX);
         const int64_t oi = b * sib + c * sic + (int64_t)y * sih + x + j, oo = b * sob + (int64_t)y * soh + x + j;
         const float p0 = occ_prev[oo] * prev[oi], p2 = occ_this[oo] * w;
         return p0 + p2;
@@ -788,14 +792,24 @@ __global__ __launch_bounds__(256, 2) void fi_fwd_ctx_img(
         }
     }
     unsigned slow = inb ? g.valid & ~done : 0u;            // not coverable within kMaxBands bands
+    if (slow == 0) return;
+    // (rare) the lane's pointers are rebuilt HERE from an opaque copy of its coordinates: as the values computed at the top
+    // of the kernel they lived through the chunk loop for this path alone -- in private scratch (64 bytes per lane, rounds 3-5)
+    unsigned tl = tid_now();
+    asm volatile("" : "+v"(tl));
+    const int xl = tile_x0 + 4 * (int)(tl % LX), yl = tile_y0 + (int)(tl / LX);
+    const float *flow_q = flow + b * s2b + (int64_t)min(yl, H - 1) * s2h + min(xl, W - 4);
+    const float *tap_q = filt + b * s3b + (int64_t)min(yl, H - 1) * s3h + min(xl, W - 4);
+    float *iout_q = img_out + b * sib + (int64_t)yl * sih + xl;
+    float *out_q = out + b * s1b + (int64_t)yl * s1h + xl;
     while (slow) {
         const int j = __ffs(slow) - 1;
         slow &= slow - 1;
-        fi_site_scalar(x + j, y, W, H, C, 4, in_b, s1c, s1h, flow_p + j, s2c, tap_p + j, s3c, out_p + j);
-        fi_site_scalar(x + j, y, W, H, 3, 4, img_b, sic, sih, flow_p + j, s2c, tap_p + j, s3c, iout_p + j);
+        fi_site_scalar(xl + j, yl, W, H, C, 4, in_b, s1c, s1h, flow_q + j, s2c, tap_q + j, s3c, out_q + j);
+        fi_site_scalar(xl + j, yl, W, H, 3, 4, img_b, sic, sih, flow_q + j, s2c, tap_q + j, s3c, iout_q + j);
         if (BLEND) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) iout_p[c * sic + j] = blend1(iout_p[c * sic + j], c, j);
+            for (int c = 0; c < 3; c++) iout_q[c * sic + j] = blend1(iout_q[c * sic + j], c, j);
         }
     }
 }

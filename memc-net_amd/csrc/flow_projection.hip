@@ -15,6 +15,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <type_traits>
 
 namespace memc {
 
@@ -456,6 +457,33 @@ __device__ __forceinline__ void motion_sample_issue(const float *flow_b, int64_t
     fxs = *p;
     fys = p[s1c];
 }
+// The same 64 samples straight into LDS (global_load_lds_dword: lane l's dword lands at dst[l], no vector register is held while
+// the loads are in flight -- proj_owner5 has none to spare over its first scan iteration): fx at dst[0 .. 63], fy at dst[64 .. 127].
+// Issued from inline assembly ON PURPOSE: told about an LDS-DMA load (__builtin_amdgcn_global_load_lds), the compiler's wait-count
+// pass makes every later LDS access that "may alias" wait for it -- s_waitcnt vmcnt(0) in front of the plane zeroing, the first
+// barrier and every splat, i.e. the very round trip this is here to take off the path.  Unknown to the compiler, the two loads
+// are simply the OLDEST of the wave's outstanding vector-memory operations: loads return in order, so every count the compiler
+// waits for still implies what it meant (never satisfied early, at most later), and the reader waits for them explicitly
+// (motion_samples_wait).
+__device__ __forceinline__ void motion_sample_issue_lds(const float *flow_b, int64_t s1c, int s1h, int W, int H, int lane, float *dst)
+{
+    const int xs = ((2 * (lane & 7) + 1) * W) >> 4, ys = ((2 * (lane >> 3) + 1) * H) >> 4;
+    const float *p = flow_b + (int64_t)ys * s1h + xs;
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned lds = (unsigned)(uintptr_t)(lds_void *)dst;       // the destination's LDS byte address (wave-uniform)
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(p), "s"(lds) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(p + s1c), "s"(lds + 256u) : "memory", "m0");
+}
+// Before the samples are read: at most `younger` vector-memory operations -- those the wave issued AFTER the two sample loads and
+// has not waited for yet; a smaller number is always safe -- may still be outstanding.
+template <int younger>
+__device__ __forceinline__ void motion_samples_wait()
+{
+    static_assert(younger >= 0 && younger < 64, "vmcnt has six bits");
+    // gfx9 s_waitcnt: vmcnt [3:0] and [15:14], expcnt [6:4] = 7 (no wait), lgkmcnt [11:8] = 15 (no wait)
+    __builtin_amdgcn_s_waitcnt((younger & 15) | ((younger >> 4) << 14) | (7 << 4) | (15 << 8));
+    asm volatile("" ::: "memory");
+}
 // A mean below kMotionDeadZone counts as none: a shifted scan costs ~15 us at 720p batch 32 whatever the shift (the loads
 // requested for m = 0 before m was known are thrown away, the tile's own sources are tested on their own), and a shift of
 // one quad buys nothing -- with m = 0 a source stays inside the scan up to 24 px, i.e. local motion of 18 px against a mean
@@ -488,6 +516,48 @@ __device__ __forceinline__ void motion_reduce(float fxs, float fys, int &mx, int
     mx = motion_round4(wave_sum_f32(fxs));
     my = motion_round4(wave_sum_f32(fys));
 }
+// The estimate through the SCALAR unit: 16 sites (a 4 x 4 grid), their addresses wave-uniform, so the loads are s_load_dword
+// through the scalar cache and touch neither the texture path nor a vector register.  Round 6 measured what round 5's 64
+// per-lane loads cost the benchmark's flow (profiles/r06_proj_motion_estimate_arms.txt): 2.7-3.4 % of the call, half of it
+// gone with 16 lanes instead of 64 -- it is the 128 scattered cache lines per workgroup on the vector memory path, not the wait.
+// Summed in a fixed order (every workgroup and proj_owner_far arrive at the same bits).  For ONE wave (uniform control flow).
+__device__ __forceinline__ void motion_estimate_scalar(const float *__restrict__ flow_b, int64_t s1c, int s1h, int W, int H, int &mx, int &my)
+{
+    float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int xs = ((2 * (k & 3) + 1) * W) >> 3, ys = ((2 * (k >> 2) + 1) * H) >> 3;
+        // (read through the CONSTANT address space: that is what makes the compiler select scalar loads; the flow tensor is an
+        // input of the call, nothing writes it while this kernel runs)
+        typedef const __attribute__((address_space(4))) float cfloat;
+        cfloat *p = reinterpret_cast<cfloat *>(reinterpret_cast<uintptr_t>(flow_b + ((int64_t)ys * s1h + xs)));
+        sx += p[0];
+        sy += p[s1c];
+    }
+    mx = __builtin_amdgcn_readfirstlane(motion_round4(4.0f * sx));   // (motion_round4 divides by 64)
+    my = __builtin_amdgcn_readfirstlane(motion_round4(4.0f * sy));
+}
+#ifdef MEMC_MEASURE
+// (timing arm, proj_owner5 MOT = 3) sixteen samples -- a 4 x 4 grid, lanes 0 .. 15 -- instead of sixty-four
+__device__ __forceinline__ void motion_sample_issue16(const float *flow_b, int64_t s1c, int s1h, int W, int H, int lane,
+                                                      float &fxs, float &fys)
+{
+    if (lane < 16) {
+        const int xs = ((2 * (lane & 3) + 1) * W) >> 3, ys = ((2 * (lane >> 2) + 1) * H) >> 3;
+        const float *p = flow_b + (int64_t)ys * s1h + xs;
+        fxs = *p;
+        fys = p[s1c];
+    }
+}
+__device__ __forceinline__ void motion_reduce16(float fxs, float fys, int &mx, int &my)
+{
+    mx = motion_round4(4.0f * wave_sum_f32(fxs));      // (lanes 16 .. 63 hold zeros; motion_round4 divides by 64)
+    my = motion_round4(4.0f * wave_sum_f32(fys));
+}
+#else
+__device__ __forceinline__ void motion_sample_issue16(const float *, int64_t, int, int, int, int, float &, float &) {}
+__device__ __forceinline__ void motion_reduce16(float, float, int &, int &) {}
+#endif
 
 // Tiles the owner-computes fast path serves: proj_owner_far deals the stamped ones out from two tables (4 + 8 bytes per 64
 // tiles) that live in its point planes' bytes; a call with more tiles takes the general path.
@@ -845,13 +915,19 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner_far(
 #include "proj_owner5.hpp"               // the production owner kernel
 
 // A call recorded into a HIP graph is replayed with the kernel arguments it was recorded with: the per-call tag of the far
-// flags then comes from a counter in the call's workspace (flag word kFlagWords + 1; any initial value will do), advanced by
-// this one-lane kernel in front of the owner kernel -- with one tag for all replays the flags and stamps of earlier
-// replays would stay "raised" and ever more tiles would be recomputed (exact, and ever slower).
+// flags then comes from the DEVICE, advanced by this one-lane kernel in front of the owner kernel -- with one tag for all replays
+// the flags and stamps of earlier replays would stay "raised" and ever more tiles would be recomputed (exact, and ever slower).
+// The counter is a device global of this module (one per GPU, never allocated, never recycled); round 5 kept it in the call's
+// workspace, which torch's graph pool hands to later tensors of the same capture between two replays: the counter then read
+// whatever those kernels had written, possibly the same value at every replay (round-5 review).  The kernels of the call read
+// the tag from the workspace word this kernel writes.
+__device__ unsigned g_proj_replay_counter = 0;
 __global__ void proj_bump_nonce(int *far_flag)
 {
-    // (sign bit set, as the host counter's tags: never one of the small non-negative numbers the tables hold)
-    far_flag[kFlagWords + 1] = (int)((((unsigned)far_flag[kFlagWords + 1] & 0x7fffffffu) + 1u) | 0x80000000u);
+    const unsigned n = atomicAdd(&g_proj_replay_counter, 1u) + 1u;
+    // (sign bit set, as the host counter's tags: never one of the small non-negative numbers the tables hold; never -1)
+    const unsigned tag = (n & 0x7fffffffu) | 0x80000000u;
+    far_flag[kFlagWords + 1] = (int)(tag == 0xffffffffu ? 0x80000000u : tag);
 }
 
 #ifdef MEMC_MEASURE
@@ -1346,6 +1422,16 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                 hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinW, false, true>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w, h,
                                    ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,
                                    bounds, stamps, ws, plan, nonce);
+            } else if (variant <= -47 && variant >= -50) {   // how the motion estimate reaches the scan (proj_owner5.hpp, MOT):
+#define MEMC_PROJ_MOT(M)                                                                                              \
+                hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinWR, false, false, RAG, M>), dim3(plan.nwg), dim3(16 * TH), 0, stream, \
+                                   w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,  \
+                                   bounds, stamps, ws, plan, nonce)
+                if (variant == -47) MEMC_PROJ_MOT(1);         // -47: speculative m = 0 pass, samples by LDS DMA (round 6, lost)
+                else if (variant == -48) MEMC_PROJ_MOT(2);    // -48: no estimate (timing arm)
+                else if (variant == -49) MEMC_PROJ_MOT(3);    // -49: 16 samples, one lane each (timing arm)
+                else MEMC_PROJ_MOT(4);                        // -50: 16 samples through the scalar unit (timing arm)
+#undef MEMC_PROJ_MOT
             } else if (variant == -41) {       // timestamps (tools/trace_kernel.py proj5)
                 hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinW, true>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w, h,
                                    ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,

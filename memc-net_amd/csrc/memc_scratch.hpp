@@ -1,4 +1,6 @@
-// memc_scratch.hpp -- the scratch block of a (Depth)FlowProjection forward call that was NOT handed a workspace (host side).
+// memc_scratch.hpp -- the scratch block of a call that needs device words of its own and was NOT handed a workspace (host side):
+// the (Depth)FlowProjection forward through the reference-signature entry points (flow_projection.hip) and the many-channel
+// backward passes (fi_bwd_cn.hip: the site tiles' target boxes, FilterInterpolation and InterpolationCh alike).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -93,6 +95,23 @@ struct CallScratch {
         }
         hipMemPool_t pool = pool_for_device(dev);
         CachedBlock *table = scratch_table(dev);
+        // The cache's events are created and recorded with the CURRENT device's context: a stream of another device (the caller
+        // did not switch) gets a stream-ordered block of its own instead -- an event of the wrong device would fail at every
+        // record, silently, and the block would be freed and re-allocated per call anyway (round-5 review).
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) (void)hipGetLastError();
+        if (cur != dev) table = nullptr;
+        // hipEventQuery / hipEventCreate / the pool allocation are "potentially unsafe" calls while ANOTHER thread captures a
+        // stream in global mode (torch's default): this thread declares itself relaxed for the length of the claim, so that it
+        // cannot invalidate somebody else's capture (its own stream is not capturing: checked above)
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        const bool exchanged = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+        if (!exchanged) (void)hipGetLastError();
+        struct Restore {
+            hipStreamCaptureMode *m;
+            bool on;
+            ~Restore() { if (on && hipThreadExchangeStreamCaptureMode(m) != hipSuccess) (void)hipGetLastError(); }
+        } restore{&mode, exchanged};
         if (table) {
             static uint64_t clock = 0;
             std::lock_guard<std::mutex> lock(scratch_mutex());

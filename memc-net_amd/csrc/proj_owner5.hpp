@@ -31,6 +31,22 @@
 // dominant motion of 2 px or more, the benchmark's among them -- is the round-4 kernel: the scan's loads are issued for
 // m = 0 before m is known (wave 0 requests the 64 samples FIRST, reduces them while the planes are zeroed and posts m
 // before the barrier that was there anyway); only m != 0 pays a second round of loads.
+//
+// Round 6 took the estimate apart on the benchmark's flow, where it buys nothing (m = 0) and round 5's kernel ran 2-3 % behind
+// round 4's (measurement build, template parameter MOT; profiles/r06_proj_motion_estimate_arms.txt, _scalar_arm.txt,
+// r06_proj_speculative_scan_ab_*.txt):
+//   * MOT 2, no estimate at all: -0 ... -3.4 % -- that is all there is to win, and it moves by more than a per cent from one build
+//     of the library to the next (the arms' code shifts the kernel in instruction memory);
+//   * MOT 1, the round-5 review's proposal -- scan speculatively for m = 0 without waiting for the samples, let wave 0 post m
+//     after its first iteration (samples by LDS DMA: no register is held while they fly), read m behind the scan's closing
+//     barrier and start over, shifted, when the image moves: +0 ... 2 % on the benchmark's flow instead of a gain (wave 0's
+//     reduction now sits INSIDE the scan, where it delays the barrier; in front of the first barrier it ran in the dead time
+//     of the scan's own loads), the depth operator lost a workgroup per CU to the samples' 512 bytes of LDS (+19 %), and a 40 px
+//     pan paid the wasted pass: 190 instead of 135 us.  Lost on every count;
+//   * MOT 3 / MOT 4, sixteen samples instead of sixty-four -- one lane each, or through the scalar unit (s_load_dword via the
+//     constant address space): -1 ... 1.5 % on the depth operator, nothing on FlowProjection.
+// The product stays round 5's order (MOT 0): wave 0 requests the samples first, reduces them while the planes are zeroed and
+// posts m in front of the first barrier.
 #pragma once
 
 // (motion_sample_issue / motion_reduce: flow_projection.hip, shared with proj_owner_far)
@@ -39,7 +55,9 @@
 // in [0.1, 1.1), a timing arm for anything else: what would the fixed-point planes of the round-4 review's item 5 buy
 // before their per-tile scale, its barrier and the outlier route are built?
 // RAG: rows whose width is not a multiple of four (tail_shift / tail_fix / st_tail4, flow_projection.hip).
-template <bool DEPTH, int TH, int kReach, int MINW, bool TRACE = false, bool FIX64 = false, bool RAG = false>
+// MOT: how the motion estimate reaches the scan (0 = the product; 1-4: measurement build, projection variants -47 ... -50, see
+// "Round 6" above).
+template <bool DEPTH, int TH, int kReach, int MINW, bool TRACE = false, bool FIX64 = false, bool RAG = false, int MOT = 0>
 __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
@@ -47,6 +65,10 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     float *__restrict__ count, float *__restrict__ out, int *__restrict__ far_flag, int *__restrict__ bounds,
     int *__restrict__ stamps, FillWs ws, WalkPlan plan, int nonce_arg)
 {
+    // MOT: how the image's motion gets to the scan.  0: round 5's order (the product).  Measurement build: 1 = the speculative m = 0
+    // pass ("Round 6" above: measured, lost); 2 = no estimate at all, m = 0 (timing arm: what does the estimate cost?); 3 = round 5's
+    // order on 16 samples instead of 64 (timing arm; proj_owner_far still takes 64: only for flows where both say 0).
+    constexpr bool SPEC = MOT == 1;
     // this call's tag: a host counter's value, or -- 0: the call was recorded into a HIP graph, every replay needs its own --
     // the device counter proj_bump_nonce advanced in front of this kernel
     const int nonce = nonce_arg ? nonce_arg : __builtin_amdgcn_readfirstlane(far_flag[kFlagWords + 1]);
@@ -65,6 +87,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     constexpr int kScanH = TH + 2 * kReach + 1;   // source rows
     constexpr int kIts = (kScanH + kRowsIt - 1) / kRowsIt;
     static_assert(kPlane % 2 == 0, "P is zeroed 16 bytes at a time");
+    static_assert(kIts >= 3, "the motion is posted in front of iteration 1 and looked at in front of iteration 2");
     static_assert(NP * kPlane * 8 >= 3 * TH * 64 * 4 + TH * 64 * 2, "the fill epilogue stages three planes and the holes' list in P");
     static_assert((2 * kReach + 1) * (2 * kReach + 1) < 4096 && kReach <= 128, "count * 2^20 + sum(vx) must split exactly");
     __shared__ __attribute__((aligned(16))) double P[NP * kPlane];
@@ -82,33 +105,57 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     trace_mark_proj<TRACE>(0);
     const float *flow_b = flow + b * s1b;
     const float *depth_b = DEPTH ? depth + b * sdb : nullptr;
-    float msx = 0.0f, msy = 0.0f;                 // wave 0: the image's 64 motion samples, requested before anything else
-    if (wave_index == 0) motion_sample_issue(flow_b, s1c, s1h, W, H, tid0, msx, msy);
+    // wave 0: the image's 64 motion samples, requested before anything else -- round 5 into two registers, consumed in front of
+    // the first barrier; SPEC into LDS (they are consumed after the first scan iteration, and the 64 registers of the eight
+    // waves per SIMD have none free until then)
+    __shared__ float msamp[SPEC ? 128 : 2];
+    float msx = 0.0f, msy = 0.0f;
+    if (wave_index == 0 && MOT != 2 && MOT != 4) {
+        if (SPEC) motion_sample_issue_lds(flow_b, s1c, s1h, W, H, tid0, msamp);
+        else if (MOT == 3) motion_sample_issue16(flow_b, s1c, s1h, W, H, tid0, msx, msy);
+        else motion_sample_issue(flow_b, s1c, s1h, W, H, tid0, msx, msy);
+    }
     fill_lds_init(fl, tid0);
-    if (tid0 >= kWave && tid0 < kWave + 5) tile_box[tid0 - kWave] = tid0 == kWave + 4 ? 0 : (tid0 & 1) ? -1 : 0x7fffffff;   // (wave 1: wave 0 waits for its samples)
-    {
+    constexpr int kUnposted = 0x7fffffff;       // tile_box[6] before wave 0 has posted the motion (never a motion: |m| <= 4096)
+    auto tile_box_init = [&]() __attribute__((always_inline)) {                // (wave 1: wave 0 has its samples to look after)
+        if (tid0 >= kWave && tid0 < kWave + 5) tile_box[tid0 - kWave] = tid0 == kWave + 4 ? 0 : (tid0 & 1) ? -1 : 0x7fffffff;
+    };
+    tile_box_init();
+    if (SPEC && tid0 == kWave + 6) tile_box[6] = kUnposted;
+    auto zero_planes = [&]() __attribute__((always_inline)) {
         f32x4 *pz = reinterpret_cast<f32x4 *>(P);
         for (int i = tid0; i < NP * kPlane / 2; i += NT) pz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    };
+    zero_planes();
 
     // scan loads: fy of every slot now, fx / depth now only for the slots whose rows lie within kNearRows of the tile (the
     // others almost never pass the row test and fetch theirs inside the branch); unconditional addresses (dead slots read
     // pixel 0)
     // near slots: rows less than 10 above / 7 below the tile (TH = 32: iterations 1 - 3 of six)
-    auto far_it = [](int it) {
+    auto far_it = [](int it) __attribute__((always_inline)) {
         const int first = kRowsIt * it, last = kRowsIt * it + kRowsIt - 1;
         return last <= kReach + 1 - 10 || first >= kReach + 1 + TH + 7;
     };
     // the last iteration may hold a row or two only (TH = 32: row 80 of 81, half of the first wave): nothing of it is
     // requested up front
-    auto partial_it = [](int it) { return kRowsIt * (it + 1) > kScanH; };
+    auto partial_it = [](int it) __attribute__((always_inline)) { return kRowsIt * (it + 1) > kScanH; };
     f32x4 fx[kIts], fy[kIts], dd[kIts];
     bool live[kIts];
+    // loads scan_issue requests up front (per lane and wave: the addresses are unconditional)
+    constexpr int kScanLoads = [&]() {
+        int n = 0;
+        for (int it = 0; it < kIts; it++) {
+            const int first = kRowsIt * it, last = kRowsIt * it + kRowsIt - 1;
+            const bool far_i = last <= kReach + 1 - 10 || first >= kReach + 1 + TH + 7, partial_i = kRowsIt * (it + 1) > kScanH;
+            if (!partial_i) n += 1 + (far_i ? 0 : (DEPTH ? 2 : 1));
+        }
+        return n;
+    }();
     int sx, sy0, rt = 0;                       // rt (RAG): sites of the lane's quads that lie past the row's end
     unsigned off0, offd0;
     const float kNaN = __int_as_float(0x7fc00000);
     // the scan's slots for the motion (mx, my) and their loads (first for (0, 0), before the motion is known; see the header)
-    auto scan_issue = [&](int mx, int my) {
+    auto scan_issue = [&](int mx, int my) __attribute__((always_inline)) {
         sx = tx0 - mx - 32 + 4 * (tid0 % kColsQ);
         sy0 = ty0 - my - kReach - 1 + tid0 / kColsQ;
         const bool colok = sx >= 0 && sx < W;     // (W % 4 == 0, or RAG: the row's last quad is partly inside)
@@ -128,23 +175,44 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         }
     };
     scan_issue(0, 0);
-    if (wave_index == 0) {                     // (the samples were requested before the scan's loads: waiting for them
-        int mx, my;                            // does not wait for the scan)
-        motion_reduce(msx, msy, mx, my);
-        if (tid0 == 0) {
-            tile_box[6] = mx;
-            tile_box[7] = my;
+    auto motion_post = [&]() __attribute__((always_inline)) {                 // wave 0: the image's motion from its 64 samples (requested before the scan's loads:
+        int pmx, pmy;                          // waiting for them does not wait for the scan), one 8-byte store
+        if (SPEC) {                            // (the scan's up-front loads are all that was issued behind the samples by then)
+            motion_samples_wait<kScanLoads>();
+            msx = msamp[tid0 & 63];
+            msy = msamp[64 + (tid0 & 63)];
         }
+        if (MOT == 3) motion_reduce16(msx, msy, pmx, pmy);
+        else motion_reduce(msx, msy, pmx, pmy);
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        if (tid0 == 0) *reinterpret_cast<i32x2 *>(&tile_box[6]) = i32x2{pmx, pmy};
+    };
+    if ((MOT == 0 || MOT == 3) && wave_index == 0) motion_post();   // (round 5: in front of the first barrier)
+    if (MOT == 4 && wave_index == 0) {             // the estimate through the scalar unit, behind the scan's requests
+        int pmx, pmy;
+        motion_estimate_scalar(flow_b, s1c, s1h, W, H, pmx, pmy);
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        if (tid0 == 0) *reinterpret_cast<i32x2 *>(&tile_box[6]) = i32x2{pmx, pmy};
     }
     // (posting m BEHIND the barrier and letting the other waves poll the LDS word, so that nobody sits at the barrier for the
     // samples' round trip, was measured: +5.1 % against round 4's kernel instead of +2.2 % -- profiles/r05_proj_motion_polled_ab.txt)
     trace_mark_proj<TRACE>(1);                 // loads issued, P zeroed
-    __syncthreads();                           // P is zero, the image's motion is posted
+    // (nothing of the scan may move in front of this barrier: with m = 0 known at compile time the first iteration's row tests
+    // depend on nothing behind it, and hoisted they made every wave wait for its first load BEFORE the barrier -- the
+    // workgroup then started its scan when its slowest wave's data had arrived)
+    if (MOT == 1 || MOT == 2) __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                           // P is zero (round 5: and the image's motion is posted)
+    if (MOT == 1 || MOT == 2) __builtin_amdgcn_sched_barrier(0);
     if (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     trace_mark_proj<TRACE>(2);                 // loads arrived
-    const int mx = __builtin_amdgcn_readfirstlane(tile_box[6]), my = __builtin_amdgcn_readfirstlane(tile_box[7]);
-    const bool shifted = (mx | my) != 0;       // (scalar)
-    const float mxf = (float)mx, myf = (float)my;
+    // the motion this pass assumes: SPEC starts with (0, 0) and learns the posted one behind the scan's closing barrier
+    int mx = 0, my = 0;
+    if (MOT == 0 || MOT == 3 || MOT == 4) {
+        mx = __builtin_amdgcn_readfirstlane(tile_box[6]);
+        my = __builtin_amdgcn_readfirstlane(tile_box[7]);
+    }
+    bool shifted = false;                      // (scalar)
+    float mxf = 0.0f, myf = 0.0f;
 
     // Window [ty0 - 1, ty0 + TH - 1] x [tx0 - 1, tx0 + 63] of the points (T, L) = ((int)y2, (int)x2), and validity
     // (0 <= x2 <= W - 1, my_lib_kernel.cu:1670), as ONE range test per axis on the bit patterns.
@@ -154,25 +222,15 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     // point (py, px) -> byte offset 8 (py * pitch + px - cell0) into a plane (the constants pinned in SGPRs: rematerialised at every use
     // they cost the scalar pipe, which is as busy as the vector one here, two or three moves per source)
     unsigned pitch8 = 8 * kPtW4, ucell8 = (unsigned)-(8 * ((ty0 - 1) * kPtW4 + (tx0 - 1)));
-    // The packed plane holds count * 2^20 + sum(mx - fx): the RESIDUAL of the image's motion, not -fx itself.  A source
-    // that is not far has |fx - mx| < kReach whatever the pan, so |sum w S| < 2^19 holds under any shift (with -fx in the
-    // plane a 47 x 24 block converging on a corner cell under a 216 px pan summed to 975 k and the split came out one count
-    // off -- round-5 review).  One source adds (2^20 + mx) - fx: the same two instructions as before, mx folded into the
-    // unit (exact: an integer below 2^13 on 2^20); the readout takes cnt * (2^20 + mx) off again.
-    // (built from integers -- scalar instructions; a conversion and an add would be vector ones.  n = 2^20 + mx lies in
-    // (2^19, 2^21): a double with exponent 20 or 19 and the integer's low bits at the top of its mantissa)
-    const unsigned kunit_n = (unsigned)(1048576 + mx);
-    const unsigned kunit_hi = kunit_n >= 1048576u ? (1043u << 20) | (kunit_n - 1048576u)        // 2^20 (1 + (n - 2^20) / 2^20)
-                                                  : (1042u << 20) | ((kunit_n - 524288u) << 1);  // 2^19 (1 + (n - 2^19) / 2^19)
-    double kunit = __longlong_as_double((long long)((unsigned long long)kunit_hi << 32));
-    asm volatile("" : "+s"(pitch8), "+s"(ucell8), "+s"(kunit));
+    asm volatile("" : "+s"(pitch8), "+s"(ucell8));
+    double kunit = kCountUnit;                 // (set per pass, below)
     bool far = false;
     unsigned long long near_seen = 0;             // (scalar) home quads of this wave that hold a source that is not far
 
     // The cold branch of the far test: the home quads of the wave that hold a far source (ballot farq != 0).  Where the
     // tile's far sources land goes to tile_box (the wave's box first, ONE lane's atomics then: 64 lanes on one LDS word
     // serialise -- a camera pan, where every source was far before round 5, ran this kernel at 1.1 ms instead of 0.12).
-    auto far_quads = [&](bool homeq, const f32x4 &a, const f32x4 &c, float sxf, float syf) {
+    auto far_quads = [&](bool homeq, const f32x4 &a, const f32x4 &c, float sxf, float syf) __attribute__((always_inline)) {
         int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
         bool nearj = false;
 #pragma unroll
@@ -203,16 +261,22 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
             }
         }
     };
-    if (__builtin_expect(shifted, 0)) {           // (scalar) the image moves as a whole: see the header
-        // the tile's own 64 x TH sources are no longer (all) inside its scan: one quad per lane, tested for far sources here
+    // the tile's own quad of sources per lane (images that move as a whole only)
+    f32x4 home_a = {0.f, 0.f, 0.f, 0.f}, home_c = home_a;
+    auto home_issue = [&]() __attribute__((always_inline)) {
         const int hx = tx0 + 4 * (tid0 % 16), hy = ty0 + tid0 / 16;
         const bool homeq = hx < W && hy < H;
         const int rh = RAG ? tail_shift(hx, W) : 0;
         const unsigned offh = homeq ? 4u * (unsigned)(hy * s1h + hx - rh) : 0u;
-        f32x4 a = ld_cached4_u(flow_b, offh), c = ld_cached4_u(flow_b + s1c, offh);
-        scan_issue(mx, my);                       // ... and the scan again, where the sources that land here come from (requested
-                                                  // behind the home quad: ONE more round trip under a pan, not two)
+        home_a = ld_cached4_u(flow_b, offh);
+        home_c = ld_cached4_u(flow_b + s1c, offh);
+    };
+    auto home_test = [&]() __attribute__((always_inline)) {
+        const int hx = tx0 + 4 * (tid0 % 16), hy = ty0 + tid0 / 16;
+        const bool homeq = hx < W && hy < H;
+        f32x4 a = home_a, c = home_c;
         if (RAG) {
+            const int rh = tail_shift(hx, W);
             a = tail_fix(a, rh, kNaN);
             c = tail_fix(c, rh, kNaN);
         }
@@ -222,10 +286,54 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         const unsigned long long farq = __builtin_amdgcn_ballot_w64(homeq && !(dmax < (float)kReach));   // (NaN: far, found not valid)
         near_seen |= __builtin_amdgcn_ballot_w64(homeq) & ~farq;
         if (farq != 0) far_quads(homeq, a, c, (float)hx, (float)hy);
+    };
+    // One pass of scan + splat for the motion in (mx, my).  MODE 0: SPEC's speculative pass -- m = 0 at compile time, the code
+    // of round 4's kernel plus wave 0's posting and one look at the posted word; MODE 1: SPEC's second pass, for an image that
+    // moves (shifted at compile time); MODE 2: round 5's single pass, the posted motion known when it starts.  (Two inlined
+    // copies rather than a loop around one: as a loop the scan's registers were live around the back edge and 30 of them
+    // spilled at the 64 the eight waves per SIMD leave; the cold copy costs instruction memory only.)
+    auto scan_pass = [&](auto mode_tag) __attribute__((always_inline)) {   // (called twice: left alone, the compiler makes it a function)
+    constexpr int MODE = decltype(mode_tag)::value;
+    shifted = MODE == 0 ? false : MODE == 1 ? true : (mx | my) != 0;
+    mxf = MODE == 0 ? 0.0f : (float)mx;
+    myf = MODE == 0 ? 0.0f : (float)my;
+    // The packed plane holds count * 2^20 + sum(mx - fx): the RESIDUAL of the image's motion, not -fx itself.  A source
+    // that is not far has |fx - mx| < kReach whatever the pan, so |sum w S| < 2^19 holds under any shift (with -fx in the
+    // plane a 47 x 24 block converging on a corner cell under a 216 px pan summed to 975 k and the split came out one count
+    // off -- round-5 review).  One source adds (2^20 + mx) - fx: the same two instructions as before, mx folded into the
+    // unit (exact: an integer below 2^13 on 2^20); the readout takes cnt * (2^20 + mx) off again.
+    {   // (built from integers -- scalar instructions; a conversion and an add would be vector ones.  n = 2^20 + mx lies in
+        // (2^19, 2^21): a double with exponent 20 or 19 and the integer's low bits at the top of its mantissa)
+        const unsigned kunit_n = (unsigned)(1048576 + (MODE == 0 ? 0 : mx));
+        const unsigned kunit_hi = kunit_n >= 1048576u ? (1043u << 20) | (kunit_n - 1048576u)        // 2^20 (1 + (n - 2^20) / 2^20)
+                                                      : (1042u << 20) | ((kunit_n - 524288u) << 1);  // 2^19 (1 + (n - 2^19) / 2^19)
+        kunit = __longlong_as_double((long long)((unsigned long long)kunit_hi << 32));
+        asm volatile("" : "+s"(kunit));
+    }
+    if (MODE != 0 && __builtin_expect(shifted, 0)) {   // (scalar) the image moves as a whole: see the header
+        // The tile's own 64 x TH sources are no longer (all) inside its scan: one quad per lane, tested for far sources here.
+        // MODE 2 requests the scan's loads behind the home quad's and tests the quad while they fly (one more round trip under
+        // a pan, not two); MODE 1's home quad was requested before the planes were cleared (home_issue, in front of the
+        // barrier) and is tested -- and its registers are free -- before the scan's loads go out.
+        if (MODE == 2) {
+            home_issue();
+            scan_issue(mx, my);
+            home_test();
+        } else {
+            home_test();
+            scan_issue(mx, my);
+        }
     }
 
 #pragma unroll
     for (int it = 0; it < kIts; it++) {
+        if (SPEC && MODE == 0 && it == 1 && wave_index == 0) motion_post();   // (its first iteration's data has come back: so have its samples)
+        if (SPEC && MODE == 0 && it == 2) {        // one look at the posted motion: a pan is not scanned to the end for m = 0
+            typedef int i32x2 __attribute__((ext_vector_type(2)));
+            const i32x2 pm = __builtin_nontemporal_load(reinterpret_cast<const i32x2 *>(&tile_box[6]));   // (a fresh LDS read)
+            const int pmx = __builtin_amdgcn_readfirstlane(pm[0]), pmy = __builtin_amdgcn_readfirstlane(pm[1]);
+            if (pmx != kUnposted && (pmx | pmy) != 0) break;                  // (wave-uniform)
+        }
         const bool lv = live[it];
         // dead slots (outside the image / the scan region) fail every window test: their row is NaN
         const int sy = sy0 + kRowsIt * it;
@@ -314,13 +422,37 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         }
     }
     if (near_seen != 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) tile_box[4] = 1;
+    };
+    if (SPEC) {
+        scan_pass(std::integral_constant<int, 0>{});
+        trace_mark_proj<TRACE>(3);             // scan + splat done (wave 0)
+        __syncthreads();                       // every wave's points are in P (and the tile's far landing box in tile_box)
+        trace_mark_proj<TRACE>(4);
+        // wave 0 posted the image's motion before it came to the barrier
+        mx = __builtin_amdgcn_readfirstlane(tile_box[6]);
+        my = __builtin_amdgcn_readfirstlane(tile_box[7]);
+        if (__builtin_expect((mx | my) != 0, 0)) {
+            // (cold) the image moves as a whole: what the first pass splatted, found far and recorded means nothing -- start over
+            home_issue();                      // (the tile's own sources: back by the time the planes are clear)
+            zero_planes();
+            tile_box_init();
+            far = false;
+            near_seen = 0;
+            __syncthreads();
+            scan_pass(std::integral_constant<int, 1>{});
+            __syncthreads();
+        }
+    } else {
+        if (MOT == 2) scan_pass(std::integral_constant<int, 0>{});
+        else scan_pass(std::integral_constant<int, 2>{});
+        trace_mark_proj<TRACE>(3);
+        __syncthreads();
+        trace_mark_proj<TRACE>(4);
+    }
     if (far) {                                 // this image is redone by proj_owner_far.  The flag words are NOT cleared
         far_flag[b % kFlagWords] = nonce;      // before the call: "raised" = "holds this call's nonce" (launcher), so stale
         far_flag[kFlagWords] = nonce;          // or uninitialised words can at worst cause a needless redo, never a missed one
     }
-    trace_mark_proj<TRACE>(3);                 // scan + splat done (wave 0)
-    __syncthreads();                           // every wave's points are in P (and the tile's far landing box in tile_box)
-    trace_mark_proj<TRACE>(4);
     // (from here on the thread index is REBUILT from the wave's index, a scalar, and the lane's rank in the wave:
     // it need not live through the scan)
     const int tid = wave_index * kWave + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));

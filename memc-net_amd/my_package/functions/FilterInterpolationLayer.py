@@ -61,6 +61,11 @@ class _FilterInterpolationFunction(Function):
         gradinput3 = torch.empty_like(input3)
         err = my_lib.FilterInterpolationLayer_gpu_backward(
             input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3)
+        if err != 0 and gradinput1 is None:
+            # the library declines a NULL gradinput1 for reasons this layer does not duplicate (a plane beyond 32-bit offsets,
+            # say): once more with a buffer that is thrown away -- one branch, taken on failure only (round-5 review)
+            err = my_lib.FilterInterpolationLayer_gpu_backward(
+                input1, input2, input3, gradoutput, torch.zeros_like(input1), gradinput2, gradinput3)
         check(err, "FilterInterpolationLayer_gpu_backward")
         return (gradinput1 if want1 else None), gradinput2, gradinput3
 

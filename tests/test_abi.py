@@ -127,9 +127,11 @@ def test_workspace_entry_points_reject_bad_workspaces(lib):
     assert d(None, P(flow), P(cnt), P(cnt), P(out), 1, 0x10000, 16) == -1
 
 
-# Kernels still allowed to spill (to be emptied): none on the path of the reference's networks -- the many-channel backward has no
-# caller there (its context warps are detached), the image + context warp is off by default (measured slower).
-KNOWN_SCRATCH_USERS = ("memc::fi_bwd_taps_c4n", "memc::fi_bwd_image_owner<memc::FpFilter", "memc::fi_fwd_ctx_img<true>")
+# Kernels allowed to spill: none.  (Rounds 2-5 listed fi_bwd_taps_c4n, fi_bwd_image_owner<FpFilter> and fi_fwd_ctx_img<true>,
+# 64-112 bytes per lane: loop-invariant values the compiler hoisted out of a loop and then could not keep -- window corners, LDS
+# addresses derived from the thread index, constant quads, the lane's pointers for a rare path.  Round 6 keeps each of them
+# inside its loop behind an opaque copy of what it is derived from; profiles/r06_spills_ab.txt has the timings.)
+KNOWN_SCRATCH_USERS = ()
 
 
 def test_no_product_kernel_uses_private_scratch():

@@ -33,6 +33,10 @@ def test_bench_line_checks_its_own_output_against_the_oracle():
     assert "traffic_source" in line["roofline"]
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
     assert line["n_gpus"] == 1 and line["dtype"] == "f32" and line["vs_baseline"] is None
+    c = line["config"]
+    assert c["windows"] == 7 and c["launch"] == "eager" and c["window_gpu_us_per_step"] > 0
+    assert c["window_ms_min_max"][0] - 1e-3 <= line["ms_per_step"] * 6 <= c["window_ms_min_max"][1] + 1e-3
+    assert len(line["roofline"]["first_launches_us"]) == 4
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the lease of this pool has one")
@@ -59,7 +63,8 @@ def test_two_ranks_sharing_one_gpu_plumbing():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29633", os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--share-gpu", "--batch", "8", "--steps", "12", "--warmup", "3", "--prewarm", "6"],
+                        "--gpus", "2", "--share-gpu", "--batch", "8", "--steps", "12", "--warmup", "3", "--prewarm", "6",
+                        "--launch", "graph", "--windows", "3"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-3000:]
     line = _line(r.stdout)
@@ -68,4 +73,6 @@ def test_two_ranks_sharing_one_gpu_plumbing():
     assert len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
     assert "PLUMBING TEST" in line["data"] and line["n_gpus"] == 2 and line["config"]["global_batch"] == 8
     assert line["config"]["launch"] == "hip_graph" and line["config"]["input_sets"] >= 4
+    assert line["config"]["windows"] == 3 and len(d["worst_window_ms"]) == 3 and d["barrier_us"] > 0
+    assert min(d["worst_window_ms"]) - 1e-3 <= line["ms_per_step"] * 12 <= max(d["worst_window_ms"]) + 1e-3      # the median window
     assert "cpu_baseline" not in line and "check" not in line          # rank 0 at N = 1 only

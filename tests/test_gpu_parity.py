@@ -832,7 +832,7 @@ def test_projection_scan_shifted_by_the_dominant_motion(oracle, case):
             close(N(out), want_out, "DepthFlowProjection under pan %s, fill %d, poison %s" % (case, fill, poison), RTOL)
 
 
-@pytest.mark.parametrize("pan", [216.0, 48.0, -120.0, 0.0])
+@pytest.mark.parametrize("pan", [216.0, -300.0, 48.0, 0.0])
 def test_projection_pan_with_heavy_convergence_on_a_corner_cell(oracle, pan):
     """Round-5 review (proj_owner5.hpp, packed plane): FlowProjection keeps count * 2^20 + sum(vx) in ONE double per point and
     splits it at the readout, which needs |sum of the weighted vx| < 2^19.  Under a pan m the sources that are "not far" carry
@@ -857,7 +857,9 @@ def test_projection_pan_with_heavy_convergence_on_a_corner_cell(oracle, pan):
     flow[1, 1][block] = (cy - ys)[block]
     for fill in (0, 1):
         want_out, want_cnt = oracle.flow_projection_forward(flow, fill)
-        assert want_cnt[0].max() >= 4 * 24 * 40 and want_cnt[1].max() >= 40 * 40       # the test is what it says it is
+        assert want_cnt[0].max() >= 2000 and want_cnt[1].max() >= 2000                 # the test is what it says it is:
+        if abs(pan) > 200:                                                              # count * |vx| at the corner cell > 2^19
+            assert want_cnt[0].max() * abs(pan) > 524288.0
         cnt, out = torch.full((B, 1, H, W), 7.0, device=dev()), torch.full((B, 2, H, W), 7.0, device=dev())
         assert my_lib.FlowProjectionLayer_gpu_forward(T(flow), cnt, out, fill) == 0
         assert my_lib.last_kernel_path() == "proj_fwd:owner"

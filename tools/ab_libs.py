@@ -2,7 +2,7 @@
 """tools/ab_libs.py -- same-session A/B of two BUILDS of the library (box-to-box spread on the pool is +-3 %, more
 than most single changes are worth: two builds can only be compared inside one process on one GPU).
 
-    python tools/ab_libs.py <libA.so> <libB.so> [--op proj|proj_fill|depth_fill|fi_fwd|fi_bwd] [--rounds 6] [--pan 40] [--scale 2]
+    python tools/ab_libs.py <libA.so> <libB.so> [--op proj|proj_fill|depth_fill|fi_fwd|fi_bwd|fi_bwd_c64|interp_bwd_c64|ctx_img_blend|...] [--rounds 6] [--pan 40] [--scale 2]
 
 Both libraries are loaded side by side (RTLD_LOCAL) and bound with my_package's own binder; launches alternate
 A, B, A, B ... in rounds, the median of each is printed."""
@@ -70,6 +70,16 @@ def main():
         "depth_bwd": lambda l: l.DepthFlowProjectionLayer_gpu_backward(f, d, cnt, out, g2src, g2, gd),
         "fi_fwd_c2": lambda l: l.FilterInterpolationLayer_gpu_forward(c2["x"], c2["flow"], c2["filt"], c2o),
     }
+    if any(o in a.op.split(",") for o in ("fi_bwd_c64", "interp_bwd_c64", "ctx_img_blend")):
+        # the many-channel operators (8 x 64 x 720 x 1280: the context features of config 4's network), allocated on demand
+        m = synth.torch_inputs(dev, 8, 64, H, W, flow_kind="smooth", with_grad=True)
+        mg1, mg2, mg3 = torch.zeros_like(m["x"]), torch.zeros_like(m["flow"]), torch.zeros_like(m["filt"])
+        mi = {k_: v[:8].contiguous() for k_, v in (("x", x), ("occ", d))}
+        mprev, mio, mco = torch.rand_like(mi["x"]), torch.zeros_like(mi["x"]), torch.zeros_like(m["x"])
+        ops["fi_bwd_c64"] = lambda l: l.FilterInterpolationLayer_gpu_backward(m["x"], m["flow"], m["filt"], m["gout"], mg1, mg2, mg3)
+        ops["interp_bwd_c64"] = lambda l: l.InterpolationChLayer_gpu_backward(m["x"], m["flow"], m["gout"], mg1, mg2)
+        ops["ctx_img_blend"] = lambda l: l.FilterInterpolationCtxLayer_gpu_forward(
+            mi["x"], m["x"], m["flow"], m["filt"], mprev, mi["occ"], mi["occ"], mio, mco)
     libs[0].FlowProjectionLayer_gpu_forward(f, cnt, out, 0)
     for _ in range(150):
         ops["proj"](libs[0])

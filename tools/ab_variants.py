@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--flows", default="smooth")
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--pan", type=float, default=0.0, help="camera pan (p, -p/2) px added to the flow")
+    ap.add_argument("--scale", type=float, default=1.0, help="the flow times this")
     ap.add_argument("--lib", default="", help="another measurement build to bind (default: lib/libmemc_hip_measure.so)")
     a = ap.parse_args()
     if a.lib:
@@ -41,6 +43,10 @@ def main():
         B, H, W = 32, 720, 1280
         t = synth.torch_inputs(dev, B, 3, H, W, flow_kind=flow, with_depth=True, with_grad=True)
         x, f, k, g, d = t["x"], t["flow"], t["filt"], t["gout"], t["depth"]
+        if a.scale != 1.0 or a.pan != 0.0:
+            f = (f * a.scale).contiguous()
+            f[:, 0] += a.pan
+            f[:, 1] -= a.pan / 2
         cnt, out = f.new_zeros((B, 1, H, W)), torch.zeros_like(f)
         g1, g2, g3 = torch.zeros_like(x), torch.zeros_like(f), torch.zeros_like(k)
         t2 = synth.torch_inputs(dev, 8, 3, 256, 448, flow_kind=flow, with_grad=True)
