@@ -76,7 +76,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* The library is built with -fvisibility=hidden: exactly the functions declared in this header are exported. */
+/* The library is built with -fvisibility=hidden: its C surface is exactly the functions declared in this header
+ * (tests/test_abi.py).  The dynamic symbol table also holds the mangled handles of the HIP kernels, which the HIP runtime
+ * resolves by name; they are not an interface. */
 #if defined(__GNUC__)
 #pragma GCC visibility push(default)
 #endif

@@ -1432,6 +1432,15 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                 else if (variant == -49) MEMC_PROJ_MOT(3);    // -49: 16 samples, one lane each (timing arm)
                 else MEMC_PROJ_MOT(4);                        // -50: 16 samples through the scalar unit (timing arm)
 #undef MEMC_PROJ_MOT
+            } else if (variant <= -51 && variant >= -53) {   // tiles with many holes leave ALL of them pending (proj_fill.hpp, PENDT)
+#define MEMC_PROJ_PENDT(T)                                                                                            \
+                hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinWR, false, false, RAG, 0, T>), dim3(plan.nwg), dim3(16 * TH), 0, stream, \
+                                   w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,  \
+                                   bounds, stamps, ws, plan, nonce)
+                if (variant == -51) MEMC_PROJ_PENDT(0);       // -51: every tile with a hole
+                else if (variant == -52) MEMC_PROJ_PENDT(8);  // -52: more than 8 lanes with a hole
+                else MEMC_PROJ_PENDT(32);                     // -53: more than 32
+#undef MEMC_PROJ_PENDT
             } else if (variant == -41) {       // timestamps (tools/trace_kernel.py proj5)
                 hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinW, true>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w, h,
                                    ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,

@@ -102,7 +102,11 @@ __device__ __forceinline__ float fill_value(float lt, float rt, float ut, float 
 // cell of a lane) with a lane or two active.  They are LISTED in LDS and dealt out one per lane instead -- with the
 // benchmark's flows the whole list is one pass of the first wave -- and the owners read their cells back from the stage.
 // Converged code only (barriers).  ws.hole[tile]: 0 no hole, 1 holes, all filled here, 2 holes pending.
-template <int TH, int NT, bool TRACE = false>
+// PENDT (measurement build; -1 = the product): a tile in which more than PENDT lanes hold a hole skips the in-tile fill -- no
+// hole list, no staged planes, no walks, no read-back: masks and summaries only, every hole of it pending -- and leaves its
+// holes to proj_fill_pending (0: every tile with a hole).  Same results either way.  Round-5 review, item 5: does the epilogue's
+// ~2000 clocks per phase, once nearly every tile holds holes (the flow twice as large, a camera pan), pay better there?
+template <int TH, int NT, bool TRACE = false, int PENDT = -1>
 __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stage, const FillWs &ws, int tid, int b, int tx,
                                                     int ty, int W, int H, int tiles_x, int tiles_y, bool inb, f32x4 &ox,
                                                     f32x4 &oy, const f32x4 &oc)
@@ -118,7 +122,8 @@ __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stag
         if (in_row && oc[j] != 0.0f) nz |= 1u << j;            // what stops a walk (my_lib_kernel.cu:1778-1797)
         if (in_row && oc[j] <= 0.0f) hole |= 1u << j;          // what pass 3 fills (:1757)
     }
-    const bool any_hole = __syncthreads_or(hole != 0);
+    const int hole_lanes = PENDT >= 0 ? __syncthreads_count(hole != 0) : __syncthreads_or(hole != 0);
+    const bool any_hole = hole_lanes != 0;
     trace_mark_proj<TRACE>(6);                 // (timestamp instance: tools/probes/proj_pan_phases.py)
     if (!any_hole) {
         // No hole: every cell of the tile inside the image has a positive count -- every walk that enters the tile stops at
@@ -145,6 +150,29 @@ __device__ __forceinline__ void owner_fill_epilogue(FillLds<TH> &fl, float *stag
         if ((nz >> j) & 1u) atomicOr(&fl.col[4 * q + j], 1u << r);
     // (round 5: the column masks from four ballots, one conflict-free LDS atomic per wave instead of these four with four
     // lanes on every word -- no difference in the phase's clocks, tools/probes/proj_pan_phases.py; left as it was)
+    if (PENDT >= 0 && hole_lanes > PENDT) {                    // (workgroup-uniform) every hole of this tile pending
+        const unsigned plo = row16_or_u32(q < 8 ? hole << (4 * q) : 0u), phi = row16_or_u32(q >= 8 ? hole << (4 * (q - 8)) : 0u);
+        if (q == 15) fl.pend[r] = ((unsigned long long)phi << 32) | plo;
+        __syncthreads();
+        if (tid < TH && ty0 + tid < H) {
+            const unsigned long long rowm = fl.row[tid];
+            const int64_t i = ((int64_t)b * tiles_x + tx) * H + ty0 + tid;
+            ws.right[i] = rowm ? tx0 + (int)__builtin_ctzll(rowm) : -1;
+            ws.left[i] = rowm ? tx0 + last_bit64(rowm) : -1;
+        }
+        if (tid < 64 && tx0 + tid < W) {
+            const unsigned cm = fl.col[tid];
+            ws.up[((int64_t)b * tiles_y + ty) * W + tx0 + tid] = cm ? ty0 + 31 - (int)__builtin_clz(cm) : -1;
+        }
+        TileMasks<TH> *tm = reinterpret_cast<TileMasks<TH> *>(ws.masks) + tile_id;
+        if (tid < TH) {
+            tm->row[tid] = fl.row[tid];
+            tm->pend[tid] = fl.pend[tid];
+        }
+        if (tid < 64) tm->col[tid] = fl.col[tid];
+        if (tid == 0) ws.hole[tile_id] = 2;
+        return;
+    }
     unsigned short *const hole_list = reinterpret_cast<unsigned short *>(stage + 3 * TH * 64);
     {   // one atomic per wave (a tile in an uncovered band is ALL holes: 64 lanes adding to one LDS word four times over)
         unsigned long long m[4];

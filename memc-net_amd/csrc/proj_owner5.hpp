@@ -57,7 +57,7 @@
 // RAG: rows whose width is not a multiple of four (tail_shift / tail_fix / st_tail4, flow_projection.hip).
 // MOT: how the motion estimate reaches the scan (0 = the product; 1-4: measurement build, projection variants -47 ... -50, see
 // "Round 6" above).
-template <bool DEPTH, int TH, int kReach, int MINW, bool TRACE = false, bool FIX64 = false, bool RAG = false, int MOT = 0>
+template <bool DEPTH, int TH, int kReach, int MINW, bool TRACE = false, bool FIX64 = false, bool RAG = false, int MOT = 0, int PENDT = -1>
 __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     int W, int H, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t sdb, int sdh, int64_t scb, int sch,
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     }
     trace_mark_proj<TRACE>(10);                // (box sums done)
     if (ws.up)                                 // pass 3 (hole filling) follows: fill what the tile can, summaries, masks
-        owner_fill_epilogue<TH, NT, TRACE>(fl, reinterpret_cast<float *>(P), ws, tid, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, inb,
+        owner_fill_epilogue<TH, NT, TRACE, PENDT>(fl, reinterpret_cast<float *>(P), ws, tid, b, tc.tx, tc.ty, W, H, tiles_x, tiles_y, inb,
                                     ox, oy, oc);
     if (inb) {                                 // single-use streams: nothing of this launch reads them back from cache
         if (RAG) {

@@ -4,7 +4,7 @@
 # 4 slots, they cost 3 + 2).
 # Usage (from the repo root, via gpurun):  bash tools/gpu_session.sh <tag> [quick]
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 QUICK=${2:-}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
@@ -17,8 +17,18 @@ cp gpurun_out/parity_errors.json "$OUT/parity_errors.json" 2>/dev/null
 echo "== sweep (product library)";   timeout 900 python tools/bench_ops.py ${QUICK:+--quick} --json "$OUT/bench_ops.json" 2>&1 | grep -v amdgpu.ids | tee "$OUT/bench_ops.log"
 echo "== baselines (reference kernels on this GPU, CPU oracle)"; timeout 900 python tests/bench_baselines.py --json "$OUT/baselines.json" 2>&1 | grep -v amdgpu.ids | tee "$OUT/baselines.log"
 echo "== bench";   timeout 900 python bench.py 2>&1 | tail -3 | tee "$OUT/bench.log"
-echo "== bench, strong-scaling shard sizes on one GPU (what rank 0 of an N-GPU run executes: batch 32 / N, HIP graph, rotating input sets)"
-for b in 16 8 4; do timeout 300 python bench.py --batch $b --no-cpu-baseline --no-secondary 2>&1 | tail -1 | tee -a "$OUT/bench_shards.log"; done
+echo "== bench at the driver's arguments (--steps 20 --warmup 5), whole line"
+timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -1 | tee "$OUT/bench_driver_args.log" | cut -c1-400
+echo "== bench, strong-scaling shard sizes on one GPU (what rank 0 of an N-GPU run executes: batch 32 / N, rotating input sets), at the driver's 20 steps and at 300"
+for b in 32 16 8 4; do for st in 20 300; do timeout 300 python bench.py --batch $b --steps $st --warmup 5 --no-cpu-baseline --no-secondary 2>&1 | tail -1 | tee -a "$OUT/bench_shards.log" | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); c=d['config']; r=d['roofline']
+print('batch %2d steps %3d %-9s value %9.1f ms/step %.4f gpu_us/step %.2f enqueue_us %.1f fixed_us %.1f kernel_us %.2f first %s windows %s' % (c['batch_per_gpu'], d['steps'], c['launch'], d['value'], d['ms_per_step'], c['window_gpu_us_per_step'], c['window_host_enqueue_us'], c['window_fixed_cost_us'], r['avg_launch_us'], r['first_launches_us'], c['window_ms_min_max']))" | tee -a "$OUT/bench_shards_summary.txt"; done; done
+echo "== the N > 1 code path on this one GPU: two ranks sharing it over gloo (PLUMBING, not a measurement), 20 and 300 steps"
+for st in 20 300; do timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29641 bench.py --gpus 2 --share-gpu --batch 8 --steps $st --warmup 5 2>&1 | grep '^{"metric"' | tee -a "$OUT/bench_share_gpu.log" | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('2 ranks on one GPU: steps %3d ms/step %.4f barrier_us %s per-rank ms/step %s' % (d['steps'], d['ms_per_step'], d['dist']['barrier_us'], d['dist']['per_rank_ms_per_step']))" | tee -a "$OUT/bench_shards_summary.txt"; done
 echo "== model"; timeout 600 python tools/bench_model.py --json "$OUT/bench_model.json" 2>&1 | tail -2 | tee "$OUT/bench_model.log"
 echo "== projection: phase clocks of the owner kernel (measurement build), A/B against round 3's set in one process"
 timeout 300 python tools/trace_kernel.py proj5 2>&1 | grep -v amdgpu.ids | tee "$OUT/proj_owner5_phases.txt"

@@ -58,6 +58,10 @@ def main():
     py = sys.executable
     bench = [py, os.path.join(ROOT, "bench.py")] + a.bench_args.split()
     probe = [py, os.path.join(ROOT, "tools", "probes", "run_probe.py"), "copyonly"]
+    probe_so = os.path.join(ROOT, "tools", "probes", "libio_skeleton.so")
+    if not os.path.exists(probe_so):            # (built here, not under the profiler: a fresh checkout has no probe library)
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", probe_so,
+                        os.path.join(ROOT, "tools", "probes", "io_skeleton.hip")], check=True)
 
     res = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
