@@ -75,9 +75,19 @@ def shard_plan(rank, world, batch, base_seed, scaling="weak"):
             "seed": base_seed + rank, "scaling": scaling}
 
 
+# `--dist-single` (a one-GPU box): the WHOLE collective layer runs on a real RCCL communicator of one rank -- communicator
+# creation with device_id, the broadcast, the barriers, the float64 MAX all-reduce, the all-gather -- instead of being skipped
+# for world == 1.  It is the closest a one-GPU lease gets to the N > 1 path over RCCL; the line's `dist` record says so.
+_FORCE_DIST = [False]
+
+
+def _dist_on(world):
+    return world > 1 or _FORCE_DIST[0]
+
+
 def broadcast_config(cfg, world, device):
     """Rank 0's run configuration wins (RCCL broadcast over xGMI on GPUs, gloo on CPU).  Ints only."""
-    if world == 1:
+    if not _dist_on(world):
         return cfg
     import torch
     import torch.distributed as dist
@@ -89,7 +99,7 @@ def broadcast_config(cfg, world, device):
 
 def barrier_sync(world, device):
     import torch
-    if world > 1:
+    if _dist_on(world):
         import torch.distributed as dist
         dist.barrier()
     if device.type == "cuda":
@@ -129,7 +139,7 @@ def timed_windows(window_fn, windows, world, device):
         enqueue.append(t_enq - t0)
     timed_windows.last_enqueue_s = enqueue
     worst = list(local)
-    if world > 1:
+    if _dist_on(world):
         import torch.distributed as dist
         t = torch.tensor(local, dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)          # the closing collective: outside every window
@@ -161,7 +171,7 @@ def timed_steps(step_fn, steps, warmup, world, device, windows=1):
 def barrier_cost_us(world, device, reps=9):
     """Evidence only: what one empty dist.barrier() costs on this job (median of `reps`), i.e. what every window would
     carry if the barrier were inside the clock."""
-    if world == 1:
+    if not _dist_on(world):
         return None
     import torch.distributed as dist
     barrier_sync(world, device)
@@ -533,6 +543,8 @@ def main(argv=None):
     # plumbing test of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, gloo instead of
     # RCCL, which refuses two ranks on one device): the line it prints is NOT a measurement
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
+    # one rank, but through torch.distributed on backend nccl (= RCCL): see _FORCE_DIST above
+    ap.add_argument("--dist-single", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 
     import torch
@@ -553,6 +565,15 @@ def main(argv=None):
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=device)  # nccl == RCCL on ROCm
+    elif args.dist_single:
+        import socket
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        with socket.socket() as sock:           # a free port on the loopback for the one-rank rendezvous
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=device)
+        _FORCE_DIST[0] = True
 
     import my_package._ext.my_lib as my_lib                  # raises if libmemc_hip.so is missing
     from tools import synth
@@ -657,7 +678,7 @@ def main(argv=None):
     total_sites = plan["global_batch"] * H * W                          # all ranks' sites per step
     value = total_sites * steps / worst / 1e6
     dist_seen = None
-    if world > 1:
+    if _dist_on(world):
         # what the collective layer actually saw (evidence fields; nothing here is on the data path)
         import torch.distributed as dist
         gdev = device if dist.get_backend() == "nccl" else torch.device("cpu")      # gloo gathers host tensors only
@@ -667,6 +688,7 @@ def main(argv=None):
         dist.all_gather(gathered, mine)
         rows = [g.tolist() for g in gathered]
         dist_seen = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                     "single_rank_communicator": bool(_FORCE_DIST[0]),
                      "per_rank_ms_per_step": [round(r[0], 4) for r in rows],
                      "per_rank_avg_launch_us": [round(r[1], 2) for r in rows],
                      "per_rank_items": [int(r[2]) for r in rows],
@@ -765,7 +787,7 @@ def main(argv=None):
         print(json.dumps(line), flush=True)
         if failed:
             raise SystemExit("bench.py: " + failed)
-    if world > 1:
+    if _dist_on(world):
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -56,6 +56,24 @@ def test_two_ranks_over_rccl():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["global_batch"] == 32
 
 
+def test_collective_layer_on_a_one_rank_rccl_communicator():
+    """The lease has one GPU, so the N > 1 path has never met RCCL -- but a communicator of ONE rank is a real RCCL communicator:
+    `--dist-single` sends the whole collective layer of the bench line through backend nccl (init with device_id, the int64
+    broadcast, the barrier in front of every window, the float64 MAX all-reduce of the window times, the timed barriers, the
+    all-gather), on device tensors, as the ranks of an 8-GPU job would."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dist-single", "--batch", "2", "--steps", "6",
+                        "--warmup", "2", "--prewarm", "4", "--windows", "3", "--no-secondary", "--cpu-seconds", "0.5"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = _line(r.stdout)
+    d = line["dist"]
+    assert d["backend"] == "nccl" and d["world_size_seen"] == 1 and d["single_rank_communicator"] is True
+    assert d["per_rank_items"] == [2] and len(d["worst_window_ms"]) == 3 and d["barrier_us"] > 0
+    assert "rccl_version" in d
+    assert line["n_gpus"] == 1 and line["check"]["ok"]                 # (still rank 0 at N = 1: the oracle check runs)
+
+
 def test_two_ranks_sharing_one_gpu_plumbing():
     """The N > 1 code path end to end on a one-GPU box: two ranks on the same device, gloo standing in for RCCL (which
     refuses two ranks on one device).  Not a measurement -- the line says so in `data` -- but every collective, the shard

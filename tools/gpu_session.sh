@@ -25,10 +25,16 @@ import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']; r=d['roofline']
 print('batch %2d steps %3d %-9s value %9.1f ms/step %.4f gpu_us/step %.2f enqueue_us %.1f fixed_us %.1f kernel_us %.2f first %s windows %s' % (c['batch_per_gpu'], d['steps'], c['launch'], d['value'], d['ms_per_step'], c['window_gpu_us_per_step'], c['window_host_enqueue_us'], c['window_fixed_cost_us'], r['avg_launch_us'], r['first_launches_us'], c['window_ms_min_max']))" | tee -a "$OUT/bench_shards_summary.txt"; done; done
 echo "== the N > 1 code path on this one GPU: two ranks sharing it over gloo (PLUMBING, not a measurement), 20 and 300 steps"
+echo "== the collective layer on a one-rank RCCL communicator (backend nccl on this one GPU)"
+timeout 600 python bench.py --dist-single --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>&1 | grep '^{"metric"' | tee "$OUT/bench_dist_single.log" | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('one-rank RCCL communicator:', json.dumps(d['dist']))" | tee -a "$OUT/bench_shards_summary.txt"
+T0=$(date +%s.%N)
 for st in 20 300; do timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29641 bench.py --gpus 2 --share-gpu --batch 8 --steps $st --warmup 5 2>&1 | grep '^{"metric"' | tee -a "$OUT/bench_share_gpu.log" | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('2 ranks on one GPU: steps %3d ms/step %.4f barrier_us %s per-rank ms/step %s' % (d['steps'], d['ms_per_step'], d['dist']['barrier_us'], d['dist']['per_rank_ms_per_step']))" | tee -a "$OUT/bench_shards_summary.txt"; done
+python -c "import sys; print('the two 2-rank runs (torch.distributed.run start-up, two processes, gloo) took %.1f s end to end together' % (float(sys.argv[2]) - float(sys.argv[1])))" $T0 $(date +%s.%N) | tee -a "$OUT/bench_shards_summary.txt"
 echo "== model"; timeout 600 python tools/bench_model.py --json "$OUT/bench_model.json" 2>&1 | tail -2 | tee "$OUT/bench_model.log"
 echo "== projection: phase clocks of the owner kernel (measurement build), A/B against round 3's set in one process"
 timeout 300 python tools/trace_kernel.py proj5 2>&1 | grep -v amdgpu.ids | tee "$OUT/proj_owner5_phases.txt"
