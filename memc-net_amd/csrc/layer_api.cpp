@@ -99,9 +99,9 @@ extern "C" const char *memc_debug_last_path(void) { return memc::t_last_path; }
 extern "C" {
 
 #ifdef MEMC_MEASURE
-const char *memc_hip_version(void) { return "memc_hip 0.5 gfx950 MEASUREMENT BUILD (ablation arms present)"; }
+const char *memc_hip_version(void) { return "memc_hip 0.6 gfx950 MEASUREMENT BUILD (ablation arms present)"; }
 #else
-const char *memc_hip_version(void) { return "memc_hip 0.5 gfx950"; }
+const char *memc_hip_version(void) { return "memc_hip 0.6 gfx950"; }
 #endif
 
 int memc_gradinput1_is_stored(int filter_size, int channel)
