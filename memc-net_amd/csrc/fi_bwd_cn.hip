@@ -28,6 +28,16 @@
 //                       EVERY path (the launcher clears it before falling back to the direct kernel), so a caller
 //                       need not zero-fill it.
 //
+// Widths that are not multiples of four (round 6; the reference serves every width with its one kernel, my_lib_kernel.cu:10-15):
+// the kernels work on the whole quads of every row, Wq = W & ~3 columns of SITES and of CELLS -- the image is still W wide for
+// every clamp and validity test, and kernel A's RAG instantiation stages boxes that reach into the last, partial quad
+// (memc_tile.hpp: loads moved left and rotated back).  What is left is one to three columns:
+//   * their CELLS are cleared first (bwd_cn_zero_tail) and only ever reached by atomics: a site whose window touches a column
+//     >= Wq counts as "far" (site_far), so the owners never see it and the far-site kernel adds its whole window;
+//   * their SITES are one lane each in fi_bwd_tail_sites / bl_bwd_tail_sites (tap and flow gradients from global memory, the
+//     image gradient by atomics), queued behind the owners' stores like the far sites.
+// Rounds 2-5 sent such shapes to the direct kernels (16 C global atomics per site: 13-41x slower, profiles/r04_slow_paths.txt).
+//
 // Sites whose window leaves the owner's search window (kOwnRX / kOwnRY site tiles around the site's own tile: motion
 // beyond ~192 px horizontally or ~64 px vertically) are "far": every owner skips them and a third kernel,
 // fi_bwd_far_sites, adds their image gradient with global atomics after the owners have stored theirs (kernel A
@@ -66,17 +76,19 @@ struct FpBilinear {                            // Interpolation / InterpolationC
 };
 
 // one site: does its (clamped) window reach a cell tile outside the search window of the site's own tile?
+// ... or (a ragged width: Wq = W & ~3 < W) a cell of the one to three columns no owner stores?
 template <class FP>
-__device__ __forceinline__ bool site_far(int x, int y, int ix, int iy, int W, int H)
+__device__ __forceinline__ bool site_far(int x, int y, int ix, int iy, int W, int H, int Wq)
 {
     const int tx = x >> 6, ty = y >> 4;
-    const int c0 = clampi(ix + FP::kOff, W - 1) >> 6, c1 = clampi(ix + FP::kOff + FP::kN - 1, W - 1) >> 6;
+    const int cl = clampi(ix + FP::kOff + FP::kN - 1, W - 1);      // the window's last column
+    const int c0 = clampi(ix + FP::kOff, W - 1) >> 6, c1 = cl >> 6;
     const int r0 = clampi(iy + FP::kOff, H - 1) >> 4, r1 = clampi(iy + FP::kOff + FP::kN - 1, H - 1) >> 4;
-    return c0 < tx - kOwnRX || c1 > tx + kOwnRX || r0 < ty - kOwnRY || r1 > ty + kOwnRY;
+    return c0 < tx - kOwnRX || c1 > tx + kOwnRX || r0 < ty - kOwnRY || r1 > ty + kOwnRY || cl >= Wq;
 }
-__device__ __forceinline__ bool fi_site_far(int x, int y, int ix, int iy, int W, int H)
+__device__ __forceinline__ bool fi_site_far(int x, int y, int ix, int iy, int W, int H, int Wq)
 {
-    return site_far<FpFilter>(x, y, ix, iy, W, H);
+    return site_far<FpFilter>(x, y, ix, iy, W, H, Wq);
 }
 
 // What the owners cull by: the target bounding box of every 64 x 4 STRIP of sites (one wave of a producer's site tile:
@@ -190,8 +202,9 @@ __device__ __forceinline__ void fi_bwd_taps_accum(const Region &r, const FiSite4
     }
 }
 
+template <bool RAG>
 __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
-    int W, int H, int C, int tiles_x, int tiles_y, int batch,
+    int W, int H, int Wq, int C, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
     const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2, float *__restrict__ gin3,
@@ -209,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
     const int b = tc.b;
     const unsigned tid = tid_now();
     const int x = tc.tx * G::kTW + 4 * (int)(tid % LX), y = tc.ty * G::kTH + (int)(tid / LX);
-    const bool inb = x < W && y < H;
-    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const bool inb = x < Wq && y < H;                      // (Wq: the whole quads of a row; == W unless RAG)
+    const int xs = min(x, Wq - 4), ys = min(y, H - 1);
     const float *flow_b = flow + b * s2b, *filt_b = filt + b * s3b, *gout_b = gout + b * s1b;
     float *gin2_b = gin2 + b * s2b, *gin3_b = gin3 + b * s3b;
     const unsigned o1 = 4u * (unsigned)(ys * s1h + xs), o2 = 4u * (unsigned)(ys * s2h + xs),
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
             g.valid |= 1u << j;
             const int c0 = max(s.ix - 1, 0), c1 = min(s.ix + 2, W - 1), r0 = max(s.iy - 1, 0), r1 = min(s.iy + 2, H - 1);
             cmin = min(cmin, c0);  cmax = max(cmax, c1);  rmin = min(rmin, r0);  rmax = max(rmax, r1);
-            if (fi_site_far(x + j, y, s.ix, s.iy, W, H)) {
+            if (fi_site_far(x + j, y, s.ix, s.iy, W, H, Wq)) {
                 far |= 1u << j;
             } else {
                 ncmin = min(ncmin, c0);  ncmax = max(ncmax, c1);  nrmin = min(nrmin, r0);  nrmax = max(nrmax, r1);
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
     unsigned done = 0;
 #pragma unroll 1
     for (int bi = 0; bi < bands.n; bi++) {
-        const Region r = band_region(box, bands, bi);
+        const Region r = band_region(box, bands, bi, RAG ? W : 0);
         // the window corners fi_covered derives from ix / iy (sixteen clamped values) are loop-invariant: hoisted out of the
         // band loop they lived in private scratch through the channel loop (28 dwords per lane, rounds 2-5); opaque here,
         // they are recomputed per band -- sixteen integer instructions
@@ -275,12 +288,15 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
                 StageRegs<4> sr;
 #pragma unroll
                 for (int it = 0; it < kStageIts; it++) {
+                    // (RAG: the box's last quad may reach past the row -- loaded from rs columns further left, rotated back by
+                    // tile_stage_store; what lies past the row is never gathered: coordinates are clamped)
+                    const int rs = RAG ? tail_shift(r.x0 + 4 * sl.q[it], W) : 0;
                     const unsigned off = sl.row[it] < r.h
-                                             ? 4u * (unsigned)((r.y0 + sl.row[it]) * s1h + r.x0 + 4 * sl.q[it]) : 0u;
+                                             ? 4u * (unsigned)((r.y0 + sl.row[it]) * s1h + r.x0 + 4 * sl.q[it] - rs) : 0u;
 #pragma unroll
                     for (int c = 0; c < 4; c++) sr.v[it][c] = ld_cached4_u(in_b + min(c0 + c, C - 1) * s1c, off);
                 }
-                tile_stage_store<4>(r, sl, sr, tile);
+                tile_stage_store<4, RAG>(r, sl, sr, tile);
             }
             __syncthreads();
             fi_bwd_taps_accum(r, g, sel, go, W, H, tile, kZeroPx, S);
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
 // The image gradient of the far sites, after the owners have stored theirs: one workgroup per site tile, gone at once
 // unless kernel A flagged the tile.
 __global__ __launch_bounds__(256) void fi_bwd_far_sites(
-    int W, int H, int C, int tiles_x, int tiles_y, int batch,
+    int W, int H, int Wq, int C, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ flow, const float *__restrict__ filt, const float *__restrict__ gout,
     float *__restrict__ gin1, const BBox *__restrict__ tbox)
@@ -360,15 +376,52 @@ __global__ __launch_bounds__(256) void fi_bwd_far_sites(
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
     if (!(tbox[(((int64_t)tc.b * tiles_y + tc.ty) * tiles_x + tc.tx) * 4].h & kTileHasFar)) return;
     const int x0 = tc.tx * 64 + 4 * (int)(threadIdx.x % 16), y = tc.ty * 16 + (int)(threadIdx.x / 16);
-    if (x0 >= W || y >= H) return;
+    if (x0 >= Wq || y >= H) return;                       // (the columns behind the whole quads: fi_bwd_tail_sites)
     const float *flow_p = flow + tc.b * s2b + (int64_t)y * s2h + x0;
     for (int j = 0; j < 4; j++) {
         const FiSite s = fi_locate(x0 + j, y, W, H, flow_p[j], flow_p[s2c + j]);
-        if (s.valid && fi_site_far(x0 + j, y, s.ix, s.iy, W, H))
+        if (s.valid && fi_site_far(x0 + j, y, s.ix, s.iy, W, H, Wq))
             fi_bwd_site_image_atomics(x0 + j, y, W, H, C, gin1 + tc.b * s1b, s1c, s1h, flow_p + j, s2c,
                                       filt + tc.b * s3b + (int64_t)y * s3h + x0 + j, s3c,
                                       gout + tc.b * s1b + (int64_t)y * s1h + x0 + j);
     }
+}
+
+// A ragged width's one to three columns behind the whole quads (see the top of the file).
+// gradinput1 = 0 in columns [Wq, W) of a strided [batch, channel, h, w] view: one lane per row
+__global__ __launch_bounds__(256) void bwd_cn_zero_tail(float *__restrict__ p, int Wq, int W, int h, int channel, int batch,
+                                                        int64_t sb, int64_t sc, int sh)
+{
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x, rows = (int64_t)batch * channel * h;
+    if (row >= rows) return;
+    const int y = (int)(row % h), c = (int)((row / h) % channel);
+    float *q = p + (row / h / channel) * sb + c * sc + (int64_t)y * sh;
+    for (int x = Wq; x < W; x++) q[x] = 0.0f;
+}
+// the sites of those columns, one lane each: tap and flow gradients from global memory, the image gradient by atomics
+// (after the owners' stores, like fi_bwd_far_sites)
+__global__ __launch_bounds__(256) void fi_bwd_tail_sites(
+    int W, int H, int Wq, int C, int batch,
+    int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
+    const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
+    const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2, float *__restrict__ gin3)
+{
+    const int nt = W - Wq;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, n = (int64_t)batch * H * nt;
+    if (i >= n) return;
+    const int x = Wq + (int)(i % nt), y = (int)((i / nt) % H), b = (int)(i / nt / H);
+    const float *flow_p = flow + b * s2b + (int64_t)y * s2h + x, *tap_p = filt + b * s3b + (int64_t)y * s3h + x;
+    const float *gout_p = gout + b * s1b + (int64_t)y * s1h + x;
+    float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x, *g3 = gin3 + b * s3b + (int64_t)y * s3h + x;
+    const FiSite s = fi_locate(x, y, W, H, flow_p[0], flow_p[s2c]);
+    if (!s.valid) {                                        // gradinput2 / gradinput3 are ASSIGNED: invalid sites store zeros
+        g2[0] = 0.0f;
+        g2[s2c] = 0.0f;
+        for (int k = 0; k < 16; k++) g3[k * s3c] = 0.0f;
+        return;
+    }
+    fi_bwd_site_taps_cn(x, y, W, H, C, in1 + b * s1b, s1c, s1h, flow_p, g2, s2c, tap_p, g3, s3c, gout_p);
+    fi_bwd_site_image_atomics(x, y, W, H, C, gin1 + b * s1b, s1c, s1h, flow_p, s2c, tap_p, s3c, gout_p);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -442,7 +495,7 @@ struct QuadHits {
     float a[4], b[4];
 };
 template <class FP, int TH>
-__device__ __forceinline__ QuadHits own_quad_hits(int x, int y, int W, int H, int tx0, int ty0, f32x4 fx4, f32x4 fy4)
+__device__ __forceinline__ QuadHits own_quad_hits(int x, int y, int W, int H, int Wq, int tx0, int ty0, f32x4 fx4, f32x4 fy4)
 {
     QuadHits h;
     h.any = 0;
@@ -451,7 +504,7 @@ __device__ __forceinline__ QuadHits own_quad_hits(int x, int y, int W, int H, in
         const FiSite s = FP::locate(x + j, y, W, H, fx4[j], fy4[j]);
         h.ix[j] = s.ix; h.iy[j] = s.iy; h.a[j] = s.a; h.b[j] = s.b;
         unsigned rm = 0, cm = 0;
-        if (s.valid && !site_far<FP>(x + j, y, s.ix, s.iy, W, H)) {
+        if (s.valid && !site_far<FP>(x + j, y, s.ix, s.iy, W, H, Wq)) {
 #pragma unroll
             for (int k = 0; k < FP::kN; k++) {
                 rm |= (unsigned)((unsigned)(clampi(s.iy + FP::kOff + k, H - 1) - ty0) < (unsigned)TH) << k;
@@ -521,7 +574,7 @@ __device__ __forceinline__ f32x4 quad_transpose(f32x4 v, unsigned my)
 // 5 lists -> registers, 6 replay, 7 slab rounds, 8 candidate tiles, 9 tail segments (last slab), 10 site-box area.
 template <class FP, int TH, bool TR>
 __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
-    int W, int H, int C, int tiles_x, int tiles_y, int site_tiles_y, int batch,
+    int W, int H, int Wq, int C, int tiles_x, int tiles_y, int site_tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ flow, const float *__restrict__ filt, const float *__restrict__ gout,
     float *__restrict__ gin1, const BBox *__restrict__ tbox, unsigned long long *__restrict__ trace)
@@ -569,8 +622,8 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
         CellOffsets o;
         o.my = t & 3;
         const int cell_x = tx0 + (int)(t & 63 & ~3u), cell_y = ty0 + (int)(t >> 6);
-        o.st0 = cell_x < W && cell_y < H;
-        o.st1 = cell_x < W && cell_y + TH / 2 < H;
+        o.st0 = cell_x < Wq && cell_y < H;                  // (cells behind the whole quads: cleared, reached by atomics only)
+        o.st1 = cell_x < Wq && cell_y + TH / 2 < H;
         o.wo0 = o.st0 ? 4u * (unsigned)((int64_t)o.my * s1c + (int64_t)cell_y * s1h + cell_x) : 0u;
         o.wo1 = o.st1 ? 4u * (unsigned)((int64_t)o.my * s1c + (int64_t)(cell_y + TH / 2) * s1h + cell_x) : 0u;
         return o;
@@ -642,9 +695,9 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
         for (int idx = tid; idx < nq; idx += kOwnThreads) {
             const int t = cand[idx >> 6], q = idx & 63;
             const int x = (t & 0xfff) * 64 + 4 * (q & 15), y = ((t >> 12) & 0xffff) * 16 + ((t >> 28) & 3) * 4 + (q >> 4);
-            if (x >= W || y >= H) continue;
+            if (x >= Wq || y >= H) continue;
             const float *fp = flow_b + (int64_t)y * s2h + x;
-            const QuadHits h = own_quad_hits<FP, TH>(x, y, W, H, tx0, ty0, ld_cached4(fp), ld_cached4(fp + s2c));
+            const QuadHits h = own_quad_hits<FP, TH>(x, y, W, H, Wq, tx0, ty0, ld_cached4(fp), ld_cached4(fp + s2c));
             if (h.any) {
                 bx0 = min(bx0, x + __ffs(h.any) - 1);
                 bx1 = max(bx1, x + 31 - __clz(h.any));
@@ -694,8 +747,8 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
             pres[tid] = 0;
             pres[tid + kOwnThreads] = 0;
             __syncthreads();
-            const QuadHits h0 = own_quad_hits<FP, TH>(xq0, yq0, W, H, tx0, ty0, ld_cached4(fp0), ld_cached4(fp0 + s2c));
-            const QuadHits h1 = own_quad_hits<FP, TH>(xq1, yq1, W, H, tx0, ty0, ld_cached4(fp1), ld_cached4(fp1 + s2c));
+            const QuadHits h0 = own_quad_hits<FP, TH>(xq0, yq0, W, H, Wq, tx0, ty0, ld_cached4(fp0), ld_cached4(fp0 + s2c));
+            const QuadHits h1 = own_quad_hits<FP, TH>(xq1, yq1, W, H, Wq, tx0, ty0, ld_cached4(fp1), ld_cached4(fp1 + s2c));
             if (on0 && h0.any) own_count<FP>(h0, oc, pres, W, H, tx0, ty0);
             if (on1 && h1.any) own_count<FP>(h1, oc, pres, W, H, tx0, ty0);
             __syncthreads();
@@ -781,7 +834,7 @@ __global__ __launch_bounds__(32 * TH, TH == 16 ? 1 : 2) void fi_bwd_image_owner(
 #pragma unroll
                 for (int k = 0; k < (FP::kTaps ? 16 : 1); k++) tp[k] = ld_cached4(tp_p + k * s3c);
             }
-            const QuadHits h = own_quad_hits<FP, TH>(x, y, W, H, tx0, ty0, fx4, fy4);
+            const QuadHits h = own_quad_hits<FP, TH>(x, y, W, H, Wq, tx0, ty0, fx4, fy4);
             if (!h.any) continue;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1059,9 +1112,9 @@ __device__ __noinline__ f32x4 bl_corner_sums_global(const float *plane0, const f
     return q;
 }
 
-template <int CAP>
+template <int CAP, bool RAG>
 __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
-    int W, int H, int C, int tiles_x, int tiles_y, int batch,
+    int W, int H, int Wq, int C, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
     float *__restrict__ gin2, BBox *__restrict__ tbox)
@@ -1077,8 +1130,8 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
     const int b = tc.b, tile_x0 = tc.tx * G::kTW, tile_y0 = tc.ty * G::kTH;
     const int x = tile_x0 + 4 * (int)(threadIdx.x % LX), y = tile_y0 + (int)(threadIdx.x / LX);
-    const bool inb = x < W && y < H;
-    const int xs = min(x, W - 4), ys = min(y, H - 1);
+    const bool inb = x < Wq && y < H;                      // (Wq: the whole quads of a row; == W unless RAG)
+    const int xs = min(x, Wq - 4), ys = min(y, H - 1);
     const float *flow_p = flow + b * s2b + (int64_t)ys * s2h + xs;
     const f32x4 fx4 = ld_stream4(flow_p), fy4 = ld_stream4(flow_p + s2c);
     const float *gout_p = gout + b * s1b + (int64_t)ys * s1h + xs;
@@ -1094,7 +1147,7 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
         if (st[j].valid) {
             cmin = min(cmin, st[j].L);  cmax = max(cmax, st[j].R);
             rmin = min(rmin, st[j].T);  rmax = max(rmax, st[j].Bm);
-            if (site_far<FpBilinear>(x + j, y, st[j].L, st[j].T, W, H)) {
+            if (site_far<FpBilinear>(x + j, y, st[j].L, st[j].T, W, H, Wq)) {
                 far |= 1u << j;
             } else {
                 ncmin = min(ncmin, st[j].L);  ncmax = max(ncmax, st[j].R);
@@ -1102,7 +1155,8 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
             }
         }
     }
-    const Region r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    Region r = tile_region<LX, true, CAP>(cmin, cmax, rmin, rmax, tile_x0, tile_y0, bb);
+    r.wimg = RAG ? W : 0;                                  // (the staged box may reach into a ragged row's last, partial quad)
     strip_box_store(tbox, ((int64_t)b * tiles_y + tc.ty) * tiles_x + tc.tx, ncmin, ncmax, nrmin, nrmax,
                     __syncthreads_or(far != 0) != 0);
 
@@ -1135,7 +1189,7 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
             plane[c] = in_b + min(c0 + c, C - 1) * s1c;
             hs[c] = s1h;
         }
-        tile_stage_load_planes<4>(r, sl, plane, hs, sr);
+        tile_stage_load_planes<4, RAG>(r, sl, plane, hs, sr);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const f32x4 gl = ld_stream4(gout_p + min(c0 + c, C - 1) * s1c);
@@ -1145,7 +1199,7 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
     fetch(0);
 #pragma unroll 1
     for (int c0 = 0; c0 < C; c0 += 4) {
-        tile_stage_store<4>(r, sl, sr, tile);
+        tile_stage_store<4, RAG>(r, sl, sr, tile);
         f32x4 gc[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) gc[c] = go[c];
@@ -1193,8 +1247,36 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
     }
 }
 
+// (a ragged width's columns behind the whole quads, as fi_bwd_tail_sites)
+__global__ __launch_bounds__(256) void bl_bwd_tail_sites(
+    int W, int H, int Wq, int C, int batch, int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
+    const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
+    float *__restrict__ gin1, float *__restrict__ gin2)
+{
+    const int nt = W - Wq;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, n = (int64_t)batch * H * nt;
+    if (i >= n) return;
+    const int x = Wq + (int)(i % nt), y = (int)((i / nt) % H), b = (int)(i / nt / H);
+    const float *flow_p = flow + b * s2b + (int64_t)y * s2h + x, *gout_p = gout + b * s1b + (int64_t)y * s1h + x;
+    float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
+    const float fx = flow_p[0], fy = flow_p[s2c];
+    const BlSite s = bl_locate<true>(x, y, W, H, fx, fy);
+    float vx = 0.0f, vy = 0.0f;                            // gradinput2 is ASSIGNED; invalid sites store zeros
+    if (s.valid) {
+        const f32x4 q = bl_corner_sums_global(in1 + b * s1b, gout_p, s1c, C, s.T * s1h + s.L, s.T * s1h + s.R,
+                                              s.Bm * s1h + s.L, s.Bm * s1h + s.R);
+        const float x2 = (float)x + fx, y2 = (float)y + fy;
+        const float gam_x = (float)s.Bm - y2, gam_y = (float)s.R - x2;         // as bl_bwd_flow_c4n
+        vx = gam_x * (q[1] - q[0]) + (1 - gam_x) * (q[3] - q[2]);
+        vy = gam_y * (q[2] - q[0]) + (1 - gam_y) * (q[3] - q[1]);
+        bl_bwd_site_image_atomics(x, y, W, H, C, gin1 + b * s1b, s1c, s1h, flow_p, s2c, gout_p);
+    }
+    g2[0] = vx;
+    g2[s2c] = vy;
+}
+
 __global__ __launch_bounds__(256) void bl_bwd_far_sites(
-    int W, int H, int C, int tiles_x, int tiles_y, int batch,
+    int W, int H, int Wq, int C, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
     const float *__restrict__ flow, const float *__restrict__ gout, float *__restrict__ gin1,
     const BBox *__restrict__ tbox)
@@ -1202,11 +1284,11 @@ __global__ __launch_bounds__(256) void bl_bwd_far_sites(
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
     if (!(tbox[(((int64_t)tc.b * tiles_y + tc.ty) * tiles_x + tc.tx) * 4].h & kTileHasFar)) return;
     const int x0 = tc.tx * 64 + 4 * (int)(threadIdx.x % 16), y = tc.ty * 16 + (int)(threadIdx.x / 16);
-    if (x0 >= W || y >= H) return;
+    if (x0 >= Wq || y >= H) return;
     const float *flow_p = flow + tc.b * s2b + (int64_t)y * s2h + x0;
     for (int j = 0; j < 4; j++) {
         const BlSite s = bl_locate<true>(x0 + j, y, W, H, flow_p[j], flow_p[s2c + j]);
-        if (s.valid && site_far<FpBilinear>(x0 + j, y, s.L, s.T, W, H))
+        if (s.valid && site_far<FpBilinear>(x0 + j, y, s.L, s.T, W, H, Wq))
             bl_bwd_site_image_atomics(x0 + j, y, W, H, C, gin1 + tc.b * s1b, s1c, s1h, flow_p + j, s2c,
                                       gout + tc.b * s1b + (int64_t)y * s1h + x0 + j);
     }
@@ -1241,10 +1323,9 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
     if (!fi_bwd_cn_class(channel, 4)) return 0;
     const int ntx = (w + 63) / 64, nty = (h + 15) / 16;
     const unsigned ntiles = (unsigned)ntx * nty * batch;
+    const int wq = w & ~3;                                 // the whole quads of a row (round 6: ragged widths, see the top)
     CallScratch scratch;                                   // the site tiles' target boxes
-    if (force_direct || !plane_fits_u32(w, h, {s1h, s2h, s3h}) ||
-        !vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h, s3b, s3c, s3h},
-                 {input1, input2, input3, gradoutput, gradinput1, gradinput2, gradinput3}) ||
+    if (force_direct || !plane_fits_u32(w, h, {s1h, s2h, s3h}) || wq < 8 ||
         4LL * (3LL * s1c + (long long)(h - 1) * s1h + w) >= (1LL << 32) ||           // the owner's 4-plane offsets
         ntx > 0xfff || nty > 0x7fff ||
         !scratch.alloc((size_t)ntiles * 4 * sizeof(BBox), stream)) {                 // e.g. inside a stream capture
@@ -1253,17 +1334,27 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
         return launch_status() == 0 ? 0 : -1;
     }
     BBox *tbox = static_cast<BBox *>(scratch.p);
-    hipLaunchKernelGGL(fi_bwd_taps_c4n, dim3(ntiles), dim3(256), tile_lds_bytes<16>() + 64, stream,
-                       w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
-                       (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2,
-                       gradinput3, tbox);
+    const bool rag = wq < w;
+    const unsigned tail_rows = (unsigned)(((int64_t)batch * channel * h + 255) / 256);
+    const unsigned tail_sites = (unsigned)(((int64_t)batch * h * (w - wq) + 255) / 256);
+    if (rag)                                               // the cells no owner stores: cleared before anything adds to them
+        hipLaunchKernelGGL(bwd_cn_zero_tail, dim3(tail_rows), dim3(256), 0, stream, gradinput1, wq, w, h, channel, batch,
+                           (int64_t)s1b, (int64_t)s1c, s1h);
+#define MEMC_TAPS(RAG_)                                                                                            \
+    hipLaunchKernelGGL(fi_bwd_taps_c4n<RAG_>, dim3(ntiles), dim3(256), tile_lds_bytes<16>() + 64, stream,          \
+                       w, h, wq, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, \
+                       (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, gradoutput, gradinput1, gradinput2,  \
+                       gradinput3, tbox)
+    if (rag) MEMC_TAPS(true);
+    else MEMC_TAPS(false);
+#undef MEMC_TAPS
 #define MEMC_OWNER(TH, TR, TRACE)                                                                                  \
     do {                                                                                                           \
         using Gm_ = OwnGeom<FpFilter, TH>;                                                                         \
         allow_big_lds(fi_bwd_image_owner<FpFilter, TH, TR>, Gm_::kBytes);   /* per launch: a per-DEVICE attribute */ \
         const int cty = (h + TH - 1) / TH;                                                                         \
         hipLaunchKernelGGL((fi_bwd_image_owner<FpFilter, TH, TR>), dim3((unsigned)ntx * cty * batch),              \
-                           dim3(Gm_::kThreads), Gm_::kBytes, stream, w, h, channel, ntx, cty, nty,                 \
+                           dim3(Gm_::kThreads), Gm_::kBytes, stream, w, h, wq, channel, ntx, cty, nty,             \
                            batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b,  \
                            (int64_t)s3c, s3h, input2, input3, gradoutput, gradinput1, tbox, TRACE);                \
     } while (0)
@@ -1273,8 +1364,12 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
 #endif
         MEMC_OWNER(16, false, nullptr);
 #undef MEMC_OWNER
+    if (rag)
+        hipLaunchKernelGGL(fi_bwd_tail_sites, dim3(tail_sites), dim3(256), 0, stream, w, h, wq, channel, batch, (int64_t)s1b,
+                           (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input1, input2,
+                           input3, gradoutput, gradinput1, gradinput2, gradinput3);
     hipLaunchKernelGGL(fi_bwd_far_sites, dim3(ntiles), dim3(256), 0, stream,
-                       w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                       w, h, wq, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                        (int64_t)s3b, (int64_t)s3c, s3h, input2, input3, gradoutput, gradinput1, tbox);
     return launch_status() == 0 ? 1 : -1;
 }
@@ -1288,9 +1383,9 @@ int bl_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
     if (!fi_bwd_cn_class(channel, 4)) return 0;
     const int ntx = (w + 63) / 64, nty = (h + 15) / 16;
     const unsigned ntiles = (unsigned)ntx * nty * batch;
+    const int wq = w & ~3;
     CallScratch scratch;                                   // the site tiles' target boxes
-    if (force_direct || !plane_fits_u32(w, h, {s1h, s2h}) ||
-        !vec4_ok(w, {s1b, s1c, s1h, s2b, s2c, s2h}, {input1, input2, gradoutput, gradinput1, gradinput2}) ||
+    if (force_direct || !plane_fits_u32(w, h, {s1h, s2h}) || wq < 8 ||
         4LL * (3LL * s1c + (long long)(h - 1) * s1h + w) >= (1LL << 32) || ntx > 0xfff || nty > 0x7fff ||
         !scratch.alloc((size_t)ntiles * 4 * sizeof(BBox), stream)) {
         hipLaunchKernelGGL(fi_bwd_zero_rows, dim3((unsigned)batch * channel * h), dim3(256), 0, stream, gradinput1, w, h,
@@ -1298,18 +1393,30 @@ int bl_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
         return launch_status() == 0 ? 0 : -1;
     }
     BBox *tbox = static_cast<BBox *>(scratch.p);
+    const bool rag = wq < w;
     constexpr int kCap = 2496;                             // the forward's staging budget: 39 KiB, 2 x 2 footprint
-    hipLaunchKernelGGL(bl_bwd_flow_c4n<kCap>, dim3(ntiles), dim3(256), (tile_lds_bytes<16, kCap>() + 64), stream,
-                       w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
-                       input1, input2, gradoutput, gradinput2, tbox);
+    if (rag)
+        hipLaunchKernelGGL(bwd_cn_zero_tail, dim3((unsigned)(((int64_t)batch * channel * h + 255) / 256)), dim3(256), 0, stream,
+                           gradinput1, wq, w, h, channel, batch, (int64_t)s1b, (int64_t)s1c, s1h);
+#define MEMC_FLOW(RAG_)                                                                                            \
+    hipLaunchKernelGGL((bl_bwd_flow_c4n<kCap, RAG_>), dim3(ntiles), dim3(256), (tile_lds_bytes<16, kCap>() + 64), stream,  \
+                       w, h, wq, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, \
+                       input1, input2, gradoutput, gradinput2, tbox)
+    if (rag) MEMC_FLOW(true);
+    else MEMC_FLOW(false);
+#undef MEMC_FLOW
     using Gm = OwnGeom<FpBilinear, 16>;
     allow_big_lds(fi_bwd_image_owner<FpBilinear, 16, false>, Gm::kBytes);   // per launch: the attribute belongs to the current device
     hipLaunchKernelGGL((fi_bwd_image_owner<FpBilinear, 16, false>), dim3(ntiles), dim3(Gm::kThreads), Gm::kBytes, stream,
-                       w, h, channel, ntx, nty, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c,
+                       w, h, wq, channel, ntx, nty, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c,
                        s2h, (int64_t)0, (int64_t)0, 0, input2, static_cast<const float *>(nullptr), gradoutput,
                        gradinput1, tbox, static_cast<unsigned long long *>(nullptr));
+    if (rag)
+        hipLaunchKernelGGL(bl_bwd_tail_sites, dim3((unsigned)(((int64_t)batch * h * (w - wq) + 255) / 256)), dim3(256), 0, stream,
+                           w, h, wq, channel, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1,
+                           input2, gradoutput, gradinput1, gradinput2);
     hipLaunchKernelGGL(bl_bwd_far_sites, dim3(ntiles), dim3(256), 0, stream,
-                       w, h, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
+                       w, h, wq, channel, ntx, nty, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,
                        input2, gradoutput, gradinput1, tbox);
     return launch_status() == 0 ? 1 : -1;
 }

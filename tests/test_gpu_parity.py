@@ -337,10 +337,14 @@ def _many_channel_flows(kind, rng, B, H, W):
 
 MANY = [(2, 8, 70, 200, "smooth"), (1, 16, 96, 384, "pan"), (1, 8, 48, 512, "far"), (1, 8, 64, 192, "converge"),
         (1, 12, 80, 256, "iid"), (1, 64, 36, 132, "smooth"),
-        (1, 8, 20, 50, "smooth"),          # width not a multiple of 4: cleared, then the direct kernel
+        (1, 8, 20, 50, "smooth"),          # width not a multiple of 4 (round 6: whole quads on the owner kernels, the tail by lanes)
         (1, 8, 5, 12, "smooth"), (1, 8, 16, 64, "iid"), (3, 8, 33, 68, "pan"),      # tiny, exactly one tile, ragged
-        (1, 4, 40, 128, "smooth"), (2, 5, 40, 132, "smooth"), (1, 6, 24, 64, "iid"), (1, 7, 70, 200, "converge")]
-# (the last four: one chunk; ragged last chunks of 1, 2 and 3 channels)
+        (1, 4, 40, 128, "smooth"), (2, 5, 40, 132, "smooth"), (1, 6, 24, 64, "iid"), (1, 7, 70, 200, "converge"),
+        # (the last four: one chunk; ragged last chunks of 1, 2 and 3 channels)
+        # round 6, ragged WIDTHS (W % 4 = 1, 2, 3) through every path of fi_bwd_cn.hip: near sites next to the tail columns,
+        # coherent motion into / out of them, far sites, converging lists, i.i.d. flow, 64 channels, a ragged last chunk too
+        (1, 8, 40, 134, "smooth"), (2, 16, 70, 201, "pan"), (1, 8, 48, 510, "far"), (1, 8, 64, 190, "converge"),
+        (1, 12, 80, 254, "iid"), (1, 64, 36, 131, "smooth"), (1, 5, 40, 133, "smooth"), (1, 8, 17, 9, "smooth")]
 
 
 @pytest.mark.parametrize("case", MANY, ids=["%dx%dx%dx%d-%s" % c for c in MANY])
@@ -495,11 +499,12 @@ def test_shapes_take_the_documented_kernel_paths():
     # a width that is not a multiple of four stays on the tiled kernels since round 5 (the scattering passes were 13-41x
     # slower on the scalar ones in round 4, the gathers 2x): the projection forward's owner kernels have a ragged-row
     # instantiation, every other operator takes the whole quads in its tiled kernel and the one to three columns behind
-    # them in the one-lane-per-site kernel (exception: the many-channel backward passes)
+    # them in the one-lane-per-site kernel (the many-channel backward passes since round 6)
     assert run(1, 3, 20, 50) == {"fi_fwd": "fi_fwd:tiled_c3", "fi_bwd": "fi_bwd:tiled_c3", "bl_fwd": "bl_fwd:tiled_c3",
                                  "bl_bwd": "bl_bwd:tiled_c3", "proj_fwd": "proj_fwd:owner", "proj_bwd": "proj_bwd:tiled"}
-    got = run(1, 8, 20, 50)
-    assert got["fi_fwd"] == "fi_fwd:tiled_c4n_ragged" and got["fi_bwd"] == "fi_bwd:direct"
+    got = run(1, 8, 20, 50)                                            # (round 6: the many-channel backward passes too)
+    assert got["fi_fwd"] == "fi_fwd:tiled_c4n_ragged" and got["fi_bwd"] == "fi_bwd:owner" and got["bl_bwd"] == "bl_bwd:owner"
+    assert run(1, 8, 20, 7)["fi_bwd"] == "fi_bwd:direct"               # (fewer than two whole quads per row: the direct kernel)
     assert run(1, 3, 20, 6)["proj_fwd"] == "proj_fwd:scalar"           # (narrower than two quads: scalar)
     assert run(1, 3, 20, 3) == {"fi_fwd": "fi_fwd:direct", "fi_bwd": "fi_bwd:direct", "bl_fwd": "bl_fwd:direct",
                                 "bl_bwd": "bl_bwd:direct", "proj_fwd": "proj_fwd:scalar", "proj_bwd": "proj_bwd:scalar"}
