@@ -149,3 +149,25 @@ def test_ctx_blend_extension_surface_and_no_cpu_path():
             FilterInterpolationCtxBlendModule()(z(1, 3, 8, w), z(1, 3, 8, w), z(1, cc, 8, w), z(1, cc, 8, w),
                                                 z(1, 2, 8, w), z(1, 2, 8, w), z(1, 16, 8, w), z(1, 16, 8, w),
                                                 z(1, 1, 8, w), z(1, 1, 8, w))
+
+
+def test_model_bench_instruments_every_operator_entry_point():
+    """tools/bench_model.py (and bench.py's config-4 row through it) put HIP-event spans around the operator entry points of the
+    loader.  Round 5's record missed both projections: the Python layers had moved to the `_ws` entry points and the list ended
+    at `_gpu_forward`.  Every name a layer in my_package.functions calls must be on the list."""
+    import os
+    import re
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import my_package._ext.my_lib as my_lib
+    from tools.bench_model import hot_path_entry_points
+    names = set(hot_path_entry_points(my_lib))
+    called = set()
+    fdir = os.path.join(root, "memc-net_amd", "my_package", "functions")
+    for fn in os.listdir(fdir):
+        if fn.endswith(".py"):
+            called |= set(re.findall(r"my_lib\.(\w+Layer_gpu_\w+)\(", open(os.path.join(fdir, fn)).read()))
+    assert called and called <= names, sorted(called - names)
+    assert {"FlowProjectionLayer_gpu_forward_ws", "DepthFlowProjectionLayer_gpu_forward_ws",
+            "FilterInterpolationLayer_gpu_forward", "FilterInterpolationLayer_gpu_backward"} <= names
