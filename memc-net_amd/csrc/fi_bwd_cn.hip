@@ -34,8 +34,8 @@
 // (memc_tile.hpp: loads moved left and rotated back).  What is left is one to three columns:
 //   * their CELLS are cleared first (bwd_cn_zero_tail) and only ever reached by atomics: a site whose window touches a column
 //     >= Wq counts as "far" (site_far), so the owners never see it and the far-site kernel adds its whole window;
-//   * their SITES are one lane each in fi_bwd_tail_sites / bl_bwd_tail_sites (tap and flow gradients from global memory, the
-//     image gradient by atomics), queued behind the owners' stores like the far sites.
+//   * their SITES are one WAVE each in fi_bwd_tail_sites / bl_bwd_tail_sites (lanes over the channels: tap and flow gradients from
+//     global memory, the image gradient by atomics), queued behind the owners' stores like the far sites.
 // Rounds 2-5 sent such shapes to the direct kernels (16 C global atomics per site: 13-41x slower, profiles/r04_slow_paths.txt).
 //
 // Sites whose window leaves the owner's search window (kOwnRX / kOwnRY site tiles around the site's own tile: motion
@@ -398,30 +398,69 @@ __global__ __launch_bounds__(256) void bwd_cn_zero_tail(float *__restrict__ p, i
     float *q = p + (row / h / channel) * sb + c * sc + (int64_t)y * sh;
     for (int x = Wq; x < W; x++) q[x] = 0.0f;
 }
-// the sites of those columns, one lane each: tap and flow gradients from global memory, the image gradient by atomics
-// (after the owners' stores, like fi_bwd_far_sites)
+// sum over the 64 lanes of a wave, result in every lane (a butterfly of shuffles; rare path)
+__device__ __forceinline__ float wave_allsum_f32(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+// The sites of those columns, one WAVE each, lane l the channels l, l + 64, ...: a lane adds its channels' image gradient with
+// atomics (after the owners' stores, like fi_bwd_far_sites) and keeps partial tap sums, which the wave then adds up.  (One
+// LANE per site -- 16 C dependent atomics and 32 C loads in a row -- took 3 ms for the 11 520 tail sites of 8 x 64 x 720 x 1278.)
 __global__ __launch_bounds__(256) void fi_bwd_tail_sites(
     int W, int H, int Wq, int C, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
     const float *__restrict__ gout, float *__restrict__ gin1, float *__restrict__ gin2, float *__restrict__ gin3)
 {
-    const int nt = W - Wq;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, n = (int64_t)batch * H * nt;
-    if (i >= n) return;
+    const int nt = W - Wq, lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave, n = (int64_t)batch * H * nt;
+    if (i >= n) return;                                    // (wave-uniform)
     const int x = Wq + (int)(i % nt), y = (int)((i / nt) % H), b = (int)(i / nt / H);
     const float *flow_p = flow + b * s2b + (int64_t)y * s2h + x, *tap_p = filt + b * s3b + (int64_t)y * s3h + x;
-    const float *gout_p = gout + b * s1b + (int64_t)y * s1h + x;
+    const float *gout_p = gout + b * s1b + (int64_t)y * s1h + x, *in_b = in1 + b * s1b;
+    float *gin1_b = gin1 + b * s1b;
     float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x, *g3 = gin3 + b * s3b + (int64_t)y * s3h + x;
     const FiSite s = fi_locate(x, y, W, H, flow_p[0], flow_p[s2c]);
     if (!s.valid) {                                        // gradinput2 / gradinput3 are ASSIGNED: invalid sites store zeros
-        g2[0] = 0.0f;
-        g2[s2c] = 0.0f;
-        for (int k = 0; k < 16; k++) g3[k * s3c] = 0.0f;
+        if (lane < 16) g3[lane * s3c] = 0.0f;
+        if (lane < 2) g2[lane * s2c] = 0.0f;
         return;
     }
-    fi_bwd_site_taps_cn(x, y, W, H, C, in1 + b * s1b, s1c, s1h, flow_p, g2, s2c, tap_p, g3, s3c, gout_p);
-    fi_bwd_site_image_atomics(x, y, W, H, C, gin1 + b * s1b, s1c, s1h, flow_p, s2c, tap_p, s3c, gout_p);
+    float sv[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) sv[t] = 0.0f;
+    for (int c = lane; c < C; c += kWave) {
+        const float g = gout_p[c * s1c];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ro = clampi(s.iy - 1 + k, H - 1) * s1h;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int o = ro + clampi(s.ix - 1 + m, W - 1);
+                const float wa = m < 2 ? (1 - s.a) : s.a, wb = k < 2 ? (1 - s.b) : s.b;
+                sv[k * 4 + m] += g * in_b[c * s1c + o];
+                atomic_add_f32(gin1_b + c * s1c + o, g * ((wa * wb) * tap_p[(k * 4 + m) * s3c]));
+            }
+        }
+    }
+    float gx = 0.0f, gy = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const float tot = wave_allsum_f32(sv[k * 4 + m]);
+            const float wa = m < 2 ? (1 - s.a) : s.a, wb = k < 2 ? (1 - s.b) : s.b;
+            if (lane == k * 4 + m) g3[(k * 4 + m) * s3c] = (wa * wb) * tot;
+            const float st = tot * tap_p[(k * 4 + m) * s3c];
+            gx += (m < 2 ? -wb : wb) * st;
+            gy += (k < 2 ? -wa : wa) * st;
+        }
+    if (lane == 0) {
+        g2[0] = gx;
+        g2[s2c] = gy;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1247,32 +1286,45 @@ __global__ __launch_bounds__(256, 2) void bl_bwd_flow_c4n(
     }
 }
 
-// (a ragged width's columns behind the whole quads, as fi_bwd_tail_sites)
+// (a ragged width's columns behind the whole quads, as fi_bwd_tail_sites: one wave per site, lane l the channels l, l + 64, ...)
 __global__ __launch_bounds__(256) void bl_bwd_tail_sites(
     int W, int H, int Wq, int C, int batch, int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ gout,
     float *__restrict__ gin1, float *__restrict__ gin2)
 {
-    const int nt = W - Wq;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, n = (int64_t)batch * H * nt;
-    if (i >= n) return;
+    const int nt = W - Wq, lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (256 / kWave) + threadIdx.x / kWave, n = (int64_t)batch * H * nt;
+    if (i >= n) return;                                    // (wave-uniform)
     const int x = Wq + (int)(i % nt), y = (int)((i / nt) % H), b = (int)(i / nt / H);
     const float *flow_p = flow + b * s2b + (int64_t)y * s2h + x, *gout_p = gout + b * s1b + (int64_t)y * s1h + x;
-    float *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
+    const float *in_b = in1 + b * s1b;
+    float *gin1_b = gin1 + b * s1b, *g2 = gin2 + b * s2b + (int64_t)y * s2h + x;
     const float fx = flow_p[0], fy = flow_p[s2c];
     const BlSite s = bl_locate<true>(x, y, W, H, fx, fy);
     float vx = 0.0f, vy = 0.0f;                            // gradinput2 is ASSIGNED; invalid sites store zeros
-    if (s.valid) {
-        const f32x4 q = bl_corner_sums_global(in1 + b * s1b, gout_p, s1c, C, s.T * s1h + s.L, s.T * s1h + s.R,
-                                              s.Bm * s1h + s.L, s.Bm * s1h + s.R);
+    if (s.valid) {                                         // (wave-uniform)
+        const int oTL = s.T * s1h + s.L, oTR = s.T * s1h + s.R, oBL = s.Bm * s1h + s.L, oBR = s.Bm * s1h + s.R;
+        float qTL = 0.0f, qTR = 0.0f, qBL = 0.0f, qBR = 0.0f;
+        for (int c = lane; c < C; c += kWave) {
+            const float g = gout_p[c * s1c];
+            const float *p = in_b + c * s1c;
+            float *q = gin1_b + c * s1c;
+            qTL += g * p[oTL];  qTR += g * p[oTR];  qBL += g * p[oBL];  qBR += g * p[oBR];
+            atomic_add_f32(q + oTL, g * ((1 - s.a) * (1 - s.b)));              // as bl_bwd_site_image_atomics
+            atomic_add_f32(q + oTR, g * (s.a * (1 - s.b)));
+            atomic_add_f32(q + oBL, g * ((1 - s.a) * s.b));
+            atomic_add_f32(q + oBR, g * (s.a * s.b));
+        }
+        qTL = wave_allsum_f32(qTL);  qTR = wave_allsum_f32(qTR);  qBL = wave_allsum_f32(qBL);  qBR = wave_allsum_f32(qBR);
         const float x2 = (float)x + fx, y2 = (float)y + fy;
         const float gam_x = (float)s.Bm - y2, gam_y = (float)s.R - x2;         // as bl_bwd_flow_c4n
-        vx = gam_x * (q[1] - q[0]) + (1 - gam_x) * (q[3] - q[2]);
-        vy = gam_y * (q[2] - q[0]) + (1 - gam_y) * (q[3] - q[1]);
-        bl_bwd_site_image_atomics(x, y, W, H, C, gin1 + b * s1b, s1c, s1h, flow_p, s2c, gout_p);
+        vx = gam_x * (qTR - qTL) + (1 - gam_x) * (qBR - qBL);
+        vy = gam_y * (qBL - qTL) + (1 - gam_y) * (qBR - qTR);
     }
-    g2[0] = vx;
-    g2[s2c] = vy;
+    if (lane == 0) {
+        g2[0] = vx;
+        g2[s2c] = vy;
+    }
 }
 
 __global__ __launch_bounds__(256) void bl_bwd_far_sites(
@@ -1336,7 +1388,7 @@ int fi_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
     BBox *tbox = static_cast<BBox *>(scratch.p);
     const bool rag = wq < w;
     const unsigned tail_rows = (unsigned)(((int64_t)batch * channel * h + 255) / 256);
-    const unsigned tail_sites = (unsigned)(((int64_t)batch * h * (w - wq) + 255) / 256);
+    const unsigned tail_sites = (unsigned)(((int64_t)batch * h * (w - wq) + 3) / 4);     // one wave per site, four per workgroup
     if (rag)                                               // the cells no owner stores: cleared before anything adds to them
         hipLaunchKernelGGL(bwd_cn_zero_tail, dim3(tail_rows), dim3(256), 0, stream, gradinput1, wq, w, h, channel, batch,
                            (int64_t)s1b, (int64_t)s1c, s1h);
@@ -1412,7 +1464,7 @@ int bl_bwd_cn_launch(hipStream_t stream, int w, int h, int channel, int batch,
                        s2h, (int64_t)0, (int64_t)0, 0, input2, static_cast<const float *>(nullptr), gradoutput,
                        gradinput1, tbox, static_cast<unsigned long long *>(nullptr));
     if (rag)
-        hipLaunchKernelGGL(bl_bwd_tail_sites, dim3((unsigned)(((int64_t)batch * h * (w - wq) + 255) / 256)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(bl_bwd_tail_sites, dim3((unsigned)(((int64_t)batch * h * (w - wq) + 3) / 4)), dim3(256), 0, stream,
                            w, h, wq, channel, batch, (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h, input1,
                            input2, gradoutput, gradinput1, gradinput2);
     hipLaunchKernelGGL(bl_bwd_far_sites, dim3(ntiles), dim3(256), 0, stream,
