@@ -57,6 +57,10 @@ def _prep(a):
         raise ValueError("expected a 4-D NCHW array")
     if a.strides[3] != 4 and a.shape[3] > 1:
         a = np.ascontiguousarray(a)
+    elif 1 in a.shape and not a.flags["C_CONTIGUOUS"]:
+        # a dimension of one element carries whatever stride numpy last gave it (a width-1 flow built by a transpose:
+        # strides (8, 4, 16, 4)): the C checks compare strides across tensors, so such arrays are normalised
+        a = np.ascontiguousarray(a)
     return a
 
 

@@ -1844,3 +1844,82 @@ def test_flow_upsample4(shape, align):
     gout = torch.rand(want.shape, device=dev(), generator=g)
     got.backward(gout); want.backward(gout)
     assert float((fr.grad - ft.grad).abs().max()) <= 1e-5 * max(1.0, float(ft.grad.abs().max()))
+
+
+def _random_shape_cases(n, seed):
+    """Seeded random shapes: batch 1-3, channels 1-9 (+ 16 / 64 now and then), heights 1-90, widths 1-260 of every residue
+    mod 4, a flow kind and scale per case -- every operator sees widths below one quad, ragged widths, partial tiles in both
+    directions, one-pixel images and motion larger than the image."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        B = int(rng.integers(1, 4))
+        C = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 7, 8, 9, 16, 64], p=None))
+        H = int(rng.choice([1, 2, 5, 16, 17, 31, 33, 48, 64, 90]))
+        W = int(rng.choice([1, 3, 4, 7, 8, 9, 13, 30, 63, 64, 65, 66, 67, 100, 129, 130, 131, 200, 258, 260]))
+        if C >= 16:
+            H, W = min(H, 40), min(W, 140)                 # (keep the oracle's time per case in milliseconds)
+        kind = str(rng.choice(["smooth", "iid", "iid", "zero"]))
+        sigma = float(rng.choice([0.5, 2.0, 5.0, 15.0, 40.0]))
+        cases.append((B, C, H, W, kind, sigma, 1000 + i))
+    return cases
+
+
+# (64 cases in the suite; MEMC_RANDOM_CASES=N for a longer sweep -- round 6 ran 600 once: tools/sessions/r06_s13.sh)
+RANDOM_CASES = _random_shape_cases(int(os.environ.get("MEMC_RANDOM_CASES", "64")), 20260601)
+
+
+@pytest.mark.parametrize("case", RANDOM_CASES, ids=["%dx%dx%dx%d-%s-%g" % c[:6] for c in RANDOM_CASES])
+def test_random_shapes_every_operator_forward_and_backward(oracle, case):
+    """Round 6: a seeded sweep of random shapes through EVERY operator of the path, forward and backward, through the C ABI,
+    against the oracle -- the fixed case lists above were written around the kernels' known edges; this one is not.  The
+    reference serves every shape with one kernel per operator (my_lib_kernel.cu:10-15)."""
+    import my_package._ext.my_lib as my_lib
+    B, C, H, W, kind, sigma, seed = case
+    d = make(case)
+    x, f, k, g, dep, gf = (T(d[n]) for n in ("x", "flow", "filt", "gout", "depth", "gflow"))
+    junk = lambda *shape: torch.full(shape, 7.0, device=dev())     # noqa: E731 -- outputs are DEFINED by the calls
+    # FilterInterpolation
+    out = junk(B, C, H, W)
+    assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+    close(N(out), oracle.filter_interpolation_forward(d["x"], d["flow"], d["filt"]), "FI fwd")
+    g1 = junk(B, C, H, W) if my_lib.gradinput1_is_stored(4, C) else torch.zeros(B, C, H, W, device=dev())
+    g2, g3 = junk(B, 2, H, W), junk(B, 16, H, W)
+    assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+    w1, w2, w3 = oracle.filter_interpolation_backward(d["x"], d["flow"], d["filt"], d["gout"])
+    close(N(g1), w1, "FI bwd gradinput1", 3 * RTOL)
+    close(N(g2), w2, "FI bwd gradinput2")
+    close(N(g3), w3, "FI bwd gradinput3")
+    # Interpolation (C == 3 only, as the reference) / InterpolationCh
+    fwd, bwd = ((my_lib.InterpolationLayer_gpu_forward, my_lib.InterpolationLayer_gpu_backward) if C == 3 else
+                (my_lib.InterpolationChLayer_gpu_forward, my_lib.InterpolationChLayer_gpu_backward))
+    out = junk(B, C, H, W)
+    assert fwd(x, f, out) == 0
+    close(N(out), oracle.interpolation_ch_forward(d["x"], d["flow"]), "Interpolation fwd")
+    g1 = junk(B, C, H, W) if my_lib.gradinput1_is_stored(0, C) else torch.zeros(B, C, H, W, device=dev())
+    g2 = junk(B, 2, H, W)
+    assert bwd(x, f, g, g1, g2) == 0
+    w1, w2 = oracle.interpolation_ch_backward(d["x"], d["flow"], d["gout"])
+    close(N(g1), w1, "Interpolation bwd gradinput1", 3 * RTOL)
+    close(N(g2), w2, "Interpolation bwd gradinput2")
+    # FlowProjection / DepthFlowProjection, with and without hole filling, and their backward passes
+    for fill in (0, 1):
+        cnt, po = junk(B, 1, H, W), junk(B, 2, H, W)
+        assert my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, fill) == 0
+        want_out, want_cnt = oracle.flow_projection_forward(d["flow"], fill)
+        assert np.array_equal(N(cnt), want_cnt), "FlowProjection count, fill %d" % fill
+        close(N(po), want_out, "FlowProjection fwd, fill %d" % fill)
+        dcnt, dpo = junk(B, 1, H, W), junk(B, 2, H, W)
+        assert my_lib.DepthFlowProjectionLayer_gpu_forward(f, dep, dcnt, dpo, fill) == 0
+        want_dout, want_dcnt = oracle.depth_flow_projection_forward(d["flow"], d["depth"], fill)
+        close(N(dcnt), want_dcnt, "DepthFlowProjection count, fill %d" % fill)
+        close(N(dpo), want_dout, "DepthFlowProjection fwd, fill %d" % fill)
+        if fill == 0:                                          # (backward sees the planes of a forward without hole filling)
+            gin = junk(B, 2, H, W)
+            assert my_lib.FlowProjectionLayer_gpu_backward(f, T(want_cnt), gf, gin) == 0
+            close(N(gin), oracle.flow_projection_backward(d["flow"], want_cnt, d["gflow"]), "FlowProjection bwd")
+            gin, gd = junk(B, 2, H, W), junk(B, 1, H, W)
+            assert my_lib.DepthFlowProjectionLayer_gpu_backward(f, dep, T(want_dcnt), T(want_dout), gf, gin, gd) == 0
+            wg1, wg2 = oracle.depth_flow_projection_backward(d["flow"], d["depth"], want_dcnt, want_dout, d["gflow"])
+            close(N(gin), wg1, "DepthFlowProjection bwd gradinput1")
+            close(N(gd), wg2, "DepthFlowProjection bwd gradinput2")
