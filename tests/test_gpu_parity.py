@@ -1859,10 +1859,24 @@ def _random_shape_cases(n, seed):
         W = int(rng.choice([1, 3, 4, 7, 8, 9, 13, 30, 63, 64, 65, 66, 67, 100, 129, 130, 131, 200, 258, 260]))
         if C >= 16:
             H, W = min(H, 40), min(W, 140)                 # (keep the oracle's time per case in milliseconds)
-        kind = str(rng.choice(["smooth", "iid", "iid", "zero"]))
+        kind = str(rng.choice(["smooth", "iid", "iid", "zero", "pan", "pan"]))
         sigma = float(rng.choice([0.5, 2.0, 5.0, 15.0, 40.0]))
         cases.append((B, C, H, W, kind, sigma, 1000 + i))
     return cases
+
+
+def _make_random(case):
+    """make(), plus the flow kind "pan": a smooth field on top of a whole-image motion of up to +-0.75 of the image's size per
+    axis, another one per image of the batch (the projection's scan follows it, far sources, sites leaving the image)."""
+    B, C, H, W, kind, sigma, seed = case
+    if kind != "pan":
+        return make(case)
+    d = make((B, C, H, W, "smooth", sigma, seed))
+    rng = np.random.default_rng(seed + 77)
+    for b in range(B):
+        d["flow"][b, 0] += np.float32(rng.uniform(-0.75, 0.75) * W)
+        d["flow"][b, 1] += np.float32(rng.uniform(-0.75, 0.75) * H)
+    return d
 
 
 # (64 cases in the suite; MEMC_RANDOM_CASES=N for a longer sweep -- round 6 ran 600 once: tools/sessions/r06_s13.sh)
@@ -1876,7 +1890,7 @@ def test_random_shapes_every_operator_forward_and_backward(oracle, case):
     reference serves every shape with one kernel per operator (my_lib_kernel.cu:10-15)."""
     import my_package._ext.my_lib as my_lib
     B, C, H, W, kind, sigma, seed = case
-    d = make(case)
+    d = _make_random(case)
     x, f, k, g, dep, gf = (T(d[n]) for n in ("x", "flow", "filt", "gout", "depth", "gflow"))
     junk = lambda *shape: torch.full(shape, 7.0, device=dev())     # noqa: E731 -- outputs are DEFINED by the calls
     # FilterInterpolation
