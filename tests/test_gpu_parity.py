@@ -1937,3 +1937,91 @@ def test_random_shapes_every_operator_forward_and_backward(oracle, case):
             wg1, wg2 = oracle.depth_flow_projection_backward(d["flow"], d["depth"], want_dcnt, want_dout, d["gflow"])
             close(N(gin), wg1, "DepthFlowProjection bwd gradinput1")
             close(N(gd), wg2, "DepthFlowProjection bwd gradinput2")
+
+
+@pytest.mark.parametrize("case", RANDOM_CASES[:48], ids=["%dx%dx%dx%d-%s-%g" % c[:6] for c in RANDOM_CASES[:48]])
+def test_random_strided_views_every_operator(oracle, case):
+    """The same sweep on VIEWS: every tensor is a window of a larger buffer -- random extra channels, rows and columns around it and a
+    random offset inside, one layout per tensor shape (image-like, flow-like, filter-like, one-plane: tensors of one shape
+    share their strides, which is what the reference's checks ask of some pairs, my_lib_cuda.c:611-646) -- so batch, channel
+    and row strides are all unrelated to the sizes and every row starts at some dword.  What surrounds a window must not change."""
+    import my_package._ext.my_lib as my_lib
+    B, C, H, W, kind, sigma, seed = case
+    d = _make_random(case)
+    rng = np.random.default_rng(seed + 4242)
+    layouts = {}
+
+    def window(channels, fill=None, src=None):
+        """A [B, channels, H, W] view inside a buffer with this shape class's margins; returns (view, buffer)."""
+        if channels not in layouts:
+            layouts[channels] = [int(v) for v in rng.integers(0, 4, size=6)]           # channel / row / column margins, before + after
+        c0, c1, h0, h1, w0, w1 = layouts[channels]
+        buf = torch.full((B, channels + c0 + c1, H + h0 + h1, W + w0 + w1), -3.0, device=dev())
+        view = buf[:, c0:c0 + channels, h0:h0 + H, w0:w0 + W]
+        if src is not None:
+            view.copy_(T(src))
+        elif fill is not None:
+            view.fill_(fill)
+        return view, buf
+
+    def untouched(buf, channels):
+        c0, c1, h0, h1, w0, w1 = layouts[channels]
+        inner = torch.zeros_like(buf, dtype=torch.bool)
+        inner[:, c0:c0 + channels, h0:h0 + H, w0:w0 + W] = True
+        return bool((buf[~inner] == -3.0).all())
+
+    x, _ = window(C, src=d["x"])
+    g, _ = window(C, src=d["gout"])
+    f, _ = window(2, src=d["flow"])
+    gf, _ = window(2, src=d["gflow"])
+    k, _ = window(16, src=d["filt"])
+    dep, _ = window(1, src=d["depth"])
+    out, out_b = window(C, fill=7.0)
+    assert my_lib.FilterInterpolationLayer_gpu_forward(x, f, k, out) == 0
+    close(N(out), oracle.filter_interpolation_forward(d["x"], d["flow"], d["filt"]), "FI fwd on views")
+    g1, g1_b = window(C, fill=7.0 if my_lib.gradinput1_is_stored(4, C) else 0.0)
+    g2, g2_b = window(2, fill=7.0)
+    g3, g3_b = window(16, fill=7.0)
+    assert my_lib.FilterInterpolationLayer_gpu_backward(x, f, k, g, g1, g2, g3) == 0
+    w1, w2, w3 = oracle.filter_interpolation_backward(d["x"], d["flow"], d["filt"], d["gout"])
+    close(N(g1), w1, "FI bwd gradinput1 on views", 3 * RTOL)
+    close(N(g2), w2, "FI bwd gradinput2 on views")
+    close(N(g3), w3, "FI bwd gradinput3 on views")
+    assert untouched(out_b, C) and untouched(g1_b, C) and untouched(g2_b, 2) and untouched(g3_b, 16)
+    fwd, bwd = ((my_lib.InterpolationLayer_gpu_forward, my_lib.InterpolationLayer_gpu_backward) if C == 3 else
+                (my_lib.InterpolationChLayer_gpu_forward, my_lib.InterpolationChLayer_gpu_backward))
+    out, out_b = window(C, fill=7.0)
+    assert fwd(x, f, out) == 0
+    close(N(out), oracle.interpolation_ch_forward(d["x"], d["flow"]), "Interpolation fwd on views")
+    g1, g1_b = window(C, fill=7.0 if my_lib.gradinput1_is_stored(0, C) else 0.0)
+    g2, g2_b = window(2, fill=7.0)
+    assert bwd(x, f, g, g1, g2) == 0
+    w1, w2 = oracle.interpolation_ch_backward(d["x"], d["flow"], d["gout"])
+    close(N(g1), w1, "Interpolation bwd gradinput1 on views", 3 * RTOL)
+    close(N(g2), w2, "Interpolation bwd gradinput2 on views")
+    assert untouched(out_b, C) and untouched(g1_b, C) and untouched(g2_b, 2)
+    for fill in (0, 1):
+        cnt, cnt_b = window(1, fill=7.0)
+        po, po_b = window(2, fill=7.0)
+        assert my_lib.FlowProjectionLayer_gpu_forward(f, cnt, po, fill) == 0
+        want_out, want_cnt = oracle.flow_projection_forward(d["flow"], fill)
+        assert np.array_equal(N(cnt), want_cnt), "FlowProjection count on views, fill %d" % fill
+        close(N(po), want_out, "FlowProjection fwd on views, fill %d" % fill)
+        dcnt, dcnt_b = window(1, fill=7.0)
+        dpo, dpo_b = window(2, fill=7.0)
+        assert my_lib.DepthFlowProjectionLayer_gpu_forward(f, dep, dcnt, dpo, fill) == 0
+        want_dout, want_dcnt = oracle.depth_flow_projection_forward(d["flow"], d["depth"], fill)
+        close(N(dcnt), want_dcnt, "DepthFlowProjection count on views, fill %d" % fill)
+        close(N(dpo), want_dout, "DepthFlowProjection fwd on views, fill %d" % fill)
+        assert untouched(cnt_b, 1) and untouched(po_b, 2) and untouched(dcnt_b, 1) and untouched(dpo_b, 2)
+        if fill == 0:
+            gin, gin_b = window(2, fill=7.0)
+            assert my_lib.FlowProjectionLayer_gpu_backward(f, cnt, gf, gin) == 0
+            close(N(gin), oracle.flow_projection_backward(d["flow"], want_cnt, d["gflow"]), "FlowProjection bwd on views")
+            gin2, gin2_b = window(2, fill=7.0)
+            gd, gd_b = window(1, fill=7.0)
+            assert my_lib.DepthFlowProjectionLayer_gpu_backward(f, dep, dcnt, dpo, gf, gin2, gd) == 0
+            wg1, wg2 = oracle.depth_flow_projection_backward(d["flow"], d["depth"], want_dcnt, want_dout, d["gflow"])
+            close(N(gin2), wg1, "DepthFlowProjection bwd gradinput1 on views")
+            close(N(gd), wg2, "DepthFlowProjection bwd gradinput2 on views")
+            assert untouched(gin_b, 2) and untouched(gin2_b, 2) and untouched(gd_b, 1)
