@@ -366,7 +366,9 @@ __global__ __launch_bounds__(256, 2) void fi_bwd_taps_c4n(
 }
 
 // The image gradient of the far sites, after the owners have stored theirs: one workgroup per site tile, gone at once
-// unless kernel A flagged the tile.
+// unless kernel A flagged the tile.  Round 6: a wave takes its far sites ONE AT A TIME with all 64 lanes, lane l the channels
+// l, l + 64, ... (16 atomics per channel): one lane per site -- 16 C atomics in a row -- made the band of sites along a ragged
+// width's last columns 1.5 ms of a 6.6 ms call (profiles/r06_many_channel_ragged_kernel_trace.txt).
 __global__ __launch_bounds__(256) void fi_bwd_far_sites(
     int W, int H, int Wq, int C, int tiles_x, int tiles_y, int batch,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
@@ -375,15 +377,35 @@ __global__ __launch_bounds__(256) void fi_bwd_far_sites(
 {
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
     if (!(tbox[(((int64_t)tc.b * tiles_y + tc.ty) * tiles_x + tc.tx) * 4].h & kTileHasFar)) return;
+    const int lane = threadIdx.x & (kWave - 1);
     const int x0 = tc.tx * 64 + 4 * (int)(threadIdx.x % 16), y = tc.ty * 16 + (int)(threadIdx.x / 16);
-    if (x0 >= Wq || y >= H) return;                       // (the columns behind the whole quads: fi_bwd_tail_sites)
-    const float *flow_p = flow + tc.b * s2b + (int64_t)y * s2h + x0;
+    const bool inq = x0 < Wq && y < H;                     // (the columns behind the whole quads: fi_bwd_tail_sites)
+    const float *flow_b = flow + tc.b * s2b, *filt_b = filt + tc.b * s3b, *gout_b = gout + tc.b * s1b;
+    float *gin1_b = gin1 + tc.b * s1b;
+    const float *flow_p = flow_b + (int64_t)min(y, H - 1) * s2h + min(x0, Wq - 4);
     for (int j = 0; j < 4; j++) {
-        const FiSite s = fi_locate(x0 + j, y, W, H, flow_p[j], flow_p[s2c + j]);
-        if (s.valid && fi_site_far(x0 + j, y, s.ix, s.iy, W, H, Wq))
-            fi_bwd_site_image_atomics(x0 + j, y, W, H, C, gin1 + tc.b * s1b, s1c, s1h, flow_p + j, s2c,
-                                      filt + tc.b * s3b + (int64_t)y * s3h + x0 + j, s3c,
-                                      gout + tc.b * s1b + (int64_t)y * s1h + x0 + j);
+        const FiSite sj = fi_locate(x0 + j, y, W, H, flow_p[j], flow_p[s2c + j]);
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(inq && sj.valid && fi_site_far(x0 + j, y, sj.ix, sj.iy, W, H, Wq));
+        while (todo) {                                     // (wave-uniform) the far site of lane `src`, by the whole wave
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int x = __builtin_amdgcn_readlane(x0, src) + j, ys = __builtin_amdgcn_readlane(y, src);
+            const float *fp = flow_b + (int64_t)ys * s2h + x, *tap_p = filt_b + (int64_t)ys * s3h + x;
+            const FiSite s = fi_locate(x, ys, W, H, fp[0], fp[s2c]);                      // (the same bits as sj of that lane)
+            for (int c = lane; c < C; c += kWave) {
+                const float g = gout_b[c * s1c + (int64_t)ys * s1h + x];
+                float *q = gin1_b + c * s1c;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int ro = clampi(s.iy - 1 + k, H - 1) * s1h;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const float wa = m < 2 ? (1 - s.a) : s.a, wb = k < 2 ? (1 - s.b) : s.b;
+                        atomic_add_f32(q + ro + clampi(s.ix - 1 + m, W - 1), g * ((wa * wb) * tap_p[(k * 4 + m) * s3c]));
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -1335,14 +1357,31 @@ __global__ __launch_bounds__(256) void bl_bwd_far_sites(
 {
     const TileCoord tc = strip_walk(blockIdx.x, gridDim.x, tiles_x, tiles_y, batch);
     if (!(tbox[(((int64_t)tc.b * tiles_y + tc.ty) * tiles_x + tc.tx) * 4].h & kTileHasFar)) return;
+    const int lane = threadIdx.x & (kWave - 1);
     const int x0 = tc.tx * 64 + 4 * (int)(threadIdx.x % 16), y = tc.ty * 16 + (int)(threadIdx.x / 16);
-    if (x0 >= Wq || y >= H) return;
-    const float *flow_p = flow + tc.b * s2b + (int64_t)y * s2h + x0;
-    for (int j = 0; j < 4; j++) {
-        const BlSite s = bl_locate<true>(x0 + j, y, W, H, flow_p[j], flow_p[s2c + j]);
-        if (s.valid && site_far<FpBilinear>(x0 + j, y, s.L, s.T, W, H, Wq))
-            bl_bwd_site_image_atomics(x0 + j, y, W, H, C, gin1 + tc.b * s1b, s1c, s1h, flow_p + j, s2c,
-                                      gout + tc.b * s1b + (int64_t)y * s1h + x0 + j);
+    const bool inq = x0 < Wq && y < H;
+    const float *flow_b = flow + tc.b * s2b, *gout_b = gout + tc.b * s1b;
+    float *gin1_b = gin1 + tc.b * s1b;
+    const float *flow_p = flow_b + (int64_t)min(y, H - 1) * s2h + min(x0, Wq - 4);
+    for (int j = 0; j < 4; j++) {                          // (as fi_bwd_far_sites: a far site at a time, lanes over the channels)
+        const BlSite sj = bl_locate<true>(x0 + j, y, W, H, flow_p[j], flow_p[s2c + j]);
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(inq && sj.valid && site_far<FpBilinear>(x0 + j, y, sj.L, sj.T, W, H, Wq));
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int x = __builtin_amdgcn_readlane(x0, src) + j, ys = __builtin_amdgcn_readlane(y, src);
+            const float *fp = flow_b + (int64_t)ys * s2h + x;
+            const BlSite s = bl_locate<true>(x, ys, W, H, fp[0], fp[s2c]);
+            const int oTL = s.T * s1h + s.L, oTR = s.T * s1h + s.R, oBL = s.Bm * s1h + s.L, oBR = s.Bm * s1h + s.R;
+            for (int c = lane; c < C; c += kWave) {
+                const float g = gout_b[c * s1c + (int64_t)ys * s1h + x];
+                float *q = gin1_b + c * s1c;
+                atomic_add_f32(q + oTL, g * ((1 - s.a) * (1 - s.b)));
+                atomic_add_f32(q + oTR, g * (s.a * (1 - s.b)));
+                atomic_add_f32(q + oBL, g * ((1 - s.a) * s.b));
+                atomic_add_f32(q + oBR, g * (s.a * s.b));
+            }
+        }
     }
 }
 
