@@ -79,16 +79,16 @@ def _window_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cpu")
     if rank == 1:
-        # rank 1 is late into EVERY collective by 50 ms: a collective inside the clock would put those 50 ms into
+        # rank 1 is late into EVERY collective by 200 ms: a collective inside the clock would put those 200 ms into
         # rank 0's window (it waits for rank 1 there)
         real_barrier, real_all_reduce = dist.barrier, dist.all_reduce
 
         def late_barrier(*a, **k):
-            time.sleep(0.05)
+            time.sleep(0.2)
             return real_barrier(*a, **k)
 
         def late_all_reduce(*a, **k):
-            time.sleep(0.05)
+            time.sleep(0.2)
             return real_all_reduce(*a, **k)
         dist.barrier, dist.all_reduce = late_barrier, late_all_reduce
     order = []
@@ -105,7 +105,8 @@ def _window_worker(rank, world, port, q):
 
 def test_closing_collective_is_outside_the_timed_window():
     """a window ends on the rank's own synchronize; the max over ranks is taken afterwards.  Rank 1
-    enters every collective 50 ms late -- none of that may appear in any window time, on either rank."""
+    enters every collective 200 ms late -- none of that may appear in any window time, on either rank (the bounds leave 100 ms
+    for a loaded host's scheduling hiccups: the windows' own work is 10 / 20 ms)."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -121,9 +122,9 @@ def test_closing_collective_is_outside_the_timed_window():
     assert worst0 == worst1 and len(worst0) == 5                       # one max-over-ranks time per window, same on both
     for w, l0, l1 in zip(worst0, local0, local1):
         assert w == max(l0, l1)
-        assert 0.020 <= w < 0.045, (w, "a 50 ms collective delay leaked into the window")
-        assert 0.010 <= l0 < 0.035                                       # rank 0 never waited for rank 1 inside its clock
-    assert sorted(worst0)[2] < 0.045
+        assert 0.020 <= w < 0.120, (w, "a 200 ms collective delay leaked into the window")
+        assert 0.010 <= l0 < 0.110                                       # rank 0 never waited for rank 1 inside its clock
+    assert sorted(worst0)[2] < 0.120
     assert cost0 is not None and cost0 > 0                             # barrier_us: evidence field, outside the windows
 
 
