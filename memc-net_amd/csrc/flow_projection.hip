@@ -22,6 +22,19 @@ namespace memc {
 constexpr int kFarWords = 8;                  // words per tile of the owner kernel's far table (proj_owner5.hpp)
 constexpr int kFarMaxTiles = 262144;          // tiles the owner-computes fast path serves (proj_owner_far deals the stamped ones out from a table in LDS)
 constexpr int kFlagWords = 256;               // far flags of the fast path: image b -> word b % 256, + 1 summary word
+// (measurement arm, proj_owner5 MOT = 5, projection variant -54; round 6) The images' motion estimates cached in the call's
+// scratch: 64-bit word b % 256 behind the far flags holds (tag << 32) | packed motion, tag = this call's nonce ^ hash(b).  The
+// first workgroups of an image (per XCD) find a foreign tag, sample the flow and publish; the later ones read ONE word instead of
+// 128 scattered cache lines.  LOST: +2.5 ... 4 % on the benchmark's flow -- one hot word per image is worse than 64 warm lines
+// (and read with device scope, past the L2, it doubled the call); profiles/r06_proj_motion_cache_arm.txt.
+constexpr int kMotionCacheAt = 320, kMotionCacheWords = 256;      // (in ints: 8-byte aligned; 2 ints per entry)
+__device__ __forceinline__ unsigned motion_tag(int nonce, int b) { return (unsigned)nonce ^ ((unsigned)b * 0x9E3779B1u); }
+__device__ __forceinline__ unsigned motion_pack(int mx, int my) { return ((unsigned)(mx & 0xffff) << 16) | (unsigned)(my & 0xffff); }
+__device__ __forceinline__ void motion_unpack(unsigned v, int &mx, int &my)
+{
+    mx = (int)(short)(v >> 16);
+    my = (int)(short)(v & 0xffffu);
+}
 
 // --------------------------------------------------------------------------------------------------
 // Pass 1: scatter.  One lane = one source site; 12 fp32 atomics per valid site (8 flow + 4 count) into
@@ -1284,7 +1297,11 @@ struct ProjWsLayout {
     size_t n_bnd, n_up, n_row, ints, mask_words;
     size_t bytes() const { return ints * sizeof(int) + mask_words * 8; }
 };
-constexpr size_t kProjWsHead = 320;
+#ifdef MEMC_MEASURE
+constexpr size_t kProjWsHead = kMotionCacheAt + 2 * kMotionCacheWords;   // far flags (+ summary, replay tag) + the motion cache arm's words
+#else
+constexpr size_t kProjWsHead = 320;            // far flags (+ summary, replay tag)
+#endif
 template <int TH>
 static ProjWsLayout proj_ws_layout(int w, int h, int batch, bool fast, bool carry, bool masks)
 {
@@ -1422,7 +1439,7 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                 hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinW, false, true>), dim3(plan.nwg), dim3(16 * TH), 0, stream, w, h,
                                    ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,
                                    bounds, stamps, ws, plan, nonce);
-            } else if (variant <= -47 && variant >= -50) {   // how the motion estimate reaches the scan (proj_owner5.hpp, MOT):
+            } else if ((variant <= -47 && variant >= -50) || variant == -54) {   // how the motion estimate reaches the scan (proj_owner5.hpp, MOT):
 #define MEMC_PROJ_MOT(M)                                                                                              \
                 hipLaunchKernelGGL((proj_owner5<DEPTH, TH, 24, kMinWR, false, false, RAG, M>), dim3(plan.nwg), dim3(16 * TH), 0, stream, \
                                    w, h, ntx, nty, s1b, s1c, s1h, sdb, sdh, scb, sch, a.flow, a.depth, a.count, a.out, flag,  \
@@ -1430,7 +1447,8 @@ static int run_proj_fwd(const ProjArgs &a, int sw, int variant)
                 if (variant == -47) MEMC_PROJ_MOT(1);         // -47: speculative m = 0 pass, samples by LDS DMA (round 6, lost)
                 else if (variant == -48) MEMC_PROJ_MOT(2);    // -48: no estimate (timing arm)
                 else if (variant == -49) MEMC_PROJ_MOT(3);    // -49: 16 samples, one lane each (timing arm)
-                else MEMC_PROJ_MOT(4);                        // -50: 16 samples through the scalar unit (timing arm)
+                else if (variant == -50) MEMC_PROJ_MOT(4);    // -50: 16 samples through the scalar unit (timing arm)
+                else MEMC_PROJ_MOT(5);                        // -54: the estimate cached per image in the call's scratch
 #undef MEMC_PROJ_MOT
             } else if (variant <= -51 && variant >= -53) {   // tiles with many holes leave ALL of them pending (proj_fill.hpp, PENDT)
 #define MEMC_PROJ_PENDT(T)                                                                                            \

@@ -43,6 +43,8 @@
 //     reduction now sits INSIDE the scan, where it delays the barrier; in front of the first barrier it ran in the dead time
 //     of the scan's own loads), the depth operator lost a workgroup per CU to the samples' 512 bytes of LDS (+19 %), and a 40 px
 //     pan paid the wasted pass: 190 instead of 135 us.  Lost on every count;
+//   * MOT 5, the estimate cached per image in the call's scratch (the image's first workgroups publish, the others read one word):
+//     +2.5 ... 4 % -- one hot word per image costs more than the 64 warm sample lines; read with device scope it doubled the call;
 //   * MOT 3 / MOT 4, sixteen samples instead of sixty-four -- one lane each, or through the scalar unit (s_load_dword via the
 //     constant address space): -1 ... 1.5 % on the depth operator, nothing on FlowProjection.
 // The product stays round 5's order (MOT 0): wave 0 requests the samples first, reduces them while the planes are zeroed and
@@ -110,7 +112,12 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     // waves per SIMD have none free until then)
     __shared__ float msamp[SPEC ? 128 : 2];
     float msx = 0.0f, msy = 0.0f;
-    if (wave_index == 0 && MOT != 2 && MOT != 4) {
+    unsigned long long mcached = 0;            // MOT 5: the image's cached estimate (requested before anything else)
+    if (MOT == 5 && wave_index == 0)
+        // (a PLAIN load: it is served by this XCD's L2, where the image's first workgroup ON THIS XCD published -- eight publishers per
+        // image, each XCD its own; a device-scope load goes past the L2 to one hot line for all 14 400 workgroups: 2x the whole call)
+        mcached = *(reinterpret_cast<const unsigned long long *>(far_flag + kMotionCacheAt) + (b % kMotionCacheWords));
+    if (wave_index == 0 && MOT != 2 && MOT != 4 && MOT != 5) {
         if (SPEC) motion_sample_issue_lds(flow_b, s1c, s1h, W, H, tid0, msamp);
         else if (MOT == 3) motion_sample_issue16(flow_b, s1c, s1h, W, H, tid0, msx, msy);
         else motion_sample_issue(flow_b, s1c, s1h, W, H, tid0, msx, msy);
@@ -188,6 +195,23 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
         if (tid0 == 0) *reinterpret_cast<i32x2 *>(&tile_box[6]) = i32x2{pmx, pmy};
     };
     if ((MOT == 0 || MOT == 3) && wave_index == 0) motion_post();   // (round 5: in front of the first barrier)
+    if (MOT == 5 && wave_index == 0) {             // the cached estimate, or -- the image's first workgroups -- sample and publish
+        const unsigned tag = motion_tag(nonce, b);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(mcached >> 32));
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)mcached);
+        int pmx, pmy;
+        if (hi == tag) {                           // (wave-uniform)
+            motion_unpack(lo, pmx, pmy);
+        } else {
+            motion_sample_issue(flow_b, s1c, s1h, W, H, tid0, msx, msy);
+            motion_reduce(msx, msy, pmx, pmy);
+            if (tid0 == 0)
+                *(reinterpret_cast<unsigned long long *>(far_flag + kMotionCacheAt) + (b % kMotionCacheWords)) =
+                    ((unsigned long long)tag << 32) | motion_pack(pmx, pmy);
+        }
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        if (tid0 == 0) *reinterpret_cast<i32x2 *>(&tile_box[6]) = i32x2{pmx, pmy};
+    }
     if (MOT == 4 && wave_index == 0) {             // the estimate through the scalar unit, behind the scan's requests
         int pmx, pmy;
         motion_estimate_scalar(flow_b, s1c, s1h, W, H, pmx, pmy);
@@ -207,7 +231,7 @@ __global__ __launch_bounds__(16 * TH, MINW) void proj_owner5(
     trace_mark_proj<TRACE>(2);                 // loads arrived
     // the motion this pass assumes: SPEC starts with (0, 0) and learns the posted one behind the scan's closing barrier
     int mx = 0, my = 0;
-    if (MOT == 0 || MOT == 3 || MOT == 4) {
+    if (MOT == 0 || MOT == 3 || MOT == 4 || MOT == 5) {
         mx = __builtin_amdgcn_readfirstlane(tile_box[6]);
         my = __builtin_amdgcn_readfirstlane(tile_box[7]);
     }
