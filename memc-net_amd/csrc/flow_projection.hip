@@ -470,6 +470,7 @@ __device__ __forceinline__ void motion_sample_issue(const float *flow_b, int64_t
     fxs = *p;
     fys = p[s1c];
 }
+#ifdef MEMC_MEASURE
 // The same 64 samples straight into LDS (global_load_lds_dword: lane l's dword lands at dst[l], no vector register is held while
 // the loads are in flight -- proj_owner5 has none to spare over its first scan iteration): fx at dst[0 .. 63], fy at dst[64 .. 127].
 // Issued from inline assembly ON PURPOSE: told about an LDS-DMA load (__builtin_amdgcn_global_load_lds), the compiler's wait-count
@@ -497,6 +498,11 @@ __device__ __forceinline__ void motion_samples_wait()
     __builtin_amdgcn_s_waitcnt((younger & 15) | ((younger >> 4) << 14) | (7 << 4) | (15 << 8));
     asm volatile("" ::: "memory");
 }
+#else                                          // (the product instantiates MOT = 0 only: the arms' helpers are stubs)
+__device__ __forceinline__ void motion_sample_issue_lds(const float *, int64_t, int, int, int, int, float *) {}
+template <int younger>
+__device__ __forceinline__ void motion_samples_wait() {}
+#endif
 // A mean below kMotionDeadZone counts as none: a shifted scan costs ~15 us at 720p batch 32 whatever the shift (the loads
 // requested for m = 0 before m was known are thrown away, the tile's own sources are tested on their own), and a shift of
 // one quad buys nothing -- with m = 0 a source stays inside the scan up to 24 px, i.e. local motion of 18 px against a mean
