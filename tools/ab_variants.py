@@ -60,6 +60,7 @@ def main():
             "fi_bwd_c2": (lambda: L.FilterInterpolationLayer_gpu_backward(t2["x"], t2["flow"], t2["filt"], t2["gout"], h1, h2, h3), h1, 20),
             "fi_bwd_nog1": (lambda: L.FilterInterpolationLayer_gpu_backward(x, f, k, g, None, g2, g3), None, 1),
             "fi_bwd_c2_nog1": (lambda: L.FilterInterpolationLayer_gpu_backward(t2["x"], t2["flow"], t2["filt"], t2["gout"], None, h2, h3), None, 20),
+            "fi_fwd": (lambda: L.FilterInterpolationLayer_gpu_forward(x, f, k, g1), None, 1),      # the headline (--op fi_fwd)
             "bl_bwd": (lambda: L.InterpolationLayer_gpu_backward(x, f, g, g1, g2), g1, 1),
             # (with --op walk: the stripe width of the tile walk, -1 = the default)
             "bl_fwd": (lambda: L.InterpolationLayer_gpu_forward(x, f, g1), None, 1),
