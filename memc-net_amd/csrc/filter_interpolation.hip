@@ -333,14 +333,17 @@ __global__ __launch_bounds__(NT, (NT == 256 && !RAGW) ? 2 : 1) void fi_fwd_tiled
 // RAGW: a ragged width (W % 4 != 0, round 5) -- this kernel serves the whole quads, sites x < W & ~3, with the image's true
 // width in every clamp, validity test and staged box (whose last quad is loaded ragged-safely: memc_tile.hpp); the one to
 // three columns behind them go to fi_fwd_direct_fs4 (launcher).
-template <int LX, int CT, int MINW, int WALK, bool RAGW = false>
+// CAP: the LDS budget in pixel quads (measurement arms only: 128 x 8 tiles need 4608 for their 137 x 21 boxes; RGB path only).
+template <int LX, int CT, int MINW, int WALK, bool RAGW = false, int CAP = 3072>
 __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
     const float *__restrict__ in1, const float *__restrict__ flow, const float *__restrict__ filt,
     float *__restrict__ out)
 {
-    using G = TileGeom<LX>;
+    using G = TileGeom<LX, CAP>;
+    constexpr int ITS = (CAP + 1023) / 1024;               // staging slots per lane (3 for the product's 3072)
+    static_assert(CAP == 3072 || CT == 3, "a larger budget: RGB path only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem);
     int *bb = reinterpret_cast<int *>(smem + G::kCapPx * 16);
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     }
     // 3. source box, swept in bands when it does not fit the LDS budget (memc_tile.hpp)
     const BBox box = tile_bbox<LX>(cmin, cmax, rmin, rmax, bb);
-    const Bands bands = make_bands<LX>(box);
+    const Bands bands = make_bands<LX, true, CAP>(box);
     const Region r = band_region(box, bands, 0, RAGW ? W : 0);
     unsigned slow = inb ? g.valid & ~fi_covered(r, g, W, H) : 0u;   // sites outside the first band
 
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
             const unsigned sel = inb ? fi_covered(rb, g, W, H) & ~done : 0u;
             if (bi > 0 && !__syncthreads_or(sel != 0)) continue;
             done |= sel;
-            tile_stage<LX, 3, 256, RAGW>(rb, in_b, s1c, s1h, tile);
+            tile_stage<LX, 3, 256, RAGW, ITS>(rb, in_b, s1c, s1h, tile);
             __syncthreads();
             // keep tap splats / blend weights inside the loop (hoisted, they spill: see the chunk loop below)
 #pragma unroll
@@ -1214,6 +1217,29 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             else if (variant == 16) MEMC_FI_STRIPE(6, 2);
             else MEMC_FI_STRIPE(4, 2);                     // 17: row-major chunk per XCD at 2 waves/SIMD
 #undef MEMC_FI_STRIPE
+        } else if (variant >= 20 && variant <= 25 && channel == 3) {
+            // 20: 128 x 8 tiles (LX = 32) with a 4608-pixel budget, strips; 21: the same in hardware order; 22: 64 x 16 tiles
+            // with a 4096-pixel budget (no band sweeps on i.i.d. flow); 23: 128 x 8 tiles on the product's 3072 pixels; 24 / 25:
+            // 128 x 8 tiles on 3392 pixels (53 KiB: the most that leaves three workgroups per CU), registers for two / three
+#define MEMC_FI_WIDE(LX, WALK, CAP) MEMC_FI_WIDE_M(LX, WALK, CAP, 2)
+#define MEMC_FI_WIDE_M(LX, WALK, CAP, MINW)                                                                             \
+            do {                                                                                                  \
+                using G = TileGeom<LX, CAP>;                                                                      \
+                const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;                       \
+                allow_big_lds(fi_fwd_tiled_fs4<LX, 3, MINW, WALK, false, CAP>, tile_lds_bytes<LX, CAP>());        \
+                hipLaunchKernelGGL((fi_fwd_tiled_fs4<LX, 3, MINW, WALK, false, CAP>), dim3((unsigned)ntx * nty * batch), \
+                                   dim3(256), (tile_lds_bytes<LX, CAP>()), stream, w, h, channel, ntx, nty,       \
+                                   (int64_t)s1b, (int64_t)s1c, s1h, (int64_t)s2b, (int64_t)s2c, s2h,              \
+                                   (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);              \
+            } while (0)
+            if (variant == 20) MEMC_FI_WIDE(32, 0, 4608);
+            else if (variant == 21) MEMC_FI_WIDE(32, 1, 4608);
+            else if (variant == 22) MEMC_FI_WIDE(16, 0, 4096);
+            else if (variant == 23) MEMC_FI_WIDE(32, 0, 3072);
+            else if (variant == 24) MEMC_FI_WIDE(32, 0, 3392);
+            else MEMC_FI_WIDE_M(32, 0, 3392, 3);
+#undef MEMC_FI_WIDE
+#undef MEMC_FI_WIDE_M
         } else if (variant == 30 && channel % 4 == 0 && channel >= 8) {
             MEMC_FI_C4N(2);
         } else if (variant == 31 && channel % 4 == 0 && channel >= 8) {

@@ -157,7 +157,6 @@ struct TileGeom {
     static constexpr int kCapPx = CAP;
     static constexpr int kRows = kCapPx / kPitch;      // staged rows that fit
     static_assert(kPitch % 16 == 0, "swizzle needs a pitch that is a multiple of 16 pixels");
-    static_assert(kPitch / 4 <= 32, "staging uses 32 lanes per region row");
 };
 
 // LDS carve: [0, kCapPx*16) pixel quads, then 16 ints of per-wave bounding boxes.
@@ -356,20 +355,24 @@ __device__ __forceinline__ Region band_region(const BBox &b, const Bands &d, int
 // the plane's first element -- so that no load result becomes a phi (see fi_fwd_tiled_fs4).
 constexpr int kStageIts = kStageItsMax;
 
-struct StageSlot {
-    int row[kStageIts], q[kStageIts];      // q = float4 column; row >= r.h marks an empty slot
+// ITS: staging slots per lane -- kStageIts (3: the 3072-pixel budget on 256 lanes) everywhere but in kernels instantiated
+// with a larger budget (CAP <= ITS * NT * 4)
+template <int ITS = kStageIts>
+struct StageSlotT {
+    int row[ITS], q[ITS];                  // q = float4 column; row >= r.h marks an empty slot
 };
+using StageSlot = StageSlotT<>;
 
-template <int NT = 256>
-__device__ __forceinline__ StageSlot stage_slots(const Region &r)
+template <int NT = 256, int ITS = kStageIts>
+__device__ __forceinline__ StageSlotT<ITS> stage_slots(const Region &r)
 {
-    StageSlot s;
+    StageSlotT<ITS> s;
     const int wq = max(r.w >> 2, 1);
     const unsigned tid = tid_now();
     int row = tid / wq, q = tid % wq;          // one run-time division per kernel
     const int drow = NT / wq, dq = NT % wq;
 #pragma unroll
-    for (int it = 0; it < kStageIts; it++) {
+    for (int it = 0; it < ITS; it++) {
         s.row[it] = r.w > 0 ? row : r.h;
         s.q[it] = q;
         q += dq;
@@ -379,21 +382,21 @@ __device__ __forceinline__ StageSlot stage_slots(const Region &r)
     return s;
 }
 
-template <int NCH>
+template <int NCH, int ITS = kStageIts>
 struct StageRegs {
-    f32x4 v[kStageIts][NCH];
+    f32x4 v[ITS][NCH];
 };
 
 // RAG: a ragged image (r.wimg = its width, not a multiple of four): the box's last quad may reach past the row's end.  It
 // is loaded to END at the row's end (rs sites further left) and rotated back where it is consumed (tile_stage_store);
 // what lies past the row is never gathered: coordinates are clamped.  Kernels instantiate RAG only for such widths.
-template <int NCH, bool RAG = false>
-__device__ __forceinline__ void tile_stage_load_planes(const Region &r, const StageSlot &sl,
+template <int NCH, bool RAG = false, int ITS = kStageIts>
+__device__ __forceinline__ void tile_stage_load_planes(const Region &r, const StageSlotT<ITS> &sl,
                                                        const float *const (&plane)[NCH], const int (&hstride)[NCH],
-                                                       StageRegs<NCH> &sr)
+                                                       StageRegs<NCH, ITS> &sr)
 {
 #pragma unroll
-    for (int it = 0; it < kStageIts; it++) {
+    for (int it = 0; it < ITS; it++) {
         const bool on = sl.row[it] < r.h;
         const int rs = RAG ? tail_shift(r.x0 + 4 * sl.q[it], r.wimg) : 0;
 #pragma unroll
@@ -404,12 +407,12 @@ __device__ __forceinline__ void tile_stage_load_planes(const Region &r, const St
     }
 }
 
-template <int NCH, bool RAG = false>
-__device__ __forceinline__ void tile_stage_store(const Region &r, const StageSlot &sl, const StageRegs<NCH> &sr,
+template <int NCH, bool RAG = false, int ITS = kStageIts>
+__device__ __forceinline__ void tile_stage_store(const Region &r, const StageSlotT<ITS> &sl, const StageRegs<NCH, ITS> &sr,
                                                  f32x4 *tile)
 {
 #pragma unroll
-    for (int it = 0; it < kStageIts; it++) {
+    for (int it = 0; it < ITS; it++) {
         if (sl.row[it] < r.h) {
             f32x4 *dst = tile + sl.row[it] * r.pitch;
             f32x4 v[NCH];
@@ -431,9 +434,9 @@ __device__ __forceinline__ void tile_stage_store(const Region &r, const StageSlo
     }
 }
 
-template <int NCH, bool RAG = false>
-__device__ __forceinline__ void tile_stage_load(const Region &r, const StageSlot &sl, const float *plane0,
-                                                int64_t cstride, int hstride, StageRegs<NCH> &sr)
+template <int NCH, bool RAG = false, int ITS = kStageIts>
+__device__ __forceinline__ void tile_stage_load(const Region &r, const StageSlotT<ITS> &sl, const float *plane0,
+                                                int64_t cstride, int hstride, StageRegs<NCH, ITS> &sr)
 {
     const float *plane[NCH];
     int hs[NCH];
@@ -442,22 +445,22 @@ __device__ __forceinline__ void tile_stage_load(const Region &r, const StageSlot
         plane[c] = plane0 + c * cstride;
         hs[c] = hstride;
     }
-    tile_stage_load_planes<NCH, RAG>(r, sl, plane, hs, sr);
+    tile_stage_load_planes<NCH, RAG, ITS>(r, sl, plane, hs, sr);
 }
 
-template <int LX, int NCH, int NT = 256, bool RAG = false>
+template <int LX, int NCH, int NT = 256, bool RAG = false, int ITS = kStageIts>
 __device__ __forceinline__ void tile_stage_planes(const Region &r, const float *const (&plane)[NCH],
                                                   const int (&hstride)[NCH], f32x4 *tile)
 {
     static_assert(TileGeom<LX>::kCapPx <= kStageIts * 256 * 4, "three float4 slots per lane cover the budget");
-    const StageSlot sl = stage_slots<NT>(r);
-    StageRegs<NCH> sr;
-    tile_stage_load_planes<NCH, RAG>(r, sl, plane, hstride, sr);
-    tile_stage_store<NCH, RAG>(r, sl, sr, tile);
+    const StageSlotT<ITS> sl = stage_slots<NT, ITS>(r);
+    StageRegs<NCH, ITS> sr;
+    tile_stage_load_planes<NCH, RAG, ITS>(r, sl, plane, hstride, sr);
+    tile_stage_store<NCH, RAG, ITS>(r, sl, sr, tile);
 }
 
 // channel planes of ONE tensor: plane c = plane0 + c * cstride, common row stride
-template <int LX, int NCH, int NT = 256, bool RAG = false>
+template <int LX, int NCH, int NT = 256, bool RAG = false, int ITS = kStageIts>
 __device__ __forceinline__ void tile_stage(const Region &r, const float *plane0, int64_t cstride, int hstride,
                                            f32x4 *tile)
 {
@@ -468,7 +471,7 @@ __device__ __forceinline__ void tile_stage(const Region &r, const float *plane0,
         plane[c] = plane0 + c * cstride;
         hs[c] = hstride;
     }
-    tile_stage_planes<LX, NCH, NT, RAG>(r, plane, hs, tile);
+    tile_stage_planes<LX, NCH, NT, RAG, ITS>(r, plane, hs, tile);
 }
 
 // ---------------------------------------------------------------------------------------------------------
