@@ -21,6 +21,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 ldnt(const float *p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p)); }
 __device__ __forceinline__ void stnt(float *p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(p)); }
 
+// stores with every combination of the cache-policy bits (WR = 8 + bits: 1 = sc0, 2 = sc1, 4 = nt)
+template <int BITS>
+__device__ __forceinline__ void st_policy(float *p, f32x4 v)
+{
+    if (BITS == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    if (BITS == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(v) : "memory");
+    if (BITS == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    if (BITS == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    if (BITS == 4) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    if (BITS == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(p), "v"(v) : "memory");
+    if (BITS == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+    if (BITS == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+
 struct Tile { int b, tx, ty; };
 
 __device__ __forceinline__ Tile walk_tile(int walk, int G, unsigned bid, unsigned nwg, int tiles_x, int tiles_y)
@@ -70,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void skeleton_walk(int W, int H, int64_t pl
         const f32x4 v = acc * im[c];
         if (WR == 0) stnt(out + (b * 3 + c) * plane + o, v);
         else if (WR == 1) *reinterpret_cast<f32x4 *>(out + (b * 3 + c) * plane + o) = v;
+        else if (WR >= 8) st_policy<(WR >= 8 ? WR - 8 : 0)>(out + (b * 3 + c) * plane + o, v);
         else if (v.x == 12345.678f) out[0] = v.y;
     }
 }
@@ -87,6 +102,14 @@ extern "C" int probe_skeleton_walk(void *stream, int lx, int wr, int walk, int G
     if (lx == 16 && wr == 0) GO(16, 0);
     else if (lx == 16 && wr == 1) GO(16, 1);
     else if (lx == 16 && wr == 2) GO(16, 2);
+    else if (lx == 16 && wr == 8) GO(16, 8);
+    else if (lx == 16 && wr == 9) GO(16, 9);
+    else if (lx == 16 && wr == 10) GO(16, 10);
+    else if (lx == 16 && wr == 11) GO(16, 11);
+    else if (lx == 16 && wr == 12) GO(16, 12);
+    else if (lx == 16 && wr == 13) GO(16, 13);
+    else if (lx == 16 && wr == 14) GO(16, 14);
+    else if (lx == 16 && wr == 15) GO(16, 15);
     else if (lx == 32 && wr == 0) GO(32, 0);
     else if (lx == 64 && wr == 0) GO(64, 0);
     else if (lx == 64 && wr == 2) GO(64, 2);

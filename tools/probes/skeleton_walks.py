@@ -31,6 +31,8 @@ def main():
             for G in ((1, 2, 5, 10, 20, 40) if walk == 3 else (0,)):
                 cases.append((lx, 0, walk, G))
     cases += [(16, 1, 2, 0), (16, 2, 2, 0), (16, 2, 1, 0), (64, 2, 1, 0)]
+    if len(sys.argv) > 2 and sys.argv[2] == "policies":      # the stores' cache-policy bits, strips, 64 x 16 tiles
+        cases = [(16, 0, 2, 0)] + [(16, 8 + bits, 2, 0) for bits in range(8)]
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     ts = {c: [] for c in cases}
     bad = set()
@@ -53,8 +55,10 @@ def main():
         lx, wr, walk, G = c
         t = statistics.median(ts[c])
         moved = nbytes if wr != 2 else nbytes * 84 // 96
-        print("tile %3dx%-2d %-9s %-22s %-5s %8.1f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (
-            4 * lx, 256 // lx, ("nt stores", "plain st.", "no stores")[wr], walks[walk], ("G=%d" % G) if walk == 3 else "",
+        wname = ("nt stores", "plain st.", "no stores")[wr] if wr < 8 else "st" + "".join(
+            n for bit, n in ((1, " sc0"), (2, " sc1"), (4, " nt")) if (wr - 8) & bit)
+        print("tile %3dx%-2d %-13s %-22s %-5s %8.1f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (
+            4 * lx, 256 // lx, wname, walks[walk], ("G=%d" % G) if walk == 3 else "",
             t * 1e6, moved / t / 1e9, 100 * moved / t / 8e12), flush=True)
 
 
