@@ -334,7 +334,11 @@ __global__ __launch_bounds__(NT, (NT == 256 && !RAGW) ? 2 : 1) void fi_fwd_tiled
 // width in every clamp, validity test and staged box (whose last quad is loaded ragged-safely: memc_tile.hpp); the one to
 // three columns behind them go to fi_fwd_direct_fs4 (launcher).
 // CAP: the LDS budget in pixel quads (measurement arms only: 128 x 8 tiles need 4608 for their 137 x 21 boxes; RGB path only).
-template <int LX, int CT, int MINW, int WALK, bool RAGW = false, int CAP = 3072>
+// PHASE (measurement arm, RGB path): hold the results until the chip-wide write window of the 100 MHz clock opens (g_fi_phase).
+#ifdef MEMC_MEASURE
+__device__ unsigned g_fi_phase[2] = {1000u, 120u};         // period, window (ticks of 10 ns)
+#endif
+template <int LX, int CT, int MINW, int WALK, bool RAGW = false, int CAP = 3072, int PHASE = 0>
 __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
     int W, int H, int C, int tiles_x, int tiles_y,
     int64_t s1b, int64_t s1c, int s1h, int64_t s2b, int64_t s2c, int s2h, int64_t s3b, int64_t s3c, int s3h,
@@ -428,6 +432,14 @@ __global__ __launch_bounds__(256, MINW) void fi_fwd_tiled_fs4(
             fi_gather<LX, 3>(rb, g, tp, sel, W, H, tile, res);
         }
         slow = inb ? g.valid & ~done : 0u;
+#ifdef MEMC_MEASURE
+        if (PHASE) {                                       // results complete: stores wait for the chip-wide write window
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(res[j]));
+            const unsigned per = g_fi_phase[0], win = g_fi_phase[1];
+            while ((unsigned)__builtin_amdgcn_s_memrealtime() % per < per - win) __builtin_amdgcn_s_sleep(8);
+        }
+#endif
         if (inb) {
             if (g.valid != 0xFu) {                         // out-of-range sites copy the input pixel
 #pragma unroll
@@ -1113,6 +1125,11 @@ using namespace memc;
 MEMC_KNOB_STATIC(g_fi_fwd_variant, -1);
 MEMC_KNOB_STATIC(g_fi_bwd_variant, -1);
 extern "C" void memc_debug_set_fi_fwd_variant(int v) { g_fi_fwd_variant = v; }
+extern "C" void memc_debug_set_fi_phase(int per_win)          // period * 65536 + window, ticks of 10 ns (arm 26)
+{
+    const unsigned pw[2] = {(unsigned)per_win >> 16, (unsigned)per_win & 0xffffu};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(memc::g_fi_phase), pw, sizeof(pw));
+}
 extern "C" void memc_debug_set_fi_bwd_variant(int v) { g_fi_bwd_variant = v; }
 #endif
 extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
@@ -1217,6 +1234,12 @@ extern "C" int FilterInterpolationLayer_gpu_forward_kernel(
             else if (variant == 16) MEMC_FI_STRIPE(6, 2);
             else MEMC_FI_STRIPE(4, 2);                     // 17: row-major chunk per XCD at 2 waves/SIMD
 #undef MEMC_FI_STRIPE
+        } else if (variant == 26 && channel == 3) {       // the product kernel with phased stores (memc_debug_set_fi_phase)
+            using G = TileGeom<16>;
+            const int ntx = (w + G::kTW - 1) / G::kTW, nty = (h + G::kTH - 1) / G::kTH;
+            hipLaunchKernelGGL((fi_fwd_tiled_fs4<16, 3, 2, 0, false, 3072, 1>), dim3((unsigned)ntx * nty * batch), dim3(256),
+                               tile_lds_bytes<16>(), stream, w, h, channel, ntx, nty, (int64_t)s1b, (int64_t)s1c, s1h,
+                               (int64_t)s2b, (int64_t)s2c, s2h, (int64_t)s3b, (int64_t)s3c, s3h, input1, input2, input3, output);
         } else if (variant >= 20 && variant <= 25 && channel == 3) {
             // 20: 128 x 8 tiles (LX = 32) with a 4608-pixel budget, strips; 21: the same in hardware order; 22: 64 x 16 tiles
             // with a 4096-pixel budget (no band sweeps on i.i.d. flow); 23: 128 x 8 tiles on the product's 3072 pixels; 24 / 25:

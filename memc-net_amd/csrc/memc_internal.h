@@ -64,6 +64,7 @@ extern "C" {
 
 // A/B measurement hooks.  variant < 0 restores automatic selection.
 void memc_debug_set_fi_fwd_variant(int variant);
+void memc_debug_set_fi_phase(int period_times_65536_plus_window);   /* arm 26: the chip-wide write window, ticks of 10 ns */
 void memc_debug_set_projection_variant(int variant);
 void memc_debug_set_projection_scratch_blocks(int n);   // (Depth)FlowProjection forward: cached scratch blocks a call may look at (1 .. 8)
 void memc_debug_set_projection_stall_us(int us);        // ... idle this long between the owner kernel and the kernels behind it

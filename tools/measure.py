@@ -22,6 +22,7 @@ _lib = None
 _SETTERS = {
     "fi_fwd": "memc_debug_set_fi_fwd_variant",
     "fi_bwd": "memc_debug_set_fi_bwd_variant",
+    "fi_phase": "memc_debug_set_fi_phase",
     "projection": "memc_debug_set_projection_variant",
     "proj_scratch_blocks": "memc_debug_set_projection_scratch_blocks",
     "proj_stall_us": "memc_debug_set_projection_stall_us",
@@ -91,4 +92,5 @@ def set_variant(op, variant):
 
 def reset():
     for op in _SETTERS:
-        set_variant(op, 0 if op in ("extra_lds", "bl_bwd_direct", "proj_stall_us") else 8 if op == "proj_scratch_blocks" else -1)
+        set_variant(op, 0 if op in ("extra_lds", "bl_bwd_direct", "proj_stall_us") else 8 if op == "proj_scratch_blocks"
+                    else 1000 * 65536 + 120 if op == "fi_phase" else -1)

@@ -89,6 +89,144 @@ __global__ __launch_bounds__(256, 2) void skeleton_walk(int W, int H, int64_t pl
     }
 }
 
+// PHASED STORES: every workgroup holds its results until the chip-wide "write window" opens -- the last `win` ticks of every
+// period of `per` ticks of the constant 100 MHz clock all CUs share (s_memrealtime) -- so that HBM sees its stores in bursts
+// instead of one eighth of its traffic at any time.  (A question to the memory system, asked on the skeleton first.)
+// MODE 0: the stores wait for the window; 1: the workgroup's START (its loads) waits for the window, stores as they come;
+// 2: the loads wait for the window and the stores for the middle of the period.
+template <int LX, int MODE>
+__global__ __launch_bounds__(256, 2) void skeleton_phased(int W, int H, int64_t plane, const float *__restrict__ in1,
+                                                          const float *__restrict__ flow, const float *__restrict__ filt,
+                                                          float *__restrict__ out, int tiles_x, int tiles_y, int walk,
+                                                          unsigned per, unsigned win)
+{
+    if (MODE >= 1) while ((unsigned)(__builtin_amdgcn_s_memrealtime() % per) < per - win) __builtin_amdgcn_s_sleep(8);
+    const Tile t = walk_tile(walk, 0, blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    const int b = t.b;
+    const int x = t.tx * 4 * LX + 4 * (threadIdx.x % LX), y = t.ty * (256 / LX) + threadIdx.x / LX;
+    if (x >= W || y >= H) return;
+    const int64_t o = (int64_t)y * W + x;
+    f32x4 acc = ldnt(flow + (b * 2 + 0) * plane + o) + ldnt(flow + (b * 2 + 1) * plane + o);
+    f32x4 tp[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) tp[k] = ldnt(filt + (b * 16 + k) * plane + o);
+    f32x4 im[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) im[c] = *reinterpret_cast<const f32x4 *>(in1 + (b * 3 + c) * plane + o);
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc += tp[k];
+    f32x4 v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) v[c] = acc * im[c];
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));           // results are complete: now wait for the window
+    if (MODE == 0) while ((unsigned)(__builtin_amdgcn_s_memrealtime() % per) < per - win) __builtin_amdgcn_s_sleep(8);
+    if (MODE == 2) while ((unsigned)((__builtin_amdgcn_s_memrealtime() + per / 2) % per) < per - win) __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+    for (int c = 0; c < 3; c++) stnt(out + (b * 3 + c) * plane + o, v[c]);
+}
+
+// PHASED STORES WITHOUT WAITING: persistent workgroups (grid = what fits the chip) that keep up to NP finished tiles' results in
+// registers and go on reading the next tile; everything held is stored when the write window opens (or when NP are held: then
+// the workgroup does wait).  NP = 0: a plain persistent loop, stores as they come.
+template <int NP>
+__global__ __launch_bounds__(256, 2) void skeleton_persistent(int W, int H, int64_t plane, const float *__restrict__ in1,
+                                                              const float *__restrict__ flow, const float *__restrict__ filt,
+                                                              float *__restrict__ out, int tiles_x, int tiles_y, unsigned ntiles,
+                                                              unsigned per, unsigned win)
+{
+    constexpr int LX = 16, NQ = NP > 0 ? NP : 1;
+    f32x4 pend[NQ][3];
+    int64_t poff[NQ];
+    int np = 0;
+    for (unsigned vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+        const Tile t = walk_tile(2, 0, vb, ntiles, tiles_x, tiles_y);
+        const int b = t.b;
+        const int x = t.tx * 4 * LX + 4 * (threadIdx.x % LX), y = t.ty * (256 / LX) + threadIdx.x / LX;
+        const int64_t o = (int64_t)y * W + x;
+        f32x4 acc = ldnt(flow + (b * 2 + 0) * plane + o) + ldnt(flow + (b * 2 + 1) * plane + o);
+        f32x4 tp[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) tp[k] = ldnt(filt + (b * 16 + k) * plane + o);
+        f32x4 im[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) im[c] = *reinterpret_cast<const f32x4 *>(in1 + (b * 3 + c) * plane + o);
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc += tp[k];
+        f32x4 v[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) v[c] = acc * im[c];
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+        const int64_t ob = (int64_t)b * 3 * plane + o;
+        if (NP == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) stnt(out + ob + c * plane, v[c]);
+            continue;
+        }
+        bool open = (unsigned)__builtin_amdgcn_s_memrealtime() % per >= per - win;
+        if (np == NP && !open) {
+            while ((unsigned)__builtin_amdgcn_s_memrealtime() % per < per - win) __builtin_amdgcn_s_sleep(4);
+            open = true;
+        }
+        if (open) {
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                if (q < np) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) stnt(out + poff[q] + c * plane, pend[q][c]);
+                }
+            np = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) stnt(out + ob + c * plane, v[c]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                if (q == np) {
+                    poff[q] = ob;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) pend[q][c] = v[c];
+                }
+            np++;
+        }
+    }
+    if (NP > 0 && np > 0) {
+        while ((unsigned)__builtin_amdgcn_s_memrealtime() % per < per - win) __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+            if (q < np) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) stnt(out + poff[q] + c * plane, pend[q][c]);
+            }
+    }
+}
+
+extern "C" int probe_skeleton_persistent(void *stream, int np, int wg_per_cu, int per, int win, int B, int H, int W,
+                                         const float *in1, const float *flow, const float *filt, float *out)
+{
+    const int tx = W / 64, ty = H / 16;
+    const unsigned ntiles = (unsigned)tx * ty * B, grid = 256u * wg_per_cu;
+    if (W % 64 || H % 16 || ntiles % 8 || per <= 0 || win <= 0 || win > per) return -1;
+#define GO(NP) hipLaunchKernelGGL((skeleton_persistent<NP>), dim3(grid), dim3(256), 0, (hipStream_t)stream, W, H, (int64_t)W * H, \
+                                  in1, flow, filt, out, tx, ty, ntiles, (unsigned)per, (unsigned)win)
+    if (np == 0) GO(0); else if (np == 1) GO(1); else if (np == 2) GO(2); else if (np == 3) GO(3); else if (np == 4) GO(4); else return -1;
+#undef GO
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int probe_skeleton_phased(void *stream, int lx, int walk, int per, int win, int B, int H, int W, const float *in1,
+                                     const float *flow, const float *filt, float *out)
+{
+    const int mode = lx >> 8;               // (lx = 16 + 256 * mode)
+    lx &= 255;
+    const int tx = (W + 4 * lx - 1) / (4 * lx), ty = (H + 256 / lx - 1) / (256 / lx);
+    const unsigned grid = (unsigned)tx * ty * B;
+    if (grid % 8 || lx != 16 || per <= 0 || win <= 0 || win > per) return -1;
+#define GO(MODE) hipLaunchKernelGGL((skeleton_phased<16, MODE>), dim3(grid), dim3(256), 0, (hipStream_t)stream, W, H, (int64_t)W * H, \
+                                    in1, flow, filt, out, tx, ty, walk, (unsigned)per, (unsigned)win)
+    if (mode == 0) GO(0); else if (mode == 1) GO(1); else GO(2);
+#undef GO
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" int probe_skeleton_walk(void *stream, int lx, int wr, int walk, int G, int B, int H, int W, const float *in1,
                                    const float *flow, const float *filt, float *out)
 {

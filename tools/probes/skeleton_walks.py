@@ -34,6 +34,10 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "policies":      # the stores' cache-policy bits, strips, 64 x 16 tiles
         cases = [(16, 0, 2, 0)] + [(16, 8 + bits, 2, 0) for bits in range(8)]
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    if len(sys.argv) > 2 and sys.argv[2] == "persistent":
+        return persistent(lib, st, P, B, H, W, x, f, k, o, nbytes, rounds)
+    if len(sys.argv) > 2 and sys.argv[2] == "phased":
+        return phased(lib, st, P, B, H, W, x, f, k, o, nbytes, rounds)
     ts = {c: [] for c in cases}
     bad = set()
     for r in range(rounds):
@@ -60,6 +64,63 @@ def main():
         print("tile %3dx%-2d %-13s %-22s %-5s %8.1f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (
             4 * lx, 256 // lx, wname, walks[walk], ("G=%d" % G) if walk == 3 else "",
             t * 1e6, moved / t / 1e9, 100 * moved / t / 8e12), flush=True)
+
+
+def persistent(lib, st, P, B, H, W, x, f, k, o, nbytes, rounds):
+    """persistent workgroups that hold up to NP tiles' results for the write window (skeleton_persistent)"""
+    cases = [("plain", 0, 0, 0, 0)]
+    for occ in (3, 4, 6):
+        cases.append(("pers", 0, occ, 1000, 100))
+        for np_ in (1, 2, 3, 4):
+            for per, win in ((500, 80), (1000, 130), (1000, 200), (2000, 260), (2000, 400), (4000, 520)):
+                cases.append(("pers", np_, occ, per, win))
+    ts = {c: [] for c in cases}
+    for r in range(rounds):
+        for c in cases:
+            kind, np_, occ, per, win = c
+            if kind == "plain":
+                call = lambda: lib.probe_skeleton_walk(st, 16, 0, 2, 0, B, H, W, P(x), P(f), P(k), P(o))
+            else:
+                call = lambda: lib.probe_skeleton_persistent(st, np_, occ, per, win, B, H, W, P(x), P(f), P(k), P(o))
+            assert call() == 0, c
+            call()
+            for _ in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); call(); b.record(); b.synchronize()
+                ts[c].append(a.elapsed_time(b) * 1e-3)
+    for c in cases:
+        kind, np_, occ, per, win = c
+        t = statistics.median(ts[c])
+        what = "one workgroup per tile, stores as they come" if kind == "plain" else (
+            "persistent %d/CU, stores as they come" % occ if np_ == 0 else
+            "persistent %d/CU, holds %d tiles, window %.1f of %.0f us" % (occ, np_, win / 100.0, per / 100.0))
+        print("64x16 strips: %-58s %8.1f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (what, t * 1e6, nbytes / t / 1e9, 100 * nbytes / t / 8e12), flush=True)
+
+
+def phased(lib, st, P, B, H, W, x, f, k, o, nbytes, rounds):
+    """stores held until a chip-wide write window of the 100 MHz clock (skeleton_phased); (0, 0) = the plain skeleton"""
+    cases = [(0, 0, 0)] + [(per, win, mode) for mode in (0, 1, 2) for per in (500, 800, 1000, 1200, 1500, 2000)
+                           for win in (per // 8, per // 5, per // 3)]
+    ts = {c: [] for c in cases}
+    for r in range(rounds):
+        for c in cases:
+            per, win, mode = c
+            if per == 0:
+                call = lambda: lib.probe_skeleton_walk(st, 16, 0, 2, 0, B, H, W, P(x), P(f), P(k), P(o))
+            else:
+                call = lambda: lib.probe_skeleton_phased(st, 16 + 256 * mode, 2, per, win, B, H, W, P(x), P(f), P(k), P(o))
+            assert call() == 0
+            call()
+            for _ in range(6):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); call(); b.record(); b.synchronize()
+                ts[c].append(a.elapsed_time(b) * 1e-3)
+    for c in cases:
+        t = statistics.median(ts[c])
+        print("64x16 strips, %-62s %8.1f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (
+            "stores as they come" if c[0] == 0 else "%s in the last %.1f us of every %.0f us" % (
+                ("stores", "workgroup starts", "starts (stores half a period later)")[c[2]], c[1] / 100.0, c[0] / 100.0),
+            t * 1e6, nbytes / t / 1e9, 100 * nbytes / t / 8e12), flush=True)
 
 
 if __name__ == "__main__":
