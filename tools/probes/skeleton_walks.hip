@@ -128,7 +128,9 @@ __global__ __launch_bounds__(256, 2) void skeleton_phased(int W, int H, int64_t 
 // PHASED STORES WITHOUT WAITING: persistent workgroups (grid = what fits the chip) that keep up to NP finished tiles' results in
 // registers and go on reading the next tile; everything held is stored when the write window opens (or when NP are held: then
 // the workgroup does wait).  NP = 0: a plain persistent loop, stores as they come.
-template <int NP>
+// PAUSE: a workgroup that stored in the window also waits for the window to CLOSE before it reads again (reads and writes
+// separated in time chip-wide, not just the stores clustered).
+template <int NP, bool PAUSE = false>
 __global__ __launch_bounds__(256, 2) void skeleton_persistent(int W, int H, int64_t plane, const float *__restrict__ in1,
                                                               const float *__restrict__ flow, const float *__restrict__ filt,
                                                               float *__restrict__ out, int tiles_x, int tiles_y, unsigned ntiles,
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void skeleton_persistent(int W, int H, int6
             np = 0;
 #pragma unroll
             for (int c = 0; c < 3; c++) stnt(out + ob + c * plane, v[c]);
+            if (PAUSE) while ((unsigned)__builtin_amdgcn_s_memrealtime() % per >= per - win) __builtin_amdgcn_s_sleep(2);
         } else {
 #pragma unroll
             for (int q = 0; q < NQ; q++)
@@ -207,7 +210,13 @@ extern "C" int probe_skeleton_persistent(void *stream, int np, int wg_per_cu, in
     if (W % 64 || H % 16 || ntiles % 8 || per <= 0 || win <= 0 || win > per) return -1;
 #define GO(NP) hipLaunchKernelGGL((skeleton_persistent<NP>), dim3(grid), dim3(256), 0, (hipStream_t)stream, W, H, (int64_t)W * H, \
                                   in1, flow, filt, out, tx, ty, ntiles, (unsigned)per, (unsigned)win)
-    if (np == 0) GO(0); else if (np == 1) GO(1); else if (np == 2) GO(2); else if (np == 3) GO(3); else if (np == 4) GO(4); else return -1;
+    if (np == 0) GO(0); else if (np == 1) GO(1); else if (np == 2) GO(2); else if (np == 3) GO(3); else if (np == 4) GO(4);
+    else if (np >= 101 && np <= 104) {
+#define GOP(NP) hipLaunchKernelGGL((skeleton_persistent<NP, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, W, H, (int64_t)W * H, \
+                                   in1, flow, filt, out, tx, ty, ntiles, (unsigned)per, (unsigned)win)
+        if (np == 101) GOP(1); else if (np == 102) GOP(2); else if (np == 103) GOP(3); else GOP(4);
+#undef GOP
+    } else return -1;
 #undef GO
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -69,10 +69,11 @@ def main():
 def persistent(lib, st, P, B, H, W, x, f, k, o, nbytes, rounds):
     """persistent workgroups that hold up to NP tiles' results for the write window (skeleton_persistent)"""
     cases = [("plain", 0, 0, 0, 0)]
-    for occ in (3, 4, 6):
+    pause = len(sys.argv) > 3 and sys.argv[3] == "pause"
+    for occ in (3, 4, 6, 8):
         cases.append(("pers", 0, occ, 1000, 100))
-        for np_ in (1, 2, 3, 4):
-            for per, win in ((500, 80), (1000, 130), (1000, 200), (2000, 260), (2000, 400), (4000, 520)):
+        for np_ in ((102, 104) if pause else (1, 2, 3, 4)):
+            for per, win in ((500, 80), (1000, 130), (1000, 200), (1500, 250), (2000, 260), (2000, 400), (3000, 500), (4000, 520)):
                 cases.append(("pers", np_, occ, per, win))
     ts = {c: [] for c in cases}
     for r in range(rounds):
@@ -93,7 +94,8 @@ def persistent(lib, st, P, B, H, W, x, f, k, o, nbytes, rounds):
         t = statistics.median(ts[c])
         what = "one workgroup per tile, stores as they come" if kind == "plain" else (
             "persistent %d/CU, stores as they come" % occ if np_ == 0 else
-            "persistent %d/CU, holds %d tiles, window %.1f of %.0f us" % (occ, np_, win / 100.0, per / 100.0))
+            "persistent %d/CU, holds %d tiles%s, window %.1f of %.0f us" % (
+                occ, np_ % 100, " + pauses reads" if np_ > 100 else "", win / 100.0, per / 100.0))
         print("64x16 strips: %-58s %8.1f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (what, t * 1e6, nbytes / t / 1e9, 100 * nbytes / t / 8e12), flush=True)
 
 
