@@ -121,6 +121,17 @@ __global__ __launch_bounds__(256, 2) void skeleton_phased(int W, int H, int64_t 
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));           // results are complete: now wait for the window
     if (MODE == 0) while ((unsigned)(__builtin_amdgcn_s_memrealtime() % per) < per - win) __builtin_amdgcn_s_sleep(8);
     if (MODE == 2) while ((unsigned)((__builtin_amdgcn_s_memrealtime() + per / 2) % per) < per - win) __builtin_amdgcn_s_sleep(8);
+    if (MODE >= 3) {
+        // nobody waits: write-back (cached) stores leave the dirty lines in the XCD's L2, and a workgroup that finishes inside
+        // the window asks its L2 to write everything back (buffer_wbl2) -- the stores reach HBM in bursts.  MODE 4: plain stores
+        // and no write-back request at all (the control)
+#pragma unroll
+        for (int c = 0; c < 3; c++) *reinterpret_cast<f32x4 *>(out + (b * 3 + c) * plane + o) = v[c];
+        if (MODE == 3 && (unsigned)(__builtin_amdgcn_s_memrealtime() % per) >= per - win) {
+            asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; c++) stnt(out + (b * 3 + c) * plane + o, v[c]);
 }
@@ -231,7 +242,7 @@ extern "C" int probe_skeleton_phased(void *stream, int lx, int walk, int per, in
     if (grid % 8 || lx != 16 || per <= 0 || win <= 0 || win > per) return -1;
 #define GO(MODE) hipLaunchKernelGGL((skeleton_phased<16, MODE>), dim3(grid), dim3(256), 0, (hipStream_t)stream, W, H, (int64_t)W * H, \
                                     in1, flow, filt, out, tx, ty, walk, (unsigned)per, (unsigned)win)
-    if (mode == 0) GO(0); else if (mode == 1) GO(1); else GO(2);
+    if (mode == 0) GO(0); else if (mode == 1) GO(1); else if (mode == 2) GO(2); else if (mode == 3) GO(3); else GO(4);
 #undef GO
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

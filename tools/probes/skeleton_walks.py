@@ -103,6 +103,9 @@ def phased(lib, st, P, B, H, W, x, f, k, o, nbytes, rounds):
     """stores held until a chip-wide write window of the 100 MHz clock (skeleton_phased); (0, 0) = the plain skeleton"""
     cases = [(0, 0, 0)] + [(per, win, mode) for mode in (0, 1, 2) for per in (500, 800, 1000, 1200, 1500, 2000)
                            for win in (per // 8, per // 5, per // 3)]
+    if len(sys.argv) > 3 and sys.argv[3] == "wbl2":
+        cases = [(0, 0, 0), (1000, 100, 4), (1000, 120, 0)] + [(per, win, 3) for per in (200, 500, 1000, 2000, 4000, 8000)
+                                                             for win in (per // 50 + 1, per // 16, per // 8)]
     ts = {c: [] for c in cases}
     for r in range(rounds):
         for c in cases:
@@ -121,7 +124,8 @@ def phased(lib, st, P, B, H, W, x, f, k, o, nbytes, rounds):
         t = statistics.median(ts[c])
         print("64x16 strips, %-62s %8.1f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (
             "stores as they come" if c[0] == 0 else "%s in the last %.1f us of every %.0f us" % (
-                ("stores", "workgroup starts", "starts (stores half a period later)")[c[2]], c[1] / 100.0, c[0] / 100.0),
+                ("stores", "workgroup starts", "starts (stores half a period later)", "cached stores, L2 write-back requested",
+                 "cached stores, no request (control):")[c[2]], c[1] / 100.0, c[0] / 100.0),
             t * 1e6, nbytes / t / 1e9, 100 * nbytes / t / 8e12), flush=True)
 
 
