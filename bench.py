@@ -531,9 +531,9 @@ def main(argv=None):
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the rows outside the timed region (i.i.d. flow, the other BASELINE configs, copy calibration)")
     ap.add_argument("--input-sets", type=int, default=0,
-                    help="input sets the launches rotate over (0 = automatic: 1 when a launch moves >= 1 GB, else enough "
-                         "to cycle >= 1.4 GB, at least 4 -- a small shard re-launched on the same tensors would be served "
-                         "by the 256 MB Infinity Cache, and its 'HBM fraction' would not be one)")
+                    help="input sets the launches rotate over (0 = automatic: enough to cycle >= 2.8 GB, what the full batch "
+                         "moves per launch -- a smaller shard re-launched on the same tensors is partly served by the 256 MB "
+                         "Infinity Cache, and its 'HBM fraction' would not be one)")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--channels", type=int, default=3)
@@ -588,7 +588,11 @@ def main(argv=None):
         raise SystemExit("rank %d has no frame pair (global batch %d over %d ranks)" % (rank, cfg["batch"], world))
     sites_per_launch = B * H * W
     alg_bytes = BYTES_PER_SITE["fi_fwd"](C, fs) * sites_per_launch
-    nsets = args.input_sets if args.input_sets > 0 else (1 if alg_bytes >= 1e9 else max(4, -(-1400000000 // alg_bytes)))
+    # Input sets the launches rotate over: enough to cycle what the FULL batch moves in one launch (2.83 GB) -- one set at batch 32,
+    # 2 / 4 / 8 at the 16 / 8 / 4-pair shards of an N = 2 / 4 / 8 run.  Measured (profiles/r06_input_sets.txt): a 16-pair shard
+    # relaunched on ONE set of 1.4 GB runs 8 % faster than on two (the 256 MB memory-side cache keeps a sixth of it from launch
+    # to launch); at 2.83 GB a second set changes 0.5 %.  Rounds 2-6 rotated only below 1 GB.
+    nsets = args.input_sets if args.input_sets > 0 else max(1, -(-2800000000 // alg_bytes))
     sets = []
     for k in range(nsets):                      # set 0 is the one the oracle check and the CPU baseline look at
         t = synth.torch_inputs(device, B, C, H, W, fs=fs, flow_kind=args.flow, seed=plan["seed"] + 7919 * k)
