@@ -1880,7 +1880,9 @@ def _make_random(case):
 
 
 # (64 cases in the suite; MEMC_RANDOM_CASES=N for a longer sweep -- round 6 ran 600 once: tools/sessions/r06_s13.sh)
-RANDOM_CASES = _random_shape_cases(int(os.environ.get("MEMC_RANDOM_CASES", "64")), 20260601)
+# (MEMC_RANDOM_SEED: another seed for such a sweep -- tools/sessions/r06_s31.sh ran 1500 + 600 fresh cases once)
+RANDOM_CASES = _random_shape_cases(int(os.environ.get("MEMC_RANDOM_CASES", "64")), int(os.environ.get("MEMC_RANDOM_SEED", "20260601")))
+_N_STRIDED = int(os.environ.get("MEMC_STRIDED_CASES", "48"))
 
 
 @pytest.mark.parametrize("case", RANDOM_CASES, ids=["%dx%dx%dx%d-%s-%g" % c[:6] for c in RANDOM_CASES])
@@ -1939,7 +1941,7 @@ def test_random_shapes_every_operator_forward_and_backward(oracle, case):
             close(N(gd), wg2, "DepthFlowProjection bwd gradinput2")
 
 
-@pytest.mark.parametrize("case", RANDOM_CASES[:48], ids=["%dx%dx%dx%d-%s-%g" % c[:6] for c in RANDOM_CASES[:48]])
+@pytest.mark.parametrize("case", RANDOM_CASES[:_N_STRIDED], ids=["%dx%dx%dx%d-%s-%g" % c[:6] for c in RANDOM_CASES[:_N_STRIDED]])
 def test_random_strided_views_every_operator(oracle, case):
     """The same sweep on VIEWS: every tensor is a window of a larger buffer -- random extra channels, rows and columns around it and a
     random offset inside, one layout per tensor shape (image-like, flow-like, filter-like, one-plane: tensors of one shape
