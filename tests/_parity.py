@@ -8,6 +8,13 @@ Rule (BASELINE.json's north star: "outputs that match the reference CUDA kernels
 The relative term exists only for sums of many scattered fp32 contributions beyond 10 in magnitude, where one ulp of the
 result already approaches 1e-6 and the reference's own atomics add in hardware order.
 
+One quantity gets a third term, `cancel`: DepthFlowProjection's gradinput2 is a sum of eight SIGNED terms go / count * (f - out)
+(my_lib.c:1805-1873), each as large as the tensor's largest cell; fp32 leaves ~1e-7 of the TERMS in a cell whatever the sum, so a cell
+that cancels to 3 from terms of 1e3 carries 2e-4 of noise in ANY fp32 evaluation -- the fp32 oracle itself is 2.0e-4 from a float64
+evaluation on such inputs, the reference's own kernel 1.2e-4 from the oracle (tools/probes/depth_bwd_cancellation.py,
+profiles/r06_depth_bwd_cancellation.txt: the one case in 2100 fresh random shapes that found this, flow of +-160 px on a 90 x 130
+image).  With cancel = c the absolute bound of every cell is max(1e-4, c * max|want| over the tensor); only those checks pass one (3e-7).
+
 Every check appends one JSON line to gpurun_out/parity_errors.jsonl (MEMC_PARITY_LOG overrides the path): the test id,
 what was compared, the largest absolute error, the largest |want|, and the largest relative error among the elements
 beyond 10 -- so that a regression from 1e-6 to 8e-5 is visible although both pass.  tests/conftest.py folds the lines
@@ -42,7 +49,7 @@ def _record(entry):
         pass                                  # a read-only tree must not fail a parity test
 
 
-def _stats_numpy(got, want, rtol):
+def _stats_numpy(got, want, rtol, cancel=0.0):
     got = np.asarray(got)
     want = np.asarray(want)
     assert got.shape == want.shape, "shape %s vs %s" % (got.shape, want.shape)
@@ -56,13 +63,14 @@ def _stats_numpy(got, want, rtol):
     err = np.where(skip, 0.0, np.abs(g - w))
     err = np.where(np.isnan(err), np.inf, err)             # NaN on one side only: a failure
     aw = np.where(skip, 0.0, np.abs(w))
-    bound = np.where(aw <= BIG, ATOL, np.maximum(ATOL, rtol * aw))
+    floor = max(ATOL, cancel * float(aw.max()))
+    bound = np.where(aw <= BIG, floor, np.maximum(floor, rtol * aw))
     big = aw > BIG
     rel = float((err[big] / aw[big]).max()) if big.any() else 0.0
     return float(err.max()), float(aw.max()), rel, float((err - bound).max())
 
 
-def _stats_torch(got, want, rtol):
+def _stats_torch(got, want, rtol, cancel=0.0):
     import torch
     assert got.shape == want.shape, "shape %s vs %s" % (tuple(got.shape), tuple(want.shape))
     if got.numel() == 0:
@@ -72,6 +80,10 @@ def _stats_torch(got, want, rtol):
     worst_err = worst_want = worst_rel = 0.0
     worst_excess = -float("inf")
     step = 1 << 26
+    floor = ATOL
+    if cancel > 0.0:
+        finite = torch.where(torch.isfinite(w1), w1.abs(), torch.zeros_like(w1))
+        floor = max(ATOL, cancel * float(finite.max()))
     for i in range(0, g1.numel(), step):
         g = g1[i:i + step].double()
         w = w1[i:i + step].double()
@@ -79,7 +91,7 @@ def _stats_torch(got, want, rtol):
         err = torch.where(skip, torch.zeros_like(g), (g - w).abs())
         err = torch.where(torch.isnan(err), torch.full_like(err, float("inf")), err)
         aw = torch.where(skip, torch.zeros_like(w), w.abs())
-        bound = torch.where(aw <= BIG, torch.full_like(aw, ATOL), torch.clamp(rtol * aw, min=ATOL))
+        bound = torch.where(aw <= BIG, torch.full_like(aw, floor), torch.clamp(rtol * aw, min=floor))
         worst_err = max(worst_err, float(err.max()))
         worst_want = max(worst_want, float(aw.max()))
         worst_excess = max(worst_excess, float((err - bound).max()))
@@ -89,12 +101,18 @@ def _stats_torch(got, want, rtol):
     return worst_err, worst_want, worst_rel, worst_excess
 
 
-def close(got, want, what, rtol=RTOL):
+CANCEL = 3e-7        # (see the module docstring: DepthFlowProjection's gradinput2 only)
+
+
+def close(got, want, what, rtol=RTOL, cancel=0.0):
     """Assert the rule above for numpy arrays or torch tensors (which stay on their device); record what was seen."""
     is_torch = hasattr(got, "is_cuda") or hasattr(want, "is_cuda")
-    err, aw, rel, excess = (_stats_torch if is_torch else _stats_numpy)(got, want, rtol)
-    _record({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": what, "max_abs_err": err,
-             "max_abs_want": aw, "max_rel_err_beyond_10": rel, "rtol_beyond_10": rtol, "ok": excess <= 0})
+    err, aw, rel, excess = (_stats_torch if is_torch else _stats_numpy)(got, want, rtol, cancel)
+    entry = {"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0], "what": what, "max_abs_err": err,
+             "max_abs_want": aw, "max_rel_err_beyond_10": rel, "rtol_beyond_10": rtol, "ok": excess <= 0}
+    if cancel > 0.0:
+        entry["abs_bound"] = max(ATOL, cancel * aw)
+    _record(entry)
     assert excess <= 0, "%s: max abs err %.3g (|want| up to %.3g, rel err beyond 10: %.3g)" % (what, err, aw, rel)
     return err
 
