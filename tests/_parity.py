@@ -12,7 +12,7 @@ One quantity gets a third term, `cancel`: DepthFlowProjection's gradinput2 is a 
 (my_lib.c:1805-1873), each as large as the tensor's largest cell; fp32 leaves ~1e-7 of the TERMS in a cell whatever the sum, so a cell
 that cancels to 3 from terms of 1e3 carries 2e-4 of noise in ANY fp32 evaluation -- the fp32 oracle itself is 2.0e-4 from a float64
 evaluation on such inputs, the reference's own kernel 1.2e-4 from the oracle (tools/probes/depth_bwd_cancellation.py,
-profiles/r06_depth_bwd_cancellation.txt: the one case in 2100 fresh random shapes that found this, flow of +-160 px on a 90 x 130
+profiles/r06_fresh_seed_sweeps.txt: the one case in 2100 fresh random shapes that found this, flow of +-160 px on a 90 x 130
 image).  With cancel = c the absolute bound of every cell is max(1e-4, c * max|want| over the tensor); only those checks pass one (3e-7).
 
 Every check appends one JSON line to gpurun_out/parity_errors.jsonl (MEMC_PARITY_LOG overrides the path): the test id,

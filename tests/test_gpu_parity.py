@@ -1853,7 +1853,14 @@ def _random_shape_cases(n, seed):
     directions, one-pixel images and motion larger than the image."""
     rng = np.random.default_rng(seed)
     cases = []
-    for i in range(n):
+    big = os.environ.get("MEMC_RANDOM_BIG", "") not in ("", "0")
+    for i in range(n if big else 0):
+        # MEMC_RANDOM_BIG=1 (sweeps run once, tools/sessions/r06_s36.sh): ANY height up to 420 and width up to 900, batch up to 5 -- tens
+        # of tile rows and columns, every remainder of the strip count modulo the eight XCDs (the walk's two XCD classes)
+        kind = str(rng.choice(["smooth", "iid", "iid", "zero", "pan", "pan"]))
+        cases.append((int(rng.integers(1, 6)), int(rng.choice([1, 2, 3, 3, 3, 4, 5, 8])), int(rng.integers(1, 421)),
+                      int(rng.integers(1, 901)), kind, float(rng.choice([0.5, 2.0, 5.0, 15.0, 40.0])), 5000 + i))
+    for i in range(0 if big else n):
         B = int(rng.integers(1, 4))
         C = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 7, 8, 9, 16, 64], p=None))
         H = int(rng.choice([1, 2, 5, 16, 17, 31, 33, 48, 64, 90]))
