@@ -727,6 +727,28 @@ def main(argv=None):
         secondary = {"iid_flow": {"avg_launch_us": round(iid_s * 1e6, 2), "mpixels_s": round(sites_per_launch / iid_s / 1e6, 1),
                                   "frac": round(alg_bytes / iid_s / HBM_PEAK_BPS, 4)},
                      "calibration": copy_calibration(my_lib, device, alg_bytes)}
+        # the headline's own tensors in a layout a caller that owns its allocation could choose (NOT what the reference's callers hand
+        # over, and not the headline): every row 64 floats longer, so that a tile's rows and a site's tap planes spread over all sixteen
+        # 256-byte slots of a 4 KiB period instead of four (tools/synth.py: padded_planes; profiles/r06_plane_strides.txt)
+        if (W * 4) % 1024 == 0:
+            px, pf, pk, po = (synth.padded_planes(v) for v in (x, flow, filt, out))
+            e = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(60)]
+            for _ in range(20):
+                my_lib.FilterInterpolationLayer_gpu_forward(px, pf, pk, po)
+            for a0, a1 in e:
+                a0.record()
+                my_lib.FilterInterpolationLayer_gpu_forward(px, pf, pk, po)
+                a1.record()
+            torch.cuda.synchronize(device)
+            pad_s = sum(a0.elapsed_time(a1) for a0, a1 in e) / len(e) / 1e3
+            my_lib.FilterInterpolationLayer_gpu_forward(x, flow, filt, out)
+            torch.cuda.synchronize(device)
+            secondary["row_stride_padded_by_256B"] = {
+                "avg_launch_us": round(pad_s * 1e6, 2), "mpixels_s": round(sites_per_launch / pad_s / 1e6, 1),
+                "frac": round(alg_bytes / pad_s / HBM_PEAK_BPS, 4), "same_result": bool(torch.equal(po, out)),
+                "note": "the headline call on views whose rows are 64 floats longer (a layout choice of the caller; the headline itself "
+                        "runs on contiguous tensors, as the reference's callers provide them)"}
+            del px, pf, pk, po
         if B == 32 and (C, H, W) == (3, 720, 1280):      # the default run: + the other BASELINE configs
             del sets[1:]
             try:
@@ -775,6 +797,8 @@ def main(argv=None):
             line["roofline"]["calibration_GBps"] = {k: round(v / 1e9, 1) for k, v in cal.items()}
             line["roofline"]["frac_of_achievable"] = round(achieved / cal[best], 4)
             line["secondary"] = {"iid_flow": secondary["iid_flow"]}
+            if "row_stride_padded_by_256B" in secondary:
+                line["secondary"]["row_stride_padded_by_256B"] = secondary["row_stride_padded_by_256B"]
             line["secondary"].update(secondary.get("rows", {}))
         if dist_seen:
             line["dist"] = dist_seen

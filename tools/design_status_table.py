@@ -7,7 +7,7 @@ import sys
 
 SECTION = {"iid_flow": "a1", "config2_fi_fwd": "a1", "config2_fi_bwd": "a2", "fi_bwd": "a2", "config3_flow_projection_fwd": "a3",
            "config3_depth_flow_projection_fwd": "a5", "flow_projection_fwd": "a3", "config3_flow_projection_bwd": "a4",
-           "config3_depth_flow_projection_bwd": "a5", "interpolation": "a6", "config5": "a1", "context_warp": "a1", "config4": "f-1"}
+           "config3_depth_flow_projection_bwd": "a5", "interpolation": "a6", "config5": "a1", "context_warp": "a1", "config4": "f-1", "row_stride": "a1"}
 
 
 def main():

@@ -83,3 +83,18 @@ def torch_inputs(device, B, C, H, W, fs=4, flow_kind="smooth", seed=1234, with_g
     if with_depth:
         out["depth"] = torch.rand((B, 1, H, W), device=device, generator=g, dtype=torch.float32) + 0.1
     return out
+
+
+def padded_planes(src, row_pad=64, plane_pad=0):
+    """The same values as `src` ([B, C, H, W], fp32) in a layout whose rows are `row_pad` floats longer and whose channel planes are
+    `plane_pad` floats further apart -- a VIEW the library takes as it is (unit w-stride; h / c / b strides are honoured as in
+    my_lib.c:950-954).  Why: a 1280-wide fp32 row is 5 x 1024 B and a 720p plane 900 x 4096 B, so the sixteen rows of a tile and
+    the sixteen tap planes of a site fall on FOUR of the sixteen 256-byte slots of a 4 KiB period; 64 more floats per row (or per
+    plane) spread them over all sixteen and the RGB forward runs 7-9 % faster (profiles/r06_plane_strides.txt).  The reference's
+    callers hand over contiguous tensors; a caller that owns its allocation can do this."""
+    import torch
+    b, c, h, w = src.shape
+    buf = torch.empty((b, c, h * (w + row_pad) + plane_pad), device=src.device, dtype=src.dtype)
+    view = buf[:, :, :h * (w + row_pad)].view(b, c, h, w + row_pad)[:, :, :, :w]
+    view.copy_(src)
+    return view
