@@ -89,6 +89,73 @@ __global__ __launch_bounds__(256, 2) void skeleton_walk(int W, int H, int64_t pl
     }
 }
 
+// LOAD POLICIES: the skeleton's 18 stream loads with every combination of the cache-policy bits (inline assembly; BITS: 1 = sc0,
+// 2 = sc1, 4 = nt), strips, nt stores.  Does any of them do for CONTIGUOUS tensors what padded strides do (profiles/r06_plane_strides.txt)?
+template <int BITS>
+__device__ __forceinline__ f32x4 ld_policy(const float *p)
+{
+    f32x4 v;
+    if (BITS == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    if (BITS == 1) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+    if (BITS == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    if (BITS == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    if (BITS == 4) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    if (BITS == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 nt" : "=v"(v) : "v"(p) : "memory");
+    if (BITS == 6) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if (BITS == 7) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256, 2) void skeleton_loads(int W, int H, int64_t plane, int64_t rowp, const float *__restrict__ in1,
+                                                         const float *__restrict__ flow, const float *__restrict__ filt,
+                                                         float *__restrict__ out, int tiles_x, int tiles_y)
+{
+    constexpr int LX = 16;
+    const Tile t = walk_tile(2, 0, blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    const int b = t.b;
+    const int x = t.tx * 4 * LX + 4 * (threadIdx.x % LX), y = t.ty * (256 / LX) + threadIdx.x / LX;
+    if (x >= W || y >= H) return;
+    const int64_t o = (int64_t)y * rowp + x;               // rowp: the row pitch in floats (W, or padded)
+    f32x4 fl[2], tp[16], im[3];
+#pragma unroll
+    for (int k = 0; k < 2; k++) fl[k] = ld_policy<BITS>(flow + (b * 2 + k) * plane + o);
+#pragma unroll
+    for (int k = 0; k < 16; k++) tp[k] = ld_policy<BITS>(filt + (b * 16 + k) * plane + o);
+#pragma unroll
+    for (int c = 0; c < 3; c++) im[c] = ld_policy<BITS>(in1 + (b * 3 + c) * plane + o);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 2; k++) asm volatile("" : "+v"(fl[k]));
+#pragma unroll
+    for (int k = 0; k < 16; k++) asm volatile("" : "+v"(tp[k]));
+#pragma unroll
+    for (int c = 0; c < 3; c++) asm volatile("" : "+v"(im[c]));
+    f32x4 acc = fl[0] + fl[1];
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc += tp[k];
+#pragma unroll
+    for (int c = 0; c < 3; c++) stnt(out + (b * 3 + c) * plane + o, acc * im[c]);
+}
+
+// (plane, rowp: strides in floats -- W * H and W for contiguous tensors)
+extern "C" int probe_skeleton_loads(void *stream, int bits, int B, int H, int W, int64_t plane, int64_t rowp, const float *in1,
+                                    const float *flow, const float *filt, float *out)
+{
+    const int tx = W / 64, ty = H / 16;
+    const unsigned grid = (unsigned)tx * ty * B;
+    if (W % 64 || H % 16 || grid % 8) return -1;
+#define GO(BITS) hipLaunchKernelGGL((skeleton_loads<BITS>), dim3(grid), dim3(256), 0, (hipStream_t)stream, W, H, plane, rowp, in1, flow, \
+                                    filt, out, tx, ty)
+    switch (bits) {
+    case 0: GO(0); break; case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break;
+    case 4: GO(4); break; case 5: GO(5); break; case 6: GO(6); break; case 7: GO(7); break;
+    default: return -1;
+    }
+#undef GO
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // PHASED STORES: every workgroup holds its results until the chip-wide "write window" opens -- the last `win` ticks of every
 // period of `per` ticks of the constant 100 MHz clock all CUs share (s_memrealtime) -- so that HBM sees its stores in bursts
 // instead of one eighth of its traffic at any time.  (A question to the memory system, asked on the skeleton first.)

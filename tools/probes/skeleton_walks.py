@@ -34,6 +34,8 @@ def main():
     if len(sys.argv) > 2 and sys.argv[2] == "policies":      # the stores' cache-policy bits, strips, 64 x 16 tiles
         cases = [(16, 0, 2, 0)] + [(16, 8 + bits, 2, 0) for bits in range(8)]
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    if len(sys.argv) > 2 and sys.argv[2] == "loads":
+        return loads(lib, st, B, H, W, nbytes, rounds)
     if len(sys.argv) > 2 and sys.argv[2] == "persistent":
         return persistent(lib, st, P, B, H, W, x, f, k, o, nbytes, rounds)
     if len(sys.argv) > 2 and sys.argv[2] == "phased":
@@ -64,6 +66,35 @@ def main():
         print("tile %3dx%-2d %-13s %-22s %-5s %8.1f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (
             4 * lx, 256 // lx, wname, walks[walk], ("G=%d" % G) if walk == 3 else "",
             t * 1e6, moved / t / 1e9, 100 * moved / t / 8e12), flush=True)
+
+
+def loads(lib, st, B, H, W, nbytes, rounds):
+    """every cache policy of the stream LOADS, on contiguous tensors and on rows padded by 64 floats / planes padded by 64 floats"""
+    dev = torch.device("cuda:0")
+    lib.probe_skeleton_loads.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                         ctypes.c_int64] + [ctypes.c_void_p] * 4
+    layouts = {"contiguous": (W * H, W), "rows + 256 B": (H * (W + 64), W + 64), "planes + 256 B": (W * H + 64, W)}
+    bufs = {}
+    for name, (plane, rowp) in layouts.items():
+        bufs[name] = tuple(torch.rand(B * c * plane + 64, device=dev) for c in (3, 2, 16)) + (torch.zeros(B * 3 * plane + 64, device=dev),)
+    cases = [(name, bits) for name in layouts for bits in range(8)]
+    ts = {c: [] for c in cases}
+    for r in range(rounds):
+        for c in cases:
+            name, bits = c
+            plane, rowp = layouts[name]
+            x, f, k, o = bufs[name]
+            call = lambda: lib.probe_skeleton_loads(st, bits, B, H, W, plane, rowp, x.data_ptr(), f.data_ptr(), k.data_ptr(), o.data_ptr())
+            assert call() == 0
+            call()
+            for _ in range(6):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); call(); b.record(); b.synchronize()
+                ts[c].append(a.elapsed_time(b) * 1e-3)
+    for c in cases:
+        t = statistics.median(ts[c])
+        pol = "ld" + "".join(n for bit, n in ((1, " sc0"), (2, " sc1"), (4, " nt")) if c[1] & bit)
+        print("64x16 strips, %-15s loads %-14s %8.1f us  %7.1f GB/s  %5.1f%% of 8 TB/s" % (c[0], pol, t * 1e6, nbytes / t / 1e9, 100 * nbytes / t / 8e12), flush=True)
 
 
 def persistent(lib, st, P, B, H, W, x, f, k, o, nbytes, rounds):
