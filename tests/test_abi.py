@@ -198,9 +198,9 @@ def test_product_library_has_no_measurement_arms(hip_lib_path):
         for arm in ("fi_fwd_refshape", "persistent", "10proj_ownerI", "11proj_owner4", "19proj_fillhole_carry"):
             assert arm not in k, k
     # the tiled FI forward exists in exactly its production instantiations: 64 x 16 tiles, two waves per SIMD, the strip walk
-    # (WALK == 0), for whole-quad and for ragged widths (RAGW), on the 3072-pixel LDS budget (CAP, the last argument)
+    # (WALK == 0), for whole-quad and for ragged widths (RAGW), on the 3072-pixel LDS budget (CAP), stores as they come (PHASE == 0, the last)
     fwd = [k for k in kernels if "16fi_fwd_tiled_fs4" in k]
-    assert fwd and all(k.split("EEEv")[0].endswith(("Li2ELi0ELb0ELi3072", "Li2ELi0ELb1ELi3072")) for k in fwd), fwd
+    assert fwd and all(k.split("EEEv")[0].endswith(("Li2ELi0ELb0ELi3072ELi0", "Li2ELi0ELb1ELi3072ELi0")) for k in fwd), fwd
     # the RGB backward: the packed-plane kernel without timestamps, and none of the round-1/2 kernels (arms/)
     assert not [k for k in kernels if "15fi_bwd_tiled_c3" in k]
     bwd = [k for k in kernels if "12fi_bwd_c3_pk" in k]
